@@ -1,0 +1,198 @@
+# -*- coding: utf-8 -*-
+"""
+Generate tests/golden/*.npz from the REFERENCE itself (authoring container only).
+
+How: builds nothing itself -- expects ``make -C oracle`` to have produced
+``oracle/_ref/qmlib.so`` from the reference's two C files where they lie under
+/root/reference -- then imports the reference's own binding
+``/root/reference/quakemigrate/core/lib.py`` (three stub
+modules stand in for the obspy/pyproj-dependent package __init__ chain) and
+records inputs and outputs of ``lib.migrate`` / ``lib.find_max_coa`` /
+``lib.*_sta_lta``.  The fixtures are data only; no reference source travels.
+
+Run:  python oracle/make_golden.py       (writes tests/golden/)
+"""
+
+import ctypes
+import hashlib
+import importlib.util
+import pathlib
+import platform
+import sys
+import types
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+REF = pathlib.Path("/root/reference")
+REFLIB = ROOT / "oracle" / "_ref" / "qmlib.so"
+OUT = ROOT / "tests" / "golden"
+
+
+def load_reference_binding():
+    qm = types.ModuleType("quakemigrate")
+    qm.__path__ = []
+    core = types.ModuleType("quakemigrate.core")
+    core.__path__ = []
+    util = types.ModuleType("quakemigrate.util")
+    util.timeit = lambda *a, **k: (lambda f: f)
+    ln = types.ModuleType("quakemigrate.core.libnames")
+    ln._load_cdll = lambda name: ctypes.CDLL(str(REFLIB))
+    sys.modules.update({"quakemigrate": qm, "quakemigrate.core": core,
+                        "quakemigrate.util": util,
+                        "quakemigrate.core.libnames": ln})
+    qm.util = util
+    spec = importlib.util.spec_from_file_location(
+        "quakemigrate.core.lib", REF / "quakemigrate" / "core" / "lib.py")
+    lib = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lib)
+    return lib
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def meta():
+    return dict(generator="oracle/make_golden.py",
+                reference="QuakeMigrate v1.2.1 core/lib.py + core/src/*.c",
+                flags="-shared -fopenmp -fPIC -Ofast -lm -lgomp",
+                gcc=platform.python_compiler(),
+                glibc=" ".join(platform.libc_ver()),
+                numpy=np.__version__)
+
+
+def run(lib, onsets, tt, fsmp, lsmp, avail, threads=4):
+    m = lib.migrate(onsets, tt, fsmp, lsmp, avail, threads)
+    a, b, c = lib.find_max_coa(m, threads)
+    return m, a, b, c
+
+
+def save(name, **arrays):
+    arrays["meta"] = np.array(repr(meta()))
+    path = OUT / f"{name}.npz"
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {path.stat().st_size / 1024:.0f} KiB")
+
+
+def sample_rows(m, k=24, seed=5):
+    vol = m.reshape(-1, m.shape[-1])
+    rows = np.random.default_rng(seed).choice(vol.shape[0], size=min(k, vol.shape[0]),
+                                              replace=False)
+    rows.sort()
+    return rows.astype(np.int64), vol[rows].copy()
+
+
+def main():
+    from quakemigrate_amd import synth
+
+    OUT.mkdir(parents=True, exist_ok=True)
+    lib = load_reference_binding()
+
+    # 1. small random case, whole volume kept -------------------------------
+    rng = np.random.default_rng(101)
+    grid, S, ns, fsmp, lsmp = (9, 8, 7), 6, 150, 11, 47
+    tt = rng.integers(0, lsmp + 1, size=grid + (S,), dtype=np.int32)
+    on = np.clip(rng.lognormal(0, 0.6, size=(S, fsmp + ns + lsmp)), 0.4, None)
+    m, a, b, c = run(lib, on, tt, fsmp, lsmp, S)
+    save("small_random", onsets=on, traveltimes=tt, fsmp=fsmp, lsmp=lsmp,
+         available=S, map4d=m, max_coa=a, max_norm_coa=b, max_coa_idx=c)
+
+    # 2. ties: every onset on the clip floor -> every node equal -> index 0 ---
+    grid, S, ns, fsmp, lsmp = (5, 4, 3), 4, 64, 3, 9
+    tt = rng.integers(0, lsmp + 1, size=grid + (S,), dtype=np.int32)
+    on = np.full((S, fsmp + ns + lsmp), 0.4)
+    m, a, b, c = run(lib, on, tt, fsmp, lsmp, S)
+    assert (c == 0).all()
+    save("ties_floor", onsets=on, traveltimes=tt, fsmp=fsmp, lsmp=lsmp,
+         available=S, map4d=m, max_coa=a, max_norm_coa=b, max_coa_idx=c)
+
+    # 3. ties between two distant nodes with identical delay rows ------------
+    grid, S, ns, fsmp, lsmp = (6, 5, 4), 5, 96, 7, 30
+    tt = rng.integers(0, lsmp + 1, size=grid + (S,), dtype=np.int32)
+    flat = tt.reshape(-1, S)
+    lo, hi = 17, 101
+    flat[hi] = flat[lo]                      # same delays -> same sums
+    on = np.clip(rng.lognormal(0, 0.3, size=(S, fsmp + ns + lsmp)), 0.4, None)
+    for r in range(S):                        # an event that both nodes see
+        on[r, fsmp + 40 + flat[lo, r]] += 25.0
+    m, a, b, c = run(lib, on, tt, fsmp, lsmp, S)
+    assert c[40] == lo
+    save("ties_twins", onsets=on, traveltimes=tt, fsmp=fsmp, lsmp=lsmp,
+         available=S, map4d=m, max_coa=a, max_norm_coa=b, max_coa_idx=c,
+         twin_lo=lo, twin_hi=hi)
+
+    # 4. edges: negative delays clamp to 0, available != rows, fsmp = 0,
+    #    lsmp == max delay exactly, onsets below the 0.01 clip and huge -------
+    grid, S, ns, fsmp, lsmp = (4, 3, 5), 5, 80, 0, 21
+    tt = rng.integers(-6, lsmp + 1, size=grid + (S,), dtype=np.int32)
+    tt.reshape(-1, S)[7, 2] = lsmp
+    on = np.clip(rng.lognormal(0, 1.0, size=(S, fsmp + ns + lsmp)), 0.0, None)
+    on[0, ::7] = 0.0005
+    on[1, 5::11] = 0.0
+    on[3, 3::13] = 4.0e6
+    m, a, b, c = run(lib, on, tt, fsmp, lsmp, S - 2)
+    save("edges", onsets=on, traveltimes=tt, fsmp=fsmp, lsmp=lsmp,
+         available=S - 2, map4d=m, max_coa=a, max_norm_coa=b, max_coa_idx=c)
+
+    # 5. ragged sizes (nothing a multiple of any tile), volume sampled -------
+    grid, S, ns, fsmp, lsmp = (23, 17, 13), 7, 333, 19, 110
+    tt = np.ascontiguousarray(
+        synth.homogeneous_lut(grid, 1.0, synth.station_positions(rng, grid, 1.0, S),
+                              [5.0, 5.0, 5.0, 5.0, 2.9, 2.9, 2.9], 10.0))
+    assert tt.max() <= lsmp
+    on = np.clip(rng.lognormal(0, 0.5, size=(S, fsmp + ns + lsmp)), 0.4, None)
+    m, a, b, c = run(lib, on, tt, fsmp, lsmp, S)
+    rows, vals = sample_rows(m)
+    save("ragged", onsets=on, traveltimes=tt, fsmp=fsmp, lsmp=lsmp, available=S,
+         max_coa=a, max_norm_coa=b, max_coa_idx=c, map4d_rows=rows,
+         map4d_vals=vals)
+
+    # 6. Icequake_Iceland-sized geometry (BASELINE configs[0], C1), one step --
+    case = synth.make_case("C1", step=0)
+    m, a, b, c = run(lib, case.onsets, case.traveltimes, case.fsmp, case.lsmp,
+                     case.available, threads=8)
+    rows, vals = sample_rows(m)
+    save("c1_icequake_geometry", onsets=case.onsets, lut_sha256=sha(case.traveltimes),
+         fsmp=case.fsmp, lsmp=case.lsmp, available=case.available,
+         max_coa=a, max_norm_coa=b, max_coa_idx=c, map4d_rows=rows,
+         map4d_vals=vals, event_nodes=np.array(
+             [np.ravel_multi_index(n[0], case.grid) for n in case.event_nodes]))
+    del m
+
+    # 7. shrunken C2 recipe (same generator the bench uses) ------------------
+    case = synth.make_case("C2", step=0, grid=(26, 25, 14), n_samples=700)
+    m, a, b, c = run(lib, case.onsets, case.traveltimes, case.fsmp, case.lsmp,
+                     case.available, threads=8)
+    rows, vals = sample_rows(m)
+    save("c2_mini", onsets=case.onsets, lut_sha256=sha(case.traveltimes),
+         grid=np.array(case.grid), fsmp=case.fsmp, lsmp=case.lsmp,
+         available=case.available, max_coa=a, max_norm_coa=b, max_coa_idx=c,
+         map4d_rows=rows, map4d_vals=vals)
+    # quiet variant: whole step on the clip floor -> index 0 everywhere
+    case = synth.make_case("C2", step=1, grid=(26, 25, 14), n_samples=200,
+                           quiet=True)
+    m, a, b, c = run(lib, case.onsets, case.traveltimes, case.fsmp, case.lsmp,
+                     case.available, threads=8)
+    assert (c == 0).all()
+    save("c2_mini_quiet", lut_sha256=sha(case.traveltimes), grid=np.array(case.grid),
+         fsmp=case.fsmp, lsmp=case.lsmp, available=case.available,
+         t_samples=case.onsets.shape[1], max_coa=a, max_norm_coa=b, max_coa_idx=c)
+
+    # 8. STA/LTA: the reference's own known answers + a random trace ---------
+    toy = np.arange(6)
+    sig = np.abs(rng.standard_normal(600)) + 0.05
+    save("stalta",
+         toy=toy.astype(np.float64),
+         toy_overlapping=lib.overlapping_sta_lta(toy, 2, 3),
+         toy_centred=lib.centred_sta_lta(toy, 2, 3),
+         toy_recursive=lib.recursive_sta_lta(toy, 2, 3),
+         signal=sig, nsta=10, nlta=50,
+         overlapping=lib.overlapping_sta_lta(sig, 10, 50),
+         centred=lib.centred_sta_lta(sig, 10, 50),
+         recursive=lib.recursive_sta_lta(sig, 10, 50))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,228 @@
+# -*- coding: utf-8 -*-
+"""
+CPU ORACLE -- test infrastructure, NOT the product path.
+
+Two independent CPU statements of the reference's migrate / find_max_coa path:
+
+* ``c_*``  : ctypes calls into ``oracle/libqm_oracle.so`` (the C restatement in
+  ``oracle/qm_oracle.c``, built with the reference's flags);
+* ``np_*`` : a NumPy restatement, vectorised over nodes, float64, rows added in
+  ascending order (the order that fixes the rounding of the sums).
+
+and, when ``oracle/_ref/qmlib.so`` exists (a build of the REFERENCE's own C
+files, see ``oracle/Makefile``), ``ref_*`` wrappers that call the real thing
+through the same Python-level semantics as ``quakemigrate/core/lib.py:52-170``.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg
+may import this module.  Parity status: pinned by ``tests/golden`` (generated
+from the reference by ``oracle/make_golden.py``).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import pathlib
+
+import numpy as np
+import numpy.ctypeslib as clib
+
+_HERE = pathlib.Path(__file__).resolve().parent
+
+_dp = clib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i32p = clib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_i64p = clib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_I32 = ctypes.c_int32
+_I64 = ctypes.c_int64
+
+stalta_header_t = np.dtype(
+    [("n", np.int32), ("nsta", np.int32), ("nlta", np.int32)], align=True
+)
+_hdrp = clib.ndpointer(stalta_header_t, flags="C_CONTIGUOUS")
+
+_STACK_ARGS = [_dp, _i32p, _dp, _I32, _I32, _I32, _I32, _I32, _I64, _I64]
+_SCAN_ARGS = [_dp, _dp, _dp, _i64p, _I32, _I64, _I64]
+
+
+def _load(path, names):
+    lib = ctypes.CDLL(str(path))
+    stack, scan, s_over, s_cent, s_rec = (getattr(lib, n) for n in names)
+    stack.argtypes, stack.restype = _STACK_ARGS, None
+    scan.argtypes, scan.restype = _SCAN_ARGS, None
+    for f in (s_over, s_cent, s_rec):
+        f.argtypes, f.restype = [_dp, _hdrp, _dp], None
+    return dict(stack=stack, scan=scan, overlapping=s_over, centred=s_cent,
+                recursive=s_rec)
+
+
+_cache = {}
+
+
+def _port():
+    if "port" not in _cache:
+        path = _HERE / "libqm_oracle.so"
+        if not path.exists():
+            raise ImportError(
+                f"{path} missing: run `make -C oracle` (or __graft_entry__.build())"
+            )
+        _cache["port"] = _load(
+            path, ["oq_stack", "oq_scan_max", "oq_stalta_overlapping",
+                   "oq_stalta_centred", "oq_stalta_recursive"])
+    return _cache["port"]
+
+
+def have_ref() -> bool:
+    return (_HERE / "_ref" / "qmlib.so").exists()
+
+
+def _ref():
+    if "ref" not in _cache:
+        _cache["ref"] = _load(
+            _HERE / "_ref" / "qmlib.so",
+            ["migrate", "find_max_coa", "overlapping_sta_lta",
+             "centred_sta_lta", "recursive_sta_lta"])
+    return _cache["ref"]
+
+
+# --------------------------------------------------------------------------
+# Python-level semantics of quakemigrate/core/lib.py:52-125 and :131-170
+# --------------------------------------------------------------------------
+def log_onsets(onsets: np.ndarray) -> np.ndarray:
+    """clip at 0.01 then natural log (lib.py:93-94)."""
+    return np.log(np.clip(onsets, 0.01, np.inf))
+
+
+def _migrate_with(fns, onsets, traveltimes, first_idx, last_idx, available,
+                  threads, prelogged=False):
+    lon = np.ascontiguousarray(onsets if prelogged else log_onsets(onsets))
+    *grid, n_luts = traveltimes.shape
+    n_onsets, t_samples = lon.shape
+    n_samples = t_samples - first_idx - last_idx
+    if n_luts != n_onsets:
+        raise ValueError(
+            f"Mismatch between number of stations for data and LUT, "
+            f"{n_onsets}:{n_luts}")
+    if lon.size < n_samples + first_idx:
+        raise ValueError("Data array smaller than coalescence array.")
+    map4d = np.zeros(tuple(grid) + (n_samples,), dtype=np.float64)
+    fns["stack"](lon, np.ascontiguousarray(traveltimes), map4d, first_idx,
+                 last_idx, n_samples, n_onsets, int(available),
+                 int(np.prod(grid)), int(threads))
+    return map4d
+
+
+def _scan_with(fns, map4d, threads):
+    *grid, n_samples = map4d.shape
+    n_nodes = int(np.prod(grid))
+    max_coa = np.zeros(n_samples)
+    max_norm = np.zeros(n_samples)
+    idx = np.zeros(n_samples, dtype=np.int64)
+    fns["scan"](np.ascontiguousarray(map4d), max_coa, max_norm, idx,
+                n_samples, n_nodes, int(threads))
+    return max_coa, max_norm, idx
+
+
+def c_migrate(onsets, traveltimes, first_idx, last_idx, available, threads=1,
+              prelogged=False):
+    return _migrate_with(_port(), onsets, traveltimes, first_idx, last_idx,
+                         available, threads, prelogged)
+
+
+def c_find_max_coa(map4d, threads=1):
+    return _scan_with(_port(), map4d, threads)
+
+
+def ref_migrate(onsets, traveltimes, first_idx, last_idx, available,
+                threads=1, prelogged=False):
+    return _migrate_with(_ref(), onsets, traveltimes, first_idx, last_idx,
+                         available, threads, prelogged)
+
+
+def ref_find_max_coa(map4d, threads=1):
+    return _scan_with(_ref(), map4d, threads)
+
+
+def detect(onsets, traveltimes, first_idx, last_idx, available, threads=1,
+           max_bytes=2 << 30, impl="port", prelogged=False):
+    """
+    migrate + find_max_coa without holding the whole 4-D volume: the scan is a
+    per-sample reduction over nodes, so the time axis is cut into chunks whose
+    volume fits ``max_bytes``; results are identical to the one-shot call
+    (same per-sample node order for max, argmax and sum).
+    """
+    fns = _port() if impl == "port" else _ref()
+    lon = np.ascontiguousarray(onsets if prelogged else log_onsets(onsets))
+    tt = np.ascontiguousarray(traveltimes)
+    *grid, n_rows = tt.shape
+    n_nodes = int(np.prod(grid))
+    t_samples = lon.shape[1]
+    n_samples = t_samples - first_idx - last_idx
+    chunk = int(max(1, min(n_samples, max_bytes // (8 * n_nodes))))
+    max_coa = np.zeros(n_samples)
+    max_norm = np.zeros(n_samples)
+    idx = np.zeros(n_samples, dtype=np.int64)
+    for k0 in range(0, n_samples, chunk):
+        k1 = min(n_samples, k0 + chunk)
+        vol = np.zeros((n_nodes, k1 - k0))
+        fns["stack"](lon, tt, vol, first_idx + k0, t_samples - first_idx - k1,
+                     k1 - k0, n_rows, int(available), n_nodes, int(threads))
+        a, b, c = (np.zeros(k1 - k0), np.zeros(k1 - k0),
+                   np.zeros(k1 - k0, dtype=np.int64))
+        fns["scan"](vol, a, b, c, k1 - k0, n_nodes, int(threads))
+        max_coa[k0:k1], max_norm[k0:k1], idx[k0:k1] = a, b, c
+    return max_coa, max_norm, idx
+
+
+# --------------------------------------------------------------------------
+# NumPy restatement (portable spec; slow, small cases only)
+# --------------------------------------------------------------------------
+def np_migrate(onsets, traveltimes, first_idx, last_idx, available,
+               prelogged=False):
+    """migratelib.c:40-65 with lib.py:93-101 in front of it."""
+    lon = onsets if prelogged else log_onsets(onsets)
+    *grid, n_rows = traveltimes.shape
+    n_nodes = int(np.prod(grid))
+    t_samples = lon.shape[1]
+    n_samples = t_samples - first_idx - last_idx
+    tt = np.maximum(traveltimes.reshape(n_nodes, n_rows), 0).astype(np.int64)
+    k = np.arange(n_samples, dtype=np.int64)[None, :]
+    acc = np.zeros((n_nodes, n_samples))
+    for r in range(n_rows):                       # ascending row order
+        acc += lon[r][tt[:, r][:, None] + first_idx + k]
+    return np.exp(acc / float(available)).reshape(tuple(grid) + (n_samples,))
+
+
+def np_find_max_coa(map4d):
+    """migratelib.c:85-111 (first maximum wins; sequential node-order sum)."""
+    *grid, n_samples = map4d.shape
+    vol = map4d.reshape(-1, n_samples)
+    n_nodes = vol.shape[0]
+    idx = np.argmax(vol, axis=0).astype(np.int64)      # first occurrence
+    max_coa = vol[idx, np.arange(n_samples)]
+    total = np.zeros(n_samples)
+    for node in range(n_nodes):                        # sequential, as in C
+        total += vol[node]
+    return max_coa, max_coa * n_nodes / total, idx
+
+
+# --------------------------------------------------------------------------
+# STA/LTA (lib.py:176-285 semantics: output pre-filled with ones / zeros)
+# --------------------------------------------------------------------------
+def _stalta(fn, signal, nsta, nlta, fill):
+    head = np.empty(1, dtype=stalta_header_t)
+    head[:] = (len(signal), nsta, nlta)
+    signal = np.ascontiguousarray(signal, dtype=np.float64)
+    onset = np.full(len(signal), fill, dtype=np.float64)
+    fn(signal, head, onset)
+    return onset
+
+
+def c_overlapping_sta_lta(signal, nsta, nlta):
+    return _stalta(_port()["overlapping"], signal, nsta, nlta, 1.0)
+
+
+def c_centred_sta_lta(signal, nsta, nlta):
+    return _stalta(_port()["centred"], signal, nsta, nlta, 1.0)
+
+
+def c_recursive_sta_lta(signal, nsta, nlta):
+    return _stalta(_port()["recursive"], signal, nsta, nlta, 0.0)

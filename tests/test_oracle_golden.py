@@ -1,0 +1,134 @@
+# -*- coding: utf-8 -*-
+"""
+Pin the CPU oracle (oracle/qm_oracle.c + the NumPy restatement) to the golden
+vectors recorded from the reference itself (oracle/make_golden.py), and to the
+reference's own known answers for the STA/LTA functions
+(/root/reference tests/test_onsets.py:27-35).  CPU only.
+"""
+
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import RTOL, load_golden
+from quakemigrate_amd import synth
+
+FULL = ["small_random", "ties_floor", "ties_twins", "edges"]
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_c_port_matches_reference_full_volume(oracle, name):
+    g = load_golden(name)
+    m = oracle.c_migrate(g["onsets"], g["traveltimes"], int(g["fsmp"]),
+                         int(g["lsmp"]), int(g["available"]), threads=3)
+    # same compiler, same flags, same loop nest -> identical bits expected;
+    # the contract is 1e-6 relative.
+    np.testing.assert_allclose(m, g["map4d"], rtol=1e-14, atol=0)
+    a, b, c = oracle.c_find_max_coa(m, threads=2)
+    assert np.array_equal(c, g["max_coa_idx"])
+    np.testing.assert_allclose(a, g["max_coa"], rtol=1e-14)
+    np.testing.assert_allclose(b, g["max_norm_coa"], rtol=1e-14)
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_numpy_restatement_matches_reference(oracle, name):
+    g = load_golden(name)
+    m = oracle.np_migrate(g["onsets"], g["traveltimes"], int(g["fsmp"]),
+                          int(g["lsmp"]), int(g["available"]))
+    np.testing.assert_allclose(m, g["map4d"], rtol=1e-13, atol=0)
+    # scan the REFERENCE volume so the index comparison is exact
+    a, b, c = oracle.np_find_max_coa(g["map4d"])
+    assert np.array_equal(c, g["max_coa_idx"])
+    np.testing.assert_allclose(a, g["max_coa"], rtol=0)
+    np.testing.assert_allclose(b, g["max_norm_coa"], rtol=1e-13)
+
+
+def test_ties_resolve_to_lowest_index(oracle):
+    g = load_golden("ties_floor")
+    assert (g["max_coa_idx"] == 0).all()
+    g = load_golden("ties_twins")
+    lo, hi = int(g["twin_lo"]), int(g["twin_hi"])
+    vol = g["map4d"].reshape(-1, g["map4d"].shape[-1])
+    assert np.array_equal(vol[lo], vol[hi])
+    assert g["max_coa_idx"][40] == lo
+
+
+def test_ragged_sampled_volume_and_chunked_detect(oracle):
+    g = load_golden("ragged")
+    m = oracle.c_migrate(g["onsets"], g["traveltimes"], int(g["fsmp"]),
+                         int(g["lsmp"]), int(g["available"]), threads=4)
+    vol = m.reshape(-1, m.shape[-1])
+    np.testing.assert_allclose(vol[g["map4d_rows"]], g["map4d_vals"], rtol=1e-14)
+    # time-chunked detect == one-shot reference outputs
+    a, b, c = oracle.detect(g["onsets"], g["traveltimes"], int(g["fsmp"]),
+                            int(g["lsmp"]), int(g["available"]), threads=4,
+                            max_bytes=8 * vol.shape[0] * 50)
+    assert np.array_equal(c, g["max_coa_idx"])
+    np.testing.assert_allclose(a, g["max_coa"], rtol=1e-14)
+    np.testing.assert_allclose(b, g["max_norm_coa"], rtol=1e-14)
+
+
+def test_c2_mini_recipe_is_reproducible_and_matches(oracle):
+    g = load_golden("c2_mini")
+    case = synth.make_case("C2", step=0, grid=tuple(g["grid"]), n_samples=700)
+    assert _sha(case.traveltimes) == str(g["lut_sha256"])
+    assert np.array_equal(case.onsets, g["onsets"])
+    a, b, c = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
+                            case.available, threads=4)
+    assert np.array_equal(c, g["max_coa_idx"])
+    np.testing.assert_allclose(a, g["max_coa"], rtol=1e-14)
+    np.testing.assert_allclose(b, g["max_norm_coa"], rtol=1e-14)
+    # the injected events are what the scan finds
+    for (ijk, t0) in case.event_nodes:
+        assert c[t0] == np.ravel_multi_index(ijk, case.grid)
+
+
+def test_c2_mini_quiet_all_index_zero(oracle):
+    g = load_golden("c2_mini_quiet")
+    case = synth.make_case("C2", step=1, grid=tuple(g["grid"]), n_samples=200,
+                           quiet=True)
+    assert _sha(case.traveltimes) == str(g["lut_sha256"])
+    a, b, c = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
+                            case.available, threads=4)
+    assert (c == 0).all() and np.array_equal(c, g["max_coa_idx"])
+    np.testing.assert_allclose(a, g["max_coa"], rtol=1e-14)
+    np.testing.assert_allclose(b, g["max_norm_coa"], rtol=1e-14)
+
+
+def test_c1_icequake_geometry(oracle):
+    g = load_golden("c1_icequake_geometry")
+    case = synth.make_case("C1", step=0)
+    assert _sha(case.traveltimes) == str(g["lut_sha256"])
+    assert np.array_equal(case.onsets, g["onsets"])
+    a, b, c = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
+                            case.available, threads=8, max_bytes=1 << 29)
+    assert np.array_equal(c, g["max_coa_idx"])
+    np.testing.assert_allclose(a, g["max_coa"], rtol=1e-14)
+    np.testing.assert_allclose(b, g["max_norm_coa"], rtol=1e-14)
+
+
+def test_stalta_known_answers_and_reference_vectors(oracle):
+    g = load_golden("stalta")
+    toy = g["toy"]
+    # reference tests/test_onsets.py:27-35
+    assert (oracle.c_overlapping_sta_lta(toy, 2, 3)
+            == np.array([1.0, 1.0, 1.5, 1.25, 21.0 / 18, 27.0 / 24])).all()
+    assert np.allclose(oracle.c_centred_sta_lta(toy, 2, 3),
+                       np.array([1.0, 1.0, 3.5, 2.25, 1.0, 1.0]))
+    for kind in ("overlapping", "centred", "recursive"):
+        fn = getattr(oracle, f"c_{kind}_sta_lta")
+        np.testing.assert_allclose(fn(toy, 2, 3), g[f"toy_{kind}"], rtol=1e-15)
+        np.testing.assert_allclose(fn(g["signal"], int(g["nsta"]), int(g["nlta"])),
+                                   g[kind], rtol=1e-13)
+
+
+def test_binding_level_errors(oracle):
+    """ValueError semantics of quakemigrate/core/lib.py:105-110."""
+    on = np.ones((3, 50))
+    with pytest.raises(ValueError, match="Mismatch"):
+        oracle.c_migrate(on, np.zeros((2, 2, 2, 4), dtype=np.int32), 2, 3, 3)
