@@ -1,0 +1,150 @@
+/*
+ * qmhip.h -- C ABI of the MI355X (gfx950) coalescence-migration engine.
+ *
+ * The shared library (quakemigrate_amd/csrc/libqmhip.so, also installed under
+ * the reference's own name qmlib<EXT_SUFFIX>) is the drop-in boundary for the
+ * hot path of QuakeMigrate: quakemigrate.core's `migrate` + `find_max_coa`.
+ * Signatures use plain pointers and sizes only (no torch / HIP types).
+ *
+ * Part 1 are the five symbols the reference binds at import
+ * (quakemigrate/core/lib.py:38-49,128,173,211,249; prototypes
+ * quakemigrate/core/src/qmlib.h:28-44, export list qmlib.def:3-7) with
+ * identical signatures, so the UNMODIFIED reference front-end runs on this
+ * library.  Part 2 is the handle API (resident travel-time table, fused
+ * stack + exp + scan that never materialises the 4-D volume) that this
+ * repository's own host side (quakemigrate_amd/) drives.
+ *
+ * Conventions: every function of part 2 returns 0 on success, non-zero on
+ * failure; qm_last_error() returns a thread-local message.  `*_on_device`
+ * flags say whether a pointer is host memory (synchronous, copied internally)
+ * or device memory on the engine's GPU (asynchronous on the engine stream).
+ * Layouts are the reference's: onsets f64 [n_rows][T] (already log(clip)),
+ * travel-times i32 [nx][ny][nz][n_rows] (C order, flat node = (ix*ny+iy)*nz+iz,
+ * quakemigrate/lut/lut.py:165-166), volume f64 [n_nodes][n_samples].
+ */
+#ifndef QMHIP_H
+#define QMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ part 1 */
+/* reference-compatible symbols (host pointers, synchronous, `threads` ignored) */
+
+/* replaces migrate(), quakemigrate/core/src/migratelib.c:40-65 (qmlib.h:28-29).
+ * map4d is accumulated INTO (the reference's `+=`), then exp(./available). */
+void migrate(double *onsets, int32_t *lookup_tables, double *map4d,
+             int32_t fsmp, int32_t lsmp, int32_t n_samples, int32_t n_stations,
+             int32_t available, int64_t n_nodes, int64_t threads);
+
+/* replaces find_max_coa(), migratelib.c:85-111 (qmlib.h:31-32). */
+void find_max_coa(double *map4d, double *max_coa, double *max_norm_coa,
+                  int64_t *max_coa_idx, int32_t n_samples, int64_t n_nodes,
+                  int64_t threads);
+
+typedef struct {
+    int n;
+    int nsta;
+    int nlta;
+} stalta_header; /* qmlib.h:34-38, numpy mirror lib.py:33-36 */
+
+/* onsetlib.c:35-59, :79-108, :126-148.  Upstream of the hot path and serial
+ * O(n) per trace in the reference; host code here too (must be exported
+ * because lib.py binds them at import). */
+void overlapping_sta_lta(const double *signal, const stalta_header *head,
+                         double *onset);
+void centred_sta_lta(const double *signal, const stalta_header *head,
+                     double *onset);
+void recursive_sta_lta(const double *signal, const stalta_header *head,
+                       double *onset);
+
+/* ------------------------------------------------------------------ part 2 */
+typedef struct qm_engine qm_engine;
+
+const char *qm_last_error(void);
+/* number of HIP devices visible, or -1 */
+int qm_device_count(void);
+
+int qm_engine_create(int device_id, qm_engine **out);
+void qm_engine_destroy(qm_engine *e);
+
+/* run all asynchronous work on this hipStream_t (e.g. torch's current stream);
+ * NULL = the engine's own stream. */
+int qm_engine_set_stream(qm_engine *e, void *hip_stream);
+int qm_engine_synchronize(qm_engine *e);
+
+/* tunables, set BEFORE qm_engine_load_lut: "brick_x","brick_y","brick_z"
+ * (node-brick shape), "samples_per_lane" (1,2,4: time tile = 64*J samples),
+ * "waves" (wavefronts per workgroup), "groups" (brick groups per time tile,
+ * 0 = auto), "lds_bytes" (window budget per workgroup), "force_direct"
+ * (1 = bypass the LDS-tiled kernel; debugging / cross-check). */
+int qm_engine_config(qm_engine *e, const char *key, int64_t value);
+int qm_engine_get(qm_engine *e, const char *key, int64_t *value);
+
+/* Make a travel-time table resident.  lut: i32 [nx][ny][nz][n_rows].
+ * node_offset: flat index of this table's first node inside the full grid
+ * (non-zero when the grid is sharded over GPUs by x-planes).  Builds the
+ * per-brick window tables on the device.  Replaces the per-call
+ * `lookup_tables` argument of migrate() (lib.py:112-123). */
+int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device,
+                       int32_t nx, int32_t ny, int32_t nz, int32_t n_rows,
+                       int64_t node_offset);
+/* largest (clamped) delay in the resident table; callers must keep it <= lsmp */
+int qm_engine_lut_max(qm_engine *e, int32_t *max_delay);
+
+/* Fused detect step == migrate() + find_max_coa() of QuakeScan._compute
+ * (quakemigrate/signal/scan.py:635-638) without the volume.
+ * n_nodes_total: node count of the FULL grid (normalisation, migratelib.c:108).
+ * Outputs [n_samples]: max_coa f64, max_norm_coa f64, max_coa_idx i64. */
+int qm_engine_detect(qm_engine *e, const double *log_onsets, int onsets_on_device,
+                     int32_t t_samples, int32_t fsmp, int32_t lsmp,
+                     int32_t available, int64_t n_nodes_total, double *max_coa,
+                     double *max_norm_coa, int64_t *max_coa_idx,
+                     int out_on_device);
+
+/* Same step, but stop before the final normalisation: this engine's partial
+ * (log-domain maximum, global node index, sum of coalescence) per sample, on
+ * the device, ready for the cross-GPU exchange.  [n_samples] each. */
+int qm_engine_detect_partial(qm_engine *e, const double *log_onsets,
+                             int onsets_on_device, int32_t t_samples,
+                             int32_t fsmp, int32_t lsmp, int32_t available,
+                             double *d_part_max, int64_t *d_part_idx,
+                             double *d_part_sum);
+
+/* Combine n_sets partials (device, [n_sets][n_samples]) -- e.g. the all-gathered
+ * per-GPU partials, in rank order -- into the final series.  Ties go to the
+ * lowest node index, as in migratelib.c:102. */
+int qm_engine_finalize(qm_engine *e, const double *d_part_max,
+                       const int64_t *d_part_idx, const double *d_part_sum,
+                       int32_t n_sets, int32_t n_samples, int64_t n_nodes_total,
+                       double *max_coa, double *max_norm_coa,
+                       int64_t *max_coa_idx, int out_on_device);
+
+/* Materialising step (locate): volume f64 [n_nodes_local][n_samples] is written
+ * (accumulate != 0: added on top of its current content first, the reference's
+ * `+=`), and, if max_coa != NULL, the scan outputs too (same meaning as
+ * qm_engine_detect).  map4d may be host or device memory. */
+int qm_engine_migrate(qm_engine *e, const double *log_onsets, int onsets_on_device,
+                      int32_t t_samples, int32_t fsmp, int32_t lsmp,
+                      int32_t available, int64_t n_nodes_total, double *map4d,
+                      int map_on_device, int accumulate, double *max_coa,
+                      double *max_norm_coa, int64_t *max_coa_idx,
+                      int out_on_device);
+
+/* Scan of an existing volume (find_max_coa semantics, no table needed). */
+int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
+                           int32_t n_samples, int64_t n_nodes, double *max_coa,
+                           double *max_norm_coa, int64_t *max_coa_idx,
+                           int out_on_device);
+
+/* Duration (ms, HIP events on the engine stream) of the stacking kernel(s) of
+ * the most recent detect / migrate call; negative if none.  Synchronises. */
+int qm_engine_last_kernel_ms(qm_engine *e, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMHIP_H */

@@ -1,0 +1,389 @@
+# -*- coding: utf-8 -*-
+"""
+Bindings for the MI355X coalescence-migration engine -- the host-side mirror of
+the reference's ``quakemigrate/core/lib.py`` for the migrate / find_max_coa path.
+
+Same function names, argument meaning, return values and error behaviour as the
+reference (``lib.py:52-125`` ``migrate``, ``lib.py:131-170`` ``find_max_coa``,
+``lib.py:176-285`` the three STA/LTA functions), so ``QuakeScan._compute``
+(``quakemigrate/signal/scan.py:635-638``) can call them unchanged.  On top of that
+``migrate_and_find_max`` is the fused call that never materialises the 4-D map
+(what ``detect()`` wants, ``scan.py:641-642``).
+
+Everything numeric below the clip/log pre-processing runs in the HIP library
+(``include/qmhip.h``); NumPy is used only for the reference's own host-side
+pre-processing (``np.clip`` + ``np.log``, ``lib.py:93-94``) and for allocating
+the caller-owned result arrays.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import logging
+import weakref
+
+import numpy as np
+import numpy.ctypeslib as clib
+
+from quakemigrate_amd.core.libnames import _load_cdll
+
+qmlib = _load_cdll("qmlib")
+
+c_int32 = ctypes.c_int32
+c_int64 = ctypes.c_int64
+c_dPt = clib.ndpointer(dtype=np.double, flags="C_CONTIGUOUS")
+c_i32Pt = clib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+c_i64Pt = clib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+
+stalta_header_t = np.dtype(
+    [("n", c_int32), ("nsta", c_int32), ("nlta", c_int32)], align=True
+)
+stalta_header_pt = clib.ndpointer(stalta_header_t, flags="C_CONTIGUOUS")
+
+# ---- reference-compatible symbols (qmlib.h:28-44) ---------------------------
+qmlib.migrate.argtypes = [c_dPt, c_i32Pt, c_dPt, c_int32, c_int32, c_int32,
+                          c_int32, c_int32, c_int64, c_int64]
+qmlib.migrate.restype = None
+qmlib.find_max_coa.argtypes = [c_dPt, c_dPt, c_dPt, c_i64Pt, c_int32, c_int64,
+                               c_int64]
+qmlib.find_max_coa.restype = None
+for _f in (qmlib.overlapping_sta_lta, qmlib.centred_sta_lta,
+           qmlib.recursive_sta_lta):
+    _f.argtypes = [c_dPt, stalta_header_pt, c_dPt]
+    _f.restype = None
+
+# ---- handle API (include/qmhip.h part 2) ------------------------------------
+_vp = ctypes.c_void_p
+qmlib.qm_last_error.restype = ctypes.c_char_p
+qmlib.qm_device_count.restype = ctypes.c_int
+qmlib.qm_engine_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
+qmlib.qm_engine_destroy.argtypes = [_vp]
+qmlib.qm_engine_destroy.restype = None
+qmlib.qm_engine_set_stream.argtypes = [_vp, _vp]
+qmlib.qm_engine_synchronize.argtypes = [_vp]
+qmlib.qm_engine_config.argtypes = [_vp, ctypes.c_char_p, c_int64]
+qmlib.qm_engine_get.argtypes = [_vp, ctypes.c_char_p, ctypes.POINTER(c_int64)]
+qmlib.qm_engine_load_lut.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32,
+                                     c_int32, c_int32, c_int64]
+qmlib.qm_engine_lut_max.argtypes = [_vp, ctypes.POINTER(c_int32)]
+qmlib.qm_engine_detect.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32,
+                                   c_int32, c_int32, c_int64, _vp, _vp, _vp,
+                                   ctypes.c_int]
+qmlib.qm_engine_detect_partial.argtypes = [_vp, _vp, ctypes.c_int, c_int32,
+                                           c_int32, c_int32, c_int32, _vp, _vp,
+                                           _vp]
+qmlib.qm_engine_finalize.argtypes = [_vp, _vp, _vp, _vp, c_int32, c_int32,
+                                     c_int64, _vp, _vp, _vp, ctypes.c_int]
+qmlib.qm_engine_migrate.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32,
+                                    c_int32, c_int32, c_int64, _vp, ctypes.c_int,
+                                    ctypes.c_int, _vp, _vp, _vp, ctypes.c_int]
+qmlib.qm_engine_find_max_coa.argtypes = [_vp, _vp, ctypes.c_int, c_int32,
+                                         c_int64, _vp, _vp, _vp, ctypes.c_int]
+qmlib.qm_engine_last_kernel_ms.argtypes = [_vp, ctypes.POINTER(ctypes.c_double)]
+
+
+class QMHipError(RuntimeError):
+    """A call into the HIP engine failed (message from ``qm_last_error``)."""
+
+
+def _check(rc):
+    if rc != 0:
+        raise QMHipError(qmlib.qm_last_error().decode(errors="replace"))
+
+
+def _host(a):
+    return a.ctypes.data_as(_vp)
+
+
+class Engine:
+    """
+    One GPU's migration engine (thin object wrapper over the C handle API).
+
+    Pointers may be NumPy arrays (host, synchronous) or integers / objects with
+    ``data_ptr()`` (device memory on this engine's GPU, asynchronous on the
+    engine's stream) -- see :func:`_ptr`.
+    """
+
+    def __init__(self, device=0, **config):
+        h = _vp()
+        _check(qmlib.qm_engine_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self._finalizer = weakref.finalize(self, qmlib.qm_engine_destroy, h)
+        self.grid = None
+        self.n_rows = None
+        self.node_offset = 0
+        for k, v in config.items():
+            self.config(k, v)
+
+    # -- plumbing -----------------------------------------------------------
+    def close(self):
+        self._finalizer()
+
+    def config(self, key, value):
+        _check(qmlib.qm_engine_config(self._h, key.encode(), int(value)))
+
+    def get(self, key):
+        v = c_int64()
+        _check(qmlib.qm_engine_get(self._h, key.encode(), ctypes.byref(v)))
+        return int(v.value)
+
+    def set_stream(self, stream_ptr):
+        _check(qmlib.qm_engine_set_stream(self._h, _vp(stream_ptr or None)))
+
+    def synchronize(self):
+        _check(qmlib.qm_engine_synchronize(self._h))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_double()
+        _check(qmlib.qm_engine_last_kernel_ms(self._h, ctypes.byref(ms)))
+        return float(ms.value)
+
+    @staticmethod
+    def _ptr(x, dtype=None):
+        """(void*, on_device) for a NumPy array, a torch tensor or a raw int."""
+        if isinstance(x, np.ndarray):
+            if dtype is not None and x.dtype != dtype:
+                raise TypeError(f"expected {dtype}, got {x.dtype}")
+            if not x.flags["C_CONTIGUOUS"]:
+                raise ValueError("array must be C-contiguous")
+            return _host(x), 0
+        if hasattr(x, "data_ptr"):                  # torch tensor on this GPU
+            if not x.is_contiguous():
+                raise ValueError("tensor must be contiguous")
+            return _vp(x.data_ptr()), (1 if x.is_cuda else 0)
+        return _vp(int(x)), 1
+
+    # -- table --------------------------------------------------------------
+    def load_lut(self, traveltimes, node_offset=0, shape=None):
+        """
+        Make the int32 travel-time table resident: shape (nx, ny, nz, n_rows), C
+        order (what ``LUT.serve_traveltimes`` returns, lut.py:538).
+        """
+        if shape is None:
+            shape = tuple(traveltimes.shape)
+        if len(shape) != 4:
+            raise ValueError("traveltimes must have shape (nx, ny, nz, n_rows)")
+        p, dev = self._ptr(traveltimes, np.int32)
+        nx, ny, nz, rows = (int(v) for v in shape)
+        _check(qmlib.qm_engine_load_lut(self._h, p, dev, nx, ny, nz, rows,
+                                        int(node_offset)))
+        self.grid = (nx, ny, nz)
+        self.n_rows = rows
+        self.node_offset = int(node_offset)
+
+    @property
+    def lut_max(self):
+        v = c_int32()
+        _check(qmlib.qm_engine_lut_max(self._h, ctypes.byref(v)))
+        return int(v.value)
+
+    @property
+    def n_nodes(self):
+        return int(np.prod(self.grid))
+
+    # -- steps --------------------------------------------------------------
+    def detect(self, log_onsets, fsmp, lsmp, available, n_nodes_total=None,
+               out=None):
+        """Fused migrate + find_max_coa; ``log_onsets`` already log(clip(.))."""
+        rows, t_samples = (int(v) for v in log_onsets.shape)
+        self._check_rows(rows)
+        n = t_samples - fsmp - lsmp
+        if out is None:
+            out = (np.zeros(max(n, 0)), np.zeros(max(n, 0)),
+                   np.zeros(max(n, 0), dtype=np.int64))
+        po, dev_on = self._ptr(log_onsets, np.float64)
+        (pa, da), (pb, _), (pc, _) = (self._ptr(out[0], np.float64),
+                                      self._ptr(out[1], np.float64),
+                                      self._ptr(out[2], np.int64))
+        total = self.n_nodes if n_nodes_total is None else int(n_nodes_total)
+        _check(qmlib.qm_engine_detect(self._h, po, dev_on, t_samples, int(fsmp),
+                                      int(lsmp), int(available), total, pa, pb,
+                                      pc, da))
+        return out
+
+    def detect_partial(self, log_onsets, fsmp, lsmp, available, part):
+        """``part`` = (max, idx, sum) device buffers of length n_samples."""
+        rows, t_samples = (int(v) for v in log_onsets.shape)
+        self._check_rows(rows)
+        po, dev_on = self._ptr(log_onsets, np.float64)
+        _check(qmlib.qm_engine_detect_partial(
+            self._h, po, dev_on, t_samples, int(fsmp), int(lsmp), int(available),
+            self._ptr(part[0])[0], self._ptr(part[1])[0], self._ptr(part[2])[0]))
+
+    def finalize(self, part_max, part_idx, part_sum, n_sets, n_samples,
+                 n_nodes_total, out=None):
+        if out is None:
+            out = (np.zeros(n_samples), np.zeros(n_samples),
+                   np.zeros(n_samples, dtype=np.int64))
+        (pa, da), (pb, _), (pc, _) = (self._ptr(out[0]), self._ptr(out[1]),
+                                      self._ptr(out[2]))
+        _check(qmlib.qm_engine_finalize(
+            self._h, self._ptr(part_max)[0], self._ptr(part_idx)[0],
+            self._ptr(part_sum)[0], int(n_sets), int(n_samples),
+            int(n_nodes_total), pa, pb, pc, da))
+        return out
+
+    def migrate(self, log_onsets, fsmp, lsmp, available, map4d, scan_out=None,
+                accumulate=False, n_nodes_total=None):
+        rows, t_samples = (int(v) for v in log_onsets.shape)
+        self._check_rows(rows)
+        po, dev_on = self._ptr(log_onsets, np.float64)
+        pm, dev_map = self._ptr(map4d, np.float64)
+        if scan_out is None:
+            pa = pb = pc = _vp(None)
+            da = 0
+        else:
+            (pa, da), (pb, _), (pc, _) = (self._ptr(scan_out[0]),
+                                          self._ptr(scan_out[1]),
+                                          self._ptr(scan_out[2]))
+        total = self.n_nodes if n_nodes_total is None else int(n_nodes_total)
+        _check(qmlib.qm_engine_migrate(
+            self._h, po, dev_on, t_samples, int(fsmp), int(lsmp), int(available),
+            total, pm, dev_map, 1 if accumulate else 0, pa, pb, pc, da))
+        return map4d
+
+    def find_max_coa(self, map4d, n_samples, n_nodes, out=None):
+        if out is None:
+            out = (np.zeros(n_samples), np.zeros(n_samples),
+                   np.zeros(n_samples, dtype=np.int64))
+        pm, dev_map = self._ptr(map4d, np.float64)
+        (pa, da), (pb, _), (pc, _) = (self._ptr(out[0]), self._ptr(out[1]),
+                                      self._ptr(out[2]))
+        _check(qmlib.qm_engine_find_max_coa(self._h, pm, dev_map, int(n_samples),
+                                            int(n_nodes), pa, pb, pc, da))
+        return out
+
+    def _check_rows(self, rows):
+        if self.n_rows is None:
+            raise QMHipError("no travel-time table resident: call load_lut first")
+        if rows != self.n_rows:
+            raise ValueError(
+                "Mismatch between number of stations for data and LUT, "
+                f"{rows}:{self.n_rows}")
+
+
+# --------------------------------------------------------------------------
+# module-level engine for the reference-signature functions.  They receive the
+# table on every call (lib.py:53-60) and upload it every call: the only safe
+# reading of that contract.  Callers that keep a table across timesteps use an
+# Engine (or quakemigrate_amd.scan.MigrationScan) and upload once.
+# --------------------------------------------------------------------------
+_default = {"engine": None}
+
+
+def default_engine():
+    if _default["engine"] is None:
+        import os
+
+        _default["engine"] = Engine(int(os.environ.get("QM_HIP_DEVICE", "0")))
+    return _default["engine"]
+
+
+def _resident(traveltimes):
+    eng = default_engine()
+    eng.load_lut(traveltimes)
+    return eng
+
+
+def _prepare(onsets, traveltimes, first_idx, last_idx):
+    """Pre-processing and checks of lib.py:93-110, in the reference's order."""
+    onsets = np.clip(onsets, 0.01, np.inf)
+    onsets = np.ascontiguousarray(np.log(onsets), dtype=np.float64)
+    *grid_dimensions, n_luts = traveltimes.shape
+    n_onsets, t_samples = onsets.shape
+    logging.debug(f"(n_onsets, t_samples) : ({n_onsets}, {t_samples})")
+    n_samples = t_samples - first_idx - last_idx
+    logging.debug(f"n_samples : {n_samples}")
+    if not n_luts == n_onsets:
+        raise ValueError(
+            f"Mismatch between number of stations for data and LUT, {n_onsets}:{n_luts}"
+        )
+    if onsets.size < n_samples + first_idx:
+        raise ValueError("Data array smaller than coalescence array.")
+    if traveltimes.dtype != np.int32 or not traveltimes.flags["C_CONTIGUOUS"]:
+        # the reference's ndpointer argtype raises ctypes.ArgumentError here
+        raise ctypes.ArgumentError(
+            "traveltimes must be a C-contiguous int32 array")
+    return onsets, tuple(grid_dimensions), n_samples
+
+
+def migrate(onsets, traveltimes, first_idx, last_idx, available, threads=1):
+    """
+    Computes 4-D coalescence map by migrating seismic phase onset functions.
+
+    Same contract as the reference's ``migrate`` (lib.py:52-125); ``threads`` is
+    accepted and ignored (the GPU engine has no thread knob).
+
+    Returns
+    -------
+    map4d: 4-D coalescence map, shape(nx, ny, nz, nsamples).
+    """
+    onsets, grid, n_samples = _prepare(onsets, traveltimes, first_idx, last_idx)
+    eng = _resident(traveltimes)
+    map4d = np.zeros(grid + (n_samples,), dtype=np.double)
+    logging.debug(f"map4d shape : {map4d.shape}")
+    eng.migrate(onsets, first_idx, last_idx, available, map4d)
+    return map4d
+
+
+def find_max_coa(map4d, threads=1):
+    """
+    Finds time series of the maximum coalescence/normalised coalescence in the
+    3-D volume, and the corresponding grid indices (reference lib.py:131-170).
+    """
+    *grid_dimensions, n_samples = map4d.shape
+    n_nodes = int(np.prod(grid_dimensions))
+    max_coa = np.zeros(n_samples, dtype=np.double)
+    max_norm_coa = np.zeros(n_samples, dtype=np.double)
+    max_coa_idx = np.zeros(n_samples, dtype=np.int64)
+    default_engine().find_max_coa(
+        np.ascontiguousarray(map4d, dtype=np.double), n_samples, n_nodes,
+        (max_coa, max_norm_coa, max_coa_idx))
+    return max_coa, max_norm_coa, max_coa_idx
+
+
+def migrate_and_find_max(onsets, traveltimes, first_idx, last_idx, available,
+                         threads=1, return_map=False):
+    """
+    Fused ``migrate`` + ``find_max_coa`` (what ``QuakeScan._compute`` does back to
+    back, scan.py:635-638).  With ``return_map=False`` (detect) the 4-D map is
+    never written anywhere.
+
+    Returns ``(max_coa, max_norm_coa, max_coa_idx)`` or, with ``return_map``,
+    ``(max_coa, max_norm_coa, max_coa_idx, map4d)``.
+    """
+    onsets, grid, n_samples = _prepare(onsets, traveltimes, first_idx, last_idx)
+    eng = _resident(traveltimes)
+    out = (np.zeros(n_samples), np.zeros(n_samples),
+           np.zeros(n_samples, dtype=np.int64))
+    if not return_map:
+        eng.detect(onsets, first_idx, last_idx, available, out=out)
+        return out
+    map4d = np.zeros(grid + (n_samples,), dtype=np.double)
+    eng.migrate(onsets, first_idx, last_idx, available, map4d, scan_out=out)
+    return out + (map4d,)
+
+
+def _stalta(fn, signal, nsta, nlta, fill):
+    head = np.empty(1, dtype=stalta_header_t)
+    head[:] = (len(signal), nsta, nlta)
+    signal = np.ascontiguousarray(signal, dtype=np.double)
+    onset = np.full(len(signal), fill, dtype=np.double)
+    fn(signal, head, onset)
+    return onset
+
+
+def overlapping_sta_lta(signal, nsta, nlta):
+    """Overlapping-window STA/LTA (reference lib.py:176-208)."""
+    return _stalta(qmlib.overlapping_sta_lta, signal, nsta, nlta, 1.0)
+
+
+def centred_sta_lta(signal, nsta, nlta):
+    """Centred STA/LTA (reference lib.py:214-246)."""
+    return _stalta(qmlib.centred_sta_lta, signal, nsta, nlta, 1.0)
+
+
+def recursive_sta_lta(signal, nsta, nlta):
+    """Recursive STA/LTA (reference lib.py:252-285)."""
+    return _stalta(qmlib.recursive_sta_lta, signal, nsta, nlta, 0.0)

@@ -1,0 +1,723 @@
+// qm_engine.hip -- host runtime + C ABI (include/qmhip.h) of the gfx950 migration engine.
+//
+// One engine = one GPU.  It keeps the travel-time table resident together with the per-brick
+// window tables derived from it, owns the scratch for partial reductions, and launches the
+// kernels of qm_kernels.hpp on a caller-supplied (e.g. torch) or private HIP stream.
+// Nothing here falls back to the CPU: if HIP fails, the call fails.
+#include "../../include/qmhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "qm_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return 1;
+}
+
+#define QM_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t err__ = (call);                                                           \
+        if (err__ != hipSuccess)                                                             \
+            return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__,   \
+                        __LINE__);                                                           \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        QM_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+        n = count;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct qm_engine {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+
+    // tunables
+    int cfg_bx = 4, cfg_by = 4, cfg_bz = 8;
+    int cfg_j = 4;
+    int cfg_waves = 8;
+    int cfg_groups = 0;
+    int cfg_lds_bytes = 80 * 1024;
+    int cfg_force_direct = 0;
+    int64_t cfg_chunk_bytes = (int64_t)4 << 30;
+
+    // resident table
+    bool have_lut = false;
+    qm::GridDesc g{};
+    int64_t n_nodes = 0;
+    int64_t node_offset = 0;
+    int32_t lut_max = 0;
+    DevBuf<int32_t> d_lut, d_bmin, d_bspan, d_boff, d_btotal, d_wide, d_scalar;
+    DevBuf<uint16_t> d_rel;
+    std::vector<int32_t> h_btotal;
+    int n_wide = 0;
+    int plan_j = -1, plan_cap = -1;
+
+    // scratch
+    DevBuf<double> d_onsets, d_pmax, d_psum, d_out_a, d_out_b, d_chunk;
+    DevBuf<int64_t> d_pidx, d_out_i;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int lds_cap_doubles(const qm_engine *e) { return e->cfg_lds_bytes / 8; }
+
+// bricks whose windows do not fit the LDS budget for the current tile length
+int plan_wide(qm_engine *e) {
+    const int KT = qm::kWave * e->cfg_j;
+    const int cap = lds_cap_doubles(e);
+    if (e->plan_j == e->cfg_j && e->plan_cap == cap) return 0;
+    std::vector<int32_t> wide;
+    for (int b = 0; b < e->g.nbricks; ++b) {
+        const int64_t total = e->h_btotal[b];
+        if (total > 65535 || total + (int64_t)e->g.n_rows * KT > cap) wide.push_back(b);
+    }
+    e->n_wide = (int)wide.size();
+    if (e->n_wide) {
+        if (e->d_wide.ensure(wide.size())) return 1;
+        QM_HIP(hipMemcpyAsync(e->d_wide.p, wide.data(), wide.size() * sizeof(int32_t),
+                              hipMemcpyHostToDevice, e->stream));
+        QM_HIP(hipStreamSynchronize(e->stream));
+    }
+    e->plan_j = e->cfg_j;
+    e->plan_cap = cap;
+    return 0;
+}
+
+template <int J>
+int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_direct,
+                   bool use_lds, bool use_direct) {
+    const int KT = qm::kWave * J;
+    const int threads = e->cfg_waves * qm::kWave;
+    const size_t publish_bytes = (size_t)3 * e->cfg_waves * KT * sizeof(double);
+    if (use_lds) {
+        const size_t lds = std::max((size_t)e->cfg_lds_bytes, publish_bytes);
+        QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_lds_kernel<J>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        a.ngroups = groups_lds;
+        a.brick_list = nullptr;
+        a.n_list = 0;
+        hipLaunchKernelGGL((qm::stack_lds_kernel<J>), dim3((unsigned)(a.ntiles * groups_lds)),
+                           dim3(threads), lds, e->stream, a);
+        QM_HIP(hipGetLastError());
+        a.set0 += groups_lds;
+    }
+    if (use_direct) {
+        QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_direct_kernel<J>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)publish_bytes));
+        a.ngroups = groups_direct;
+        if (e->cfg_force_direct) {
+            a.brick_list = nullptr;
+            a.n_list = e->g.nbricks;
+        } else {
+            a.brick_list = e->d_wide.p;
+            a.n_list = e->n_wide;
+        }
+        hipLaunchKernelGGL(qm::stack_direct_kernel<J>,
+                           dim3((unsigned)(a.ntiles * groups_direct)), dim3(threads),
+                           publish_bytes, e->stream, a);
+        QM_HIP(hipGetLastError());
+        a.set0 += groups_direct;
+    }
+    return 0;
+}
+
+int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu) {
+    // enough workgroups for ~4 rounds over the chip, never more than there are bricks
+    int64_t want = ((int64_t)4 * e->n_cu * blocks_per_cu + ntiles - 1) / ntiles;
+    want = std::max<int64_t>(1, std::min<int64_t>(want, units));
+    return (int)want;
+}
+
+// Stack samples [sample0, sample0+n_chunk) of the scan.  Partials (if want_scan) land in
+// e->d_pmax/d_pidx/d_psum as [*n_sets][n_chunk].
+int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_samples,
+              int available, int sample0, int n_chunk, double *volume, int64_t vol_stride,
+              int accumulate, bool want_scan, int *n_sets) {
+    if (plan_wide(e)) return 1;
+    const int J = e->cfg_j;
+    const int KT = qm::kWave * J;
+    qm::StackArgs a{};
+    a.g = e->g;
+    a.onsets = d_onsets;
+    a.lut = e->d_lut.p;
+    a.rel = e->d_rel.p;
+    a.brick_min = e->d_bmin.p;
+    a.brick_span = e->d_bspan.p;
+    a.brick_off = e->d_boff.p;
+    a.brick_total = e->d_btotal.p;
+    a.T = T;
+    a.fsmp = fsmp;
+    a.n_samples = n_samples;
+    a.sample0 = sample0;
+    a.n_chunk = n_chunk;
+    a.ntiles = (n_chunk + KT - 1) / KT;
+    a.cap_doubles = lds_cap_doubles(e);
+    a.inv_available = 1.0 / (double)available;      // -Ofast turns /available into this
+    a.volume = volume;
+    a.vol_stride = vol_stride;
+    a.accumulate = accumulate;
+    a.want_scan = want_scan ? 1 : 0;
+    a.set0 = 0;
+
+    const bool use_direct = e->cfg_force_direct || e->n_wide > 0;
+    const bool use_lds = !e->cfg_force_direct && e->n_wide < e->g.nbricks;
+    const int threads = e->cfg_waves * qm::kWave;
+    const int lds_blocks_per_cu =
+        std::max(1, std::min(160 * 1024 / std::max(1, e->cfg_lds_bytes), 2048 / threads));
+    int groups_lds = 0, groups_direct = 0;
+    if (use_lds)
+        groups_lds = e->cfg_groups > 0 ? std::min(e->cfg_groups, e->g.nbricks)
+                                       : auto_groups(e, a.ntiles, e->g.nbricks, lds_blocks_per_cu);
+    if (use_direct) {
+        const int units = e->cfg_force_direct ? e->g.nbricks : e->n_wide;
+        groups_direct = e->cfg_groups > 0 ? std::min(e->cfg_groups, units)
+                                          : auto_groups(e, a.ntiles, units, 2048 / threads);
+    }
+    const int sets = groups_lds + groups_direct;
+    if (want_scan) {
+        const size_t need = (size_t)sets * n_chunk;
+        if (e->d_pmax.ensure(need) || e->d_psum.ensure(need) || e->d_pidx.ensure(need)) return 1;
+    }
+    a.part_max = e->d_pmax.p;
+    a.part_idx = e->d_pidx.p;
+    a.part_sum = e->d_psum.p;
+    *n_sets = sets;
+
+    QM_HIP(hipEventRecord(e->ev0, e->stream));
+    int rc = 0;
+    switch (J) {
+        case 1: rc = launch_stack_j<1>(e, a, groups_lds, groups_direct, use_lds, use_direct); break;
+        case 2: rc = launch_stack_j<2>(e, a, groups_lds, groups_direct, use_lds, use_direct); break;
+        case 4: rc = launch_stack_j<4>(e, a, groups_lds, groups_direct, use_lds, use_direct); break;
+        default: return fail("samples_per_lane must be 1, 2 or 4 (got %d)", J);
+    }
+    if (rc) return rc;
+    QM_HIP(hipEventRecord(e->ev1, e->stream));
+    e->timed = true;
+    return 0;
+}
+
+int combine(qm_engine *e, const double *pmax, const int64_t *pidx, const double *psum, int sets,
+            int n, int mode, int64_t node_offset, int64_t n_nodes_total, double *o_max,
+            double *o_second, int64_t *o_idx) {
+    const int threads = 256;
+    hipLaunchKernelGGL(qm::combine_kernel, dim3((n + threads - 1) / threads), dim3(threads), 0,
+                       e->stream, pmax, pidx, psum, sets, n, mode, node_offset,
+                       (double)n_nodes_total, o_max, o_second, o_idx);
+    QM_HIP(hipGetLastError());
+    return 0;
+}
+
+int check_step(qm_engine *e, int T, int fsmp, int lsmp, int available, int *n_samples) {
+    if (!e->have_lut) return fail("no travel-time table resident: call qm_engine_load_lut first");
+    if (fsmp < 0 || lsmp < 0) return fail("negative pad (fsmp=%d, lsmp=%d)", fsmp, lsmp);
+    const int ns = T - fsmp - lsmp;
+    if (ns <= 0) return fail("no samples to scan: T=%d fsmp=%d lsmp=%d", T, fsmp, lsmp);
+    if (available <= 0) return fail("available must be positive (got %d)", available);
+    if (e->lut_max > lsmp)
+        return fail("largest travel time (%d samples) exceeds the post-pad lsmp=%d: the scan "
+                    "would read past the onset rows (undefined behaviour in the reference)",
+                    e->lut_max, lsmp);
+    *n_samples = ns;
+    return 0;
+}
+
+// device-resident copy of the onsets (or the caller's device pointer)
+int stage_onsets(qm_engine *e, const double *onsets, int on_device, int T, const double **out) {
+    if (on_device) {
+        *out = onsets;
+        return 0;
+    }
+    const size_t n = (size_t)e->g.n_rows * T;
+    if (e->d_onsets.ensure(n)) return 1;
+    QM_HIP(hipMemcpyAsync(e->d_onsets.p, onsets, n * sizeof(double), hipMemcpyHostToDevice,
+                          e->stream));
+    *out = e->d_onsets.p;
+    return 0;
+}
+
+// where the kernels write the three series; copies back afterwards if the caller is on host
+struct OutStage {
+    double *a, *b;
+    int64_t *i;
+};
+int stage_out(qm_engine *e, int n, int out_on_device, double *max_coa, double *max_norm,
+              int64_t *idx, OutStage *st) {
+    if (out_on_device) {
+        *st = OutStage{max_coa, max_norm, idx};
+        return 0;
+    }
+    if (e->d_out_a.ensure(n) || e->d_out_b.ensure(n) || e->d_out_i.ensure(n)) return 1;
+    *st = OutStage{e->d_out_a.p, e->d_out_b.p, e->d_out_i.p};
+    return 0;
+}
+int fetch_out(qm_engine *e, int n, int out_on_device, const OutStage &st, double *max_coa,
+              double *max_norm, int64_t *idx) {
+    if (out_on_device) return 0;
+    QM_HIP(hipMemcpyAsync(max_coa, st.a, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    QM_HIP(hipMemcpyAsync(max_norm, st.b, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    QM_HIP(hipMemcpyAsync(idx, st.i, n * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
+    QM_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+const char *qm_last_error(void) { return g_error.c_str(); }
+
+int qm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+int qm_engine_create(int device_id, qm_engine **out) {
+    if (!out) return fail("qm_engine_create: out is NULL");
+    int n = 0;
+    QM_HIP(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n)
+        return fail("device %d not available (%d HIP devices visible)", device_id, n);
+    DeviceGuard guard(device_id);
+    qm_engine *e = new qm_engine();
+    e->device = device_id;
+    hipDeviceProp_t prop;
+    QM_HIP(hipGetDeviceProperties(&prop, device_id));
+    e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    QM_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    e->stream = e->own_stream;
+    QM_HIP(hipEventCreate(&e->ev0));
+    QM_HIP(hipEventCreate(&e->ev1));
+    *out = e;
+    return 0;
+}
+
+void qm_engine_destroy(qm_engine *e) {
+    if (!e) return;
+    DeviceGuard guard(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    e->d_lut.release(); e->d_bmin.release(); e->d_bspan.release(); e->d_boff.release();
+    e->d_btotal.release(); e->d_wide.release(); e->d_scalar.release(); e->d_rel.release();
+    e->d_onsets.release(); e->d_pmax.release(); e->d_psum.release(); e->d_out_a.release();
+    e->d_out_b.release(); e->d_chunk.release(); e->d_pidx.release(); e->d_out_i.release();
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+int qm_engine_set_stream(qm_engine *e, void *hip_stream) {
+    if (!e) return fail("engine is NULL");
+    e->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : e->own_stream;
+    return 0;
+}
+
+int qm_engine_synchronize(qm_engine *e) {
+    if (!e) return fail("engine is NULL");
+    DeviceGuard guard(e->device);
+    QM_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
+    if (!e || !key) return fail("qm_engine_config: NULL argument");
+    const std::string k(key);
+    if (k == "brick_x" || k == "brick_y" || k == "brick_z") {
+        if (v < 1 || v > 64) return fail("%s must be in 1..64", key);
+        if (e->have_lut) return fail("%s must be set before qm_engine_load_lut", key);
+        (k == "brick_x" ? e->cfg_bx : k == "brick_y" ? e->cfg_by : e->cfg_bz) = (int)v;
+    } else if (k == "samples_per_lane") {
+        if (v != 1 && v != 2 && v != 4) return fail("samples_per_lane must be 1, 2 or 4");
+        e->cfg_j = (int)v;
+    } else if (k == "waves") {
+        if (v < 1 || v > 16) return fail("waves must be 1..16");
+        e->cfg_waves = (int)v;
+    } else if (k == "groups") {
+        if (v < 0) return fail("groups must be >= 0");
+        e->cfg_groups = (int)v;
+    } else if (k == "lds_bytes") {
+        if (v < 1024 || v > 160 * 1024) return fail("lds_bytes must be in 1 KiB..160 KiB");
+        e->cfg_lds_bytes = (int)(v / 16 * 16);
+    } else if (k == "force_direct") {
+        e->cfg_force_direct = v ? 1 : 0;
+    } else if (k == "chunk_bytes") {
+        if (v < (1 << 20)) return fail("chunk_bytes must be >= 1 MiB");
+        e->cfg_chunk_bytes = v;
+    } else {
+        return fail("unknown config key '%s'", key);
+    }
+    return 0;
+}
+
+int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
+    if (!e || !key || !v) return fail("qm_engine_get: NULL argument");
+    const std::string k(key);
+    if (k == "brick_x") *v = e->cfg_bx;
+    else if (k == "brick_y") *v = e->cfg_by;
+    else if (k == "brick_z") *v = e->cfg_bz;
+    else if (k == "samples_per_lane") *v = e->cfg_j;
+    else if (k == "waves") *v = e->cfg_waves;
+    else if (k == "groups") *v = e->cfg_groups;
+    else if (k == "lds_bytes") *v = e->cfg_lds_bytes;
+    else if (k == "force_direct") *v = e->cfg_force_direct;
+    else if (k == "chunk_bytes") *v = e->cfg_chunk_bytes;
+    else if (k == "n_bricks") *v = e->g.nbricks;
+    else if (k == "n_wide_bricks") {
+        if (e->have_lut) {
+            DeviceGuard guard(e->device);
+            if (plan_wide(e)) return 1;
+        }
+        *v = e->n_wide;
+    } else if (k == "n_cu") *v = e->n_cu;
+    else if (k == "n_nodes") *v = e->n_nodes;
+    else if (k == "n_rows") *v = e->g.n_rows;
+    else return fail("unknown key '%s'", key);
+    return 0;
+}
+
+int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int32_t nx,
+                       int32_t ny, int32_t nz, int32_t n_rows, int64_t node_offset) {
+    if (!e || !lut) return fail("qm_engine_load_lut: NULL argument");
+    if (nx < 1 || ny < 1 || nz < 1 || n_rows < 1) return fail("bad table shape");
+    const int64_t n_nodes = (int64_t)nx * ny * nz;
+    if (n_nodes >= INT32_MAX) return fail("more than 2^31-1 nodes on one GPU is not supported");
+    DeviceGuard guard(e->device);
+    e->have_lut = false;
+    qm::GridDesc g{};
+    g.nx = nx; g.ny = ny; g.nz = nz;
+    g.bx = std::min(e->cfg_bx, (int)nx);
+    g.by = std::min(e->cfg_by, (int)ny);
+    g.bz = std::min(e->cfg_bz, (int)nz);
+    g.nbx = (nx + g.bx - 1) / g.bx;
+    g.nby = (ny + g.by - 1) / g.by;
+    g.nbz = (nz + g.bz - 1) / g.bz;
+    const int64_t nbricks = (int64_t)g.nbx * g.nby * g.nbz;
+    if (nbricks >= INT32_MAX) return fail("too many bricks");
+    g.nbricks = (int)nbricks;
+    g.brick_nodes = g.bx * g.by * g.bz;
+    g.n_rows = n_rows;
+    g.row_pad = (n_rows + 7) / 8 * 8;
+
+    const size_t lut_elems = (size_t)n_nodes * n_rows;
+    if (e->d_lut.ensure(lut_elems)) return 1;
+    QM_HIP(hipMemcpyAsync(e->d_lut.p, lut, lut_elems * sizeof(int32_t),
+                          lut_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                          e->stream));
+    const size_t br = (size_t)nbricks * n_rows;
+    if (e->d_bmin.ensure(br) || e->d_bspan.ensure(br) || e->d_boff.ensure(br) ||
+        e->d_btotal.ensure(nbricks) || e->d_scalar.ensure(4) ||
+        e->d_rel.ensure((size_t)nbricks * g.brick_nodes * g.row_pad))
+        return 1;
+    QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
+    hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
+                       e->d_lut.p, e->d_bmin.p, e->d_bspan.p, e->d_scalar.p);
+    QM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(qm::brick_prefix_kernel, dim3((g.nbricks + 255) / 256), dim3(256), 0,
+                       e->stream, g, e->d_bspan.p, e->d_boff.p, e->d_btotal.p);
+    QM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(qm::brick_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
+                       e->d_lut.p, e->d_bmin.p, e->d_boff.p, e->d_btotal.p, e->d_rel.p);
+    QM_HIP(hipGetLastError());
+    e->h_btotal.resize(nbricks);
+    QM_HIP(hipMemcpyAsync(e->h_btotal.data(), e->d_btotal.p, nbricks * sizeof(int32_t),
+                          hipMemcpyDeviceToHost, e->stream));
+    QM_HIP(hipMemcpyAsync(&e->lut_max, e->d_scalar.p, sizeof(int32_t), hipMemcpyDeviceToHost,
+                          e->stream));
+    QM_HIP(hipStreamSynchronize(e->stream));
+    e->g = g;
+    e->n_nodes = n_nodes;
+    e->node_offset = node_offset;
+    e->plan_j = -1;
+    e->have_lut = true;
+    return plan_wide(e);
+}
+
+int qm_engine_lut_max(qm_engine *e, int32_t *max_delay) {
+    if (!e || !max_delay) return fail("NULL argument");
+    if (!e->have_lut) return fail("no travel-time table resident");
+    *max_delay = e->lut_max;
+    return 0;
+}
+
+int qm_engine_detect_partial(qm_engine *e, const double *log_onsets, int onsets_on_device,
+                             int32_t T, int32_t fsmp, int32_t lsmp, int32_t available,
+                             double *d_part_max, int64_t *d_part_idx, double *d_part_sum) {
+    if (!e || !log_onsets || !d_part_max || !d_part_idx || !d_part_sum)
+        return fail("qm_engine_detect_partial: NULL argument");
+    DeviceGuard guard(e->device);
+    int ns = 0, sets = 0;
+    if (check_step(e, T, fsmp, lsmp, available, &ns)) return 1;
+    const double *d_on = nullptr;
+    if (stage_onsets(e, log_onsets, onsets_on_device, T, &d_on)) return 1;
+    if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, &sets)) return 1;
+    return combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, 0, e->node_offset, 0,
+                   d_part_max, d_part_sum, d_part_idx);
+}
+
+int qm_engine_finalize(qm_engine *e, const double *d_part_max, const int64_t *d_part_idx,
+                       const double *d_part_sum, int32_t n_sets, int32_t n_samples,
+                       int64_t n_nodes_total, double *max_coa, double *max_norm_coa,
+                       int64_t *max_coa_idx, int out_on_device) {
+    if (!e || !d_part_max || !d_part_idx || !d_part_sum || !max_coa || !max_norm_coa ||
+        !max_coa_idx)
+        return fail("qm_engine_finalize: NULL argument");
+    if (n_sets < 1 || n_samples < 1) return fail("qm_engine_finalize: empty input");
+    DeviceGuard guard(e->device);
+    OutStage st;
+    if (stage_out(e, n_samples, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st)) return 1;
+    if (combine(e, d_part_max, d_part_idx, d_part_sum, n_sets, n_samples, 1, 0, n_nodes_total,
+                st.a, st.b, st.i))
+        return 1;
+    return fetch_out(e, n_samples, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
+}
+
+int qm_engine_detect(qm_engine *e, const double *log_onsets, int onsets_on_device, int32_t T,
+                     int32_t fsmp, int32_t lsmp, int32_t available, int64_t n_nodes_total,
+                     double *max_coa, double *max_norm_coa, int64_t *max_coa_idx,
+                     int out_on_device) {
+    if (!e || !log_onsets || !max_coa || !max_norm_coa || !max_coa_idx)
+        return fail("qm_engine_detect: NULL argument");
+    DeviceGuard guard(e->device);
+    int ns = 0, sets = 0;
+    if (check_step(e, T, fsmp, lsmp, available, &ns)) return 1;
+    const double *d_on = nullptr;
+    if (stage_onsets(e, log_onsets, onsets_on_device, T, &d_on)) return 1;
+    OutStage st;
+    if (stage_out(e, ns, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st)) return 1;
+    if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, &sets)) return 1;
+    if (combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, 1, e->node_offset,
+                n_nodes_total, st.a, st.b, st.i))
+        return 1;
+    return fetch_out(e, ns, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
+}
+
+int qm_engine_migrate(qm_engine *e, const double *log_onsets, int onsets_on_device, int32_t T,
+                      int32_t fsmp, int32_t lsmp, int32_t available, int64_t n_nodes_total,
+                      double *map4d, int map_on_device, int accumulate, double *max_coa,
+                      double *max_norm_coa, int64_t *max_coa_idx, int out_on_device) {
+    if (!e || !log_onsets || !map4d) return fail("qm_engine_migrate: NULL argument");
+    const bool want_scan = max_coa != nullptr;
+    if (want_scan && (!max_norm_coa || !max_coa_idx))
+        return fail("qm_engine_migrate: all three scan outputs or none");
+    DeviceGuard guard(e->device);
+    int ns = 0, sets = 0;
+    if (check_step(e, T, fsmp, lsmp, available, &ns)) return 1;
+    const double *d_on = nullptr;
+    if (stage_onsets(e, log_onsets, onsets_on_device, T, &d_on)) return 1;
+    OutStage st{nullptr, nullptr, nullptr};
+    if (want_scan &&
+        stage_out(e, ns, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st))
+        return 1;
+
+    if (map_on_device) {
+        if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, map4d, ns, accumulate, want_scan,
+                      &sets))
+            return 1;
+        if (want_scan && combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, 1,
+                                 e->node_offset, n_nodes_total, st.a, st.b, st.i))
+            return 1;
+    } else {
+        // host volume: stream it through a device chunk buffer, time-chunk by time-chunk
+        const int KT = qm::kWave * e->cfg_j;
+        int64_t chunk = e->cfg_chunk_bytes / (8 * e->n_nodes);
+        chunk = std::max<int64_t>(KT, chunk / KT * KT);
+        chunk = std::min<int64_t>(chunk, ns);
+        if (e->d_chunk.ensure((size_t)e->n_nodes * chunk)) return 1;
+        for (int k0 = 0; k0 < ns; k0 += (int)chunk) {
+            const int nk = (int)std::min<int64_t>(chunk, ns - k0);
+            if (accumulate)
+                QM_HIP(hipMemcpy2DAsync(e->d_chunk.p, nk * sizeof(double), map4d + k0,
+                                        (size_t)ns * sizeof(double), nk * sizeof(double),
+                                        e->n_nodes, hipMemcpyHostToDevice, e->stream));
+            if (run_stack(e, d_on, T, fsmp, ns, available, k0, nk, e->d_chunk.p, nk, accumulate,
+                          want_scan, &sets))
+                return 1;
+            if (want_scan && combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, nk, 1,
+                                     e->node_offset, n_nodes_total, st.a + k0, st.b + k0,
+                                     st.i + k0))
+                return 1;
+            QM_HIP(hipMemcpy2DAsync(map4d + k0, (size_t)ns * sizeof(double), e->d_chunk.p,
+                                    nk * sizeof(double), nk * sizeof(double), e->n_nodes,
+                                    hipMemcpyDeviceToHost, e->stream));
+            QM_HIP(hipStreamSynchronize(e->stream));
+        }
+    }
+    if (want_scan) return fetch_out(e, ns, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
+    if (!map_on_device) QM_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
+                           int32_t n_samples, int64_t n_nodes, double *max_coa,
+                           double *max_norm_coa, int64_t *max_coa_idx, int out_on_device) {
+    if (!e || !map4d || !max_coa || !max_norm_coa || !max_coa_idx)
+        return fail("qm_engine_find_max_coa: NULL argument");
+    if (n_samples < 1 || n_nodes < 1) return fail("qm_engine_find_max_coa: empty volume");
+    DeviceGuard guard(e->device);
+    OutStage st;
+    if (stage_out(e, n_samples, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st)) return 1;
+    const int threads = 256;
+    auto scan = [&](const double *vol, int64_t stride, int nk, int k0) -> int {
+        const int tiles = (nk + threads - 1) / threads;
+        int64_t sets = std::max<int64_t>(1, ((int64_t)8 * e->n_cu * 8 + tiles - 1) / tiles);
+        sets = std::min<int64_t>(sets, std::max<int64_t>(1, n_nodes / 64));
+        sets = std::min<int64_t>(sets, 65535);
+        const int64_t per = (n_nodes + sets - 1) / sets;
+        sets = (n_nodes + per - 1) / per;
+        const size_t need = (size_t)sets * nk;
+        if (e->d_pmax.ensure(need) || e->d_psum.ensure(need) || e->d_pidx.ensure(need)) return 1;
+        hipLaunchKernelGGL(qm::scan_volume_kernel, dim3(tiles, (unsigned)sets), dim3(threads), 0,
+                           e->stream, vol, stride, nk, n_nodes, per, e->d_pmax.p, e->d_pidx.p,
+                           e->d_psum.p);
+        QM_HIP(hipGetLastError());
+        return combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, (int)sets, nk, 2, 0, n_nodes,
+                       st.a + k0, st.b + k0, st.i + k0);
+    };
+    if (map_on_device) {
+        if (scan(map4d, n_samples, n_samples, 0)) return 1;
+    } else {
+        int64_t chunk = std::max<int64_t>(1, e->cfg_chunk_bytes / (8 * n_nodes));
+        chunk = std::min<int64_t>(chunk, n_samples);
+        if (e->d_chunk.ensure((size_t)n_nodes * chunk)) return 1;
+        for (int k0 = 0; k0 < n_samples; k0 += (int)chunk) {
+            const int nk = (int)std::min<int64_t>(chunk, n_samples - k0);
+            QM_HIP(hipMemcpy2DAsync(e->d_chunk.p, nk * sizeof(double), map4d + k0,
+                                    (size_t)n_samples * sizeof(double), nk * sizeof(double),
+                                    n_nodes, hipMemcpyHostToDevice, e->stream));
+            if (scan(e->d_chunk.p, nk, nk, k0)) return 1;
+            QM_HIP(hipStreamSynchronize(e->stream));
+        }
+    }
+    return fetch_out(e, n_samples, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
+}
+
+int qm_engine_last_kernel_ms(qm_engine *e, double *ms) {
+    if (!e || !ms) return fail("NULL argument");
+    *ms = -1.0;
+    if (!e->timed) return 0;
+    DeviceGuard guard(e->device);
+    QM_HIP(hipEventSynchronize(e->ev1));
+    float f = 0.f;
+    QM_HIP(hipEventElapsedTime(&f, e->ev0, e->ev1));
+    *ms = f;
+    return 0;
+}
+
+// ---------------------------------------------------------------- reference-compatible part
+// A process-wide engine on device $QM_HIP_DEVICE (default 0).  These two entry points receive
+// host arrays and no grid shape (qmlib.h:28-32), so the node axis is bricked along the flat
+// index.  They cannot report errors through their signature (void, like the reference): a
+// failure is printed and the process aborted rather than returning wrong numbers.
+static std::mutex g_compat_mutex;
+static qm_engine *g_compat = nullptr;
+
+static qm_engine *compat_engine() {
+    if (!g_compat) {
+        const char *dev = getenv("QM_HIP_DEVICE");
+        if (qm_engine_create(dev ? atoi(dev) : 0, &g_compat)) {
+            fprintf(stderr, "qmlib (HIP): %s\n", qm_last_error());
+            abort();
+        }
+    }
+    return g_compat;
+}
+
+static void compat_check(int rc, const char *what) {
+    if (rc) {
+        fprintf(stderr, "qmlib (HIP) %s: %s\n", what, qm_last_error());
+        abort();
+    }
+}
+
+void migrate(double *onsets, int32_t *lookup_tables, double *map4d, int32_t fsmp, int32_t lsmp,
+             int32_t n_samples, int32_t n_stations, int32_t available, int64_t n_nodes,
+             int64_t threads) {
+    (void)threads;
+    std::lock_guard<std::mutex> lock(g_compat_mutex);
+    qm_engine *e = compat_engine();
+    e->have_lut = false;
+    e->cfg_bx = 1;
+    e->cfg_by = 1;
+    e->cfg_bz = 32;
+    if (n_nodes >= INT32_MAX) compat_check(fail("n_nodes too large"), "migrate");
+    compat_check(qm_engine_load_lut(e, lookup_tables, 0, 1, 1, (int32_t)n_nodes, n_stations, 0),
+                 "migrate/load");
+    // the reference adds on top of map4d; the Python binding always passes zeros (lib.py:101),
+    // so only pay for the upload when something is there
+    const size_t total = (size_t)n_nodes * n_samples;
+    int accumulate = 0;
+    for (size_t i = 0; i < total; ++i)
+        if (map4d[i] != 0.0) {
+            accumulate = 1;
+            break;
+        }
+    compat_check(qm_engine_migrate(e, onsets, 0, fsmp + lsmp + n_samples, fsmp, lsmp, available,
+                                   n_nodes, map4d, 0, accumulate, nullptr, nullptr, nullptr, 0),
+                 "migrate");
+}
+
+void find_max_coa(double *map4d, double *max_coa, double *max_norm_coa, int64_t *max_coa_idx,
+                  int32_t n_samples, int64_t n_nodes, int64_t threads) {
+    (void)threads;
+    std::lock_guard<std::mutex> lock(g_compat_mutex);
+    qm_engine *e = compat_engine();
+    compat_check(qm_engine_find_max_coa(e, map4d, 0, n_samples, n_nodes, max_coa, max_norm_coa,
+                                        max_coa_idx, 0),
+                 "find_max_coa");
+}
+
+}  // extern "C"

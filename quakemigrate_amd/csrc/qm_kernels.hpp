@@ -1,0 +1,481 @@
+// qm_kernels.hpp -- gfx950 (CDNA4) device code of the coalescence-migration engine.
+//
+// What is computed (reference: quakemigrate/core/src/migratelib.c:40-65 and :85-111):
+//   stack[n][t] = sum_{r=0..S-1} L[r][max(0,tt[n][r]) + fsmp + t]    (float64, ascending r)
+//   coa[n][t]   = exp(stack[n][t] * (1/available))
+//   per t: max_n coa, first n reaching it, sum_n coa.
+//
+// Design: a gather + reduce, so no MFMA.  The grid is cut into small
+// 3-D bricks of nodes whose delays to any one station differ little; for one brick and one
+// tile of 64*J samples the window of every log-onset row that the brick can touch is staged
+// in LDS once, then every node of the brick streams its S operands per sample out of LDS
+// (lanes = consecutive samples -> conflict-free ds_read_b64).  The per-node window offsets
+// come from a brick-relative 16-bit table built once per travel-time table, read through the
+// scalar cache.  exp, the running max / argmax / sum are fused, so the detect path never
+// writes the 4-D volume.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qm {
+
+constexpr int kWave = 64;
+constexpr int64_t kNoIndex = INT64_MAX;
+
+struct GridDesc {
+    int nx, ny, nz;        // nodes of the resident (possibly sharded) table
+    int bx, by, bz;        // brick shape
+    int nbx, nby, nbz;     // bricks per axis
+    int nbricks;
+    int brick_nodes;       // bx*by*bz
+    int n_rows;            // S
+    int row_pad;           // S rounded up to a multiple of 8 (uint16 entries per node row)
+};
+
+struct StackArgs {
+    GridDesc g;
+    const double *onsets;          // [S][T] log-onsets
+    const int32_t *lut;            // [N][S] original table
+    const uint16_t *rel;           // [nbricks][brick_nodes][row_pad] window offsets (doubles)
+    const int32_t *brick_min;      // [nbricks][S]
+    const int32_t *brick_span;     // [nbricks][S]
+    const int32_t *brick_off;      // [nbricks][S] exclusive prefix of span
+    const int32_t *brick_total;    // [nbricks] sum of span
+    const int32_t *brick_list;     // direct kernel: bricks to process (or nullptr = all)
+    int n_list;
+    int T, fsmp, n_samples;
+    int sample0;                   // first scanned sample handled by this launch (chunking)
+    int n_chunk;                   // samples handled by this launch
+    int ntiles, ngroups;
+    int cap_doubles;               // LDS window capacity in doubles
+    double inv_available;
+    double *volume;                // [N][vol_stride] or nullptr
+    int64_t vol_stride;            // samples per node row in `volume`
+    int accumulate;                // start from the volume's content (reference '+=')
+    double *part_max;              // [sets][n_chunk]  log-domain maxima
+    int64_t *part_idx;             // [sets][n_chunk]  local flat node index
+    double *part_sum;              // [sets][n_chunk]
+    int set0;                      // first partial set written by this launch
+    int want_scan;                 // write partials at all
+};
+
+template <typename I>
+__device__ __forceinline__ bool better(double v, I i, double best, I bi) {
+    return (v > best) || (v == best && i < bi);
+}
+
+// ---------------------------------------------------------------------------------------
+// Table preparation (once per qm_engine_load_lut)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool brick_node(const GridDesc &g, int b, int m, int &node) {
+    const int bzi = b % g.nbz, byi = (b / g.nbz) % g.nby, bxi = b / (g.nbz * g.nby);
+    const int lz = m % g.bz, ly = (m / g.bz) % g.by, lx = m / (g.bz * g.by);
+    const int ix = bxi * g.bx + lx, iy = byi * g.by + ly, iz = bzi * g.bz + lz;
+    node = (ix * g.ny + iy) * g.nz + iz;
+    return ix < g.nx && iy < g.ny && iz < g.nz;
+}
+
+// one workgroup per brick, thread r <-> table row r: min / span of the clamped delays.
+__global__ void brick_minmax_kernel(GridDesc g, const int32_t *__restrict__ lut,
+                                    int32_t *__restrict__ bmin, int32_t *__restrict__ bspan,
+                                    int32_t *__restrict__ global_max) {
+    const int b = blockIdx.x;
+    for (int r = threadIdx.x; r < g.n_rows; r += blockDim.x) {
+        int lo = INT32_MAX, hi = 0;
+        for (int m = 0; m < g.brick_nodes; ++m) {
+            int node;
+            if (!brick_node(g, b, m, node)) continue;
+            int d = lut[(int64_t)node * g.n_rows + r];
+            d = d < 0 ? 0 : d;                           // migratelib.c:55
+            lo = d < lo ? d : lo;
+            hi = d > hi ? d : hi;
+        }
+        if (lo == INT32_MAX) lo = 0;
+        bmin[(int64_t)b * g.n_rows + r] = lo;
+        bspan[(int64_t)b * g.n_rows + r] = hi - lo;
+        atomicMax(global_max, hi);
+    }
+}
+
+__global__ void brick_prefix_kernel(GridDesc g, const int32_t *__restrict__ bspan,
+                                    int32_t *__restrict__ boff, int32_t *__restrict__ btotal) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= g.nbricks) return;
+    int64_t run = 0;
+    for (int r = 0; r < g.n_rows; ++r) {
+        boff[(int64_t)b * g.n_rows + r] = (int32_t)(run > INT32_MAX ? INT32_MAX : run);
+        run += bspan[(int64_t)b * g.n_rows + r];
+    }
+    btotal[b] = (int32_t)(run > INT32_MAX ? INT32_MAX : run);
+}
+
+// Brick-relative window offsets, uint16, one row of row_pad entries per node.  Rows are stored
+// in the order the stacking kernel walks a brick: only the nodes inside the grid, lexicographic
+// in (x, y, z) over the brick's VALID extents (so ascending flat index, and no gaps).
+__device__ __forceinline__ void brick_extents(const GridDesc &g, int b, int &x0, int &y0, int &z0,
+                                              int &vx, int &vy, int &vz) {
+    const int bzi = b % g.nbz, byi = (b / g.nbz) % g.nby, bxi = b / (g.nbz * g.nby);
+    x0 = bxi * g.bx; y0 = byi * g.by; z0 = bzi * g.bz;
+    vx = min(g.bx, g.nx - x0); vy = min(g.by, g.ny - y0); vz = min(g.bz, g.nz - z0);
+}
+
+__global__ void brick_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
+                                 const int32_t *__restrict__ bmin,
+                                 const int32_t *__restrict__ boff,
+                                 const int32_t *__restrict__ btotal,
+                                 uint16_t *__restrict__ rel) {
+    const int b = blockIdx.x;
+    const bool narrow = btotal[b] <= 65535;
+    const int per = g.brick_nodes * g.row_pad;
+    int x0, y0, z0, vx, vy, vz;
+    brick_extents(g, b, x0, y0, z0, vx, vy, vz);
+    const int nvalid = vx * vy * vz;
+    for (int i = threadIdx.x; i < per; i += blockDim.x) {
+        const int m = i / g.row_pad, r = i % g.row_pad;
+        uint16_t v = 0;
+        if (narrow && r < g.n_rows && m < nvalid) {
+            const int lz = m % vz, ly = (m / vz) % vy, lx = m / (vz * vy);
+            const int node = ((x0 + lx) * g.ny + (y0 + ly)) * g.nz + (z0 + lz);
+            int d = lut[(int64_t)node * g.n_rows + r];
+            d = d < 0 ? 0 : d;
+            v = (uint16_t)(boff[(int64_t)b * g.n_rows + r] + d - bmin[(int64_t)b * g.n_rows + r]);
+        }
+        rel[(int64_t)b * per + i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// exp in float64.  Device-library exp (<= 1 ulp).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double qm_exp(double x) { return exp(x); }
+
+// ---------------------------------------------------------------------------------------
+// Shared epilogue state of a wavefront: J samples per lane (t = t0 + lane + 64*j).
+// ---------------------------------------------------------------------------------------
+template <int J>
+struct Running {
+    double vmax[J];
+    double vsum[J];
+    int vidx[J];                    // local flat node index (< 2^31), INT32_MAX = none
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            vmax[j] = -__builtin_inf();
+            vsum[j] = 0.0;
+            vidx[j] = INT32_MAX;
+        }
+    }
+};
+
+template <int J>
+__device__ __forceinline__ void finish_node(const StackArgs &a, Running<J> &run,
+                                            const double (&acc)[J], int node, int t_first,
+                                            int lane) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const double x = acc[j] * a.inv_available;
+        const double e = qm_exp(x);
+        const int t = t_first + lane + kWave * j;
+        if (a.volume != nullptr && t < a.n_chunk)
+            a.volume[(int64_t)node * a.vol_stride + t] = e;
+        run.vsum[j] += e;
+        if (better(x, node, run.vmax[j], run.vidx[j])) {
+            run.vmax[j] = x;
+            run.vidx[j] = node;
+        }
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void start_node(const StackArgs &a, double (&acc)[J], int node,
+                                           int t_first, int lane) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int t = t_first + lane + kWave * j;
+        acc[j] = (a.accumulate && t < a.n_chunk)
+                     ? a.volume[(int64_t)node * a.vol_stride + t]
+                     : 0.0;
+    }
+}
+
+// cross-wave combine through LDS and write of this workgroup's partial set.
+template <int J>
+__device__ __forceinline__ void publish(const StackArgs &a, Running<J> &run, double *lds,
+                                        int wave, int nwaves, int lane, int t_first, int set) {
+    constexpr int KT = kWave * J;
+    double *smax = lds;
+    double *ssum = lds + (size_t)nwaves * KT;
+    int64_t *sidx = reinterpret_cast<int64_t *>(lds + (size_t)2 * nwaves * KT);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = wave * KT + j * kWave + lane;
+        smax[k] = run.vmax[j];
+        ssum[k] = run.vsum[j];
+        sidx[k] = run.vidx[j] == INT32_MAX ? kNoIndex : (int64_t)run.vidx[j];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < KT; k += blockDim.x) {
+        double best = smax[k], total = ssum[k];
+        int64_t bi = sidx[k];
+        for (int w = 1; w < nwaves; ++w) {
+            const double v = smax[w * KT + k];
+            const int64_t i = sidx[w * KT + k];
+            total += ssum[w * KT + k];
+            if (better(v, i, best, bi)) {
+                best = v;
+                bi = i;
+            }
+        }
+        const int t = t_first + k;
+        if (t < a.n_chunk) {
+            const int64_t o = (int64_t)set * a.n_chunk + t;
+            a.part_max[o] = best;
+            a.part_idx[o] = bi;
+            a.part_sum[o] = total;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS-tiled stacking kernel.  Workgroup = (time tile, brick group); loops over the bricks of
+// its group; wavefront w takes brick nodes w, w+nwaves, ...
+//
+// The inner loop is the generated, hand-scheduled asm of qm_ring_asm.inc (8 table rows per
+// statement, 8 ds_read_b64 in flight, ascending row order per sample).  Around it the compiler
+// only computes LDS addresses from the 16-bit window offsets, which are prefetched 8 rows at a
+// time with a VECTOR load (vmcnt) -- a scalar load would share lgkmcnt with the LDS reads.
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) double lds_f64;
+
+#include "qm_ring_asm.inc"
+
+__device__ __forceinline__ void unpack8(const uint4 &q, unsigned base, unsigned (&addr)[8]) {
+    addr[0] = base + ((q.x & 0xffffu) << 3); addr[1] = base + ((q.x >> 16) << 3);
+    addr[2] = base + ((q.y & 0xffffu) << 3); addr[3] = base + ((q.y >> 16) << 3);
+    addr[4] = base + ((q.z & 0xffffu) << 3); addr[5] = base + ((q.z >> 16) << 3);
+    addr[6] = base + ((q.w & 0xffffu) << 3); addr[7] = base + ((q.w >> 16) << 3);
+}
+
+// vector (not scalar) 16-byte load of 8 packed offsets: the index is made opaque so the
+// compiler cannot prove the address wave-uniform and turn it into an s_load.
+__device__ __forceinline__ uint4 load_offsets(const uint16_t *rel, int64_t entry) {
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    return *reinterpret_cast<const uint4 *>(rel + entry + zero);
+}
+
+template <int J>
+__global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    constexpr int KT = kWave * J;
+    const GridDesc &g = a.g;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int tile = blockIdx.x % a.ntiles;
+    const int group = blockIdx.x / a.ntiles;
+    const int t_first = tile * KT;                    // relative to sample0
+    const int S = g.n_rows;
+    const int nchunks = g.row_pad >> 3;
+    // LDS byte address of this lane's column in the window area
+    const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 8u;
+
+    Running<J> run;
+    run.reset();
+
+    for (int b = group; b < g.nbricks; b += a.ngroups) {
+        const int total = a.brick_total[b];
+        if (total > 65535 || total + S * KT > a.cap_doubles) continue;   // direct kernel's job
+        __syncthreads();                              // previous brick fully consumed
+        // ---- stage the windows: row r occupies [off_r + r*KT, off_r + r*KT + span_r + KT)
+        for (int r = wave; r < S; r += nwaves) {
+            const int64_t br = (int64_t)b * S + r;
+            const int lo = a.brick_min[br];
+            const int len = a.brick_span[br] + KT;
+            const int dst = a.brick_off[br] + r * KT;
+            const int first = lo + a.fsmp + a.sample0 + t_first;   // index inside the row
+            const int room = a.T - first;              // readable elements from `first`
+            const double *src = a.onsets + (int64_t)r * a.T + first;
+            for (int u = lane; u < len; u += kWave)
+                win[dst + u] = (u < room) ? src[u] : 0.0;
+        }
+        __syncthreads();
+
+        // ---- this wave's walk over the brick's valid nodes (no divisions inside the loop)
+        int x0, y0, z0, vx, vy, vz;
+        brick_extents(g, b, x0, y0, z0, vx, vy, vz);
+        const int nvalid = vx * vy * vz;
+        int lz = wave % vz, ly = (wave / vz) % vy, lx = wave / (vz * vy);
+        const int64_t brick_entry = (int64_t)b * g.brick_nodes * g.row_pad;
+
+        // offset-chunk prefetch: one 8-row chunk ahead of consumption, in this wave's order
+        int pm = wave, pc = 0;
+        auto fetch_next = [&]() -> uint4 {
+            const int mm = pm < nvalid ? pm : 0;       // past the end: harmless reload
+            const uint4 v = load_offsets(a.rel, brick_entry + (int64_t)mm * g.row_pad + pc * 8);
+            if (++pc == nchunks) { pc = 0; pm += nwaves; }
+            return v;
+        };
+        uint4 q = fetch_next();
+
+        for (int m = wave; m < nvalid; m += nwaves) {
+            const int node = ((x0 + lx) * g.ny + (y0 + ly)) * g.nz + (z0 + lz);
+            lz += nwaves;
+            while (lz >= vz) { lz -= vz; ++ly; }
+            while (ly >= vy) { ly -= vy; ++lx; }
+
+            double acc[J];
+            start_node<J>(a, acc, node, t_first, lane);
+            unsigned chunk_addr = lane_addr;
+            for (int c = 0; c < nchunks; ++c) {
+                unsigned addr[8];
+                unpack8(q, chunk_addr, addr);
+                q = fetch_next();
+                const int rows = S - c * 8;
+                ring_chunk<J>(acc, addr, rows < 8 ? rows : 8);
+                chunk_addr += 8 * KT * 8;
+            }
+            finish_node<J>(a, run, acc, node, t_first, lane);
+        }
+    }
+    if (a.want_scan) publish<J>(a, run, win, wave, nwaves, lane, t_first, a.set0 + group);
+}
+
+// ---------------------------------------------------------------------------------------
+// Direct kernel: same decomposition, operands straight from global memory (the log-onset
+// array is a few MB and lives in L2 / Infinity Cache).  Handles bricks whose windows do not
+// fit the LDS budget (arbitrary tables stay correct), and serves as an on-device cross-check.
+// ---------------------------------------------------------------------------------------
+template <int J>
+__global__ __launch_bounds__(1024) void stack_direct_kernel(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    constexpr int KT = kWave * J;
+    const GridDesc &g = a.g;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int tile = blockIdx.x % a.ntiles;
+    const int group = blockIdx.x / a.ntiles;
+    const int t_first = tile * KT;
+    const int S = g.n_rows;
+    const int n_list = a.brick_list ? a.n_list : g.nbricks;
+
+    Running<J> run;
+    run.reset();
+
+    int tcl[J];                                         // clamped sample index per lane
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        int t = t_first + lane + kWave * j;
+        t = t < a.n_chunk ? t : a.n_chunk - 1;          // stay inside the rows
+        tcl[j] = t + a.sample0 + a.fsmp;
+    }
+
+    for (int i = group; i < n_list; i += a.ngroups) {
+        const int b = a.brick_list ? a.brick_list[i] : i;
+        for (int m = wave; m < g.brick_nodes; m += nwaves) {
+            int node;
+            if (!brick_node(g, b, m, node)) continue;
+            const int32_t *row = a.lut + (int64_t)node * S;
+            double acc[J];
+            start_node<J>(a, acc, node, t_first, lane);
+            for (int r = 0; r < S; ++r) {
+                int d = row[r];
+                d = d < 0 ? 0 : d;
+                const double *p = a.onsets + (int64_t)r * a.T + d;
+#pragma unroll
+                for (int j = 0; j < J; ++j) acc[j] += p[tcl[j]];
+            }
+            finish_node<J>(a, run, acc, node, t_first, lane);
+        }
+    }
+    if (a.want_scan) publish<J>(a, run, win, wave, nwaves, lane, t_first, a.set0 + group);
+}
+
+// ---------------------------------------------------------------------------------------
+// Scan of a materialised volume (find_max_coa).  Thread <-> sample (coalesced along t),
+// blockIdx.y <-> node chunk; values compared as stored (already exp'd).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scan_volume_kernel(const double *__restrict__ vol,
+                                                          int64_t vol_stride, int n_chunk,
+                                                          int64_t n_nodes, int64_t nodes_per_set,
+                                                          double *__restrict__ part_max,
+                                                          int64_t *__restrict__ part_idx,
+                                                          double *__restrict__ part_sum) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int set = blockIdx.y;
+    if (t >= n_chunk) return;
+    const int64_t n0 = (int64_t)set * nodes_per_set;
+    int64_t n1 = n0 + nodes_per_set;
+    n1 = n1 < n_nodes ? n1 : n_nodes;
+    double best = -__builtin_inf(), total = 0.0;
+    int64_t bi = kNoIndex;
+    int64_t n = n0;
+    for (; n + 8 <= n1; n += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = vol[(n + k) * vol_stride + t];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            total += v[k];
+            if (v[k] > best) {                          // strict: first node wins
+                best = v[k];
+                bi = n + k;
+            }
+        }
+    }
+    for (; n < n1; ++n) {
+        const double v = vol[n * vol_stride + t];
+        total += v;
+        if (v > best) {
+            best = v;
+            bi = n;
+        }
+    }
+    const int64_t o = (int64_t)set * n_chunk + t;
+    part_max[o] = best;
+    part_idx[o] = bi;
+    part_sum[o] = total;
+}
+
+// ---------------------------------------------------------------------------------------
+// Combine partial sets.  mode 0: emit one combined partial (index + node_offset, still in the
+// log domain); mode 1: final series from log-domain partials; mode 2: final series from
+// partials that already hold coalescence values (volume scan).
+// ---------------------------------------------------------------------------------------
+__global__ void combine_kernel(const double *__restrict__ part_max,
+                               const int64_t *__restrict__ part_idx,
+                               const double *__restrict__ part_sum, int n_sets, int n, int mode,
+                               int64_t node_offset, double n_nodes_total,
+                               double *__restrict__ out_max, double *__restrict__ out_norm_or_sum,
+                               int64_t *__restrict__ out_idx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double best = -__builtin_inf(), total = 0.0;
+    int64_t bi = kNoIndex;
+    for (int s = 0; s < n_sets; ++s) {
+        const int64_t o = (int64_t)s * n + t;
+        const double v = part_max[o];
+        const int64_t i = part_idx[o];
+        total += part_sum[o];
+        if (better(v, i, best, bi)) {
+            best = v;
+            bi = i;
+        }
+    }
+    if (bi != kNoIndex) bi += node_offset;
+    if (mode == 0) {
+        out_max[t] = best;
+        out_norm_or_sum[t] = total;
+        out_idx[t] = bi;
+    } else {
+        const double peak = (mode == 1) ? qm_exp(best) : best;
+        out_max[t] = peak;
+        out_norm_or_sum[t] = peak * n_nodes_total / total;     // migratelib.c:108
+        out_idx[t] = (bi == kNoIndex) ? 0 : bi;
+    }
+}
+
+}  // namespace qm

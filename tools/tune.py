@@ -1,0 +1,61 @@
+# -*- coding: utf-8 -*-
+"""GPU-side sweep of engine tunables on the bench workloads (development aid)."""
+
+import argparse
+import itertools
+import json
+import sys
+import time
+import pathlib
+
+import numpy as np
+
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+from quakemigrate_amd import synth  # noqa: E402
+from quakemigrate_amd.core import lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--sweep", default="default")
+    args = ap.parse_args()
+    t0 = time.time()
+    case = synth.make_case(args.config)
+    print(f"case {args.config} built in {time.time()-t0:.1f}s grid={case.grid} S={case.available} "
+          f"ns={case.n_samples} lutmax={case.traveltimes.max()}", flush=True)
+    lon = np.ascontiguousarray(np.log(np.clip(case.onsets, 0.01, np.inf)))
+    work = case.n_nodes_total * case.n_samples
+    if args.sweep == "default":
+        grid = [dict(samples_per_lane=j, waves=w, lds_bytes=l, brick=b)
+                for j, w, l, b in itertools.product(
+                    [4, 2], [8, 16], [80 * 1024, 160 * 1024, 53 * 1024],
+                    [(4, 4, 8), (4, 4, 4), (2, 4, 8), (8, 8, 8)])]
+    else:
+        grid = json.loads(args.sweep)
+    ref = None
+    for cfg in grid:
+        cfg = dict(cfg)
+        bx, by, bz = cfg.pop("brick", (4, 4, 8))
+        try:
+            eng = lib.Engine(0, brick_x=bx, brick_y=by, brick_z=bz, **cfg)
+            eng.load_lut(case.traveltimes)
+            wide = eng.get("n_wide_bricks")
+            best = 1e9
+            for _ in range(args.reps):
+                out = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+                best = min(best, eng.last_kernel_ms())
+            if ref is None:
+                ref = out
+            same = bool(np.array_equal(out[2], ref[2]) and np.allclose(out[0], ref[0], rtol=1e-12))
+            print(json.dumps(dict(cfg=cfg, brick=[bx, by, bz], wide=wide, nbricks=eng.get("n_bricks"),
+                                  ms=round(best, 3), gns=round(work / best / 1e6, 2), same=same)),
+                  flush=True)
+            eng.close()
+        except Exception as e:  # noqa: BLE001
+            print(json.dumps(dict(cfg=cfg, brick=[bx, by, bz], error=str(e)[:200])), flush=True)
+
+
+if __name__ == "__main__":
+    main()
