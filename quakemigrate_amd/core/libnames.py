@@ -8,10 +8,42 @@ be loaded the import fails loudly.
 """
 
 import ctypes
+import importlib.util
+import os
 import pathlib
 
 _CSRC = pathlib.Path(__file__).resolve().parent.parent / "csrc"
 LIBRARY_FILE = {"qmlib": "libqmhip.so"}
+
+
+def _share_torch_hip_runtime():
+    """
+    PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` / ``libhsa-runtime64.so``.
+    Two HIP runtimes in one process do not share the GPU ("No HIP GPUs are
+    available" in whichever initialises second), so when torch is installed its
+    copy is loaded first and globally: our library's ``libamdhip64.so.7``
+    dependency then binds to that same runtime, and device pointers / streams of
+    torch tensors are valid inside the engine.  Without torch the system ROCm
+    runtime is used.  (No ``import torch`` here: that costs seconds.)
+    """
+    if os.environ.get("QM_HIP_SYSTEM_RUNTIME"):
+        return None
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    libdir = pathlib.Path(list(spec.submodule_search_locations)[0]) / "lib"
+    loaded = None
+    for soname in ("libhsa-runtime64.so", "libamdhip64.so"):
+        cand = libdir / soname
+        if cand.exists():
+            try:
+                loaded = ctypes.CDLL(str(cand), mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return None
+    return loaded
 
 
 def _load_cdll(name):
@@ -28,6 +60,7 @@ def _load_cdll(name):
     cdll : `ctypes.CDLL`
     """
     lib = _CSRC / LIBRARY_FILE.get(name, name)
+    _share_torch_hip_runtime()
     try:
         cdll = ctypes.CDLL(str(lib))
     except Exception as e:

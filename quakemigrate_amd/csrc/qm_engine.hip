@@ -119,8 +119,7 @@ int plan_wide(qm_engine *e) {
     if (e->plan_j == e->cfg_j && e->plan_cap == cap) return 0;
     std::vector<int32_t> wide;
     for (int b = 0; b < e->g.nbricks; ++b) {
-        const int64_t total = e->h_btotal[b];
-        if (total > 65535 || total + (int64_t)e->g.n_rows * KT > cap) wide.push_back(b);
+        if (!qm::brick_fits(e->h_btotal[b], e->g.n_rows, KT, cap)) wide.push_back(b);
     }
     e->n_wide = (int)wide.size();
     if (e->n_wide) {
@@ -134,7 +133,7 @@ int plan_wide(qm_engine *e) {
     return 0;
 }
 
-template <int J>
+template <int J, bool VOLUME>
 int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_direct,
                    bool use_lds, bool use_direct) {
     const int KT = qm::kWave * J;
@@ -142,18 +141,18 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
     const size_t publish_bytes = (size_t)3 * e->cfg_waves * KT * sizeof(double);
     if (use_lds) {
         const size_t lds = std::max((size_t)e->cfg_lds_bytes, publish_bytes);
-        QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_lds_kernel<J>),
+        QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_lds_kernel<J, VOLUME>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         a.ngroups = groups_lds;
         a.brick_list = nullptr;
         a.n_list = 0;
-        hipLaunchKernelGGL((qm::stack_lds_kernel<J>), dim3((unsigned)(a.ntiles * groups_lds)),
+        hipLaunchKernelGGL((qm::stack_lds_kernel<J, VOLUME>), dim3((unsigned)(a.ntiles * groups_lds)),
                            dim3(threads), lds, e->stream, a);
         QM_HIP(hipGetLastError());
         a.set0 += groups_lds;
     }
     if (use_direct) {
-        QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_direct_kernel<J>),
+        QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_direct_kernel<J, VOLUME>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)publish_bytes));
         a.ngroups = groups_direct;
@@ -164,7 +163,7 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
             a.brick_list = e->d_wide.p;
             a.n_list = e->n_wide;
         }
-        hipLaunchKernelGGL(qm::stack_direct_kernel<J>,
+        hipLaunchKernelGGL((qm::stack_direct_kernel<J, VOLUME>),
                            dim3((unsigned)(a.ntiles * groups_direct)), dim3(threads),
                            publish_bytes, e->stream, a);
         QM_HIP(hipGetLastError());
@@ -174,8 +173,13 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
 }
 
 int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu) {
-    // enough workgroups for ~4 rounds over the chip, never more than there are bricks
-    int64_t want = ((int64_t)4 * e->n_cu * blocks_per_cu + ntiles - 1) / ntiles;
+    // Workgroups all do the same amount of work, so the grid should be a whole number of
+    // "rounds" over the resident slots (n_cu * blocks_per_cu): ntiles * groups <= rounds * slots,
+    // as close from below as possible; 4 rounds keep the partial-set count small while the
+    // dispatcher still has slack.  Never more groups than there are bricks.
+    const int64_t slots = (int64_t)e->n_cu * blocks_per_cu;
+    int64_t want = (4 * slots) / ntiles;
+    if (want < 1) want = std::max<int64_t>(1, slots / ntiles);
     want = std::max<int64_t>(1, std::min<int64_t>(want, units));
     return (int)want;
 }
@@ -237,12 +241,16 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
 
     QM_HIP(hipEventRecord(e->ev0, e->stream));
     int rc = 0;
+#define QM_LAUNCH(JJ)                                                                        \
+    rc = volume ? launch_stack_j<JJ, true>(e, a, groups_lds, groups_direct, use_lds, use_direct) \
+                : launch_stack_j<JJ, false>(e, a, groups_lds, groups_direct, use_lds, use_direct)
     switch (J) {
-        case 1: rc = launch_stack_j<1>(e, a, groups_lds, groups_direct, use_lds, use_direct); break;
-        case 2: rc = launch_stack_j<2>(e, a, groups_lds, groups_direct, use_lds, use_direct); break;
-        case 4: rc = launch_stack_j<4>(e, a, groups_lds, groups_direct, use_lds, use_direct); break;
+        case 1: QM_LAUNCH(1); break;
+        case 2: QM_LAUNCH(2); break;
+        case 4: QM_LAUNCH(4); break;
         default: return fail("samples_per_lane must be 1, 2 or 4 (got %d)", J);
     }
+#undef QM_LAUNCH
     if (rc) return rc;
     QM_HIP(hipEventRecord(e->ev1, e->stream));
     e->timed = true;

@@ -10,9 +10,8 @@
 // tile of 64*J samples the window of every log-onset row that the brick can touch is staged
 // in LDS once, then every node of the brick streams its S operands per sample out of LDS
 // (lanes = consecutive samples -> conflict-free ds_read_b64).  The per-node window offsets
-// come from a brick-relative 16-bit table built once per travel-time table, read through the
-// scalar cache.  exp, the running max / argmax / sum are fused, so the detect path never
-// writes the 4-D volume.
+// come from a brick-relative 16-bit table built once per travel-time table.  exp, the running
+// max / argmax / sum are fused, so the detect path never writes the 4-D volume.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -22,6 +21,7 @@ namespace qm {
 
 constexpr int kWave = 64;
 constexpr int64_t kNoIndex = INT64_MAX;
+constexpr int kMaxSpanBytes = 65535;   // window offsets are stored as uint16 BYTE offsets
 
 struct GridDesc {
     int nx, ny, nz;        // nodes of the resident (possibly sharded) table
@@ -37,7 +37,7 @@ struct StackArgs {
     GridDesc g;
     const double *onsets;          // [S][T] log-onsets
     const int32_t *lut;            // [N][S] original table
-    const uint16_t *rel;           // [nbricks][brick_nodes][row_pad] window offsets (doubles)
+    const uint16_t *rel;           // [nbricks][brick_nodes][row_pad] window byte offsets
     const int32_t *brick_min;      // [nbricks][S]
     const int32_t *brick_span;     // [nbricks][S]
     const int32_t *brick_off;      // [nbricks][S] exclusive prefix of span
@@ -65,15 +65,28 @@ __device__ __forceinline__ bool better(double v, I i, double best, I bi) {
     return (v > best) || (v == best && i < bi);
 }
 
+// a brick fits the LDS-tiled kernel iff its byte offsets fit uint16 and its windows fit LDS
+__host__ __device__ __forceinline__ bool brick_fits(int64_t total_span, int n_rows, int kt,
+                                                    int cap_doubles) {
+    return total_span * 8 <= kMaxSpanBytes && total_span + (int64_t)n_rows * kt <= cap_doubles;
+}
+
 // ---------------------------------------------------------------------------------------
 // Table preparation (once per qm_engine_load_lut)
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool brick_node(const GridDesc &g, int b, int m, int &node) {
+__device__ __forceinline__ void brick_extents(const GridDesc &g, int b, int &x0, int &y0, int &z0,
+                                              int &vx, int &vy, int &vz) {
     const int bzi = b % g.nbz, byi = (b / g.nbz) % g.nby, bxi = b / (g.nbz * g.nby);
-    const int lz = m % g.bz, ly = (m / g.bz) % g.by, lx = m / (g.bz * g.by);
-    const int ix = bxi * g.bx + lx, iy = byi * g.by + ly, iz = bzi * g.bz + lz;
-    node = (ix * g.ny + iy) * g.nz + iz;
-    return ix < g.nx && iy < g.ny && iz < g.nz;
+    x0 = bxi * g.bx; y0 = byi * g.by; z0 = bzi * g.bz;
+    vx = min(g.bx, g.nx - x0); vy = min(g.by, g.ny - y0); vz = min(g.bz, g.nz - z0);
+}
+
+// m-th node of brick b in walk order: only nodes inside the grid, lexicographic in (x, y, z)
+// over the brick's valid extents (ascending flat index, no gaps)
+__device__ __forceinline__ int brick_walk_node(const GridDesc &g, int x0, int y0, int z0, int vy,
+                                               int vz, int m) {
+    const int lz = m % vz, ly = (m / vz) % vy, lx = m / (vz * vy);
+    return ((x0 + lx) * g.ny + (y0 + ly)) * g.nz + (z0 + lz);
 }
 
 // one workgroup per brick, thread r <-> table row r: min / span of the clamped delays.
@@ -81,17 +94,18 @@ __global__ void brick_minmax_kernel(GridDesc g, const int32_t *__restrict__ lut,
                                     int32_t *__restrict__ bmin, int32_t *__restrict__ bspan,
                                     int32_t *__restrict__ global_max) {
     const int b = blockIdx.x;
+    int x0, y0, z0, vx, vy, vz;
+    brick_extents(g, b, x0, y0, z0, vx, vy, vz);
+    const int nvalid = vx * vy * vz;
     for (int r = threadIdx.x; r < g.n_rows; r += blockDim.x) {
         int lo = INT32_MAX, hi = 0;
-        for (int m = 0; m < g.brick_nodes; ++m) {
-            int node;
-            if (!brick_node(g, b, m, node)) continue;
+        for (int m = 0; m < nvalid; ++m) {
+            const int node = brick_walk_node(g, x0, y0, z0, vy, vz, m);
             int d = lut[(int64_t)node * g.n_rows + r];
             d = d < 0 ? 0 : d;                           // migratelib.c:55
             lo = d < lo ? d : lo;
             hi = d > hi ? d : hi;
         }
-        if (lo == INT32_MAX) lo = 0;
         bmin[(int64_t)b * g.n_rows + r] = lo;
         bspan[(int64_t)b * g.n_rows + r] = hi - lo;
         atomicMax(global_max, hi);
@@ -110,23 +124,15 @@ __global__ void brick_prefix_kernel(GridDesc g, const int32_t *__restrict__ bspa
     btotal[b] = (int32_t)(run > INT32_MAX ? INT32_MAX : run);
 }
 
-// Brick-relative window offsets, uint16, one row of row_pad entries per node.  Rows are stored
-// in the order the stacking kernel walks a brick: only the nodes inside the grid, lexicographic
-// in (x, y, z) over the brick's VALID extents (so ascending flat index, and no gaps).
-__device__ __forceinline__ void brick_extents(const GridDesc &g, int b, int &x0, int &y0, int &z0,
-                                              int &vx, int &vy, int &vz) {
-    const int bzi = b % g.nbz, byi = (b / g.nbz) % g.nby, bxi = b / (g.nbz * g.nby);
-    x0 = bxi * g.bx; y0 = byi * g.by; z0 = bzi * g.bz;
-    vx = min(g.bx, g.nx - x0); vy = min(g.by, g.ny - y0); vz = min(g.bz, g.nz - z0);
-}
-
+// Brick-relative window offsets: rel[b][m][r] = 8 * (off_r + clamp(tt) - min_r) BYTES, uint16,
+// one row of row_pad entries per node, nodes in walk order (see brick_walk_node).
 __global__ void brick_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
                                  const int32_t *__restrict__ bmin,
                                  const int32_t *__restrict__ boff,
                                  const int32_t *__restrict__ btotal,
                                  uint16_t *__restrict__ rel) {
     const int b = blockIdx.x;
-    const bool narrow = btotal[b] <= 65535;
+    const bool narrow = (int64_t)btotal[b] * 8 <= kMaxSpanBytes;
     const int per = g.brick_nodes * g.row_pad;
     int x0, y0, z0, vx, vy, vz;
     brick_extents(g, b, x0, y0, z0, vx, vy, vz);
@@ -135,29 +141,54 @@ __global__ void brick_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
         const int m = i / g.row_pad, r = i % g.row_pad;
         uint16_t v = 0;
         if (narrow && r < g.n_rows && m < nvalid) {
-            const int lz = m % vz, ly = (m / vz) % vy, lx = m / (vz * vy);
-            const int node = ((x0 + lx) * g.ny + (y0 + ly)) * g.nz + (z0 + lz);
+            const int node = brick_walk_node(g, x0, y0, z0, vy, vz, m);
             int d = lut[(int64_t)node * g.n_rows + r];
             d = d < 0 ? 0 : d;
-            v = (uint16_t)(boff[(int64_t)b * g.n_rows + r] + d - bmin[(int64_t)b * g.n_rows + r]);
+            v = (uint16_t)(8 * (boff[(int64_t)b * g.n_rows + r] + d -
+                                bmin[(int64_t)b * g.n_rows + r]));
         }
         rel[(int64_t)b * per + i] = v;
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// exp in float64.  Device-library exp (<= 1 ulp).
+// exp in float64 without the device library's special-case handling: the argument is a mean
+// of log-onsets (|x| < ~50 for any finite input), far from overflow / underflow.
+//   x = k ln2 + r, |r| <= ln2/2;  exp(r) by its degree-12 Taylor polynomial (truncation
+//   0.3466^13/13! = 1.7e-16 relative), scaled by 2^k with v_ldexp_f64.  ~2 ulp.
+// 19 FP64-rate VALU ops.  The reference's own exp is glibc libmvec (<= 4 ulp).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ double qm_exp(double x) { return exp(x); }
+__device__ __forceinline__ double qm_exp(double x) {
+    const double kf = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 479001600.0;                       // 1/12!
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)kf);
+}
 
 // ---------------------------------------------------------------------------------------
-// Shared epilogue state of a wavefront: J samples per lane (t = t0 + lane + 64*j).
+// Per-wavefront reduction state: J samples per lane (t = t_first + lane + 64*j).
+// `b*` follows the nodes of the current brick, which a wave visits in ascending flat index,
+// so a strict '>' keeps the first maximum (migratelib.c:102); bricks are not visited in
+// ascending order, so at the end of a brick the pair is merged into `v*` with the explicit
+// lowest-index tie-break.
 // ---------------------------------------------------------------------------------------
 template <int J>
 struct Running {
-    double vmax[J];
-    double vsum[J];
-    int vidx[J];                    // local flat node index (< 2^31), INT32_MAX = none
+    double vmax[J], vsum[J], bmax[J];
+    int vidx[J], bidx[J];           // local flat node index (< 2^31), INT32_MAX = none
     __device__ __forceinline__ void reset() {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
@@ -165,10 +196,28 @@ struct Running {
             vsum[j] = 0.0;
             vidx[j] = INT32_MAX;
         }
+        reset_brick();
+    }
+    __device__ __forceinline__ void reset_brick() {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            bmax[j] = -__builtin_inf();
+            bidx[j] = INT32_MAX;
+        }
+    }
+    __device__ __forceinline__ void merge_brick() {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (better(bmax[j], bidx[j], vmax[j], vidx[j])) {
+                vmax[j] = bmax[j];
+                vidx[j] = bidx[j];
+            }
+        }
+        reset_brick();
     }
 };
 
-template <int J>
+template <int J, bool VOLUME>
 __device__ __forceinline__ void finish_node(const StackArgs &a, Running<J> &run,
                                             const double (&acc)[J], int node, int t_first,
                                             int lane) {
@@ -176,26 +225,28 @@ __device__ __forceinline__ void finish_node(const StackArgs &a, Running<J> &run,
     for (int j = 0; j < J; ++j) {
         const double x = acc[j] * a.inv_available;
         const double e = qm_exp(x);
-        const int t = t_first + lane + kWave * j;
-        if (a.volume != nullptr && t < a.n_chunk)
-            a.volume[(int64_t)node * a.vol_stride + t] = e;
+        if (VOLUME) {
+            const int t = t_first + lane + kWave * j;
+            if (t < a.n_chunk) a.volume[(int64_t)node * a.vol_stride + t] = e;
+        }
         run.vsum[j] += e;
-        if (better(x, node, run.vmax[j], run.vidx[j])) {
-            run.vmax[j] = x;
-            run.vidx[j] = node;
+        if (x > run.bmax[j]) {
+            run.bmax[j] = x;
+            run.bidx[j] = node;
         }
     }
 }
 
-template <int J>
+template <int J, bool VOLUME>
 __device__ __forceinline__ void start_node(const StackArgs &a, double (&acc)[J], int node,
                                            int t_first, int lane) {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const int t = t_first + lane + kWave * j;
-        acc[j] = (a.accumulate && t < a.n_chunk)
-                     ? a.volume[(int64_t)node * a.vol_stride + t]
-                     : 0.0;
+        acc[j] = 0.0;
+        if (VOLUME) {
+            const int t = t_first + lane + kWave * j;
+            if (a.accumulate && t < a.n_chunk) acc[j] = a.volume[(int64_t)node * a.vol_stride + t];
+        }
     }
 }
 
@@ -240,22 +291,23 @@ __device__ __forceinline__ void publish(const StackArgs &a, Running<J> &run, dou
 
 // ---------------------------------------------------------------------------------------
 // LDS-tiled stacking kernel.  Workgroup = (time tile, brick group); loops over the bricks of
-// its group; wavefront w takes brick nodes w, w+nwaves, ...
+// its group; wavefront w takes brick nodes w, w+nwaves, ... (walk order).
 //
 // The inner loop is the generated, hand-scheduled asm of qm_ring_asm.inc (8 table rows per
 // statement, 8 ds_read_b64 in flight, ascending row order per sample).  Around it the compiler
-// only computes LDS addresses from the 16-bit window offsets, which are prefetched 8 rows at a
-// time with a VECTOR load (vmcnt) -- a scalar load would share lgkmcnt with the LDS reads.
+// only forms LDS addresses: lane column + chunk base + the row's 16-bit byte offset, which is
+// prefetched 8 rows at a time with a VECTOR load (vmcnt) -- a scalar load would share lgkmcnt
+// with the LDS reads and force every wait down to 0.
 // ---------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) double lds_f64;
 
 #include "qm_ring_asm.inc"
 
 __device__ __forceinline__ void unpack8(const uint4 &q, unsigned base, unsigned (&addr)[8]) {
-    addr[0] = base + ((q.x & 0xffffu) << 3); addr[1] = base + ((q.x >> 16) << 3);
-    addr[2] = base + ((q.y & 0xffffu) << 3); addr[3] = base + ((q.y >> 16) << 3);
-    addr[4] = base + ((q.z & 0xffffu) << 3); addr[5] = base + ((q.z >> 16) << 3);
-    addr[6] = base + ((q.w & 0xffffu) << 3); addr[7] = base + ((q.w >> 16) << 3);
+    addr[0] = base + (q.x & 0xffffu); addr[1] = base + (q.x >> 16);
+    addr[2] = base + (q.y & 0xffffu); addr[3] = base + (q.y >> 16);
+    addr[4] = base + (q.z & 0xffffu); addr[5] = base + (q.z >> 16);
+    addr[6] = base + (q.w & 0xffffu); addr[7] = base + (q.w >> 16);
 }
 
 // vector (not scalar) 16-byte load of 8 packed offsets: the index is made opaque so the
@@ -266,7 +318,7 @@ __device__ __forceinline__ uint4 load_offsets(const uint16_t *rel, int64_t entry
     return *reinterpret_cast<const uint4 *>(rel + entry + zero);
 }
 
-template <int J>
+template <int J, bool VOLUME>
 __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int KT = kWave * J;
@@ -278,7 +330,8 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
     const int group = blockIdx.x / a.ntiles;
     const int t_first = tile * KT;                    // relative to sample0
     const int S = g.n_rows;
-    const int nchunks = g.row_pad >> 3;
+    const int nfull = S >> 3, ntail = S & 7;
+    const int nchunks = g.row_pad >> 3;               // nfull + (ntail != 0)
     // LDS byte address of this lane's column in the window area
     const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 8u;
 
@@ -286,8 +339,7 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
     run.reset();
 
     for (int b = group; b < g.nbricks; b += a.ngroups) {
-        const int total = a.brick_total[b];
-        if (total > 65535 || total + S * KT > a.cap_doubles) continue;   // direct kernel's job
+        if (!brick_fits(a.brick_total[b], S, KT, a.cap_doubles)) continue;   // direct kernel's job
         __syncthreads();                              // previous brick fully consumed
         // ---- stage the windows: row r occupies [off_r + r*KT, off_r + r*KT + span_r + KT)
         for (int r = wave; r < S; r += nwaves) {
@@ -327,18 +379,23 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
             while (ly >= vy) { ly -= vy; ++lx; }
 
             double acc[J];
-            start_node<J>(a, acc, node, t_first, lane);
+            start_node<J, VOLUME>(a, acc, node, t_first, lane);
             unsigned chunk_addr = lane_addr;
-            for (int c = 0; c < nchunks; ++c) {
-                unsigned addr[8];
+            unsigned addr[8];
+            for (int c = 0; c < nfull; ++c) {
                 unpack8(q, chunk_addr, addr);
                 q = fetch_next();
-                const int rows = S - c * 8;
-                ring_chunk<J>(acc, addr, rows < 8 ? rows : 8);
+                ring_full<J>(acc, addr);
                 chunk_addr += 8 * KT * 8;
             }
-            finish_node<J>(a, run, acc, node, t_first, lane);
+            if (ntail) {
+                unpack8(q, chunk_addr, addr);
+                q = fetch_next();
+                ring_tail<J>(acc, addr, ntail);
+            }
+            finish_node<J, VOLUME>(a, run, acc, node, t_first, lane);
         }
+        run.merge_brick();
     }
     if (a.want_scan) publish<J>(a, run, win, wave, nwaves, lane, t_first, a.set0 + group);
 }
@@ -348,7 +405,7 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
 // array is a few MB and lives in L2 / Infinity Cache).  Handles bricks whose windows do not
 // fit the LDS budget (arbitrary tables stay correct), and serves as an on-device cross-check.
 // ---------------------------------------------------------------------------------------
-template <int J>
+template <int J, bool VOLUME>
 __global__ __launch_bounds__(1024) void stack_direct_kernel(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int KT = kWave * J;
@@ -375,12 +432,14 @@ __global__ __launch_bounds__(1024) void stack_direct_kernel(StackArgs a) {
 
     for (int i = group; i < n_list; i += a.ngroups) {
         const int b = a.brick_list ? a.brick_list[i] : i;
-        for (int m = wave; m < g.brick_nodes; m += nwaves) {
-            int node;
-            if (!brick_node(g, b, m, node)) continue;
+        int x0, y0, z0, vx, vy, vz;
+        brick_extents(g, b, x0, y0, z0, vx, vy, vz);
+        const int nvalid = vx * vy * vz;
+        for (int m = wave; m < nvalid; m += nwaves) {
+            const int node = brick_walk_node(g, x0, y0, z0, vy, vz, m);
             const int32_t *row = a.lut + (int64_t)node * S;
             double acc[J];
-            start_node<J>(a, acc, node, t_first, lane);
+            start_node<J, VOLUME>(a, acc, node, t_first, lane);
             for (int r = 0; r < S; ++r) {
                 int d = row[r];
                 d = d < 0 ? 0 : d;
@@ -388,8 +447,9 @@ __global__ __launch_bounds__(1024) void stack_direct_kernel(StackArgs a) {
 #pragma unroll
                 for (int j = 0; j < J; ++j) acc[j] += p[tcl[j]];
             }
-            finish_node<J>(a, run, acc, node, t_first, lane);
+            finish_node<J, VOLUME>(a, run, acc, node, t_first, lane);
         }
+        run.merge_brick();
     }
     if (a.want_scan) publish<J>(a, run, win, wave, nwaves, lane, t_first, a.set0 + group);
 }
