@@ -1,0 +1,277 @@
+# -*- coding: utf-8 -*-
+"""
+bench.py -- detect-sweep throughput of the MI355X migration engine.
+
+Metric (BASELINE.json): grid-nodes x time-samples stacked per second on the detect
+sweep.  A "step" is one fused migrate + find_max_coa pass (QuakeScan._compute's hot
+path, quakemigrate/signal/scan.py:635-638) over one timestep of synthetic onsets
+(BASELINE.md recipe, quakemigrate_amd/synth.py) with the travel-time table and the
+log-onsets already resident in HBM.
+
+Workload at N=1: C3 = 201x201x101 nodes x 30 onset rows x 6000 samples -- the
+configuration the north-star's target is quoted on.  N>1 (launched by
+torch.distributed.run, one rank per GPU): weak scaling -- every rank holds a
+C3-sized slab of x-planes of a grid N times longer in x, stacks it, and the ranks
+exchange their per-sample (max, argmax, sum) partials with three 48 KB RCCL
+all-reduces per step (the path's only exchange).
+
+One JSON line on stdout (rank 0).  Besides the contract's keys it carries
+  roofline      : the dominant kernel (fused LDS-tiled stack) against HBM with its
+                  ALGORITHMIC bytes (table + onsets + outputs) -- by construction far
+                  below 1 %: the fused kernel is LDS-gather / FP64-VALU bound, not
+                  HBM bound;
+  roofline_onchip : the ceilings that do bind it (LDS operand bytes, FP64 VALU ops);
+  roofline_materialised : the locate-style variant that writes the 4-D volume
+                  (8 B per node-sample of real HBM traffic), the figure the
+                  north-star's ">= 50 % of HBM" maps to;
+  cpu_baseline  : the reference's two loops (oracle/_ref when present, else the
+                  oracle port) timed on this host's cores on a bounded sample.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12           # B/s  (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
+LDS_PEAK = 150.0e12         # B/s  aggregate ds_read_b64/b128
+FP64_PEAK = 39.3e12         # vector FP64 instructions-lanes / s (78.6 TFLOP/s FMA)
+EXP_FP64_OPS = 19           # FP64-rate VALU ops of qm_exp (qm_kernels.hpp)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", help="C3 (default), C2 or C1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-materialised", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--engine", default="{}", help="json dict of engine tunables")
+    return ap.parse_args()
+
+
+def cpu_baseline(case, budget_s):
+    """Reference loops on the host cores over a bounded time-chunk of the workload."""
+    from oracle import qm_oracle as oq
+
+    impl = "ref" if oq.have_ref() else "port"
+    fns = oq._ref() if impl == "ref" else oq._port()
+    threads = os.cpu_count() or 1
+    lon = np.ascontiguousarray(oq.log_onsets(case.onsets))
+    tt = np.ascontiguousarray(case.traveltimes)
+    n_nodes = int(np.prod(tt.shape[:-1]))
+    rows, t_samples = lon.shape
+
+    def run(ns, prefault):
+        vol = np.zeros((n_nodes, ns))
+        if prefault:
+            vol.fill(1.0)
+            vol.fill(0.0)
+        a, b, c = np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64)
+        t0 = time.perf_counter()
+        fns["stack"](lon, tt, vol, case.fsmp, t_samples - case.fsmp - ns, ns, rows,
+                     case.available, n_nodes, threads)
+        t1 = time.perf_counter()
+        fns["scan"](vol, a, b, c, ns, n_nodes, threads)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1
+
+    ns = 8
+    m, s = run(ns, True)                               # rate probe (and library warm-up)
+    rate = n_nodes * ns / max(m + s, 1e-6)
+    max_ns_mem = max(8, int((4 << 30) // (8 * n_nodes)))
+    ns = int(min(case.n_samples, max_ns_mem, max(8, rate * budget_s / 2.5 / n_nodes)))
+    warm = run(ns, True)
+    reps = 1
+    while sum(warm) < budget_s / 2 and reps < 16:      # accumulate a bounded amount of work
+        w = run(ns, True)
+        warm = (warm[0] + w[0], warm[1] + w[1])
+        reps += 1
+    warm = (warm[0] / reps, warm[1] / reps)
+    cold = run(ns, False)                              # fresh np.zeros: the reference's case
+    work = n_nodes * ns
+    return {
+        "value": work / sum(warm), "unit": "node-samples/s", "cores": threads,
+        "kind": "reference" if impl == "ref" else "port",
+        "sample": f"{case.name} grid {tuple(tt.shape[:-1])} x {rows} rows, {ns} of "
+                  f"{case.n_samples} samples (time chunk) x {reps} repeats, "
+                  f"migrate+find_max_coa, volume pre-faulted",
+        "migrate_s": warm[0], "find_max_coa_s": warm[1],
+        "cold_value": work / sum(cold),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from quakemigrate_amd import distributed as qd
+    from quakemigrate_amd import synth
+    from quakemigrate_amd.core import lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus > 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py ...")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    # ---- workload: this rank's slab of the (weak-scaled) grid -----------------------
+    base = synth.CONFIGS[args.config]
+    nx, ny, nz = base["grid"]
+    grid = (nx * world, ny, nz)
+    x_range = (nx * rank, nx * (rank + 1))
+    n_pool = 3                                          # distinct timesteps cycled through
+    cases = [synth.make_case(args.config, step=s, grid=grid, x_range=x_range)
+             for s in range(n_pool)]
+    case = cases[0]
+    S, ns = case.available, case.n_samples
+    n_total = case.n_nodes_total
+    n_local = int(np.prod(case.traveltimes.shape[:-1]))
+    t_samples = case.onsets.shape[1]
+
+    tunables = dict(brick_x=8, brick_y=8, brick_z=8, samples_per_lane=4, waves=8)
+    tunables.update(json.loads(args.engine))
+    eng = lib.Engine(local_rank, **tunables)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.load_lut(case.traveltimes, node_offset=x_range[0] * ny * nz)
+    assert eng.lut_max <= case.lsmp
+    onsets_dev = [torch.from_numpy(np.ascontiguousarray(
+        np.log(np.clip(c.onsets, 0.01, np.inf)))).to(dev) for c in cases]
+    out = (torch.empty(ns, dtype=torch.float64, device=dev),
+           torch.empty(ns, dtype=torch.float64, device=dev),
+           torch.empty(ns, dtype=torch.int64, device=dev))
+    sharded = qd.ShardedDetector(eng, n_total, ns, dev) if world > 1 else None
+
+    def step(i):
+        on = onsets_dev[i % n_pool]
+        if sharded is None:
+            eng.detect(on, case.fsmp, case.lsmp, case.available, n_nodes_total=n_total,
+                       out=out)
+            return out
+        return sharded.detect(on, case.fsmp, case.lsmp, case.available)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        res = step(i)
+    fence()
+    eng.config("log_timing", 1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms, kern_calls = eng.kernel_log()
+    eng.config("log_timing", 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- in-bench sanity: injected events are found where they were put ------------
+    last = (args.warmup + args.steps - 1) % n_pool
+    idx = res[2].cpu().numpy()
+    for (ijk, t_ev) in cases[last].event_nodes:
+        want = np.ravel_multi_index(ijk, grid)
+        assert idx[t_ev] == want, f"event at sample {t_ev}: node {idx[t_ev]} != {want}"
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    work_step = n_total * ns                            # node-samples per step, whole job
+    value = work_step * args.steps / elapsed
+    kern_s = kern_ms / 1e3 / max(kern_calls, 1)         # avg stacking-kernel time, this rank
+    local_ns = n_local * ns
+    b_fused = 4.0 * n_local * S + 8.0 * S * t_samples + 24.0 * ns   # SURVEY 8d B_F
+    result = {
+        "metric": "grid-nodes x time-samples stacked /sec (detect sweep)",
+        "value": value, "unit": "node-samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.config} detect sweep: {nx}x{ny}x{nz} nodes per GPU "
+                               f"(grid {grid[0]}x{ny}x{nz}), {S} onset rows, {ns} samples "
+                               f"per step @50 Hz, fused migrate+find_max_coa, table and "
+                               f"onsets resident in HBM",
+                   "n_nodes_per_gpu": n_local, "n_rows": S, "n_samples": ns,
+                   "sharding": "x-planes" if world > 1 else "none",
+                   "exchange": "3 x all_reduce(n_samples) per step (RCCL)" if world > 1
+                   else "none", "engine": tunables},
+        "kernel": {"name": "qm::stack_lds_kernel<4,false,NCH>", "avg_ms": kern_s * 1e3,
+                   "launches": kern_calls, "timing": "HIP events on the launch stream"},
+        "roofline": {"bound": "hbm", "achieved": b_fused / kern_s / 1e9,
+                     "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": b_fused / kern_s / HBM_PEAK, "traffic": None,
+                     "algorithmic_bytes_per_launch": b_fused,
+                     "note": "fused detect never writes the volume: compulsory HBM bytes "
+                             "are the table, the onsets and the outputs only; the kernel "
+                             "is LDS-gather / FP64-VALU bound (see roofline_onchip)"},
+        "roofline_onchip": {
+            "lds": {"achieved": 8.0 * local_ns * S / kern_s / 1e12, "peak": LDS_PEAK / 1e12,
+                    "unit": "TB/s", "frac": 8.0 * local_ns * S / kern_s / LDS_PEAK},
+            "fp64_valu": {"achieved": local_ns * (S + EXP_FP64_OPS) / kern_s / 1e12,
+                          "peak": FP64_PEAK / 1e12, "unit": "Tinstr-lanes/s",
+                          "frac": local_ns * (S + EXP_FP64_OPS) / kern_s / FP64_PEAK,
+                          "ops_per_node_sample": S + EXP_FP64_OPS}},
+    }
+
+    # ---- locate-style materialising variant on the same grid (HBM-write bound) ------
+    if not args.no_materialised and world == 1:
+        ns_loc = 401                                    # 4 * marginal_window(2 s) * 50 Hz + 1
+        on = onsets_dev[0][:, : case.fsmp + ns_loc + case.lsmp].contiguous()
+        vol = torch.empty((n_local, ns_loc), dtype=torch.float64, device=dev)
+        o2 = tuple(torch.empty(ns_loc, dtype=d, device=dev)
+                   for d in (torch.float64, torch.float64, torch.int64))
+        eng.migrate(on, case.fsmp, case.lsmp, case.available, vol, scan_out=o2)
+        torch.cuda.synchronize()
+        eng.config("log_timing", 1)
+        reps = 5
+        for _ in range(reps):
+            eng.migrate(on, case.fsmp, case.lsmp, case.available, vol, scan_out=o2)
+        torch.cuda.synchronize()
+        ms, calls = eng.kernel_log()
+        eng.config("log_timing", 0)
+        sec = ms / 1e3 / calls
+        b_mat = 8.0 * n_local * ns_loc + 4.0 * n_local * S + \
+            8.0 * S * on.shape[1] + 24.0 * ns_loc      # SURVEY 8d figure 1
+        result["roofline_materialised"] = {
+            "bound": "hbm", "achieved": b_mat / sec / 1e9, "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s", "frac": b_mat / sec / HBM_PEAK, "avg_ms": sec * 1e3,
+            "node_samples_per_s": n_local * ns_loc / sec,
+            "workload": f"locate window: same grid, {ns_loc} samples, volume "
+                        f"({8.0 * n_local * ns_loc / 1e9:.1f} GB) written to HBM + scan"}
+        del vol
+
+    if not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline(case, args.cpu_seconds)
+    else:
+        result["cpu_baseline"] = None
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

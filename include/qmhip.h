@@ -144,6 +144,11 @@ int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
  * the most recent detect / migrate call; negative if none.  Synchronises. */
 int qm_engine_last_kernel_ms(qm_engine *e, double *ms);
 
+/* With config "log_timing" = 1 every stacking launch is bracketed by its own
+ * pair of HIP events (on the engine stream); this returns the summed duration
+ * and the number of launches since the last call, and resets the log. */
+int qm_engine_kernel_log(qm_engine *e, double *total_ms, int32_t *n_calls);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,8 @@ qmlib.qm_engine_migrate.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32,
 qmlib.qm_engine_find_max_coa.argtypes = [_vp, _vp, ctypes.c_int, c_int32,
                                          c_int64, _vp, _vp, _vp, ctypes.c_int]
 qmlib.qm_engine_last_kernel_ms.argtypes = [_vp, ctypes.POINTER(ctypes.c_double)]
+qmlib.qm_engine_kernel_log.argtypes = [_vp, ctypes.POINTER(ctypes.c_double),
+                                       ctypes.POINTER(c_int32)]
 
 
 class QMHipError(RuntimeError):
@@ -138,6 +140,12 @@ class Engine:
         ms = ctypes.c_double()
         _check(qmlib.qm_engine_last_kernel_ms(self._h, ctypes.byref(ms)))
         return float(ms.value)
+
+    def kernel_log(self):
+        """(total ms, launches) of the stacking kernels since the last call."""
+        ms, n = ctypes.c_double(), c_int32()
+        _check(qmlib.qm_engine_kernel_log(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)
 
     @staticmethod
     def _ptr(x, dtype=None):

@@ -60,6 +60,8 @@ def _load_cdll(name):
     cdll : `ctypes.CDLL`
     """
     lib = _CSRC / LIBRARY_FILE.get(name, name)
+    if os.environ.get("QM_HIP_LIB"):            # development: alternative build of the library
+        lib = pathlib.Path(os.environ["QM_HIP_LIB"])
     _share_torch_hip_runtime()
     try:
         cdll = ctypes.CDLL(str(lib))

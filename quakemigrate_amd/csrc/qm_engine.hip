@@ -70,6 +70,10 @@ struct qm_engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // optional per-call timing log (bench): pairs of events around every stacking launch
+    bool log_timing = false;
+    std::vector<hipEvent_t> ev_log;     // 2 events per recorded call
+    size_t ev_used = 0;
 
     // tunables
     int cfg_bx = 4, cfg_by = 4, cfg_bz = 8;
@@ -78,6 +82,7 @@ struct qm_engine {
     int cfg_groups = 0;
     int cfg_lds_bytes = 80 * 1024;
     int cfg_force_direct = 0;
+    int cfg_generic = 0;            // 1 = always the generic (any row count) LDS kernel
     int64_t cfg_chunk_bytes = (int64_t)4 << 30;
 
     // resident table
@@ -86,7 +91,7 @@ struct qm_engine {
     int64_t n_nodes = 0;
     int64_t node_offset = 0;
     int32_t lut_max = 0;
-    DevBuf<int32_t> d_lut, d_bmin, d_bspan, d_boff, d_btotal, d_wide, d_scalar;
+    DevBuf<int32_t> d_lut, d_bmeta, d_btotal, d_wide, d_scalar;
     DevBuf<uint16_t> d_rel;
     std::vector<int32_t> h_btotal;
     int n_wide = 0;
@@ -133,6 +138,16 @@ int plan_wide(qm_engine *e) {
     return 0;
 }
 
+template <int J, bool VOLUME, int NCH>
+int launch_lds(qm_engine *e, qm::StackArgs &a, int groups_lds, int threads, size_t lds) {
+    QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_lds_kernel<J, VOLUME, NCH>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((qm::stack_lds_kernel<J, VOLUME, NCH>),
+                       dim3((unsigned)(a.ntiles * groups_lds)), dim3(threads), lds, e->stream, a);
+    QM_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int J, bool VOLUME>
 int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_direct,
                    bool use_lds, bool use_direct) {
@@ -141,14 +156,23 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
     const size_t publish_bytes = (size_t)3 * e->cfg_waves * KT * sizeof(double);
     if (use_lds) {
         const size_t lds = std::max((size_t)e->cfg_lds_bytes, publish_bytes);
-        QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_lds_kernel<J, VOLUME>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         a.ngroups = groups_lds;
         a.brick_list = nullptr;
         a.n_list = 0;
-        hipLaunchKernelGGL((qm::stack_lds_kernel<J, VOLUME>), dim3((unsigned)(a.ntiles * groups_lds)),
-                           dim3(threads), lds, e->stream, a);
-        QM_HIP(hipGetLastError());
+        int rc;
+        // specialised (whole-node prefetch, unrolled) variants for up to 64 table rows
+        switch (e->cfg_generic ? 0 : e->g.row_pad / 8) {
+            case 1: rc = launch_lds<J, VOLUME, 1>(e, a, groups_lds, threads, lds); break;
+            case 2: rc = launch_lds<J, VOLUME, 2>(e, a, groups_lds, threads, lds); break;
+            case 3: rc = launch_lds<J, VOLUME, 3>(e, a, groups_lds, threads, lds); break;
+            case 4: rc = launch_lds<J, VOLUME, 4>(e, a, groups_lds, threads, lds); break;
+            case 5: rc = launch_lds<J, VOLUME, 5>(e, a, groups_lds, threads, lds); break;
+            case 6: rc = launch_lds<J, VOLUME, 6>(e, a, groups_lds, threads, lds); break;
+            case 7: rc = launch_lds<J, VOLUME, 7>(e, a, groups_lds, threads, lds); break;
+            case 8: rc = launch_lds<J, VOLUME, 8>(e, a, groups_lds, threads, lds); break;
+            default: rc = launch_lds<J, VOLUME, 0>(e, a, groups_lds, threads, lds); break;
+        }
+        if (rc) return rc;
         a.set0 += groups_lds;
     }
     if (use_direct) {
@@ -197,9 +221,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     a.onsets = d_onsets;
     a.lut = e->d_lut.p;
     a.rel = e->d_rel.p;
-    a.brick_min = e->d_bmin.p;
-    a.brick_span = e->d_bspan.p;
-    a.brick_off = e->d_boff.p;
+    a.brick_meta = e->d_bmeta.p;
     a.brick_total = e->d_btotal.p;
     a.T = T;
     a.fsmp = fsmp;
@@ -239,7 +261,20 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     a.part_sum = e->d_psum.p;
     *n_sets = sets;
 
-    QM_HIP(hipEventRecord(e->ev0, e->stream));
+    hipEvent_t ev_begin = e->ev0, ev_end = e->ev1;
+    if (e->log_timing) {
+        if (e->ev_used + 2 > e->ev_log.size()) {
+            for (int i = 0; i < 2; ++i) {
+                hipEvent_t ev;
+                QM_HIP(hipEventCreate(&ev));
+                e->ev_log.push_back(ev);
+            }
+        }
+        ev_begin = e->ev_log[e->ev_used];
+        ev_end = e->ev_log[e->ev_used + 1];
+        e->ev_used += 2;
+    }
+    QM_HIP(hipEventRecord(ev_begin, e->stream));
     int rc = 0;
 #define QM_LAUNCH(JJ)                                                                        \
     rc = volume ? launch_stack_j<JJ, true>(e, a, groups_lds, groups_direct, use_lds, use_direct) \
@@ -252,8 +287,8 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     }
 #undef QM_LAUNCH
     if (rc) return rc;
-    QM_HIP(hipEventRecord(e->ev1, e->stream));
-    e->timed = true;
+    QM_HIP(hipEventRecord(ev_end, e->stream));
+    e->timed = !e->log_timing;
     return 0;
 }
 
@@ -358,10 +393,11 @@ void qm_engine_destroy(qm_engine *e) {
     if (!e) return;
     DeviceGuard guard(e->device);
     (void)hipStreamSynchronize(e->stream);
-    e->d_lut.release(); e->d_bmin.release(); e->d_bspan.release(); e->d_boff.release();
+    e->d_lut.release(); e->d_bmeta.release();
     e->d_btotal.release(); e->d_wide.release(); e->d_scalar.release(); e->d_rel.release();
     e->d_onsets.release(); e->d_pmax.release(); e->d_psum.release(); e->d_out_a.release();
     e->d_out_b.release(); e->d_chunk.release(); e->d_pidx.release(); e->d_out_i.release();
+    for (hipEvent_t ev : e->ev_log) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -402,6 +438,11 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
         e->cfg_lds_bytes = (int)(v / 16 * 16);
     } else if (k == "force_direct") {
         e->cfg_force_direct = v ? 1 : 0;
+    } else if (k == "generic") {
+        e->cfg_generic = v ? 1 : 0;
+    } else if (k == "log_timing") {
+        e->log_timing = v != 0;
+        e->ev_used = 0;
     } else if (k == "chunk_bytes") {
         if (v < (1 << 20)) return fail("chunk_bytes must be >= 1 MiB");
         e->cfg_chunk_bytes = v;
@@ -466,19 +507,19 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
                           lut_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                           e->stream));
     const size_t br = (size_t)nbricks * n_rows;
-    if (e->d_bmin.ensure(br) || e->d_bspan.ensure(br) || e->d_boff.ensure(br) ||
-        e->d_btotal.ensure(nbricks) || e->d_scalar.ensure(4) ||
+    if (e->d_bmeta.ensure(4 * br) || e->d_btotal.ensure(nbricks) || e->d_scalar.ensure(4) ||
         e->d_rel.ensure((size_t)nbricks * g.brick_nodes * g.row_pad))
         return 1;
     QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
     hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
-                       e->d_lut.p, e->d_bmin.p, e->d_bspan.p, e->d_scalar.p);
+                       e->d_lut.p, reinterpret_cast<int4 *>(e->d_bmeta.p), e->d_scalar.p);
     QM_HIP(hipGetLastError());
     hipLaunchKernelGGL(qm::brick_prefix_kernel, dim3((g.nbricks + 255) / 256), dim3(256), 0,
-                       e->stream, g, e->d_bspan.p, e->d_boff.p, e->d_btotal.p);
+                       e->stream, g, reinterpret_cast<int4 *>(e->d_bmeta.p), e->d_btotal.p);
     QM_HIP(hipGetLastError());
     hipLaunchKernelGGL(qm::brick_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
-                       e->d_lut.p, e->d_bmin.p, e->d_boff.p, e->d_btotal.p, e->d_rel.p);
+                       e->d_lut.p, reinterpret_cast<const int4 *>(e->d_bmeta.p), e->d_btotal.p,
+                       e->d_rel.p);
     QM_HIP(hipGetLastError());
     e->h_btotal.resize(nbricks);
     QM_HIP(hipMemcpyAsync(e->h_btotal.data(), e->d_btotal.p, nbricks * sizeof(int32_t),
@@ -651,6 +692,22 @@ int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
         }
     }
     return fetch_out(e, n_samples, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
+}
+
+int qm_engine_kernel_log(qm_engine *e, double *total_ms, int32_t *n_calls) {
+    if (!e || !total_ms || !n_calls) return fail("NULL argument");
+    DeviceGuard guard(e->device);
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+        QM_HIP(hipEventSynchronize(e->ev_log[i + 1]));
+        float f = 0.f;
+        QM_HIP(hipEventElapsedTime(&f, e->ev_log[i], e->ev_log[i + 1]));
+        sum += f;
+    }
+    *total_ms = sum;
+    *n_calls = (int32_t)(e->ev_used / 2);
+    e->ev_used = 0;
+    return 0;
 }
 
 int qm_engine_last_kernel_ms(qm_engine *e, double *ms) {

@@ -38,9 +38,8 @@ struct StackArgs {
     const double *onsets;          // [S][T] log-onsets
     const int32_t *lut;            // [N][S] original table
     const uint16_t *rel;           // [nbricks][brick_nodes][row_pad] window byte offsets
-    const int32_t *brick_min;      // [nbricks][S]
-    const int32_t *brick_span;     // [nbricks][S]
-    const int32_t *brick_off;      // [nbricks][S] exclusive prefix of span
+    const int32_t *brick_meta;     // [nbricks][S][4] = (min delay, span, exclusive prefix of
+                                   //                    span, 0) per table row
     const int32_t *brick_total;    // [nbricks] sum of span
     const int32_t *brick_list;     // direct kernel: bricks to process (or nullptr = all)
     int n_list;
@@ -91,8 +90,7 @@ __device__ __forceinline__ int brick_walk_node(const GridDesc &g, int x0, int y0
 
 // one workgroup per brick, thread r <-> table row r: min / span of the clamped delays.
 __global__ void brick_minmax_kernel(GridDesc g, const int32_t *__restrict__ lut,
-                                    int32_t *__restrict__ bmin, int32_t *__restrict__ bspan,
-                                    int32_t *__restrict__ global_max) {
+                                    int4 *__restrict__ meta, int32_t *__restrict__ global_max) {
     const int b = blockIdx.x;
     int x0, y0, z0, vx, vy, vz;
     brick_extents(g, b, x0, y0, z0, vx, vy, vz);
@@ -106,20 +104,19 @@ __global__ void brick_minmax_kernel(GridDesc g, const int32_t *__restrict__ lut,
             lo = d < lo ? d : lo;
             hi = d > hi ? d : hi;
         }
-        bmin[(int64_t)b * g.n_rows + r] = lo;
-        bspan[(int64_t)b * g.n_rows + r] = hi - lo;
+        meta[(int64_t)b * g.n_rows + r] = make_int4(lo, hi - lo, 0, 0);
         atomicMax(global_max, hi);
     }
 }
 
-__global__ void brick_prefix_kernel(GridDesc g, const int32_t *__restrict__ bspan,
-                                    int32_t *__restrict__ boff, int32_t *__restrict__ btotal) {
+__global__ void brick_prefix_kernel(GridDesc g, int4 *__restrict__ meta,
+                                    int32_t *__restrict__ btotal) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= g.nbricks) return;
     int64_t run = 0;
     for (int r = 0; r < g.n_rows; ++r) {
-        boff[(int64_t)b * g.n_rows + r] = (int32_t)(run > INT32_MAX ? INT32_MAX : run);
-        run += bspan[(int64_t)b * g.n_rows + r];
+        meta[(int64_t)b * g.n_rows + r].z = (int32_t)(run > INT32_MAX ? INT32_MAX : run);
+        run += meta[(int64_t)b * g.n_rows + r].y;
     }
     btotal[b] = (int32_t)(run > INT32_MAX ? INT32_MAX : run);
 }
@@ -127,8 +124,7 @@ __global__ void brick_prefix_kernel(GridDesc g, const int32_t *__restrict__ bspa
 // Brick-relative window offsets: rel[b][m][r] = 8 * (off_r + clamp(tt) - min_r) BYTES, uint16,
 // one row of row_pad entries per node, nodes in walk order (see brick_walk_node).
 __global__ void brick_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
-                                 const int32_t *__restrict__ bmin,
-                                 const int32_t *__restrict__ boff,
+                                 const int4 *__restrict__ meta,
                                  const int32_t *__restrict__ btotal,
                                  uint16_t *__restrict__ rel) {
     const int b = blockIdx.x;
@@ -144,8 +140,8 @@ __global__ void brick_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
             const int node = brick_walk_node(g, x0, y0, z0, vy, vz, m);
             int d = lut[(int64_t)node * g.n_rows + r];
             d = d < 0 ? 0 : d;
-            v = (uint16_t)(8 * (boff[(int64_t)b * g.n_rows + r] + d -
-                                bmin[(int64_t)b * g.n_rows + r]));
+            const int4 rec = meta[(int64_t)b * g.n_rows + r];
+            v = (uint16_t)(8 * (rec.z + d - rec.x));
         }
         rel[(int64_t)b * per + i] = v;
     }
@@ -318,7 +314,52 @@ __device__ __forceinline__ uint4 load_offsets(const uint16_t *rel, int64_t entry
     return *reinterpret_cast<const uint4 *>(rel + entry + zero);
 }
 
-template <int J, bool VOLUME>
+// ---------------------------------------------------------------------------------------
+// Stage the windows of brick b for the tile starting at t_first: row r occupies LDS doubles
+// [off_r + r*KT, off_r + r*KT + span_r + KT).  Lane r fetches row r's (min, span, off) record
+// with one coalesced 16-byte load; a wave then copies its rows with J+1 independent loads in
+// flight per pass (a pass covers KT + 64 samples, i.e. the whole row unless its span > 64).
+// ---------------------------------------------------------------------------------------
+template <int J>
+__device__ __forceinline__ void stage_windows(const StackArgs &a, double *win, int b, int wave,
+                                              int nwaves, int lane, int t_first) {
+    constexpr int KT = kWave * J;
+    constexpr int U = J + 1;
+    const int S = a.g.n_rows;
+    for (int r0 = 0; r0 < S; r0 += kWave) {
+        int4 rec = make_int4(0, 0, 0, 0);
+        if (r0 + lane < S)
+            rec = reinterpret_cast<const int4 *>(a.brick_meta)[(int64_t)b * S + r0 + lane];
+        const int rend = (S - r0 < kWave) ? S - r0 : kWave;
+        for (int k = wave; k < rend; k += nwaves) {
+            const int r = r0 + k;
+            const int lo = __builtin_amdgcn_readlane(rec.x, k);
+            const int len = __builtin_amdgcn_readlane(rec.y, k) + KT;
+            const int dst = __builtin_amdgcn_readlane(rec.z, k) + r * KT;
+            const int first = lo + a.fsmp + a.sample0 + t_first;   // index inside the row
+            const int room = a.T - first;                          // readable from `first`
+            const double *src = a.onsets + (int64_t)r * a.T + first;
+            for (int u0 = 0; u0 < len; u0 += kWave * U) {
+                double v[U];
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    const int u = u0 + kWave * i + lane;
+                    v[i] = (u < len && u < room) ? src[u] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    const int u = u0 + kWave * i + lane;
+                    if (u < len) win[dst + u] = v[i];
+                }
+            }
+        }
+    }
+}
+
+// NCH > 0: the node's offsets are exactly NCH 16-byte chunks (row_pad == 8*NCH); the whole next
+// node is prefetched into registers while the current one is stacked, and the chunk loop is
+// unrolled.  NCH == 0: any row count, one-chunk-ahead prefetch (slower, always valid).
+template <int J, bool VOLUME, int NCH>
 __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int KT = kWave * J;
@@ -341,18 +382,7 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
     for (int b = group; b < g.nbricks; b += a.ngroups) {
         if (!brick_fits(a.brick_total[b], S, KT, a.cap_doubles)) continue;   // direct kernel's job
         __syncthreads();                              // previous brick fully consumed
-        // ---- stage the windows: row r occupies [off_r + r*KT, off_r + r*KT + span_r + KT)
-        for (int r = wave; r < S; r += nwaves) {
-            const int64_t br = (int64_t)b * S + r;
-            const int lo = a.brick_min[br];
-            const int len = a.brick_span[br] + KT;
-            const int dst = a.brick_off[br] + r * KT;
-            const int first = lo + a.fsmp + a.sample0 + t_first;   // index inside the row
-            const int room = a.T - first;              // readable elements from `first`
-            const double *src = a.onsets + (int64_t)r * a.T + first;
-            for (int u = lane; u < len; u += kWave)
-                win[dst + u] = (u < room) ? src[u] : 0.0;
-        }
+        stage_windows<J>(a, win, b, wave, nwaves, lane, t_first);
         __syncthreads();
 
         // ---- this wave's walk over the brick's valid nodes (no divisions inside the loop)
@@ -360,40 +390,75 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
         brick_extents(g, b, x0, y0, z0, vx, vy, vz);
         const int nvalid = vx * vy * vz;
         int lz = wave % vz, ly = (wave / vz) % vy, lx = wave / (vz * vy);
-        const int64_t brick_entry = (int64_t)b * g.brick_nodes * g.row_pad;
+        const uint16_t *brick_rel = a.rel + (int64_t)b * g.brick_nodes * g.row_pad;
 
-        // offset-chunk prefetch: one 8-row chunk ahead of consumption, in this wave's order
-        int pm = wave, pc = 0;
-        auto fetch_next = [&]() -> uint4 {
-            const int mm = pm < nvalid ? pm : 0;       // past the end: harmless reload
-            const uint4 v = load_offsets(a.rel, brick_entry + (int64_t)mm * g.row_pad + pc * 8);
-            if (++pc == nchunks) { pc = 0; pm += nwaves; }
-            return v;
-        };
-        uint4 q = fetch_next();
-
-        for (int m = wave; m < nvalid; m += nwaves) {
-            const int node = ((x0 + lx) * g.ny + (y0 + ly)) * g.nz + (z0 + lz);
-            lz += nwaves;
-            while (lz >= vz) { lz -= vz; ++ly; }
-            while (ly >= vy) { ly -= vy; ++lx; }
-
-            double acc[J];
-            start_node<J, VOLUME>(a, acc, node, t_first, lane);
-            unsigned chunk_addr = lane_addr;
-            unsigned addr[8];
-            for (int c = 0; c < nfull; ++c) {
-                unpack8(q, chunk_addr, addr);
-                q = fetch_next();
-                ring_full<J>(acc, addr);
-                chunk_addr += 8 * KT * 8;
+        if constexpr (NCH > 0) {
+            uint4 qn[NCH];
+            {
+                const uint16_t *p = brick_rel + (int64_t)(wave < nvalid ? wave : 0) * g.row_pad;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) qn[c] = load_offsets(p, c * 8);
             }
-            if (ntail) {
-                unpack8(q, chunk_addr, addr);
-                q = fetch_next();
-                ring_tail<J>(acc, addr, ntail);
+            const int last_rows = S - 8 * (NCH - 1);
+            for (int m = wave; m < nvalid; m += nwaves) {
+                const int node = ((x0 + lx) * g.ny + (y0 + ly)) * g.nz + (z0 + lz);
+                lz += nwaves;
+                while (lz >= vz) { lz -= vz; ++ly; }
+                while (ly >= vy) { ly -= vy; ++lx; }
+
+                uint4 qc[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) qc[c] = qn[c];
+                {   // whole next node (or a harmless reload of this one at the end)
+                    const int mn = m + nwaves < nvalid ? m + nwaves : m;
+                    const uint16_t *p = brick_rel + (int64_t)mn * g.row_pad;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) qn[c] = load_offsets(p, c * 8);
+                }
+                double acc[J];
+                start_node<J, VOLUME>(a, acc, node, t_first, lane);
+                unsigned addr[8];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    unpack8(qc[c], lane_addr + (unsigned)(c * 8 * KT * 8), addr);
+                    if (c + 1 < NCH || last_rows == 8) ring_full<J>(acc, addr);
+                    else ring_tail<J>(acc, addr, last_rows);
+                }
+                finish_node<J, VOLUME>(a, run, acc, node, t_first, lane);
             }
-            finish_node<J, VOLUME>(a, run, acc, node, t_first, lane);
+        } else {
+            // offset-chunk prefetch: one 8-row chunk ahead of consumption, in this wave's order
+            int pm = wave, pc = 0;
+            auto fetch_next = [&]() -> uint4 {
+                const int mm = pm < nvalid ? pm : 0;   // past the end: harmless reload
+                const uint4 v = load_offsets(brick_rel, (int64_t)mm * g.row_pad + pc * 8);
+                if (++pc == nchunks) { pc = 0; pm += nwaves; }
+                return v;
+            };
+            uint4 q = fetch_next();
+            for (int m = wave; m < nvalid; m += nwaves) {
+                const int node = ((x0 + lx) * g.ny + (y0 + ly)) * g.nz + (z0 + lz);
+                lz += nwaves;
+                while (lz >= vz) { lz -= vz; ++ly; }
+                while (ly >= vy) { ly -= vy; ++lx; }
+
+                double acc[J];
+                start_node<J, VOLUME>(a, acc, node, t_first, lane);
+                unsigned chunk_addr = lane_addr;
+                unsigned addr[8];
+                for (int c = 0; c < nfull; ++c) {
+                    unpack8(q, chunk_addr, addr);
+                    q = fetch_next();
+                    ring_full<J>(acc, addr);
+                    chunk_addr += 8 * KT * 8;
+                }
+                if (ntail) {
+                    unpack8(q, chunk_addr, addr);
+                    q = fetch_next();
+                    ring_tail<J>(acc, addr, ntail);
+                }
+                finish_node<J, VOLUME>(a, run, acc, node, t_first, lane);
+            }
         }
         run.merge_brick();
     }
