@@ -1,0 +1,135 @@
+# -*- coding: utf-8 -*-
+"""
+Host-side counterpart of ``QuakeScan._compute`` for the migrate / find_max_coa path.
+
+``MigrationScan._compute(data, event=None)`` reproduces the glue of the reference's
+``quakemigrate/signal/scan.py:593-647`` around the hot path -- onset plugin ->
+served travel-time table -> ``fsmp`` / ``lsmp`` -> ``available`` -> migrate ->
+find_max_coa -> ``index2coord`` -- with the same argument meaning, return tuples and
+error behaviour, but:
+
+* the table is made resident on the GPU once per ``(sampling_rate, availability)``
+  (the reference rebuilds and re-passes it every timestep, ``lut.py:502-538``), and
+* in the detect stage the fused kernel runs, so the 4-D map is never materialised
+  (the reference allocates it only to reduce and delete it, ``scan.py:641-642``).
+
+It is duck-typed against the reference's plugin API, so the reference's own objects
+drop in unchanged:
+
+* ``onset``  : ``calculate_onsets(data) -> (onsets[S, T] float64, onset_data)`` with
+  ``onset_data.sampling_rate`` and ``onset_data.availability`` (dict "STATION_PHASE"
+  -> 0/1), see ``quakemigrate/signal/onsets/base.py:24-130, 133-191``;
+* ``lut``    : ``serve_traveltimes(sampling_rate, availability) -> int32
+  (nx, ny, nz, S)`` and ``index2coord(idx, unravel=True)``
+  (``quakemigrate/lut/lut.py:502-538, 211-243``).
+
+obspy / pyproj are not needed here: whatever ``data.starttime`` and
+``event.mw_times`` return is passed through.
+"""
+
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+
+from quakemigrate_amd.core import lib
+
+
+class LUTPhasesException(Exception):
+    """Mirror of ``quakemigrate.util.LUTPhasesException`` (util.py)."""
+
+
+def time2sample(time, sampling_rate):
+    """Seconds -> whole samples, as ``quakemigrate/util.py:152-172``."""
+    return int(round(time * int(sampling_rate)))
+
+
+class MigrationScan:
+    """
+    Parameters
+    ----------
+    lut, onset : plugin objects (see module docstring).
+    pre_pad, post_pad : float
+        Seconds of onset data before / after the scanned window (what
+        ``QuakeScan`` gets from ``onset.pad(timestep)``, scan.py:425).
+    stage : {"detect", "locate"}
+        ``run.stage`` of the reference (scan.py:641).
+    scan_rate : int, optional
+        Passed to ``event.mw_times`` in the locate stage (scan.py:646).
+    engine : quakemigrate_amd.core.Engine, optional
+        Defaults to the process-wide engine on ``$QM_HIP_DEVICE``.
+    threads : int
+        Accepted for signature compatibility; the GPU engine ignores it.
+    """
+
+    def __init__(self, lut, onset, pre_pad, post_pad, stage="detect", scan_rate=None,
+                 engine=None, threads=1):
+        self.lut = lut
+        self.onset = onset
+        self.pre_pad = pre_pad
+        self.post_pad = post_pad
+        self.stage = stage
+        self.scan_rate = scan_rate
+        self.threads = threads
+        self.engine = engine if engine is not None else lib.default_engine()
+        self._resident_key = None
+
+    # -- table residency ------------------------------------------------------
+    def _ensure_table(self, sampling_rate, availability):
+        key = (sampling_rate, tuple(availability.items()))
+        if key != self._resident_key:
+            try:
+                traveltimes = self.lut.serve_traveltimes(sampling_rate, availability)
+            except KeyError as e:
+                phases = sorted({k.split("_")[-1] for k in availability})
+                raise LUTPhasesException(
+                    f"Attempting to migrate phases {phases}; but traveltimes for {e} "
+                    f"not found in the LUT. Please create a new lookup table with "
+                    f"phases={phases}")
+            traveltimes = np.ascontiguousarray(traveltimes, dtype=np.int32)
+            self.engine.load_lut(traveltimes)
+            self._resident_key = key
+            logging.debug("travel-time table %s made resident", traveltimes.shape)
+        return self.engine
+
+    # -- the hot-path glue ------------------------------------------------------
+    def _compute(self, data, event=None):
+        """
+        Compute 3-D coalescence between two time stamps (reference scan.py:593-647).
+
+        Returns (detect) ``time, max_coa, max_coa_n, coord, onset_data`` or
+        (locate) ``times, max_coa, max_coa_n, coord, map4d, onset_data``.
+        """
+        onsets, onset_data = self.onset.calculate_onsets(data)
+        eng = self._ensure_table(onset_data.sampling_rate, onset_data.availability)
+        fsmp = time2sample(self.pre_pad, onset_data.sampling_rate)
+        lsmp = time2sample(self.post_pad, onset_data.sampling_rate)
+        avail = int(np.sum([value for _, value in onset_data.availability.items()]))
+
+        # lib.py:93-110 -- same pre-processing and checks, same order
+        onsets = np.ascontiguousarray(np.log(np.clip(onsets, 0.01, np.inf)))
+        n_onsets, t_samples = onsets.shape
+        n_samples = t_samples - fsmp - lsmp
+        if n_onsets != eng.n_rows:
+            raise ValueError("Mismatch between number of stations for data and LUT, "
+                             f"{n_onsets}:{eng.n_rows}")
+        if onsets.size < n_samples + fsmp:
+            raise ValueError("Data array smaller than coalescence array.")
+
+        series = (np.zeros(n_samples), np.zeros(n_samples),
+                  np.zeros(n_samples, dtype=np.int64))
+        if self.stage == "detect":
+            eng.detect(onsets, fsmp, lsmp, avail, out=series)
+            map4d = None
+        else:
+            map4d = np.zeros(tuple(eng.grid) + (n_samples,), dtype=np.double)
+            eng.migrate(onsets, fsmp, lsmp, avail, map4d, scan_out=series)
+        max_coa, max_coa_n, max_idx = series
+        coord = self.lut.index2coord(max_idx, unravel=True)
+
+        if self.stage == "detect":
+            time = data.starttime + self.pre_pad
+            return time, max_coa, max_coa_n, coord, onset_data
+        times = event.mw_times(self.scan_rate)
+        return times, max_coa, max_coa_n, coord, map4d, onset_data

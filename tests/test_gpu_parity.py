@@ -206,3 +206,121 @@ def test_sharded_partials_combine_to_single_gpu_result(lib, oracle):
     assert np.array_equal(c.cpu().numpy(), want[2])
     np.testing.assert_allclose(a.cpu().numpy(), want[0], rtol=TIGHT)
     np.testing.assert_allclose(b.cpu().numpy(), want[1], rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------------
+# BASELINE.json's full sizes: oracle on a time chunk (the scan is independent per
+# sample, so a chunk of the full grid is an exact check) + size-independent properties
+# ---------------------------------------------------------------------------------
+def _oracle_chunk(oracle, case, k0, nk, threads=None):
+    import os
+
+    t_samples = case.onsets.shape[1]
+    first = case.fsmp + k0
+    return oracle.detect(case.onsets, case.traveltimes, first, t_samples - first - nk,
+                         case.available, threads=threads or os.cpu_count(),
+                         max_bytes=6 << 30)
+
+
+@pytest.mark.parametrize("name,nk", [("C2", 96), ("C3", 24)])
+def test_full_size_configs_chunk_oracle_and_properties(lib, oracle, name, nk):
+    case = synth.make_case(name, step=0)
+    lon = oracle.log_onsets(case.onsets)
+    eng = lib.Engine(0, brick_x=8, brick_y=8, brick_z=8)
+    eng.load_lut(case.traveltimes)
+    assert eng.get("n_wide_bricks") == 0
+    got = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+    ns = case.n_samples
+    # (a) the injected events are found at their nodes and samples
+    for (ijk, t0) in case.event_nodes:
+        assert got[2][t0] == np.ravel_multi_index(ijk, case.grid)
+    # (b) exact oracle comparison on time chunks of the FULL grid: around an event,
+    #     at the very start and at the ragged end of the scan
+    t_ev = case.event_nodes[0][1]
+    for k0 in (0, max(0, t_ev - nk // 2), ns - nk):
+        want = _oracle_chunk(oracle, case, k0, nk)
+        _assert_series(tuple(g[k0:k0 + nk] for g in got), want)
+    # (c) shift invariance: scanning 5 samples later yields the same series, shifted --
+    #     bit for bit (same sums, same node order per sample)
+    shifted = eng.detect(lon, case.fsmp + 5, case.lsmp - 5, case.available)
+    for g0, g5 in zip(got, shifted):
+        assert np.array_equal(g0[5:], g5[:-5])
+    # (d) two x-slabs + finalize == the unsharded engine (index and maximum exactly)
+    import torch
+
+    half = case.grid[0] // 2 + 3
+    plane = case.grid[1] * case.grid[2]
+    pmax = torch.empty((2, ns), dtype=torch.float64, device="cuda")
+    psum = torch.empty((2, ns), dtype=torch.float64, device="cuda")
+    pidx = torch.empty((2, ns), dtype=torch.int64, device="cuda")
+    for r, (x0, x1) in enumerate([(0, half), (half, case.grid[0])]):
+        eng.load_lut(np.ascontiguousarray(case.traveltimes[x0:x1]), node_offset=x0 * plane)
+        eng.detect_partial(lon, case.fsmp, case.lsmp, case.available,
+                           (pmax[r], pidx[r], psum[r]))
+    eng.synchronize()
+    both = eng.finalize(pmax, pidx, psum, 2, ns, case.n_nodes_total)
+    assert np.array_equal(both[2], got[2]) and np.array_equal(both[0], got[0])
+    np.testing.assert_allclose(both[1], got[1], rtol=1e-12)
+    # (e) a quiet step (all onsets on the clip floor): every node ties -> index 0
+    quiet = synth.make_case(name, step=1, quiet=True, n_samples=300,
+                            grid=(case.grid[0] // 4, case.grid[1], case.grid[2]))
+    eng.load_lut(quiet.traveltimes)
+    q = eng.detect(oracle.log_onsets(quiet.onsets), quiet.fsmp, quiet.lsmp, quiet.available)
+    assert (q[2] == 0).all()
+    np.testing.assert_allclose(q[0], 0.4, rtol=1e-14)
+    np.testing.assert_allclose(q[1], 1.0, rtol=1e-12)
+    eng.close()
+
+
+def test_migration_scan_compute_mirrors_reference_glue(lib, oracle):
+    """MigrationScan._compute with duck-typed LUT / onset plugins, both stages."""
+    from quakemigrate_amd import scan
+
+    case = synth.make_case("C2", step=4, grid=(15, 12, 10), rows=6, n_samples=250)
+    rate = 50
+    keys = [f"ST{i}_{'P' if i < 3 else 'S'}" for i in range(6)]
+
+    class OnsetData:
+        sampling_rate = rate
+        availability = {k: 1 for k in keys}
+        availability["ST9_S"] = 0                       # an unavailable station
+
+    class Onset:
+        def calculate_onsets(self, data):
+            return case.onsets, OnsetData()
+
+    class Lut:
+        served = 0
+
+        def serve_traveltimes(self, sampling_rate, availability):
+            Lut.served += 1
+            assert sampling_rate == rate and sum(availability.values()) == 6
+            return case.traveltimes
+
+        def index2coord(self, idx, unravel=True):
+            return np.stack(np.unravel_index(idx, case.grid), axis=-1) * 1.0
+
+    class Data:
+        starttime = 1000.0
+
+    class Event:
+        def mw_times(self, scan_rate):
+            return np.arange(case.n_samples) / scan_rate
+
+    pre, post = case.fsmp / rate, case.lsmp / rate
+    want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, 6, threads=4)
+    eng = lib.Engine(0)
+    det = scan.MigrationScan(Lut(), Onset(), pre, post, stage="detect", engine=eng)
+    time, a, b, coord, od = det._compute(Data())
+    assert time == 1000.0 + pre and isinstance(od, OnsetData)
+    _assert_series((a, b, np.ravel_multi_index(coord.astype(int).T, case.grid)), want)
+    det._compute(Data())
+    assert Lut.served == 1                               # table stayed resident
+    loc = scan.MigrationScan(Lut(), Onset(), pre, post, stage="locate", scan_rate=rate,
+                             engine=eng)
+    times, a, b, coord, map4d, od = loc._compute(Data(), Event())
+    assert map4d.shape == case.grid + (case.n_samples,) and len(times) == case.n_samples
+    _assert_series((a, b, np.ravel_multi_index(coord.astype(int).T, case.grid)), want)
+    ref = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp, 6, threads=4)
+    np.testing.assert_allclose(map4d, ref, rtol=TIGHT)
+    eng.close()

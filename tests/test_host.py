@@ -1,0 +1,184 @@
+# -*- coding: utf-8 -*-
+"""
+CPU-side checks of the boundary and the host logic (no GPU, no compute calls):
+
+* the C-ABI library loads and exports every symbol include/qmhip.h declares;
+* the binding-level error behaviour of quakemigrate/core/lib.py:105-110;
+* the host STA/LTA symbols of the drop-in library against the reference vectors;
+* x-plane sharding arithmetic;
+* the cross-rank exchange (world_size 2, gloo) against the oracle's one-shot result.
+"""
+
+import ctypes
+import os
+import pathlib
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+
+    g.build_engine()
+    return g
+
+
+def _declared_functions():
+    text = (ROOT / "include" / "qmhip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(built):
+    names = _declared_functions()
+    assert {"migrate", "find_max_coa", "overlapping_sta_lta", "centred_sta_lta",
+            "recursive_sta_lta", "qm_engine_create", "qm_engine_detect",
+            "qm_engine_migrate", "qm_engine_finalize"} <= set(names)
+    import sysconfig
+
+    for libname in ("libqmhip.so", "qmlib" + sysconfig.get_config_var("EXT_SUFFIX")):
+        lib = ctypes.CDLL(str(ROOT / "quakemigrate_amd" / "csrc" / libname))
+        missing = [n for n in names if not hasattr(lib, n)]
+        assert not missing, f"{libname} lacks {missing}"
+
+
+def test_binding_imports_and_validates_like_the_reference(built):
+    from quakemigrate_amd.core import lib
+
+    on = np.ones((3, 50))
+    with pytest.raises(ValueError, match="Mismatch"):
+        lib.migrate(on, np.zeros((2, 2, 2, 4), dtype=np.int32), 2, 3, 3, 1)
+    with pytest.raises(ValueError, match="smaller"):
+        lib.migrate(np.ones((1, 4)), np.zeros((2, 2, 2, 1), dtype=np.int32), 8, -10, 1, 1)
+    with pytest.raises(ctypes.ArgumentError):
+        lib.migrate(on, np.zeros((2, 2, 2, 3), dtype=np.int64), 2, 3, 3, 1)
+    assert lib.qmlib.qm_last_error() is not None
+
+
+def test_drop_in_stalta_symbols_match_reference_vectors(built):
+    from quakemigrate_amd.core import lib
+
+    g = load_golden("stalta")
+    toy = g["toy"]
+    # reference tests/test_onsets.py:27-35
+    assert (lib.overlapping_sta_lta(toy, 2, 3)
+            == np.array([1.0, 1.0, 1.5, 1.25, 21.0 / 18, 27.0 / 24])).all()
+    assert np.allclose(lib.centred_sta_lta(toy, 2, 3),
+                       np.array([1.0, 1.0, 3.5, 2.25, 1.0, 1.0]))
+    for kind in ("overlapping", "centred", "recursive"):
+        fn = getattr(lib, f"{kind}_sta_lta")
+        np.testing.assert_allclose(fn(toy, 2, 3), g[f"toy_{kind}"], rtol=1e-15)
+        np.testing.assert_allclose(fn(g["signal"], int(g["nsta"]), int(g["nlta"])),
+                                   g[kind], rtol=1e-12)
+
+
+def test_engine_calls_fail_loudly_without_a_gpu(built):
+    """No CPU fallback: on a box without a HIP device the engine refuses to exist."""
+    from quakemigrate_amd.core import lib
+
+    if lib.qmlib.qm_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(lib.QMHipError):
+        lib.Engine(0)
+    g = load_golden("ties_floor")
+    with pytest.raises(lib.QMHipError):
+        lib.migrate_and_find_max(g["onsets"], g["traveltimes"], int(g["fsmp"]),
+                                 int(g["lsmp"]), int(g["available"]))
+
+
+def test_shard_planes_partition():
+    from quakemigrate_amd.distributed import shard_planes
+
+    for nx, world in [(201, 8), (7, 8), (401, 3), (5, 1)]:
+        spans = [shard_planes(nx, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == nx
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_scan_glue_shapes_and_errors(built):
+    """MigrationScan validates before touching the GPU (no device needed here)."""
+    from quakemigrate_amd import scan
+
+    assert scan.time2sample(1.6, 50) == 80 and scan.time2sample(0.65, 250) == 162
+
+    class Lut:
+        def serve_traveltimes(self, sr, availability):
+            raise KeyError("P")
+
+    class Onset:
+        def calculate_onsets(self, data):
+            class OD:
+                sampling_rate = 50
+                availability = {"A_P": 1, "B_P": 0}
+            return np.ones((1, 300)), OD()
+
+    s = scan.MigrationScan(Lut(), Onset(), 1.0, 2.0, engine=object())
+    with pytest.raises(scan.LUTPhasesException, match="phases"):
+        s._compute(object())
+
+
+# ---------------------------------------------------------------------------------
+# world_size-2 exchange on CPU (gloo): per-shard partials come from the oracle (the
+# checker generating inputs), the exchange under test is quakemigrate_amd.distributed
+# ---------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, str(ROOT))
+    from oracle import qm_oracle
+    from quakemigrate_amd import distributed as qd
+    from quakemigrate_amd import synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grid = (17, 9, 8)
+    x0, x1 = qd.shard_planes(grid[0], world, rank)
+    case = synth.make_case("C2", step=5, grid=grid, rows=6, n_samples=211,
+                           x_range=(x0, x1))
+    # this rank's slab through the oracle: log-domain max, global argmax, sum
+    vol = qm_oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
+                              case.available, threads=2)
+    vol = vol.reshape(-1, vol.shape[-1])
+    local_idx = np.argmax(vol, axis=0)
+    pmax = torch.from_numpy(np.log(vol[local_idx, np.arange(vol.shape[1])]))
+    pidx = torch.from_numpy(local_idx.astype(np.int64) + x0 * grid[1] * grid[2])
+    psum = torch.from_numpy(vol.sum(axis=0))
+    a, b, c = qd.exchange_partials(pmax, pidx, psum, int(np.prod(grid)))
+    np.savez(pathlib.Path(tmp) / f"rank{rank}.npz", a=a.numpy(), b=b.numpy(), c=c.numpy())
+    dist.destroy_process_group()
+
+
+def test_exchange_partials_world_size_2_gloo(oracle, tmp_path):
+    import torch.multiprocessing as mp
+
+    from quakemigrate_amd import synth
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    grid = (17, 9, 8)
+    case = synth.make_case("C2", step=5, grid=grid, rows=6, n_samples=211)
+    want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
+                         case.available, threads=2)
+    for rank in range(2):
+        got = np.load(tmp_path / f"rank{rank}.npz")
+        assert np.array_equal(got["c"], want[2])
+        np.testing.assert_allclose(got["a"], want[0], rtol=1e-12)
+        np.testing.assert_allclose(got["b"], want[1], rtol=1e-12)
