@@ -106,7 +106,7 @@ int qm_engine_detect(qm_engine *e, const double *log_onsets, int onsets_on_devic
                      int out_on_device);
 
 /* Same step, but stop before the final normalisation: this engine's partial
- * (log-domain maximum, global node index, sum of coalescence) per sample, on
+ * (log2-domain maximum, global node index, sum of coalescence) per sample, on
  * the device, ready for the cross-GPU exchange.  [n_samples] each. */
 int qm_engine_detect_partial(qm_engine *e, const double *log_onsets,
                              int onsets_on_device, int32_t t_samples,

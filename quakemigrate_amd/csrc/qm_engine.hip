@@ -230,7 +230,8 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     a.n_chunk = n_chunk;
     a.ntiles = (n_chunk + KT - 1) / KT;
     a.cap_doubles = lds_cap_doubles(e);
-    a.inv_available = 1.0 / (double)available;      // -Ofast turns /available into this
+    // coa = exp(stack/available) = 2^(stack * log2(e)/available)
+    a.z_scale = 1.4426950408889634074 / (double)available;
     a.volume = volume;
     a.vol_stride = vol_stride;
     a.accumulate = accumulate;

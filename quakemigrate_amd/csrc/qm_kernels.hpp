@@ -48,11 +48,11 @@ struct StackArgs {
     int n_chunk;                   // samples handled by this launch
     int ntiles, ngroups;
     int cap_doubles;               // LDS window capacity in doubles
-    double inv_available;
+    double z_scale;                // log2(e) / available: z = stack * z_scale, coa = 2^z
     double *volume;                // [N][vol_stride] or nullptr
     int64_t vol_stride;            // samples per node row in `volume`
     int accumulate;                // start from the volume's content (reference '+=')
-    double *part_max;              // [sets][n_chunk]  log-domain maxima
+    double *part_max;              // [sets][n_chunk]  log2-domain maxima (z)
     int64_t *part_idx;             // [sets][n_chunk]  local flat node index
     double *part_sum;              // [sets][n_chunk]
     int set0;                      // first partial set written by this launch
@@ -148,30 +148,57 @@ __global__ void brick_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
 }
 
 // ---------------------------------------------------------------------------------------
-// exp in float64 without the device library's special-case handling: the argument is a mean
-// of log-onsets (|x| < ~50 for any finite input), far from overflow / underflow.
-//   x = k ln2 + r, |r| <= ln2/2;  exp(r) by its degree-12 Taylor polynomial (truncation
-//   0.3466^13/13! = 1.7e-16 relative), scaled by 2^k with v_ldexp_f64.  ~2 ulp.
-// 19 FP64-rate VALU ops.  The reference's own exp is glibc libmvec (<= 4 ulp).
+// exp in float64, in the base-2 domain, without the device library's special-case handling: the
+// argument is a mean of log-onsets (|x| < ~50 for any finite input), far from overflow.
+//   z = stack * (log2(e)/available) = k + f, |f| <= 1/2;   coa = 2^z = 2^k * 2^f
+//   2^f = sum_i (f ln2)^i / i!  as a Horner polynomial, scaled with v_ldexp_f64.
+// Per node-sample (kExp2Degree = 10): truncation 0.3466^11/11! = 2.2e-13 relative -- this feeds
+// the volume and the sum behind max_norm_coa (contract: 1e-6).  The running maximum is tracked
+// on z itself (monotone in the stack), and the final peak 2^z_best is evaluated once per sample
+// with the degree-13 form (~1 ulp + the 1-ulp rounding of z).  The reference's own exp is glibc
+// libmvec (<= 4 ulp).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ double qm_exp(double x) {
-    const double kf = __builtin_rint(x * 1.4426950408889634074);
-    double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);
-    r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
-    double p = 1.0 / 479001600.0;                       // 1/12!
-    p = __builtin_fma(p, r, 1.0 / 39916800.0);
-    p = __builtin_fma(p, r, 1.0 / 3628800.0);
-    p = __builtin_fma(p, r, 1.0 / 362880.0);
-    p = __builtin_fma(p, r, 1.0 / 40320.0);
-    p = __builtin_fma(p, r, 1.0 / 5040.0);
-    p = __builtin_fma(p, r, 1.0 / 720.0);
-    p = __builtin_fma(p, r, 1.0 / 120.0);
-    p = __builtin_fma(p, r, 1.0 / 24.0);
-    p = __builtin_fma(p, r, 1.0 / 6.0);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    return __builtin_amdgcn_ldexp(p, (int)kf);
+#define QM_LOG2E 1.4426950408889634074
+// polynomial degree of the per-node-sample 2^f: 10 when the value only feeds the sum behind
+// max_norm_coa (truncation 2.2e-13), 12 when it is stored in the volume (1.7e-16)
+template <bool VOLUME> struct Exp2Degree { static constexpr int value = VOLUME ? 12 : 10; };
+
+// coefficient of f^i in 2^f: ln2^i / i!
+__device__ __forceinline__ constexpr double exp2_coeff(int i) {
+    constexpr double c[14] = {1.0,
+                              0.6931471805599453,    0.24022650695910072,   0.05550410866482158,
+                              0.009618129107628477,  0.0013333558146428443, 0.0001540353039338161,
+                              1.5252733804059841e-05, 1.321548679014431e-06, 1.01780860092397e-07,
+                              7.054911620801123e-09, 4.4455382718708116e-10, 2.5678435993488206e-11,
+                              1.3691488853904128e-12};
+    return c[i];
+}
+
+// Horner step I of a degree-D polynomial: I = 0 starts with the two highest coefficients
+template <int D, int I>
+__device__ __forceinline__ double exp2_horner(double p, double f) {
+    return __builtin_fma(I == 0 ? exp2_coeff(D) : p, f, exp2_coeff(D - 1 - I));
+}
+
+template <int D, int I = 0>
+__device__ __forceinline__ double exp2_poly(double p, double f) {
+    if constexpr (I < D) return exp2_poly<D, I + 1>(exp2_horner<D, I>(p, f), f);
+    else return p;
+}
+
+// 2^z for the per-node path
+template <int D>
+__device__ __forceinline__ double qm_exp2(double z) {
+    const double kf = __builtin_rint(z);
+    const double f = z - kf;
+    return __builtin_amdgcn_ldexp(exp2_poly<D>(0.0, f), (int)kf);
+}
+
+// 2^z for the final peak (once per sample)
+__device__ __forceinline__ double qm_exp2_peak(double z) {
+    const double kf = __builtin_rint(z);
+    const double f = z - kf;
+    return __builtin_amdgcn_ldexp(exp2_poly<13>(0.0, f), (int)kf);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -219,8 +246,8 @@ __device__ __forceinline__ void finish_node(const StackArgs &a, Running<J> &run,
                                             int lane) {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const double x = acc[j] * a.inv_available;
-        const double e = qm_exp(x);
+        const double x = acc[j] * a.z_scale;            // z: log2 of the coalescence
+        const double e = qm_exp2<Exp2Degree<VOLUME>::value>(x);
         if (VOLUME) {
             const int t = t_first + lane + kWave * j;
             if (t < a.n_chunk) a.volume[(int64_t)node * a.vol_stride + t] = e;
@@ -356,6 +383,156 @@ __device__ __forceinline__ void stage_windows(const StackArgs &a, double *win, i
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Software-pipelined node loop (NCH > 0 kernels).  While the rows of node B stream out of LDS,
+// the epilogue of the previous node A (exp, sum, running maximum: ~22 VALU ops per sample slot)
+// is issued in slices between "issue next batch of ds_read_b64" and "wait + add this batch", so
+// a wavefront has LDS requests in flight while it does its VALU-only work.  This part is plain
+// C++: the LDS loads are volatile (not fused into ds_read2st64_b64, order kept), the compiler
+// counts them (s_waitcnt lgkmcnt(N)), and sched_barrier pins the three phases of each batch.
+// ---------------------------------------------------------------------------------------
+template <int J>
+struct Epilogue {              // node whose sums are complete but not yet exponentiated
+    double x[J], f[J], p[J];
+    int k[J];
+    int node;
+};
+
+// steps: 0 z | 1 k | 2 f | 3..3+D-1 Horner | then ldexp | sum(+store) | track
+template <bool VOLUME> struct EpiSteps { static constexpr int value = 3 + Exp2Degree<VOLUME>::value + 3; };
+
+template <int J, bool VOLUME, int STEP>
+__device__ __forceinline__ void epi_step(Epilogue<J> &s, Running<J> &run, const StackArgs &a,
+                                         int t_first, int lane) {
+    constexpr int D = Exp2Degree<VOLUME>::value;
+    constexpr int H0 = 3, H1 = 3 + D;                  // Horner steps [H0, H1)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        if constexpr (STEP == 0) s.x[j] *= a.z_scale;                  // z = stack * log2e/avail
+        else if constexpr (STEP == 1) s.p[j] = __builtin_rint(s.x[j]); // k (as double)
+        else if constexpr (STEP == 2) {
+            s.f[j] = s.x[j] - s.p[j];                                  // f = z - k
+            s.k[j] = (int)s.p[j];
+        } else if constexpr (STEP >= H0 && STEP < H1)
+            s.p[j] = exp2_horner<D, STEP - H0>(s.p[j], s.f[j]);
+        else if constexpr (STEP == H1) s.p[j] = __builtin_amdgcn_ldexp(s.p[j], s.k[j]);
+        else if constexpr (STEP == H1 + 1) {
+            run.vsum[j] += s.p[j];
+            if (VOLUME) {
+                const int t = t_first + lane + kWave * j;
+                if (t < a.n_chunk) a.volume[(int64_t)s.node * a.vol_stride + t] = s.p[j];
+            }
+        } else if constexpr (STEP == H1 + 2) {
+            const bool gt = s.x[j] > run.bmax[j];                      // strict: first node wins
+            run.bidx[j] = gt ? s.node : run.bidx[j];
+            run.bmax[j] = __builtin_fmax(run.bmax[j], s.x[j]);
+        }
+    }
+}
+
+template <int J, bool VOLUME, int FIRST, int LAST>
+__device__ __forceinline__ void epi_steps(Epilogue<J> &s, Running<J> &run, const StackArgs &a,
+                                          int t_first, int lane) {
+    if constexpr (FIRST < LAST) {
+        epi_step<J, VOLUME, FIRST>(s, run, a, t_first, lane);
+        epi_steps<J, VOLUME, FIRST + 1, LAST>(s, run, a, t_first, lane);
+    }
+}
+
+// byte offset of table row r (0..7) inside one packed 16-byte chunk
+__device__ __forceinline__ unsigned chunk_entry(const uint4 &q, int r) {
+    const unsigned w = (r < 2) ? q.x : (r < 4) ? q.y : (r < 6) ? q.z : q.w;
+    return (r & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+template <int J> struct BatchRows { static constexpr int value = (J == 1) ? 4 : (J == 2) ? 2 : 1; };
+
+template <int J, int RB>
+__device__ __forceinline__ void issue_rows(double (&buf)[RB * J], const uint4 &q,
+                                           unsigned chunk_addr, int r0) {
+    constexpr int KT = kWave * J;
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {
+        const volatile lds_f64 *p =
+            (const volatile lds_f64 *)(uintptr_t)(chunk_addr + chunk_entry(q, r0 + k));
+#pragma unroll
+        for (int j = 0; j < J; ++j) buf[k * J + j] = p[(r0 + k) * KT + kWave * j];
+    }
+}
+
+template <int J, int RB>
+__device__ __forceinline__ void retire_rows(double (&acc)[J], const double (&buf)[RB * J]) {
+#pragma unroll
+    for (int k = 0; k < RB; ++k)                       // ascending row order per sample
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[j] += buf[k * J + j];
+}
+
+// Stack the (NCH-1)*8 rows of the full chunks of one node (offsets in q[0..NCH-2]); as soon as a
+// chunk's last row has been issued, its registers are refilled with the NEXT node's chunk
+// (`next` points at that node's offsets).  If WITH_EPI, `epi` is interleaved.
+template <int J, bool VOLUME, int NCH, bool WITH_EPI>
+__device__ __forceinline__ void stack_full_chunks(double (&acc)[J], uint4 (&q)[NCH],
+                                                  const uint16_t *next, unsigned lane_addr,
+                                                  Epilogue<J> &epi, Running<J> &run,
+                                                  const StackArgs &a, int t_first, int lane) {
+    constexpr int KT = kWave * J;
+    constexpr int RB = BatchRows<J>::value;
+    constexpr int NB = (NCH - 1) * 8 / RB;              // batches
+    constexpr int BPC = 8 / RB;                         // batches per chunk
+    if constexpr (NB == 0) {
+        if constexpr (WITH_EPI) epi_steps<J, VOLUME, 0, EpiSteps<VOLUME>::value>(epi, run, a, t_first, lane);
+        return;
+    } else {
+        double b0[RB * J], b1[RB * J];
+        issue_rows<J, RB>(b0, q[0], lane_addr, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (i + 1 < NB) {
+                const int ci = (i + 1) / BPC, bj = (i + 1) % BPC;
+                const unsigned ca = lane_addr + (unsigned)(ci * 8 * KT * 8);
+                if (i & 1) issue_rows<J, RB>(b0, q[ci], ca, bj * RB);
+                else issue_rows<J, RB>(b1, q[ci], ca, bj * RB);
+                if (bj == BPC - 1) q[ci] = load_offsets(next, ci * 8);   // chunk ci consumed
+            } else if (BPC == 1 || true) {
+                // the very last batch was issued one iteration ago
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (WITH_EPI) {
+                // this batch's share of the previous node's epilogue
+                switch (i) {
+#define QM_EPI_CASE(I)                                                                       \
+    case I:                                                                                  \
+        epi_steps<J, VOLUME, (I) * EpiSteps<VOLUME>::value / NB,                             \
+                  ((I) + 1) * EpiSteps<VOLUME>::value / NB>(epi, run, a,                      \
+                                                                               t_first, lane); \
+        break;
+                    QM_EPI_CASE(0) QM_EPI_CASE(1) QM_EPI_CASE(2) QM_EPI_CASE(3) QM_EPI_CASE(4)
+                    QM_EPI_CASE(5) QM_EPI_CASE(6) QM_EPI_CASE(7) QM_EPI_CASE(8) QM_EPI_CASE(9)
+                    QM_EPI_CASE(10) QM_EPI_CASE(11) QM_EPI_CASE(12) QM_EPI_CASE(13)
+                    QM_EPI_CASE(14) QM_EPI_CASE(15) QM_EPI_CASE(16) QM_EPI_CASE(17)
+                    QM_EPI_CASE(18) QM_EPI_CASE(19) QM_EPI_CASE(20) QM_EPI_CASE(21)
+                    QM_EPI_CASE(22) QM_EPI_CASE(23) QM_EPI_CASE(24) QM_EPI_CASE(25)
+                    QM_EPI_CASE(26) QM_EPI_CASE(27) QM_EPI_CASE(28) QM_EPI_CASE(29)
+                    QM_EPI_CASE(30) QM_EPI_CASE(31) QM_EPI_CASE(32) QM_EPI_CASE(33)
+                    QM_EPI_CASE(34) QM_EPI_CASE(35) QM_EPI_CASE(36) QM_EPI_CASE(37)
+                    QM_EPI_CASE(38) QM_EPI_CASE(39) QM_EPI_CASE(40) QM_EPI_CASE(41)
+                    QM_EPI_CASE(42) QM_EPI_CASE(43) QM_EPI_CASE(44) QM_EPI_CASE(45)
+                    QM_EPI_CASE(46) QM_EPI_CASE(47) QM_EPI_CASE(48) QM_EPI_CASE(49)
+                    QM_EPI_CASE(50) QM_EPI_CASE(51) QM_EPI_CASE(52) QM_EPI_CASE(53)
+                    QM_EPI_CASE(54) QM_EPI_CASE(55)
+#undef QM_EPI_CASE
+                    default: break;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (i & 1) retire_rows<J, RB>(acc, b1);
+            else retire_rows<J, RB>(acc, b0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // NCH > 0: the node's offsets are exactly NCH 16-byte chunks (row_pad == 8*NCH); the whole next
 // node is prefetched into registers while the current one is stacked, and the chunk loop is
 // unrolled.  NCH == 0: any row count, one-chunk-ahead prefetch (slower, always valid).
@@ -393,39 +570,46 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
         const uint16_t *brick_rel = a.rel + (int64_t)b * g.brick_nodes * g.row_pad;
 
         if constexpr (NCH > 0) {
-            uint4 qn[NCH];
+            uint4 q[NCH];                              // offsets of the node about to be stacked
             {
                 const uint16_t *p = brick_rel + (int64_t)(wave < nvalid ? wave : 0) * g.row_pad;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) qn[c] = load_offsets(p, c * 8);
+                for (int c = 0; c < NCH; ++c) q[c] = load_offsets(p, c * 8);
             }
             const int last_rows = S - 8 * (NCH - 1);
+            Epilogue<J> epi;
+            bool pending = false;                      // wave-uniform: epi holds a node
             for (int m = wave; m < nvalid; m += nwaves) {
                 const int node = ((x0 + lx) * g.ny + (y0 + ly)) * g.nz + (z0 + lz);
                 lz += nwaves;
                 while (lz >= vz) { lz -= vz; ++ly; }
                 while (ly >= vy) { ly -= vy; ++lx; }
+                // the node after this one (or a harmless reload of this one at the end)
+                const uint16_t *next =
+                    brick_rel + (int64_t)(m + nwaves < nvalid ? m + nwaves : m) * g.row_pad;
 
-                uint4 qc[NCH];
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) qc[c] = qn[c];
-                {   // whole next node (or a harmless reload of this one at the end)
-                    const int mn = m + nwaves < nvalid ? m + nwaves : m;
-                    const uint16_t *p = brick_rel + (int64_t)mn * g.row_pad;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) qn[c] = load_offsets(p, c * 8);
-                }
                 double acc[J];
                 start_node<J, VOLUME>(a, acc, node, t_first, lane);
-                unsigned addr[8];
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    unpack8(qc[c], lane_addr + (unsigned)(c * 8 * KT * 8), addr);
-                    if (c + 1 < NCH || last_rows == 8) ring_full<J>(acc, addr);
+                if (pending)
+                    stack_full_chunks<J, VOLUME, NCH, true>(acc, q, next, lane_addr, epi, run, a,
+                                                            t_first, lane);
+                else
+                    stack_full_chunks<J, VOLUME, NCH, false>(acc, q, next, lane_addr, epi, run,
+                                                             a, t_first, lane);
+                {   // last chunk (1..8 rows): generated asm, drains the LDS queue
+                    unsigned addr[8];
+                    unpack8(q[NCH - 1], lane_addr + (unsigned)((NCH - 1) * 8 * KT * 8), addr);
+                    q[NCH - 1] = load_offsets(next, (NCH - 1) * 8);
+                    if (last_rows == 8) ring_full<J>(acc, addr);
                     else ring_tail<J>(acc, addr, last_rows);
                 }
-                finish_node<J, VOLUME>(a, run, acc, node, t_first, lane);
+#pragma unroll
+                for (int j = 0; j < J; ++j) epi.x[j] = acc[j];
+                epi.node = node;
+                pending = true;
             }
+            if (pending)                               // the brick's last node: not overlapped
+                epi_steps<J, VOLUME, 0, EpiSteps<VOLUME>::value>(epi, run, a, t_first, lane);
         } else {
             // offset-chunk prefetch: one 8-row chunk ahead of consumption, in this wave's order
             int pm = wave, pc = 0;
@@ -596,7 +780,7 @@ __global__ void combine_kernel(const double *__restrict__ part_max,
         out_norm_or_sum[t] = total;
         out_idx[t] = bi;
     } else {
-        const double peak = (mode == 1) ? qm_exp(best) : best;
+        const double peak = (mode == 1) ? qm_exp2_peak(best) : best;
         out_max[t] = peak;
         out_norm_or_sum[t] = peak * n_nodes_total / total;     // migratelib.c:108
         out_idx[t] = (bi == kNoIndex) ? 0 : bi;

@@ -7,7 +7,7 @@ nodes, so the 3-D grid is sharded by contiguous ranges of x-planes (= contiguous
 ranges of flat node indices, flat = (ix*ny+iy)*nz+iz, quakemigrate/lut/lut.py:165-166):
 one process per GPU, each with its slab of the travel-time table resident, the
 (small) onset array replicated.  Per timestep every rank produces its partial
-``(log-domain max, global argmax, sum of coalescence)`` per sample with
+``(log2-domain max, global argmax, sum of coalescence)`` per sample with
 ``Engine.detect_partial`` and the only exchange is three tiny all-reduces over
 ``n_samples`` elements (48 KB each at 6000 samples) -- RCCL over xGMI on the GPU
 box, gloo in the CPU tests:
@@ -15,7 +15,7 @@ box, gloo in the CPU tests:
     gmax = all_reduce(pmax, MAX)
     gidx = all_reduce(where(pmax == gmax, pidx, INT64_MAX), MIN)   # lowest index wins
     gsum = all_reduce(psum, SUM)
-    max_coa = exp(gmax);  max_norm_coa = max_coa * n_nodes_total / gsum
+    max_coa = 2**gmax;  max_norm_coa = max_coa * n_nodes_total / gsum
 
 which reproduces the reference's tie-break (strict '>' in ascending node order,
 migratelib.c:102) exactly, because equal maxima on two ranks resolve to the lower
@@ -48,7 +48,7 @@ def combine_partials_local(pmax, pidx, psum, n_nodes_total):
                        torch.full_like(pidx, INT64_MAX))
     gidx = cand.min(dim=0).values
     gsum = psum.sum(dim=0)
-    peak = torch.exp(gmax)
+    peak = torch.exp2(gmax)
     return peak, peak * float(n_nodes_total) / gsum, gidx
 
 
@@ -65,7 +65,7 @@ def exchange_partials(pmax, pidx, psum, n_nodes_total, group=None):
     dist.all_reduce(gidx, op=dist.ReduceOp.MIN, group=group)
     gsum = psum.clone()
     dist.all_reduce(gsum, op=dist.ReduceOp.SUM, group=group)
-    peak = torch.exp(gmax)
+    peak = torch.exp2(gmax)
     return peak, peak * float(n_nodes_total) / gsum, gidx
 
 

@@ -158,7 +158,7 @@ def _worker(rank, world, port, tmp):
                               case.available, threads=2)
     vol = vol.reshape(-1, vol.shape[-1])
     local_idx = np.argmax(vol, axis=0)
-    pmax = torch.from_numpy(np.log(vol[local_idx, np.arange(vol.shape[1])]))
+    pmax = torch.from_numpy(np.log2(vol[local_idx, np.arange(vol.shape[1])]))
     pidx = torch.from_numpy(local_idx.astype(np.int64) + x0 * grid[1] * grid[2])
     psum = torch.from_numpy(vol.sum(axis=0))
     a, b, c = qd.exchange_partials(pmax, pidx, psum, int(np.prod(grid)))
