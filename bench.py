@@ -146,7 +146,7 @@ def main():
     n_local = int(np.prod(case.traveltimes.shape[:-1]))
     t_samples = case.onsets.shape[1]
 
-    tunables = dict(brick_x=8, brick_y=8, brick_z=8, samples_per_lane=4, waves=8)
+    tunables = dict(samples_per_lane=4, waves=8)       # brick shape: chosen per table
     tunables.update(json.loads(args.engine))
     eng = lib.Engine(local_rank, **tunables)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -218,7 +218,9 @@ def main():
                    "n_nodes_per_gpu": n_local, "n_rows": S, "n_samples": ns,
                    "sharding": "x-planes" if world > 1 else "none",
                    "exchange": "3 x all_reduce(n_samples) per step (RCCL)" if world > 1
-                   else "none", "engine": tunables},
+                   else "none", "engine": dict(tunables, brick=[eng.get("brick_x"),
+                                                                   eng.get("brick_y"),
+                                                                   eng.get("brick_z")])},
         "kernel": {"name": "qm::stack_lds_kernel<4,false,NCH>", "avg_ms": kern_s * 1e3,
                    "launches": kern_calls, "timing": "HIP events on the launch stream"},
         "roofline": {"bound": "hbm", "achieved": b_fused / kern_s / 1e9,

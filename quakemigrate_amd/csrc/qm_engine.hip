@@ -76,7 +76,7 @@ struct qm_engine {
     size_t ev_used = 0;
 
     // tunables
-    int cfg_bx = 4, cfg_by = 4, cfg_bz = 8;
+    int cfg_bx = 0, cfg_by = 0, cfg_bz = 0;      // 0 = choose the brick shape per table
     int cfg_j = 4;
     int cfg_waves = 8;
     int cfg_groups = 0;
@@ -422,9 +422,12 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
     if (!e || !key) return fail("qm_engine_config: NULL argument");
     const std::string k(key);
     if (k == "brick_x" || k == "brick_y" || k == "brick_z") {
-        if (v < 1 || v > 64) return fail("%s must be in 1..64", key);
-        if (e->have_lut) return fail("%s must be set before qm_engine_load_lut", key);
+        if (v < 0 || v > 64) return fail("%s must be in 0..64 (0 = automatic)", key);
         (k == "brick_x" ? e->cfg_bx : k == "brick_y" ? e->cfg_by : e->cfg_bz) = (int)v;
+        if (e->cfg_bx > 0) {                           // an explicit shape needs all three
+            if (e->cfg_by < 1) e->cfg_by = 1;
+            if (e->cfg_bz < 1) e->cfg_bz = 1;
+        }
     } else if (k == "samples_per_lane") {
         if (v != 1 && v != 2 && v != 4) return fail("samples_per_lane must be 1, 2 or 4");
         e->cfg_j = (int)v;
@@ -456,9 +459,9 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
 int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     if (!e || !key || !v) return fail("qm_engine_get: NULL argument");
     const std::string k(key);
-    if (k == "brick_x") *v = e->cfg_bx;
-    else if (k == "brick_y") *v = e->cfg_by;
-    else if (k == "brick_z") *v = e->cfg_bz;
+    if (k == "brick_x") *v = e->have_lut ? e->g.bx : e->cfg_bx;
+    else if (k == "brick_y") *v = e->have_lut ? e->g.by : e->cfg_by;
+    else if (k == "brick_z") *v = e->have_lut ? e->g.bz : e->cfg_bz;
     else if (k == "samples_per_lane") *v = e->cfg_j;
     else if (k == "waves") *v = e->cfg_waves;
     else if (k == "groups") *v = e->cfg_groups;
@@ -487,46 +490,60 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     if (n_nodes >= INT32_MAX) return fail("more than 2^31-1 nodes on one GPU is not supported");
     DeviceGuard guard(e->device);
     e->have_lut = false;
-    qm::GridDesc g{};
-    g.nx = nx; g.ny = ny; g.nz = nz;
-    g.bx = std::min(e->cfg_bx, (int)nx);
-    g.by = std::min(e->cfg_by, (int)ny);
-    g.bz = std::min(e->cfg_bz, (int)nz);
-    g.nbx = (nx + g.bx - 1) / g.bx;
-    g.nby = (ny + g.by - 1) / g.by;
-    g.nbz = (nz + g.bz - 1) / g.bz;
-    const int64_t nbricks = (int64_t)g.nbx * g.nby * g.nbz;
-    if (nbricks >= INT32_MAX) return fail("too many bricks");
-    g.nbricks = (int)nbricks;
-    g.brick_nodes = g.bx * g.by * g.bz;
-    g.n_rows = n_rows;
-    g.row_pad = (n_rows + 7) / 8 * 8;
-
     const size_t lut_elems = (size_t)n_nodes * n_rows;
-    if (e->d_lut.ensure(lut_elems)) return 1;
+    if (e->d_lut.ensure(lut_elems) || e->d_scalar.ensure(4)) return 1;
     QM_HIP(hipMemcpyAsync(e->d_lut.p, lut, lut_elems * sizeof(int32_t),
                           lut_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                           e->stream));
-    const size_t br = (size_t)nbricks * n_rows;
-    if (e->d_bmeta.ensure(4 * br) || e->d_btotal.ensure(nbricks) || e->d_scalar.ensure(4) ||
-        e->d_rel.ensure((size_t)nbricks * g.brick_nodes * g.row_pad))
-        return 1;
-    QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
-    hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
-                       e->d_lut.p, reinterpret_cast<int4 *>(e->d_bmeta.p), e->d_scalar.p);
-    QM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(qm::brick_prefix_kernel, dim3((g.nbricks + 255) / 256), dim3(256), 0,
-                       e->stream, g, reinterpret_cast<int4 *>(e->d_bmeta.p), e->d_btotal.p);
-    QM_HIP(hipGetLastError());
+
+    // Brick shape: the configured one, or (brick_x == 0) the largest candidate whose windows fit
+    // the LDS budget for (almost) every brick -- larger bricks amortise window staging, smaller
+    // ones have smaller delay spans.  Bricks that still do not fit go to the direct kernel.
+    static const int kShapes[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4},
+                                     {2, 4, 4}, {2, 2, 4}, {2, 2, 2}, {1, 1, 2}, {1, 1, 1}};
+    const int n_shapes = e->cfg_bx > 0 ? 1 : (int)(sizeof(kShapes) / sizeof(kShapes[0]));
+    const int KT = qm::kWave * e->cfg_j;
+    qm::GridDesc g{};
+    for (int s = 0; s < n_shapes; ++s) {
+        g = qm::GridDesc{};
+        g.nx = nx; g.ny = ny; g.nz = nz;
+        g.bx = std::min(e->cfg_bx > 0 ? e->cfg_bx : kShapes[s][0], (int)nx);
+        g.by = std::min(e->cfg_bx > 0 ? e->cfg_by : kShapes[s][1], (int)ny);
+        g.bz = std::min(e->cfg_bx > 0 ? e->cfg_bz : kShapes[s][2], (int)nz);
+        g.nbx = (nx + g.bx - 1) / g.bx;
+        g.nby = (ny + g.by - 1) / g.by;
+        g.nbz = (nz + g.bz - 1) / g.bz;
+        const int64_t nbricks = (int64_t)g.nbx * g.nby * g.nbz;
+        if (nbricks >= INT32_MAX) return fail("too many bricks");
+        g.nbricks = (int)nbricks;
+        g.brick_nodes = g.bx * g.by * g.bz;
+        g.n_rows = n_rows;
+        g.row_pad = (n_rows + 7) / 8 * 8;
+        const size_t br = (size_t)nbricks * n_rows;
+        if (e->d_bmeta.ensure(4 * br) || e->d_btotal.ensure(nbricks)) return 1;
+        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
+        hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
+                           e->d_lut.p, reinterpret_cast<int4 *>(e->d_bmeta.p), e->d_scalar.p);
+        QM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(qm::brick_prefix_kernel, dim3((g.nbricks + 255) / 256), dim3(256), 0,
+                           e->stream, g, reinterpret_cast<int4 *>(e->d_bmeta.p), e->d_btotal.p);
+        QM_HIP(hipGetLastError());
+        e->h_btotal.resize(nbricks);
+        QM_HIP(hipMemcpyAsync(e->h_btotal.data(), e->d_btotal.p, nbricks * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, e->stream));
+        QM_HIP(hipMemcpyAsync(&e->lut_max, e->d_scalar.p, sizeof(int32_t), hipMemcpyDeviceToHost,
+                              e->stream));
+        QM_HIP(hipStreamSynchronize(e->stream));
+        int64_t wide = 0;
+        for (int64_t b = 0; b < nbricks; ++b)
+            if (!qm::brick_fits(e->h_btotal[b], n_rows, KT, lds_cap_doubles(e))) ++wide;
+        if (wide * 200 <= nbricks) break;              // <= 0.5 % of the bricks on the slow path
+    }
+    if (e->d_rel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;
     hipLaunchKernelGGL(qm::brick_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
                        e->d_lut.p, reinterpret_cast<const int4 *>(e->d_bmeta.p), e->d_btotal.p,
                        e->d_rel.p);
     QM_HIP(hipGetLastError());
-    e->h_btotal.resize(nbricks);
-    QM_HIP(hipMemcpyAsync(e->h_btotal.data(), e->d_btotal.p, nbricks * sizeof(int32_t),
-                          hipMemcpyDeviceToHost, e->stream));
-    QM_HIP(hipMemcpyAsync(&e->lut_max, e->d_scalar.p, sizeof(int32_t), hipMemcpyDeviceToHost,
-                          e->stream));
     QM_HIP(hipStreamSynchronize(e->stream));
     e->g = g;
     e->n_nodes = n_nodes;

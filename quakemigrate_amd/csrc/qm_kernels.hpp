@@ -59,6 +59,14 @@ struct StackArgs {
     int want_scan;                 // write partials at all
 };
 
+// max of two non-NaN-producing operands without the canonicalising copy clang adds to fmax()
+// (NaN in `x` is ignored exactly like the reference's `current > max` test ignores it)
+__device__ __forceinline__ double max_keep(double best, double x) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(best), "v"(x));
+    return r;
+}
+
 template <typename I>
 __device__ __forceinline__ bool better(double v, I i, double best, I bi) {
     return (v > best) || (v == best && i < bi);
@@ -253,10 +261,8 @@ __device__ __forceinline__ void finish_node(const StackArgs &a, Running<J> &run,
             if (t < a.n_chunk) a.volume[(int64_t)node * a.vol_stride + t] = e;
         }
         run.vsum[j] += e;
-        if (x > run.bmax[j]) {
-            run.bmax[j] = x;
-            run.bidx[j] = node;
-        }
+        run.bidx[j] = (x > run.bmax[j]) ? node : run.bidx[j];   // strict: first node wins
+        run.bmax[j] = max_keep(run.bmax[j], x);
     }
 }
 
@@ -425,7 +431,7 @@ __device__ __forceinline__ void epi_step(Epilogue<J> &s, Running<J> &run, const 
         } else if constexpr (STEP == H1 + 2) {
             const bool gt = s.x[j] > run.bmax[j];                      // strict: first node wins
             run.bidx[j] = gt ? s.node : run.bidx[j];
-            run.bmax[j] = __builtin_fmax(run.bmax[j], s.x[j]);
+            run.bmax[j] = max_keep(run.bmax[j], s.x[j]);
         }
     }
 }

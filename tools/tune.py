@@ -37,7 +37,7 @@ def main():
     ref = None
     for cfg in grid:
         cfg = dict(cfg)
-        bx, by, bz = cfg.pop("brick", (4, 4, 8))
+        bx, by, bz = cfg.pop("brick", (0, 0, 0))
         try:
             eng = lib.Engine(0, brick_x=bx, brick_y=by, brick_z=bz, **cfg)
             eng.load_lut(case.traveltimes)
@@ -49,6 +49,7 @@ def main():
             if ref is None:
                 ref = out
             same = bool(np.array_equal(out[2], ref[2]) and np.allclose(out[0], ref[0], rtol=1e-12))
+            bx, by, bz = eng.get("brick_x"), eng.get("brick_y"), eng.get("brick_z")
             print(json.dumps(dict(cfg=cfg, brick=[bx, by, bz], wide=wide, nbricks=eng.get("n_bricks"),
                                   ms=round(best, 3), gns=round(work / best / 1e6, 2), same=same)),
                   flush=True)
