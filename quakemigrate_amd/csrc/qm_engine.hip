@@ -160,8 +160,10 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
         a.brick_list = nullptr;
         a.n_list = 0;
         int rc;
-        // specialised (whole-node prefetch, unrolled) variants for up to 64 table rows
-        switch (e->cfg_generic ? 0 : e->g.row_pad / 8) {
+        // Variants specialised on the number of 8-row offset chunks (whole-node offset prefetch;
+        // detect: software-pipelined node loop) for up to 64 table rows; otherwise, and for the
+        // reference's accumulate-into-volume semantics, the generic kernel.
+        switch ((e->cfg_generic || a.accumulate) ? 0 : e->g.row_pad / 8) {
             case 1: rc = launch_lds<J, VOLUME, 1>(e, a, groups_lds, threads, lds); break;
             case 2: rc = launch_lds<J, VOLUME, 2>(e, a, groups_lds, threads, lds); break;
             case 3: rc = launch_lds<J, VOLUME, 3>(e, a, groups_lds, threads, lds); break;

@@ -252,27 +252,32 @@ template <int J, bool VOLUME>
 __device__ __forceinline__ void finish_node(const StackArgs &a, Running<J> &run,
                                             const double (&acc)[J], int node, int t_first,
                                             int lane) {
+    double e[J];
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
+    for (int j = 0; j < J; ++j) {                       // branch-free: the J chains interleave
         const double x = acc[j] * a.z_scale;            // z: log2 of the coalescence
-        const double e = qm_exp2<Exp2Degree<VOLUME>::value>(x);
-        if (VOLUME) {
-            const int t = t_first + lane + kWave * j;
-            if (t < a.n_chunk) a.volume[(int64_t)node * a.vol_stride + t] = e;
-        }
-        run.vsum[j] += e;
+        e[j] = qm_exp2<Exp2Degree<VOLUME>::value>(x);
+        run.vsum[j] += e[j];
         run.bidx[j] = (x > run.bmax[j]) ? node : run.bidx[j];   // strict: first node wins
         run.bmax[j] = max_keep(run.bmax[j], x);
     }
+    if (VOLUME) {
+        double *row = a.volume + (int64_t)node * a.vol_stride + (t_first + lane);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (t_first + lane + kWave * j < a.n_chunk) row[kWave * j] = e[j];
+    }
 }
 
-template <int J, bool VOLUME>
+// ACCUM: start from the volume's current content (the reference's `+=`, migratelib.c:57); only
+// the generic kernels are built with it (the engine routes accumulate requests there).
+template <int J, bool ACCUM>
 __device__ __forceinline__ void start_node(const StackArgs &a, double (&acc)[J], int node,
                                            int t_first, int lane) {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         acc[j] = 0.0;
-        if (VOLUME) {
+        if (ACCUM) {
             const int t = t_first + lane + kWave * j;
             if (a.accumulate && t < a.n_chunk) acc[j] = a.volume[(int64_t)node * a.vol_stride + t];
         }
@@ -575,7 +580,44 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
         int lz = wave % vz, ly = (wave / vz) % vy, lx = wave / (vz * vy);
         const uint16_t *brick_rel = a.rel + (int64_t)b * g.brick_nodes * g.row_pad;
 
-        if constexpr (NCH > 0) {
+        if constexpr (NCH > 0 && VOLUME) {
+            // Volume-writing variant: asm ring + epilogue in place.  The next node's offsets
+            // are loaded BEFORE this node's stores are issued: gfx9 has one vmcnt for loads and
+            // stores, so a load issued after the stores could only be waited for together with
+            // them (an HBM write round trip per chunk).
+            uint4 qn[NCH];
+            {
+                const uint16_t *p = brick_rel + (int64_t)(wave < nvalid ? wave : 0) * g.row_pad;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) qn[c] = load_offsets(p, c * 8);
+            }
+            const int last_rows = S - 8 * (NCH - 1);
+            for (int m = wave; m < nvalid; m += nwaves) {
+                const int node = ((x0 + lx) * g.ny + (y0 + ly)) * g.nz + (z0 + lz);
+                lz += nwaves;
+                while (lz >= vz) { lz -= vz; ++ly; }
+                while (ly >= vy) { ly -= vy; ++lx; }
+                uint4 qc[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) qc[c] = qn[c];
+                {
+                    const uint16_t *p =
+                        brick_rel + (int64_t)(m + nwaves < nvalid ? m + nwaves : m) * g.row_pad;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) qn[c] = load_offsets(p, c * 8);
+                }
+                double acc[J];
+                start_node<J, false>(a, acc, node, t_first, lane);
+                unsigned addr[8];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    unpack8(qc[c], lane_addr + (unsigned)(c * 8 * KT * 8), addr);
+                    if (c + 1 < NCH || last_rows == 8) ring_full<J>(acc, addr);
+                    else ring_tail<J>(acc, addr, last_rows);
+                }
+                finish_node<J, VOLUME>(a, run, acc, node, t_first, lane);
+            }
+        } else if constexpr (NCH > 0) {
             uint4 q[NCH];                              // offsets of the node about to be stacked
             {
                 const uint16_t *p = brick_rel + (int64_t)(wave < nvalid ? wave : 0) * g.row_pad;
@@ -595,7 +637,7 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
                     brick_rel + (int64_t)(m + nwaves < nvalid ? m + nwaves : m) * g.row_pad;
 
                 double acc[J];
-                start_node<J, VOLUME>(a, acc, node, t_first, lane);
+                start_node<J, false>(a, acc, node, t_first, lane);
                 if (pending)
                     stack_full_chunks<J, VOLUME, NCH, true>(acc, q, next, lane_addr, epi, run, a,
                                                             t_first, lane);

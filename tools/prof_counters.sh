@@ -2,7 +2,7 @@
 # PMC passes over one engine configuration (development aid; run on the GPU box via gpurun).
 # usage: tools/prof_counters.sh <config> '<sweep json>' <tag>
 set -u
-CFG=${1:-C2}; SWEEP=${2:-'[{"samples_per_lane":4,"waves":8}]'}; TAG=${3:-pmc}
+CFG=${1:-C2}; SWEEP=${2:-'[{"samples_per_lane":4,"waves":8}]'}; TAG=${3:-pmc}; EXTRA=${4:-}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   local name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o $name -- \
-      python $ROOT/tools/tune.py --config $CFG --reps 1 --sweep "$SWEEP" > $OUT/$name.log 2>&1
+      python $ROOT/tools/tune.py --config $CFG --reps 1 --sweep "$SWEEP" $EXTRA > $OUT/$name.log 2>&1
   local f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
     python - "$f" <<'PY'

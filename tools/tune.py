@@ -20,9 +20,17 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--sweep", default="default")
+    ap.add_argument("--ns", type=int, default=0, help="override n_samples")
+    ap.add_argument("--volume", action="store_true", help="materialising path (device volume)")
     args = ap.parse_args()
     t0 = time.time()
-    case = synth.make_case(args.config)
+    case = synth.make_case(args.config, n_samples=args.ns or None)
+    vol = None
+    if args.volume:
+        import torch
+        vol = torch.empty((case.n_nodes_total, case.n_samples), dtype=torch.float64, device="cuda")
+        scan = tuple(torch.empty(case.n_samples, dtype=d, device="cuda")
+                     for d in (torch.float64, torch.float64, torch.int64))
     print(f"case {args.config} built in {time.time()-t0:.1f}s grid={case.grid} S={case.available} "
           f"ns={case.n_samples} lutmax={case.traveltimes.max()}", flush=True)
     lon = np.ascontiguousarray(np.log(np.clip(case.onsets, 0.01, np.inf)))
@@ -44,7 +52,11 @@ def main():
             wide = eng.get("n_wide_bricks")
             best = 1e9
             for _ in range(args.reps):
-                out = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+                if vol is None:
+                    out = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+                else:
+                    eng.migrate(lon, case.fsmp, case.lsmp, case.available, vol, scan_out=scan)
+                    out = tuple(t.cpu().numpy() for t in scan)
                 best = min(best, eng.last_kernel_ms())
             if ref is None:
                 ref = out
