@@ -51,7 +51,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C3", help="C3 (default), C2 or C1")
+    ap.add_argument("--config", default="C3",
+                    help="C3 (default, weak-scaled slab per GPU), C2, C1; C4 = the 401x401x201 x "
+                         "60 x 12000 grid partitioned over the N GPUs; C5 = C3 as a continuous "
+                         "stream of --steps timesteps with copies overlapped on HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-materialised", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -122,10 +125,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # development aid: QM_BENCH_ONE_DEVICE=1 runs the N>1 code path with every rank on GPU 0 and
+    # the gloo backend (RCCL refuses two ranks on one device) -- plumbing check on a 1-GPU box
+    one_device = os.environ.get("QM_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     elif args.gpus > 1:
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
                          f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py ...")
@@ -133,12 +144,18 @@ def main():
     torch.cuda.set_device(dev)
 
     # ---- workload: this rank's slab of the (weak-scaled) grid -----------------------
-    base = synth.CONFIGS[args.config]
+    streaming = args.config == "C5"
+    cfg_name = "C3" if streaming else args.config
+    base = synth.CONFIGS[cfg_name]
     nx, ny, nz = base["grid"]
-    grid = (nx * world, ny, nz)
-    x_range = (nx * rank, nx * (rank + 1))
+    if cfg_name == "C4":                                # fixed grid, partitioned over the GPUs
+        grid = (nx, ny, nz)
+        x_range = qd.shard_planes(nx, world, rank)
+    else:                                               # weak scaling: a full slab per GPU
+        grid = (nx * world, ny, nz)
+        x_range = (nx * rank, nx * (rank + 1))
     n_pool = 3                                          # distinct timesteps cycled through
-    cases = [synth.make_case(args.config, step=s, grid=grid, x_range=x_range)
+    cases = [synth.make_case(cfg_name, step=s, grid=grid, x_range=x_range)
              for s in range(n_pool)]
     case = cases[0]
     S, ns = case.available, case.n_samples
@@ -177,8 +194,20 @@ def main():
     fence()
     eng.config("log_timing", 1)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        res = step(args.warmup + i)
+    if streaming:
+        # host onset windows -> pinned -> H2D on a copy stream, detect + D2H on a compute
+        # stream; the timed region includes every copy (PCIe-inclusive rate)
+        from quakemigrate_amd.stream import StreamingDetector
+
+        host = [np.ascontiguousarray(np.log(np.clip(c.onsets, 0.01, np.inf))) for c in cases]
+        sd = StreamingDetector(eng, S, t_samples, case.fsmp, case.lsmp, case.available,
+                               n_nodes_total=n_total, depth=3, device=dev)
+        got = sd.run(host[(args.warmup + i) % n_pool] for i in range(args.steps))
+        res = tuple(torch.from_numpy(a) for a in got[-1])
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    else:
+        for i in range(args.steps):
+            res = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
     kern_ms, kern_calls = eng.kernel_log()
@@ -211,10 +240,12 @@ def main():
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.config} detect sweep: {nx}x{ny}x{nz} nodes per GPU "
-                               f"(grid {grid[0]}x{ny}x{nz}), {S} onset rows, {ns} samples "
-                               f"per step @50 Hz, fused migrate+find_max_coa, table and "
-                               f"onsets resident in HBM",
+        "config": {"workload": f"{args.config} detect sweep: {x_range[1] - x_range[0]}x{ny}x{nz} "
+                               f"nodes on rank 0 (grid {grid[0]}x{ny}x{nz}), {S} onset rows, "
+                               f"{ns} samples per step, fused migrate+find_max_coa, table "
+                               f"resident in HBM, onsets "
+                               + ("streamed from pinned host memory (copies inside the timed "
+                                  "region)" if streaming else "resident in HBM"),
                    "n_nodes_per_gpu": n_local, "n_rows": S, "n_samples": ns,
                    "sharding": "x-planes" if world > 1 else "none",
                    "exchange": "3 x all_reduce(n_samples) per step (RCCL)" if world > 1
@@ -240,7 +271,7 @@ def main():
     }
 
     # ---- locate-style materialising variant on the same grid (HBM-write bound) ------
-    if not args.no_materialised and world == 1:
+    if not args.no_materialised and world == 1 and cfg_name == "C3" and not streaming:
         ns_loc = 401                                    # 4 * marginal_window(2 s) * 50 Hz + 1
         on = onsets_dev[0][:, : case.fsmp + ns_loc + case.lsmp].contiguous()
         vol = torch.empty((n_local, ns_loc), dtype=torch.float64, device=dev)
@@ -266,7 +297,7 @@ def main():
                         f"({8.0 * n_local * ns_loc / 1e9:.1f} GB) written to HBM + scan"}
         del vol
 
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and not streaming:
         result["cpu_baseline"] = cpu_baseline(case, args.cpu_seconds)
     else:
         result["cpu_baseline"] = None

@@ -324,3 +324,24 @@ def test_migration_scan_compute_mirrors_reference_glue(lib, oracle):
     ref = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp, 6, threads=4)
     np.testing.assert_allclose(map4d, ref, rtol=TIGHT)
     eng.close()
+
+
+def test_streaming_detector_matches_step_by_step(lib, oracle):
+    """configs[4] plumbing: overlapped H2D / compute / D2H gives the per-step results."""
+    from quakemigrate_amd.stream import StreamingDetector
+
+    steps = 7
+    cases = [synth.make_case("C2", step=s, grid=(14, 12, 11), rows=6, n_samples=300)
+             for s in range(steps)]
+    c0 = cases[0]
+    eng = lib.Engine(0)
+    eng.load_lut(c0.traveltimes)
+    windows = [oracle.log_onsets(c.onsets) for c in cases]
+    sd = StreamingDetector(eng, 6, windows[0].shape[1], c0.fsmp, c0.lsmp, c0.available,
+                           depth=3)
+    got = sd.run(iter(windows))
+    assert len(got) == steps
+    for c, g in zip(cases, got):
+        want = oracle.detect(c.onsets, c.traveltimes, c.fsmp, c.lsmp, c.available, threads=4)
+        _assert_series(g, want)
+    eng.close()
