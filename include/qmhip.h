@@ -71,9 +71,10 @@ int qm_device_count(void);
 int qm_engine_create(int device_id, qm_engine **out);
 void qm_engine_destroy(qm_engine *e);
 
-/* run all asynchronous work on this hipStream_t (e.g. torch's current stream);
- * NULL = the engine's own stream. */
-int qm_engine_set_stream(qm_engine *e, void *hip_stream);
+/* run all asynchronous work on this hipStream_t (e.g. torch's current stream; a
+ * NULL handle is the device's default stream), or, with use_own != 0, on the
+ * engine's private non-blocking stream (the initial state). */
+int qm_engine_set_stream(qm_engine *e, void *hip_stream, int use_own);
 int qm_engine_synchronize(qm_engine *e);
 
 /* tunables, set BEFORE qm_engine_load_lut: "brick_x","brick_y","brick_z"

@@ -59,7 +59,7 @@ qmlib.qm_device_count.restype = ctypes.c_int
 qmlib.qm_engine_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
 qmlib.qm_engine_destroy.argtypes = [_vp]
 qmlib.qm_engine_destroy.restype = None
-qmlib.qm_engine_set_stream.argtypes = [_vp, _vp]
+qmlib.qm_engine_set_stream.argtypes = [_vp, _vp, ctypes.c_int]
 qmlib.qm_engine_synchronize.argtypes = [_vp]
 qmlib.qm_engine_config.argtypes = [_vp, ctypes.c_char_p, c_int64]
 qmlib.qm_engine_get.argtypes = [_vp, ctypes.c_char_p, ctypes.POINTER(c_int64)]
@@ -131,7 +131,15 @@ class Engine:
         return int(v.value)
 
     def set_stream(self, stream_ptr):
-        _check(qmlib.qm_engine_set_stream(self._h, _vp(stream_ptr or None)))
+        """
+        Run on the given ``hipStream_t`` handle (an int; 0 is the device's default stream,
+        i.e. ``torch.cuda.current_stream().cuda_stream`` outside a stream context), or on
+        the engine's private stream with ``None``.
+        """
+        if stream_ptr is None:
+            _check(qmlib.qm_engine_set_stream(self._h, _vp(None), 1))
+        else:
+            _check(qmlib.qm_engine_set_stream(self._h, _vp(int(stream_ptr) or None), 0))
 
     def synchronize(self):
         _check(qmlib.qm_engine_synchronize(self._h))

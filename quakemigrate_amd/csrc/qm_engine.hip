@@ -407,9 +407,11 @@ void qm_engine_destroy(qm_engine *e) {
     delete e;
 }
 
-int qm_engine_set_stream(qm_engine *e, void *hip_stream) {
+int qm_engine_set_stream(qm_engine *e, void *hip_stream, int use_own) {
     if (!e) return fail("engine is NULL");
-    e->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : e->own_stream;
+    // NULL with use_own == 0 is the device's default (null) stream -- what
+    // torch.cuda.current_stream().cuda_stream is unless a stream context is active
+    e->stream = use_own ? e->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
     return 0;
 }
 
