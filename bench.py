@@ -163,7 +163,7 @@ def main():
     n_local = int(np.prod(case.traveltimes.shape[:-1]))
     t_samples = case.onsets.shape[1]
 
-    tunables = dict(samples_per_lane=4, waves=8)       # brick shape: chosen per table
+    tunables = dict(waves=8)       # brick shape and samples per lane: chosen per table
     tunables.update(json.loads(args.engine))
     eng = lib.Engine(local_rank, **tunables)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -251,8 +251,10 @@ def main():
                    "exchange": "3 x all_reduce(n_samples) per step (RCCL)" if world > 1
                    else "none", "engine": dict(tunables, brick=[eng.get("brick_x"),
                                                                    eng.get("brick_y"),
-                                                                   eng.get("brick_z")])},
-        "kernel": {"name": "qm::stack_lds_kernel<4,false,NCH>", "avg_ms": kern_s * 1e3,
+                                                                   eng.get("brick_z")],
+                                               samples_per_lane=eng.get("samples_per_lane"))},
+        "kernel": {"name": f"qm::stack_lds_kernel<{eng.get('samples_per_lane')},false,"
+                           f"{(S + 7) // 8}>", "avg_ms": kern_s * 1e3,
                    "launches": kern_calls, "timing": "HIP events on the launch stream"},
         "roofline": {"bound": "hbm", "achieved": b_fused / kern_s / 1e9,
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s",

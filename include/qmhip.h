@@ -79,7 +79,8 @@ int qm_engine_synchronize(qm_engine *e);
 
 /* tunables, set BEFORE qm_engine_load_lut: "brick_x","brick_y","brick_z"
  * (node-brick shape; brick_x = 0, the default, picks the largest shape whose
- * windows fit LDS for >= 99.5 % of the bricks), "samples_per_lane" (1,2,4: time tile = 64*J samples),
+ * windows fit LDS for >= 99.5 % of the bricks), "samples_per_lane" (0 = by table width (default), 1, 2, 4: time tile = 64*J
+ * samples),
  * "waves" (wavefronts per workgroup), "groups" (brick groups per time tile,
  * 0 = auto), "lds_bytes" (window budget per workgroup), "force_direct"
  * (1 = bypass the LDS-tiled kernel; debugging / cross-check). */

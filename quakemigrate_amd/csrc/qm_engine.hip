@@ -77,7 +77,8 @@ struct qm_engine {
 
     // tunables
     int cfg_bx = 0, cfg_by = 0, cfg_bz = 0;      // 0 = choose the brick shape per table
-    int cfg_j = 4;
+    int cfg_j = 0;                  // samples per lane (time tile = 64*J); 0 = by table width
+    int n_rows_hint = 0;            // row count the automatic choice is based on
     int cfg_waves = 8;
     int cfg_groups = 0;
     int cfg_lds_bytes = 80 * 1024;
@@ -117,11 +118,24 @@ struct DeviceGuard {
 
 int lds_cap_doubles(const qm_engine *e) { return e->cfg_lds_bytes / 8; }
 
+// Samples per lane: explicit, or the largest J whose S row windows leave >= 20 % of the LDS
+// budget for the delay spans (J = 4 additionally needs S <= 40: beyond that its software-
+// pipelined kernel no longer fits 128 VGPRs).
+int eff_j(const qm_engine *e) {
+    if (e->cfg_j > 0) return e->cfg_j;
+    const int S = e->n_rows_hint > 0 ? e->n_rows_hint : 1;
+    for (int j : {4, 2, 1}) {
+        if (j == 4 && S > 40) continue;
+        if ((int64_t)S * qm::kWave * j * 8 * 5 <= (int64_t)e->cfg_lds_bytes * 4) return j;
+    }
+    return 1;
+}
+
 // bricks whose windows do not fit the LDS budget for the current tile length
 int plan_wide(qm_engine *e) {
-    const int KT = qm::kWave * e->cfg_j;
+    const int KT = qm::kWave * eff_j(e);
     const int cap = lds_cap_doubles(e);
-    if (e->plan_j == e->cfg_j && e->plan_cap == cap) return 0;
+    if (e->plan_j == eff_j(e) && e->plan_cap == cap) return 0;
     std::vector<int32_t> wide;
     for (int b = 0; b < e->g.nbricks; ++b) {
         if (!qm::brick_fits(e->h_btotal[b], e->g.n_rows, KT, cap)) wide.push_back(b);
@@ -133,7 +147,7 @@ int plan_wide(qm_engine *e) {
                               hipMemcpyHostToDevice, e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
     }
-    e->plan_j = e->cfg_j;
+    e->plan_j = eff_j(e);
     e->plan_cap = cap;
     return 0;
 }
@@ -216,7 +230,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
               int available, int sample0, int n_chunk, double *volume, int64_t vol_stride,
               int accumulate, bool want_scan, int *n_sets) {
     if (plan_wide(e)) return 1;
-    const int J = e->cfg_j;
+    const int J = eff_j(e);
     const int KT = qm::kWave * J;
     qm::StackArgs a{};
     a.g = e->g;
@@ -433,7 +447,8 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
             if (e->cfg_bz < 1) e->cfg_bz = 1;
         }
     } else if (k == "samples_per_lane") {
-        if (v != 1 && v != 2 && v != 4) return fail("samples_per_lane must be 1, 2 or 4");
+        if (v != 0 && v != 1 && v != 2 && v != 4)
+            return fail("samples_per_lane must be 0 (automatic), 1, 2 or 4");
         e->cfg_j = (int)v;
     } else if (k == "waves") {
         if (v < 1 || v > 16) return fail("waves must be 1..16");
@@ -466,7 +481,7 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     if (k == "brick_x") *v = e->have_lut ? e->g.bx : e->cfg_bx;
     else if (k == "brick_y") *v = e->have_lut ? e->g.by : e->cfg_by;
     else if (k == "brick_z") *v = e->have_lut ? e->g.bz : e->cfg_bz;
-    else if (k == "samples_per_lane") *v = e->cfg_j;
+    else if (k == "samples_per_lane") *v = e->have_lut ? eff_j(e) : e->cfg_j;
     else if (k == "waves") *v = e->cfg_waves;
     else if (k == "groups") *v = e->cfg_groups;
     else if (k == "lds_bytes") *v = e->cfg_lds_bytes;
@@ -506,7 +521,8 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     static const int kShapes[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4},
                                      {2, 4, 4}, {2, 2, 4}, {2, 2, 2}, {1, 1, 2}, {1, 1, 1}};
     const int n_shapes = e->cfg_bx > 0 ? 1 : (int)(sizeof(kShapes) / sizeof(kShapes[0]));
-    const int KT = qm::kWave * e->cfg_j;
+    e->n_rows_hint = n_rows;
+    const int KT = qm::kWave * eff_j(e);
     qm::GridDesc g{};
     for (int s = 0; s < n_shapes; ++s) {
         g = qm::GridDesc{};
@@ -643,7 +659,7 @@ int qm_engine_migrate(qm_engine *e, const double *log_onsets, int onsets_on_devi
             return 1;
     } else {
         // host volume: stream it through a device chunk buffer, time-chunk by time-chunk
-        const int KT = qm::kWave * e->cfg_j;
+        const int KT = qm::kWave * eff_j(e);
         int64_t chunk = e->cfg_chunk_bytes / (8 * e->n_nodes);
         chunk = std::max<int64_t>(KT, chunk / KT * KT);
         chunk = std::min<int64_t>(chunk, ns);

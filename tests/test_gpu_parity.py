@@ -345,3 +345,19 @@ def test_streaming_detector_matches_step_by_step(lib, oracle):
         want = oracle.detect(c.onsets, c.traveltimes, c.fsmp, c.lsmp, c.available, threads=4)
         _assert_series(g, want)
     eng.close()
+
+
+@pytest.mark.parametrize("rows", [3, 8, 17, 33, 47, 60, 64, 70, 130])
+def test_any_row_count_picks_a_fitting_tile_and_matches_oracle(lib, oracle, rows):
+    """Automatic samples-per-lane / brick choice for narrow to very wide tables."""
+    case = synth.make_case("C2", step=6, grid=(12, 10, 9), rows=rows, n_samples=301)
+    want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
+                         case.available, threads=4)
+    eng = lib.Engine(0)
+    eng.load_lut(case.traveltimes)
+    j = eng.get("samples_per_lane")
+    assert j == (4 if rows <= 32 else 2 if rows <= 64 else 1)
+    got = eng.detect(oracle.log_onsets(case.onsets), case.fsmp, case.lsmp, case.available)
+    _assert_series(got, want)
+    assert eng.get("n_wide_bricks") == 0
+    eng.close()

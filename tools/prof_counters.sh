@@ -32,5 +32,7 @@ PY
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT
+run fetch FETCH_SIZE
+run write WRITE_SIZE
 # keep only the small csv summaries
 find $OUT -name "*.csv" -size +2M -delete
