@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--no-materialised", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--engine", default="{}", help="json dict of engine tunables")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="single process: build and time the slab rank --emulate-rank of an "
+                         "N-GPU partition would hold (no exchange); for measuring C4 on 1 GPU")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     return ap.parse_args()
 
 
@@ -142,6 +146,9 @@ def main():
                          f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py ...")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    part_world, part_rank = world, rank                 # partition used to cut the grid
+    if args.emulate_world > 0 and world == 1:
+        part_world, part_rank = args.emulate_world, args.emulate_rank
 
     # ---- workload: this rank's slab of the (weak-scaled) grid -----------------------
     streaming = args.config == "C5"
@@ -150,10 +157,10 @@ def main():
     nx, ny, nz = base["grid"]
     if cfg_name == "C4":                                # fixed grid, partitioned over the GPUs
         grid = (nx, ny, nz)
-        x_range = qd.shard_planes(nx, world, rank)
+        x_range = qd.shard_planes(nx, part_world, part_rank)
     else:                                               # weak scaling: a full slab per GPU
-        grid = (nx * world, ny, nz)
-        x_range = (nx * rank, nx * (rank + 1))
+        grid = (nx * part_world, ny, nz)
+        x_range = (nx * part_rank, nx * (part_rank + 1))
     n_pool = 3                                          # distinct timesteps cycled through
     cases = [synth.make_case(cfg_name, step=s, grid=grid, x_range=x_range)
              for s in range(n_pool)]
@@ -221,6 +228,8 @@ def main():
     last = (args.warmup + args.steps - 1) % n_pool
     idx = res[2].cpu().numpy()
     for (ijk, t_ev) in cases[last].event_nodes:
+        if part_world != world and not (x_range[0] <= ijk[0] < x_range[1]):
+            continue                                    # emulated slab: event lies elsewhere
         want = np.ravel_multi_index(ijk, grid)
         assert idx[t_ev] == want, f"event at sample {t_ev}: node {idx[t_ev]} != {want}"
 
@@ -229,6 +238,8 @@ def main():
             dist.destroy_process_group()
         return
 
+    if part_world != world:
+        n_total = n_local                               # emulated slab: count what was stacked
     work_step = n_total * ns                            # node-samples per step, whole job
     value = work_step * args.steps / elapsed
     kern_s = kern_ms / 1e3 / max(kern_calls, 1)         # avg stacking-kernel time, this rank

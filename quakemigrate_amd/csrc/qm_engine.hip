@@ -215,10 +215,11 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
 int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu) {
     // Workgroups all do the same amount of work, so the grid should be a whole number of
     // "rounds" over the resident slots (n_cu * blocks_per_cu): ntiles * groups <= rounds * slots,
-    // as close from below as possible; 4 rounds keep the partial-set count small while the
-    // dispatcher still has slack.  Never more groups than there are bricks.
+    // as close from below as possible.  12 rounds measured best on C2/C3 (finer load balance
+    // than 4; flat beyond); the partial sets stay a few tens of MB.  Never more groups than
+    // there are bricks.
     const int64_t slots = (int64_t)e->n_cu * blocks_per_cu;
-    int64_t want = (4 * slots) / ntiles;
+    int64_t want = (12 * slots) / ntiles;
     if (want < 1) want = std::max<int64_t>(1, slots / ntiles);
     want = std::max<int64_t>(1, std::min<int64_t>(want, units));
     return (int)want;
