@@ -43,7 +43,7 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12           # B/s  (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 LDS_PEAK = 150.0e12         # B/s  aggregate ds_read_b64/b128
 FP64_PEAK = 39.3e12         # vector FP64 instructions-lanes / s (78.6 TFLOP/s FMA)
-EXP_FP64_OPS = 19           # FP64-rate VALU ops of qm_exp (qm_kernels.hpp)
+EXP_FP64_OPS = 18           # FP64-rate VALU ops per node-sample besides the S adds (2^z, sum, max)
 
 
 def parse():

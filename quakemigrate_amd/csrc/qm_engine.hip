@@ -122,8 +122,8 @@ int lds_cap_doubles(const qm_engine *e) { return e->cfg_lds_bytes / 8; }
 // budget for the delay spans (J = 4 additionally needs S <= 40: beyond that its software-
 // pipelined kernel no longer fits 128 VGPRs).
 int eff_j(const qm_engine *e) {
-    if (e->cfg_j > 0) return e->cfg_j;
     const int S = e->n_rows_hint > 0 ? e->n_rows_hint : 1;
+    if (e->cfg_j > 0) return (e->cfg_j == 4 && S > 40) ? 2 : e->cfg_j;   // see below
     for (int j : {4, 2, 1}) {
         if (j == 4 && S > 40) continue;
         if ((int64_t)S * qm::kWave * j * 8 * 5 <= (int64_t)e->cfg_lds_bytes * 4) return j;

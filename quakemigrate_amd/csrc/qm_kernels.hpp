@@ -505,8 +505,6 @@ __device__ __forceinline__ void stack_full_chunks(double (&acc)[J], uint4 (&q)[N
                 if (i & 1) issue_rows<J, RB>(b0, q[ci], ca, bj * RB);
                 else issue_rows<J, RB>(b1, q[ci], ca, bj * RB);
                 if (bj == BPC - 1) q[ci] = load_offsets(next, ci * 8);   // chunk ci consumed
-            } else if (BPC == 1 || true) {
-                // the very last batch was issued one iteration ago
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (WITH_EPI) {
