@@ -308,6 +308,19 @@ def main():
             "node_samples_per_s": n_local * ns_loc / sec,
             "workload": f"locate window: same grid, {ns_loc} samples, volume "
                         f"({8.0 * n_local * ns_loc / 1e9:.1f} GB) written to HBM + scan"}
+        # find_max_coa alone on that resident volume (scan_volume_kernel): pure HBM read
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        eng.find_max_coa(vol, ns_loc, n_local, o2)
+        e0.record()
+        for _ in range(reps):
+            eng.find_max_coa(vol, ns_loc, n_local, o2)
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) / 1e3 / reps
+        result["roofline_find_max_coa"] = {
+            "bound": "hbm", "achieved": 8.0 * n_local * ns_loc / sec / 1e9, "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s", "frac": 8.0 * n_local * ns_loc / sec / HBM_PEAK, "avg_ms": sec * 1e3,
+            "workload": "find_max_coa of the resident locate volume (scan + combine kernels)"}
         del vol
 
     if not args.no_cpu_baseline and world == 1 and not streaming:

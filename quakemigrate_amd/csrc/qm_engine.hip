@@ -313,8 +313,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
 int combine(qm_engine *e, const double *pmax, const int64_t *pidx, const double *psum, int sets,
             int n, int mode, int64_t node_offset, int64_t n_nodes_total, double *o_max,
             double *o_second, int64_t *o_idx) {
-    const int threads = 256;
-    hipLaunchKernelGGL(qm::combine_kernel, dim3((n + threads - 1) / threads), dim3(threads), 0,
+    hipLaunchKernelGGL(qm::combine_kernel, dim3((n + qm::kWave - 1) / qm::kWave), dim3(256), 0,
                        e->stream, pmax, pidx, psum, sets, n, mode, node_offset,
                        (double)n_nodes_total, o_max, o_second, o_idx);
     QM_HIP(hipGetLastError());
@@ -698,17 +697,17 @@ int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
     DeviceGuard guard(e->device);
     OutStage st;
     if (stage_out(e, n_samples, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st)) return 1;
-    const int threads = 256;
     auto scan = [&](const double *vol, int64_t stride, int nk, int k0) -> int {
-        const int tiles = (nk + threads - 1) / threads;
-        int64_t sets = std::max<int64_t>(1, ((int64_t)8 * e->n_cu * 8 + tiles - 1) / tiles);
-        sets = std::min<int64_t>(sets, std::max<int64_t>(1, n_nodes / 64));
+        // ~32 workgroups per CU in total; at least 256 nodes per chunk
+        const int tiles = (nk + qm::kWave - 1) / qm::kWave;
+        int64_t sets = std::max<int64_t>(1, ((int64_t)32 * e->n_cu + tiles - 1) / tiles);
+        sets = std::min<int64_t>(sets, std::max<int64_t>(1, n_nodes / 256));
         sets = std::min<int64_t>(sets, 65535);
         const int64_t per = (n_nodes + sets - 1) / sets;
         sets = (n_nodes + per - 1) / per;
         const size_t need = (size_t)sets * nk;
         if (e->d_pmax.ensure(need) || e->d_psum.ensure(need) || e->d_pidx.ensure(need)) return 1;
-        hipLaunchKernelGGL(qm::scan_volume_kernel, dim3(tiles, (unsigned)sets), dim3(threads), 0,
+        hipLaunchKernelGGL(qm::scan_volume_kernel, dim3(tiles, (unsigned)sets), dim3(256), 0,
                            e->stream, vol, stride, nk, n_nodes, per, e->d_pmax.p, e->d_pidx.p,
                            e->d_psum.p);
         QM_HIP(hipGetLastError());

@@ -750,8 +750,11 @@ __global__ __launch_bounds__(1024) void stack_direct_kernel(StackArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Scan of a materialised volume (find_max_coa).  Thread <-> sample (coalesced along t),
-// blockIdx.y <-> node chunk; values compared as stored (already exp'd).
+// Scan of a materialised volume (find_max_coa).  Workgroup = (64-sample tile, node chunk);
+// lanes <-> samples (512-byte coalesced row segments), wavefront w walks nodes w, w+4, ... of the
+// chunk in ascending order (strict '>' keeps the first maximum, migratelib.c:102) with 8 loads in
+// flight; the 4 wavefronts are combined through LDS with the lowest-index tie-break.  Values are
+// compared as stored (already exponentiated).  HBM-read bound: 8 bytes per node-sample.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scan_volume_kernel(const double *__restrict__ vol,
                                                           int64_t vol_stride, int n_chunk,
@@ -759,65 +762,100 @@ __global__ __launch_bounds__(256) void scan_volume_kernel(const double *__restri
                                                           double *__restrict__ part_max,
                                                           int64_t *__restrict__ part_idx,
                                                           double *__restrict__ part_sum) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double smax[4][kWave], ssum[4][kWave];
+    __shared__ int64_t sidx[4][kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * kWave + lane;
+    const int tc = t < n_chunk ? t : n_chunk - 1;       // clamp: keep every lane's loads in range
     const int set = blockIdx.y;
-    if (t >= n_chunk) return;
     const int64_t n0 = (int64_t)set * nodes_per_set;
     int64_t n1 = n0 + nodes_per_set;
     n1 = n1 < n_nodes ? n1 : n_nodes;
     double best = -__builtin_inf(), total = 0.0;
     int64_t bi = kNoIndex;
-    int64_t n = n0;
-    for (; n + 8 <= n1; n += 8) {
+    const double *col = vol + tc;
+    int64_t n = n0 + wave;
+    for (; n + 4 * 7 < n1; n += 4 * 8) {
         double v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = vol[(n + k) * vol_stride + t];
+        for (int k = 0; k < 8; ++k) v[k] = col[(n + 4 * k) * vol_stride];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             total += v[k];
-            if (v[k] > best) {                          // strict: first node wins
+            if (v[k] > best) {
                 best = v[k];
-                bi = n + k;
+                bi = n + 4 * k;
             }
         }
     }
-    for (; n < n1; ++n) {
-        const double v = vol[n * vol_stride + t];
+    for (; n < n1; n += 4) {
+        const double v = col[n * vol_stride];
         total += v;
         if (v > best) {
             best = v;
             bi = n;
         }
     }
-    const int64_t o = (int64_t)set * n_chunk + t;
-    part_max[o] = best;
-    part_idx[o] = bi;
-    part_sum[o] = total;
+    smax[wave][lane] = best;
+    ssum[wave][lane] = total;
+    sidx[wave][lane] = bi;
+    __syncthreads();
+    if (wave == 0 && t < n_chunk) {
+        for (int w = 1; w < 4; ++w) {
+            total += ssum[w][lane];
+            if (better(smax[w][lane], sidx[w][lane], best, bi)) {
+                best = smax[w][lane];
+                bi = sidx[w][lane];
+            }
+        }
+        const int64_t o = (int64_t)set * n_chunk + t;
+        part_max[o] = best;
+        part_idx[o] = bi;
+        part_sum[o] = total;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
-// Combine partial sets.  mode 0: emit one combined partial (index + node_offset, still in the
-// log domain); mode 1: final series from log-domain partials; mode 2: final series from
-// partials that already hold coalescence values (volume scan).
+// Combine partial sets ([n_sets][n]): lanes <-> samples, the 4 wavefronts of a workgroup split
+// the sets, LDS combine.  mode 0: emit one combined partial (index + node_offset, still in the
+// log2 domain); mode 1: final series from log2-domain partials; mode 2: final series from
+// partials that already hold coalescence values (volume scan).  Ties -> lowest node index.
 // ---------------------------------------------------------------------------------------
-__global__ void combine_kernel(const double *__restrict__ part_max,
-                               const int64_t *__restrict__ part_idx,
-                               const double *__restrict__ part_sum, int n_sets, int n, int mode,
-                               int64_t node_offset, double n_nodes_total,
-                               double *__restrict__ out_max, double *__restrict__ out_norm_or_sum,
-                               int64_t *__restrict__ out_idx) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+__global__ __launch_bounds__(256) void combine_kernel(const double *__restrict__ part_max,
+                                                      const int64_t *__restrict__ part_idx,
+                                                      const double *__restrict__ part_sum,
+                                                      int n_sets, int n, int mode,
+                                                      int64_t node_offset, double n_nodes_total,
+                                                      double *__restrict__ out_max,
+                                                      double *__restrict__ out_norm_or_sum,
+                                                      int64_t *__restrict__ out_idx) {
+    __shared__ double smax[4][kWave], ssum[4][kWave];
+    __shared__ int64_t sidx[4][kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * kWave + lane;
+    const int tc = t < n ? t : n - 1;
     double best = -__builtin_inf(), total = 0.0;
     int64_t bi = kNoIndex;
-    for (int s = 0; s < n_sets; ++s) {
-        const int64_t o = (int64_t)s * n + t;
+    for (int s = wave; s < n_sets; s += 4) {
+        const int64_t o = (int64_t)s * n + tc;
         const double v = part_max[o];
         const int64_t i = part_idx[o];
         total += part_sum[o];
         if (better(v, i, best, bi)) {
             best = v;
             bi = i;
+        }
+    }
+    smax[wave][lane] = best;
+    ssum[wave][lane] = total;
+    sidx[wave][lane] = bi;
+    __syncthreads();
+    if (wave != 0 || t >= n) return;
+    for (int w = 1; w < 4; ++w) {
+        total += ssum[w][lane];
+        if (better(smax[w][lane], sidx[w][lane], best, bi)) {
+            best = smax[w][lane];
+            bi = sidx[w][lane];
         }
     }
     if (bi != kNoIndex) bi += node_offset;
