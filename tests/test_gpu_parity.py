@@ -361,3 +361,27 @@ def test_any_row_count_picks_a_fitting_tile_and_matches_oracle(lib, oracle, rows
     _assert_series(got, want)
     assert eng.get("n_wide_bricks") == 0
     eng.close()
+
+
+def test_incoherent_table_and_tiny_scans(lib, oracle):
+    """A table with no spatial coherence (random delays up to 3000 samples) and scans of 1..70
+    samples: the engine falls back to tiny bricks / the direct kernel and stays exact."""
+    rng = np.random.default_rng(77)
+    grid, S, lsmp, fsmp = (10, 9, 8), 6, 3000, 13
+    tt = rng.integers(0, lsmp + 1, size=grid + (S,), dtype=np.int32)
+    for ns in (1, 5, 63, 70):
+        on = np.clip(rng.lognormal(0, 0.5, size=(S, fsmp + ns + lsmp)), 0.4, None)
+        want = oracle.detect(on, tt, fsmp, lsmp, S, threads=4)
+        eng = lib.Engine(0)
+        eng.load_lut(tt)
+        got = eng.detect(oracle.log_onsets(on), fsmp, lsmp, S)
+        _assert_series(got, want)
+        assert eng.get("brick_x") * eng.get("brick_y") * eng.get("brick_z") <= 2
+        eng.close()
+    # a forced big brick on the same table: every brick is "wide" -> direct kernel
+    eng = lib.Engine(0, brick_x=4, brick_y=4, brick_z=4)
+    eng.load_lut(tt)
+    assert eng.get("n_wide_bricks") == eng.get("n_bricks")
+    got = eng.detect(oracle.log_onsets(on), fsmp, lsmp, S)
+    _assert_series(got, want)
+    eng.close()
