@@ -95,6 +95,18 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *value);
 int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device,
                        int32_t nx, int32_t ny, int32_t nz, int32_t n_rows,
                        int64_t node_offset);
+/* On-device table serving -- replaces LUT.serve_traveltimes (quakemigrate/lut/lut.py:502-538)
+ * and Grid3D.decimate (lut.py:102-140) on the host.  Upload the float64 travel-time grids (seconds,
+ * [nx][ny][nz] each, one per station/phase) once; qm_engine_serve then builds and makes
+ * resident the int32 table of the selected grids, rint(tt * sampling_rate) in half-to-even
+ * rounding like np.rint, decimated by (dfx, dfy, dfz) exactly like the reference. */
+int qm_engine_grids_begin(qm_engine *e, int32_t nx, int32_t ny, int32_t nz, int32_t n_grids);
+int qm_engine_grids_set(qm_engine *e, int32_t index, const double *grid, int on_device);
+int qm_engine_serve(qm_engine *e, double sampling_rate, const int32_t *rows, int32_t n_rows,
+                    int32_t dfx, int32_t dfy, int32_t dfz, int64_t node_offset);
+/* copy the resident int32 table ([n_nodes][n_rows]) back to the host (tests, inspection) */
+int qm_engine_lut_download(qm_engine *e, int32_t *out);
+
 /* largest (clamped) delay in the resident table; callers must keep it <= lsmp */
 int qm_engine_lut_max(qm_engine *e, int32_t *max_delay);
 

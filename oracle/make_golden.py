@@ -50,6 +50,23 @@ def load_reference_binding():
     return lib
 
 
+def load_reference_lut_module():
+    """
+    The reference's quakemigrate/lut/lut.py, imported as a plain module.  It only fails to import
+    here because pyproj is absent; LUT.serve_traveltimes and Grid3D.decimate, the two methods
+    recorded below, never touch it, so an empty stand-in for the import is enough.
+    """
+    if "pyproj" not in sys.modules:
+        pj = types.ModuleType("pyproj")
+        pj.Transformer = type("Transformer", (), {})
+        sys.modules["pyproj"] = pj
+    spec = importlib.util.spec_from_file_location(
+        "qm_reference_lut", REF / "quakemigrate" / "lut" / "lut.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -179,6 +196,36 @@ def main():
     save("c2_mini_quiet", lut_sha256=sha(case.traveltimes), grid=np.array(case.grid),
          fsmp=case.fsmp, lsmp=case.lsmp, available=case.available,
          t_samples=case.onsets.shape[1], max_coa=a, max_norm_coa=b, max_coa_idx=c)
+
+    # 9. table serving + decimation through the reference's own LUT class ------
+    lutmod = load_reference_lut_module()
+    rng9 = np.random.default_rng(909)
+    shape = (13, 12, 10)
+    stations, phases = ["AAA", "BBB", "CCC", "DDD"], ["P", "S"]
+    lut = lutmod.LUT.__new__(lutmod.LUT)              # bypass the pyproj-based constructor
+    lut.node_count = np.array(shape, dtype=float)
+    lut.node_spacing = np.array([0.5, 0.5, 0.5])
+    lut.phases = phases
+    lut.traveltimes = {}
+    grids = {}
+    for st in stations:
+        for ph in phases:
+            g = rng9.uniform(0.0, 9.0, size=shape)
+            g[rng9.integers(0, shape[0]), rng9.integers(0, shape[1]), rng9.integers(0, shape[2])] = 2.5 / 50
+            lut.traveltimes.setdefault(st, {})[ph] = g      # what LUT.__getitem__ serves
+            grids[f"{st}_{ph}"] = g
+    availability = {f"{st}_{ph}": 1 for ph in phases for st in stations}
+    availability["CCC_P"] = 0
+    availability["AAA_S"] = 0
+    served = lut.serve_traveltimes(50, availability)
+    dec = lut.decimate([2, 3, 4])
+    served_dec = dec.serve_traveltimes(250, availability)
+    save("serve_traveltimes",
+         keys=np.array(list(grids.keys())), grids=np.stack(list(grids.values())),
+         availability_keys=np.array(list(availability.keys())),
+         availability_values=np.array(list(availability.values())),
+         served_50=served, decimate=np.array([2, 3, 4]), served_dec_250=served_dec,
+         dec_node_count=np.array(dec.node_count))
 
     # 8. STA/LTA: the reference's own known answers + a random trace ---------
     toy = np.arange(6)

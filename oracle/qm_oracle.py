@@ -205,6 +205,24 @@ def np_find_max_coa(map4d):
 
 
 # --------------------------------------------------------------------------
+# Table serving (host-side NumPy in the reference)
+# --------------------------------------------------------------------------
+def np_decimate(grid, df):
+    """Grid3D.decimate on one travel-time grid (quakemigrate/lut/lut.py:120-136)."""
+    df = np.array(df, dtype=int)
+    node_count = np.array(grid.shape)
+    new_node_count = 1 + (node_count - 1) // df
+    c1 = (node_count - df * (new_node_count - 1) - 1) // 2
+    return grid[c1[0]::df[0], c1[1]::df[1], c1[2]::df[2]]
+
+
+def np_serve_traveltimes(grids, sampling_rate):
+    """LUT.serve_traveltimes (lut.py:536-538): stack on the last axis, rint, int32."""
+    traveltimes = np.stack(list(grids), axis=-1)
+    return np.rint(traveltimes * sampling_rate).astype(np.int32)
+
+
+# --------------------------------------------------------------------------
 # STA/LTA (lib.py:176-285 semantics: output pre-filled with ones / zeros)
 # --------------------------------------------------------------------------
 def _stalta(fn, signal, nsta, nlta, fill):

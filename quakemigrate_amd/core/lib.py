@@ -66,6 +66,11 @@ qmlib.qm_engine_get.argtypes = [_vp, ctypes.c_char_p, ctypes.POINTER(c_int64)]
 qmlib.qm_engine_load_lut.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32,
                                      c_int32, c_int32, c_int64]
 qmlib.qm_engine_lut_max.argtypes = [_vp, ctypes.POINTER(c_int32)]
+qmlib.qm_engine_grids_begin.argtypes = [_vp, c_int32, c_int32, c_int32, c_int32]
+qmlib.qm_engine_grids_set.argtypes = [_vp, c_int32, _vp, ctypes.c_int]
+qmlib.qm_engine_serve.argtypes = [_vp, ctypes.c_double, c_i32Pt, c_int32, c_int32, c_int32,
+                                  c_int32, c_int64]
+qmlib.qm_engine_lut_download.argtypes = [_vp, c_i32Pt]
 qmlib.qm_engine_detect.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32,
                                    c_int32, c_int32, c_int64, _vp, _vp, _vp,
                                    ctypes.c_int]
@@ -187,6 +192,41 @@ class Engine:
         self.grid = (nx, ny, nz)
         self.n_rows = rows
         self.node_offset = int(node_offset)
+
+    # -- on-device serving (lut.py:502-538 / :102-140 moved to the GPU) ----------
+    def set_traveltime_grids(self, grids):
+        """
+        Upload float64 travel-time grids in seconds, each (nx, ny, nz): one per
+        station/phase, e.g. ``[lut[station][phase] for ...]``.  Done once per LUT.
+        """
+        grids = list(grids)
+        nx, ny, nz = (int(v) for v in grids[0].shape)
+        _check(qmlib.qm_engine_grids_begin(self._h, nx, ny, nz, len(grids)))
+        for i, g in enumerate(grids):
+            if tuple(g.shape) != (nx, ny, nz):
+                raise ValueError("all travel-time grids must share one shape")
+            if isinstance(g, np.ndarray):
+                g = np.ascontiguousarray(g, dtype=np.float64)
+            p, dev = self._ptr(g, np.float64)
+            _check(qmlib.qm_engine_grids_set(self._h, i, p, dev))
+
+    def serve(self, sampling_rate, rows, decimate=(1, 1, 1), node_offset=0):
+        """
+        Build and make resident the int32 table ``rint(grid[rows[s]] * sampling_rate)`` of
+        the selected grids, decimated like ``Grid3D.decimate``.
+        """
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        dfx, dfy, dfz = (int(v) for v in decimate)
+        _check(qmlib.qm_engine_serve(self._h, float(sampling_rate), rows, len(rows), dfx, dfy,
+                                     dfz, int(node_offset)))
+        self.grid = (self.get("nx"), self.get("ny"), self.get("nz"))
+        self.n_rows = len(rows)
+        self.node_offset = int(node_offset)
+
+    def download_lut(self):
+        out = np.empty(tuple(self.grid) + (self.n_rows,), dtype=np.int32)
+        _check(qmlib.qm_engine_lut_download(self._h, out))
+        return out
 
     @property
     def lut_max(self):

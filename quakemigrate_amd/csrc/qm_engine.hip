@@ -98,6 +98,11 @@ struct qm_engine {
     int n_wide = 0;
     int plan_j = -1, plan_cap = -1;
 
+    // float64 travel-time grids in seconds (optional; on-device table serving)
+    DevBuf<double> d_grids;
+    DevBuf<int32_t> d_rows, d_served;
+    int gx = 0, gy = 0, gz = 0, g_rows = 0;
+
     // scratch
     DevBuf<double> d_onsets, d_pmax, d_psum, d_out_a, d_out_b, d_chunk;
     DevBuf<int64_t> d_pidx, d_out_i;
@@ -410,6 +415,7 @@ void qm_engine_destroy(qm_engine *e) {
     if (!e) return;
     DeviceGuard guard(e->device);
     (void)hipStreamSynchronize(e->stream);
+    e->d_grids.release(); e->d_rows.release(); e->d_served.release();
     e->d_lut.release(); e->d_bmeta.release();
     e->d_btotal.release(); e->d_wide.release(); e->d_scalar.release(); e->d_rel.release();
     e->d_onsets.release(); e->d_pmax.release(); e->d_psum.release(); e->d_out_a.release();
@@ -497,6 +503,9 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     } else if (k == "n_cu") *v = e->n_cu;
     else if (k == "n_nodes") *v = e->n_nodes;
     else if (k == "n_rows") *v = e->g.n_rows;
+    else if (k == "nx") *v = e->g.nx;
+    else if (k == "ny") *v = e->g.ny;
+    else if (k == "nz") *v = e->g.nz;
     else return fail("unknown key '%s'", key);
     return 0;
 }
@@ -571,6 +580,71 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     e->plan_j = -1;
     e->have_lut = true;
     return plan_wide(e);
+}
+
+int qm_engine_grids_begin(qm_engine *e, int32_t nx, int32_t ny, int32_t nz, int32_t n_grids) {
+    if (!e) return fail("engine is NULL");
+    if (nx < 1 || ny < 1 || nz < 1 || n_grids < 1) return fail("bad grid shape");
+    DeviceGuard guard(e->device);
+    if (e->d_grids.ensure((size_t)n_grids * nx * ny * nz)) return 1;
+    e->gx = nx; e->gy = ny; e->gz = nz; e->g_rows = n_grids;
+    return 0;
+}
+
+int qm_engine_grids_set(qm_engine *e, int32_t index, const double *grid, int on_device) {
+    if (!e || !grid) return fail("NULL argument");
+    if (index < 0 || index >= e->g_rows) return fail("grid index %d out of range", index);
+    DeviceGuard guard(e->device);
+    const size_t n = (size_t)e->gx * e->gy * e->gz;
+    QM_HIP(hipMemcpyAsync(e->d_grids.p + (size_t)index * n, grid, n * sizeof(double),
+                          on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                          e->stream));
+    if (!on_device) QM_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int qm_engine_serve(qm_engine *e, double sampling_rate, const int32_t *rows, int32_t n_rows,
+                    int32_t dfx, int32_t dfy, int32_t dfz, int64_t node_offset) {
+    if (!e || !rows) return fail("NULL argument");
+    if (e->g_rows < 1) return fail("no travel-time grids resident: call qm_engine_grids_begin/set");
+    if (n_rows < 1) return fail("no rows selected");
+    if (dfx < 1 || dfy < 1 || dfz < 1) return fail("decimation factors must be >= 1");
+    for (int i = 0; i < n_rows; ++i)
+        if (rows[i] < 0 || rows[i] >= e->g_rows) return fail("row %d selects grid %d of %d", i, rows[i], e->g_rows);
+    DeviceGuard guard(e->device);
+    qm::ServeArgs a{};
+    a.nxf = e->gx; a.nyf = e->gy; a.nzf = e->gz;
+    a.dfx = dfx; a.dfy = dfy; a.dfz = dfz;
+    // Grid3D.decimate (lut.py:121-122): new = 1 + (n - 1) // df ; c1 = (n - df*(new-1) - 1) // 2
+    a.nx = 1 + (e->gx - 1) / dfx; a.ny = 1 + (e->gy - 1) / dfy; a.nz = 1 + (e->gz - 1) / dfz;
+    a.c1x = (e->gx - dfx * (a.nx - 1) - 1) / 2;
+    a.c1y = (e->gy - dfy * (a.ny - 1) - 1) / 2;
+    a.c1z = (e->gz - dfz * (a.nz - 1) - 1) / 2;
+    a.S = n_rows;
+    a.rate = sampling_rate;
+    const int64_t n_out = (int64_t)a.nx * a.ny * a.nz;
+    if (e->d_rows.ensure(n_rows) || e->d_served.ensure((size_t)n_out * n_rows)) return 1;
+    QM_HIP(hipMemcpyAsync(e->d_rows.p, rows, n_rows * sizeof(int32_t), hipMemcpyHostToDevice,
+                          e->stream));
+    a.grids = e->d_grids.p;
+    a.rows = e->d_rows.p;
+    a.out = e->d_served.p;
+    const size_t lds = (size_t)64 * (n_rows + 1) * sizeof(int32_t);
+    if (lds > 64 * 1024) return fail("too many rows (%d) for the serving kernel", n_rows);
+    hipLaunchKernelGGL(qm::serve_table_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(256), lds,
+                       e->stream, a);
+    QM_HIP(hipGetLastError());
+    return qm_engine_load_lut(e, e->d_served.p, 1, a.nx, a.ny, a.nz, n_rows, node_offset);
+}
+
+int qm_engine_lut_download(qm_engine *e, int32_t *out) {
+    if (!e || !out) return fail("NULL argument");
+    if (!e->have_lut) return fail("no travel-time table resident");
+    DeviceGuard guard(e->device);
+    QM_HIP(hipMemcpyAsync(out, e->d_lut.p, (size_t)e->n_nodes * e->g.n_rows * sizeof(int32_t),
+                          hipMemcpyDeviceToHost, e->stream));
+    QM_HIP(hipStreamSynchronize(e->stream));
+    return 0;
 }
 
 int qm_engine_lut_max(qm_engine *e, int32_t *max_delay) {

@@ -156,6 +156,54 @@ __global__ void brick_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
 }
 
 // ---------------------------------------------------------------------------------------
+// Table serving on the device (what LUT.serve_traveltimes does on the host every timestep,
+// quakemigrate/lut/lut.py:502-538): from float64 travel-time grids in seconds, one [N_full] grid
+// per station/phase, build the int32 [N][S] table of the selected rows as rint(tt * rate)
+// (v_rndne_f64 = numpy's half-to-even rint), optionally decimated like Grid3D.decimate
+// (lut.py:102-140: every df-th node starting at c1).  64 nodes x all rows per workgroup, staged
+// through LDS so that both the reads (along nodes) and the writes (along rows) are coalesced.
+// ---------------------------------------------------------------------------------------
+struct ServeArgs {
+    const double *grids;       // [rows_total][nx_full*ny_full*nz_full]
+    const int32_t *rows;       // [S] selected grid index per table row
+    int32_t *out;              // [N][S]
+    int nxf, nyf, nzf;         // full grid
+    int nx, ny, nz;            // served (decimated) grid
+    int dfx, dfy, dfz, c1x, c1y, c1z;
+    int S;
+    double rate;
+};
+
+__global__ __launch_bounds__(256) void serve_table_kernel(ServeArgs a) {
+    extern __shared__ int32_t tile[];                   // [64][S + 1]
+    const int64_t n_out = (int64_t)a.nx * a.ny * a.nz;
+    const int64_t n_full = (int64_t)a.nxf * a.nyf * a.nzf;
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = n0 + lane;
+    int64_t src = 0;
+    if (n < n_out) {
+        const int iz = (int)(n % a.nz), iy = (int)((n / a.nz) % a.ny), ix = (int)(n / ((int64_t)a.nz * a.ny));
+        src = ((int64_t)(a.c1x + ix * a.dfx) * a.nyf + (a.c1y + iy * a.dfy)) * a.nzf +
+              (a.c1z + iz * a.dfz);
+    }
+    for (int s = wave; s < a.S; s += 4) {
+        int32_t v = 0;
+        if (n < n_out) {
+            const double t = a.grids[(int64_t)a.rows[s] * n_full + src] * a.rate;
+            v = (int32_t)__builtin_rint(t);
+        }
+        tile[lane * (a.S + 1) + s] = v;
+    }
+    __syncthreads();
+    const int64_t count = (n_out - n0 < 64 ? n_out - n0 : 64) * a.S;
+    for (int64_t i = threadIdx.x; i < count; i += blockDim.x) {
+        const int node = (int)(i / a.S), s = (int)(i % a.S);
+        a.out[n0 * a.S + i] = tile[node * (a.S + 1) + s];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // exp in float64, in the base-2 domain, without the device library's special-case handling: the
 // argument is a mean of log-onsets (|x| < ~50 for any finite input), far from overflow.
 //   z = stack * (log2(e)/available) = k + f, |f| <= 1/2;   coa = 2^z = 2^k * 2^f

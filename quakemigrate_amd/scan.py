@@ -64,7 +64,7 @@ class MigrationScan:
     """
 
     def __init__(self, lut, onset, pre_pad, post_pad, stage="detect", scan_rate=None,
-                 engine=None, threads=1):
+                 engine=None, threads=1, device_serving=False):
         self.lut = lut
         self.onset = onset
         self.pre_pad = pre_pad
@@ -74,11 +74,43 @@ class MigrationScan:
         self.threads = threads
         self.engine = engine if engine is not None else lib.default_engine()
         self._resident_key = None
+        # device_serving: the float64 grids of ``lut.traveltimes`` ({station: {phase: grid}},
+        # quakemigrate/lut/lut.py) are uploaded once and the int32 table of the available
+        # station/phase pairs is built on the GPU (rint(tt * sampling_rate), lut.py:536-538)
+        # whenever the availability changes -- no per-timestep host stack / rint / upload.
+        self.device_serving = bool(device_serving)
+        self._grid_index = None
 
     # -- table residency ------------------------------------------------------
     def _ensure_table(self, sampling_rate, availability):
         key = (sampling_rate, tuple(availability.items()))
-        if key != self._resident_key:
+        if key != self._resident_key and self.device_serving:
+            if self._grid_index is None:
+                names, grids = [], []
+                for station, phases in self.lut.traveltimes.items():
+                    for phase, grid in phases.items():
+                        names.append(f"{station}_{phase}")
+                        grids.append(grid)
+                self.engine.set_traveltime_grids(grids)
+                self._grid_index = {n: i for i, n in enumerate(names)}
+            rows = []
+            for k, available in availability.items():
+                if available != 1:
+                    continue
+                station, phase = k.split("_")
+                if k in self._grid_index:
+                    rows.append(self._grid_index[k])
+                elif f"{station}_TIME_{phase}" in self._grid_index:      # lut.py:534-535
+                    rows.append(self._grid_index[f"{station}_TIME_{phase}"])
+                else:
+                    phases = sorted({kk.split("_")[-1] for kk in availability})
+                    raise LUTPhasesException(
+                        f"Attempting to migrate phases {phases}; but traveltimes for "
+                        f"'{phase}' not found in the LUT. Please create a new lookup table "
+                        f"with phases={phases}")
+            self.engine.serve(sampling_rate, rows)
+            self._resident_key = key
+        elif key != self._resident_key:
             try:
                 traveltimes = self.lut.serve_traveltimes(sampling_rate, availability)
             except KeyError as e:

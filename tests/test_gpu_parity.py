@@ -385,3 +385,67 @@ def test_incoherent_table_and_tiny_scans(lib, oracle):
     got = eng.detect(oracle.log_onsets(on), fsmp, lsmp, S)
     _assert_series(got, want)
     eng.close()
+
+
+def test_on_device_table_serving_matches_reference_lut_class(lib, oracle):
+    """qm_engine_serve == LUT.serve_traveltimes (+ Grid3D.decimate), bit for bit, against
+    outputs recorded from the reference's own LUT class; and the scan on the served table."""
+    from quakemigrate_amd import scan
+
+    g = load_golden("serve_traveltimes")
+    index = {k: i for i, k in enumerate(g["keys"])}
+    rows = [index[k] for k, v in zip(g["availability_keys"], g["availability_values"]) if v == 1]
+    eng = lib.Engine(0)
+    eng.set_traveltime_grids(list(g["grids"]))
+    eng.serve(50, rows)
+    assert eng.grid == g["served_50"].shape[:3]
+    assert np.array_equal(eng.download_lut(), g["served_50"])
+    eng.serve(250, rows, decimate=tuple(int(v) for v in g["decimate"]))
+    assert np.array_equal(eng.download_lut(), g["served_dec_250"])
+    # half-to-even: 2.5 samples -> 2 (the fixture plants tt = 2.5/50 s in every grid)
+    assert (g["served_50"] == 2).any()
+
+    # MigrationScan with device serving == with the host-served table
+    keys = [str(k) for k in g["keys"]]
+
+    class Lut:
+        traveltimes = {}
+        for k, grid in zip(keys, g["grids"]):
+            st, ph = k.split("_")
+            traveltimes.setdefault(st, {})[ph] = grid
+
+        def serve_traveltimes(self, sr, availability):
+            picked = [self.traveltimes[k.split("_")[0]][k.split("_")[1]]
+                      for k, v in availability.items() if v == 1]
+            return oracle.np_serve_traveltimes(picked, sr)
+
+        def index2coord(self, idx, unravel=True):
+            return idx
+
+    rng = np.random.default_rng(4)
+    availability = {str(k): int(v) for k, v in zip(g["availability_keys"],
+                                                    g["availability_values"])}
+    lsmp, fsmp, ns = int(g["served_50"].max()) + 3, 7, 130
+    onsets = np.clip(rng.lognormal(0, 0.5, size=(6, fsmp + ns + lsmp)), 0.4, None)
+
+    class OnsetData:
+        sampling_rate = 50
+
+    OnsetData.availability = availability
+
+    class Onset:
+        def calculate_onsets(self, data):
+            return onsets, OnsetData()
+
+    class Data:
+        starttime = 0.0
+
+    out = {}
+    for dev in (False, True):
+        s = scan.MigrationScan(Lut(), Onset(), fsmp / 50, lsmp / 50, engine=eng,
+                               device_serving=dev)
+        out[dev] = s._compute(Data())
+    want = oracle.detect(onsets, g["served_50"], fsmp, lsmp, 6, threads=2)
+    for dev in (False, True):
+        _assert_series((out[dev][1], out[dev][2], out[dev][3]), want)
+    eng.close()

@@ -132,3 +132,16 @@ def test_binding_level_errors(oracle):
     on = np.ones((3, 50))
     with pytest.raises(ValueError, match="Mismatch"):
         oracle.c_migrate(on, np.zeros((2, 2, 2, 4), dtype=np.int32), 2, 3, 3)
+
+
+def test_table_serving_restatement_matches_reference_lut_class(oracle):
+    """np_serve_traveltimes / np_decimate vs LUT.serve_traveltimes / Grid3D.decimate outputs
+    recorded from the reference's own class (oracle/make_golden.py section 9)."""
+    g = load_golden("serve_traveltimes")
+    index = {k: i for i, k in enumerate(g["keys"])}
+    picked = [g["grids"][index[k]] for k, v in zip(g["availability_keys"],
+                                                    g["availability_values"]) if v == 1]
+    assert np.array_equal(oracle.np_serve_traveltimes(picked, 50), g["served_50"])
+    dec = [oracle.np_decimate(p, g["decimate"]) for p in picked]
+    assert dec[0].shape == tuple(int(v) for v in g["dec_node_count"])
+    assert np.array_equal(oracle.np_serve_traveltimes(dec, 250), g["served_dec_250"])
