@@ -308,6 +308,22 @@ def main():
             "node_samples_per_s": n_local * ns_loc / sec,
             "workload": f"locate window: same grid, {ns_loc} samples, volume "
                         f"({8.0 * n_local * ns_loc / 1e9:.1f} GB) written to HBM + scan"}
+        # locate without the volume: marginalised 3-D map over the central half of the window
+        cmap = torch.empty(n_local, dtype=torch.float64, device=dev)
+        eng.marginal_map(on, case.fsmp, case.lsmp, case.available, 100, 301, out=cmap,
+                         scan_out=o2)
+        torch.cuda.synchronize()
+        eng.config("log_timing", 1)
+        for _ in range(reps):
+            eng.marginal_map(on, case.fsmp, case.lsmp, case.available, 100, 301, out=cmap,
+                             scan_out=o2)
+        torch.cuda.synchronize()
+        ms, calls = eng.kernel_log()
+        eng.config("log_timing", 0)
+        result["locate_marginal"] = {
+            "avg_ms": ms / calls, "node_samples_per_s": n_local * ns_loc / (ms / 1e3 / calls),
+            "workload": "same window, marginalised map (sum over samples 100..300) + scan; "
+                        "no n_nodes x n_samples store"}
         # find_max_coa alone on that resident volume (scan_volume_kernel): pure HBM read
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         eng.find_max_coa(vol, ns_loc, n_local, o2)

@@ -149,6 +149,17 @@ int qm_engine_migrate(qm_engine *e, const double *log_onsets, int onsets_on_devi
                       double *max_norm_coa, int64_t *max_coa_idx,
                       int out_on_device);
 
+/* Locate without the volume: the coalescence of every node summed over the scanned samples
+ * [first_sample, end_sample) -- what `event.trim2window()` followed by
+ * `np.sum(event.map4d, axis=-1)` computes from the 4-D map (quakemigrate/io/event.py:421-439,
+ * signal/scan.py:720) -- written as f64 [n_nodes_local]; the scan outputs as in
+ * qm_engine_migrate if max_coa != NULL.  Nothing of size n_nodes x n_samples is stored. */
+int qm_engine_marginal(qm_engine *e, const double *log_onsets, int onsets_on_device,
+                       int32_t t_samples, int32_t fsmp, int32_t lsmp, int32_t available,
+                       int64_t n_nodes_total, int32_t first_sample, int32_t end_sample,
+                       double *coa_map, int map_on_device, double *max_coa,
+                       double *max_norm_coa, int64_t *max_coa_idx, int out_on_device);
+
 /* Scan of an existing volume (find_max_coa semantics, no table needed). */
 int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
                            int32_t n_samples, int64_t n_nodes, double *max_coa,

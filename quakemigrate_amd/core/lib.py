@@ -82,6 +82,9 @@ qmlib.qm_engine_finalize.argtypes = [_vp, _vp, _vp, _vp, c_int32, c_int32,
 qmlib.qm_engine_migrate.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32,
                                     c_int32, c_int32, c_int64, _vp, ctypes.c_int,
                                     ctypes.c_int, _vp, _vp, _vp, ctypes.c_int]
+qmlib.qm_engine_marginal.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32, c_int32,
+                                     c_int32, c_int64, c_int32, c_int32, _vp, ctypes.c_int,
+                                     _vp, _vp, _vp, ctypes.c_int]
 qmlib.qm_engine_find_max_coa.argtypes = [_vp, _vp, ctypes.c_int, c_int32,
                                          c_int64, _vp, _vp, _vp, ctypes.c_int]
 qmlib.qm_engine_last_kernel_ms.argtypes = [_vp, ctypes.POINTER(ctypes.c_double)]
@@ -298,6 +301,30 @@ class Engine:
             self._h, po, dev_on, t_samples, int(fsmp), int(lsmp), int(available),
             total, pm, dev_map, 1 if accumulate else 0, pa, pb, pc, da))
         return map4d
+
+    def marginal_map(self, log_onsets, fsmp, lsmp, available, first_sample, end_sample,
+                     out=None, scan_out=None, n_nodes_total=None):
+        """
+        Sum over scanned samples ``[first_sample, end_sample)`` of every node's coalescence,
+        shape ``grid`` -- ``np.sum(map4d[..., first:end], axis=-1)`` without the 4-D map.
+        """
+        rows, t_samples = (int(v) for v in log_onsets.shape)
+        self._check_rows(rows)
+        if out is None:
+            out = np.zeros(self.grid, dtype=np.float64)
+        po, dev_on = self._ptr(log_onsets, np.float64)
+        pm, dev_map = self._ptr(out, np.float64)
+        if scan_out is None:
+            pa = pb = pc = _vp(None)
+            da = 0
+        else:
+            (pa, da), (pb, _), (pc, _) = (self._ptr(scan_out[0]), self._ptr(scan_out[1]),
+                                          self._ptr(scan_out[2]))
+        total = self.n_nodes if n_nodes_total is None else int(n_nodes_total)
+        _check(qmlib.qm_engine_marginal(
+            self._h, po, dev_on, t_samples, int(fsmp), int(lsmp), int(available), total,
+            int(first_sample), int(end_sample), pm, dev_map, pa, pb, pc, da))
+        return out
 
     def find_max_coa(self, map4d, n_samples, n_nodes, out=None):
         if out is None:

@@ -104,7 +104,7 @@ struct qm_engine {
     int gx = 0, gy = 0, gz = 0, g_rows = 0;
 
     // scratch
-    DevBuf<double> d_onsets, d_pmax, d_psum, d_out_a, d_out_b, d_chunk;
+    DevBuf<double> d_onsets, d_pmax, d_psum, d_out_a, d_out_b, d_chunk, d_marg, d_marg_out;
     DevBuf<int64_t> d_pidx, d_out_i;
 };
 
@@ -234,7 +234,8 @@ int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu) {
 // e->d_pmax/d_pidx/d_psum as [*n_sets][n_chunk].
 int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_samples,
               int available, int sample0, int n_chunk, double *volume, int64_t vol_stride,
-              int accumulate, bool want_scan, int *n_sets) {
+              int accumulate, bool want_scan, int *n_sets, double *marginal = nullptr,
+              int m0 = 0, int m1 = 0) {
     if (plan_wide(e)) return 1;
     const int J = eff_j(e);
     const int KT = qm::kWave * J;
@@ -259,6 +260,10 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     a.accumulate = accumulate;
     a.want_scan = want_scan ? 1 : 0;
     a.set0 = 0;
+    a.marginal = marginal;
+    a.m0 = m0;
+    a.m1 = m1;
+    a.n_nodes = e->n_nodes;
 
     const bool use_direct = e->cfg_force_direct || e->n_wide > 0;
     const bool use_lds = !e->cfg_force_direct && e->n_wide < e->g.nbricks;
@@ -300,7 +305,8 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     QM_HIP(hipEventRecord(ev_begin, e->stream));
     int rc = 0;
 #define QM_LAUNCH(JJ)                                                                        \
-    rc = volume ? launch_stack_j<JJ, true>(e, a, groups_lds, groups_direct, use_lds, use_direct) \
+    rc = (volume || marginal)                                                                 \
+             ? launch_stack_j<JJ, true>(e, a, groups_lds, groups_direct, use_lds, use_direct)  \
                 : launch_stack_j<JJ, false>(e, a, groups_lds, groups_direct, use_lds, use_direct)
     switch (J) {
         case 1: QM_LAUNCH(1); break;
@@ -419,7 +425,7 @@ void qm_engine_destroy(qm_engine *e) {
     e->d_lut.release(); e->d_bmeta.release();
     e->d_btotal.release(); e->d_wide.release(); e->d_scalar.release(); e->d_rel.release();
     e->d_onsets.release(); e->d_pmax.release(); e->d_psum.release(); e->d_out_a.release();
-    e->d_out_b.release(); e->d_chunk.release(); e->d_pidx.release(); e->d_out_i.release();
+    e->d_out_b.release(); e->d_chunk.release(); e->d_marg.release(); e->d_marg_out.release(); e->d_pidx.release(); e->d_out_i.release();
     for (hipEvent_t ev : e->ev_log) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -759,6 +765,52 @@ int qm_engine_migrate(qm_engine *e, const double *log_onsets, int onsets_on_devi
     }
     if (want_scan) return fetch_out(e, ns, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
     if (!map_on_device) QM_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int qm_engine_marginal(qm_engine *e, const double *log_onsets, int onsets_on_device, int32_t T,
+                       int32_t fsmp, int32_t lsmp, int32_t available, int64_t n_nodes_total,
+                       int32_t first_sample, int32_t end_sample, double *coa_map,
+                       int map_on_device, double *max_coa, double *max_norm_coa,
+                       int64_t *max_coa_idx, int out_on_device) {
+    if (!e || !log_onsets || !coa_map) return fail("qm_engine_marginal: NULL argument");
+    const bool want_scan = max_coa != nullptr;
+    if (want_scan && (!max_norm_coa || !max_coa_idx))
+        return fail("qm_engine_marginal: all three scan outputs or none");
+    DeviceGuard guard(e->device);
+    int ns = 0, sets = 0;
+    if (check_step(e, T, fsmp, lsmp, available, &ns)) return 1;
+    if (first_sample < 0 || end_sample > ns || first_sample >= end_sample)
+        return fail("marginal window [%d, %d) outside the %d scanned samples", first_sample,
+                    end_sample, ns);
+    const double *d_on = nullptr;
+    if (stage_onsets(e, log_onsets, onsets_on_device, T, &d_on)) return 1;
+    OutStage st{nullptr, nullptr, nullptr};
+    if (want_scan && stage_out(e, ns, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st))
+        return 1;
+    const int KT = qm::kWave * eff_j(e);
+    const int ntiles = (ns + KT - 1) / KT;
+    if (e->d_marg.ensure((size_t)ntiles * e->n_nodes)) return 1;
+    double *d_map = coa_map;
+    if (!map_on_device) {
+        if (e->d_marg_out.ensure((size_t)e->n_nodes)) return 1;
+        d_map = e->d_marg_out.p;
+    }
+    if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, want_scan, &sets,
+                  e->d_marg.p, first_sample, end_sample))
+        return 1;
+    hipLaunchKernelGGL(qm::marginal_reduce_kernel, dim3((unsigned)((e->n_nodes + 255) / 256)),
+                       dim3(256), 0, e->stream, e->d_marg.p, ntiles, e->n_nodes, d_map);
+    QM_HIP(hipGetLastError());
+    if (want_scan && combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, 1,
+                             e->node_offset, n_nodes_total, st.a, st.b, st.i))
+        return 1;
+    if (!map_on_device) {
+        QM_HIP(hipMemcpyAsync(coa_map, d_map, (size_t)e->n_nodes * sizeof(double),
+                              hipMemcpyDeviceToHost, e->stream));
+        QM_HIP(hipStreamSynchronize(e->stream));
+    }
+    if (want_scan) return fetch_out(e, ns, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
     return 0;
 }
 

@@ -57,6 +57,9 @@ struct StackArgs {
     double *part_sum;              // [sets][n_chunk]
     int set0;                      // first partial set written by this launch
     int want_scan;                 // write partials at all
+    double *marginal;              // [ntiles][n_nodes] per-tile sums over samples [m0, m1) of the
+    int m0, m1;                    //   coalescence (VOLUME kernels; replaces the volume store)
+    int64_t n_nodes;
 };
 
 // max of two non-NaN-producing operands without the canonicalising copy clang adds to fmax()
@@ -310,10 +313,25 @@ __device__ __forceinline__ void finish_node(const StackArgs &a, Running<J> &run,
         run.bmax[j] = max_keep(run.bmax[j], x);
     }
     if (VOLUME) {
-        double *row = a.volume + (int64_t)node * a.vol_stride + (t_first + lane);
+        if (a.marginal != nullptr) {
+            // marginalise over time instead of storing: sum of this node's coalescence over the
+            // samples [m0, m1) that fall into this tile (event.trim2window + np.sum(axis=-1),
+            // quakemigrate/io/event.py:421-439, signal/scan.py:720)
+            double m = 0.0;
 #pragma unroll
-        for (int j = 0; j < J; ++j)
-            if (t_first + lane + kWave * j < a.n_chunk) row[kWave * j] = e[j];
+            for (int j = 0; j < J; ++j) {
+                const int t = t_first + lane + kWave * j;
+                m += (t >= a.m0 && t < a.m1) ? e[j] : 0.0;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off, kWave);
+            if (lane == 0) a.marginal[(int64_t)(t_first / (kWave * J)) * a.n_nodes + node] = m;
+        } else {
+            double *row = a.volume + (int64_t)node * a.vol_stride + (t_first + lane);
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                if (t_first + lane + kWave * j < a.n_chunk) row[kWave * j] = e[j];
+        }
     }
 }
 
@@ -861,6 +879,16 @@ __global__ __launch_bounds__(256) void scan_volume_kernel(const double *__restri
         part_idx[o] = bi;
         part_sum[o] = total;
     }
+}
+
+// per-tile marginal sums -> marginal map (fixed tile order: deterministic)
+__global__ void marginal_reduce_kernel(const double *__restrict__ part, int ntiles, int64_t n,
+                                       double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int t = 0; t < ntiles; ++t) s += part[(int64_t)t * n + i];
+    out[i] = s;
 }
 
 // ---------------------------------------------------------------------------------------

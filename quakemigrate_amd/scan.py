@@ -165,3 +165,25 @@ class MigrationScan:
             return time, max_coa, max_coa_n, coord, onset_data
         times = event.mw_times(self.scan_rate)
         return times, max_coa, max_coa_n, coord, map4d, onset_data
+
+
+    def marginal_coalescence(self, data, first_sample, end_sample):
+        """
+        The marginalised 3-D coalescence map of one event window without the 4-D map: what
+        ``event.trim2window()`` + ``np.sum(event.map4d, axis=-1)`` produce in the reference
+        (quakemigrate/io/event.py:421-439, signal/scan.py:720), for the scanned samples
+        ``[first_sample, end_sample)``.  Returns ``(coa_map (nx, ny, nz), max_coa, max_coa_n,
+        max_idx, onset_data)``; the caller normalises by ``nanmax`` as the reference does.
+        """
+        onsets, onset_data = self.onset.calculate_onsets(data)
+        eng = self._ensure_table(onset_data.sampling_rate, onset_data.availability)
+        fsmp = time2sample(self.pre_pad, onset_data.sampling_rate)
+        lsmp = time2sample(self.post_pad, onset_data.sampling_rate)
+        avail = int(np.sum([value for _, value in onset_data.availability.items()]))
+        onsets = np.ascontiguousarray(np.log(np.clip(onsets, 0.01, np.inf)))
+        n_samples = onsets.shape[1] - fsmp - lsmp
+        series = (np.zeros(n_samples), np.zeros(n_samples),
+                  np.zeros(n_samples, dtype=np.int64))
+        coa_map = eng.marginal_map(onsets, fsmp, lsmp, avail, first_sample, end_sample,
+                                   scan_out=series)
+        return (coa_map,) + series + (onset_data,)

@@ -449,3 +449,25 @@ def test_on_device_table_serving_matches_reference_lut_class(lib, oracle):
     for dev in (False, True):
         _assert_series((out[dev][1], out[dev][2], out[dev][3]), want)
     eng.close()
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(generic=1), dict(samples_per_lane=2),
+                                 dict(brick_x=2, brick_y=2, brick_z=3, waves=3)])
+def test_marginal_map_equals_time_sum_of_the_volume(lib, oracle, cfg):
+    """Locate's marginalised map without the 4-D volume == np.sum(map4d[..., i0:i1], -1)."""
+    case = synth.make_case("C2", step=7, grid=(13, 11, 9), rows=9, n_samples=401)
+    ref = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
+                           case.available, threads=4)
+    want_series = oracle.c_find_max_coa(ref, threads=2)
+    eng = lib.Engine(0, **cfg)
+    eng.load_lut(case.traveltimes)
+    lon = oracle.log_onsets(case.onsets)
+    for i0, i1 in [(100, 301), (0, 401), (255, 257), (400, 401)]:
+        series = (np.zeros(401), np.zeros(401), np.zeros(401, dtype=np.int64))
+        got = eng.marginal_map(lon, case.fsmp, case.lsmp, case.available, i0, i1,
+                               scan_out=series)
+        np.testing.assert_allclose(got, ref[..., i0:i1].sum(axis=-1), rtol=1e-12)
+        _assert_series(series, want_series)
+    with pytest.raises(lib.QMHipError, match="window"):
+        eng.marginal_map(lon, case.fsmp, case.lsmp, case.available, 10, 500)
+    eng.close()
