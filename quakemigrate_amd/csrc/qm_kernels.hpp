@@ -545,66 +545,57 @@ __device__ __forceinline__ void retire_rows(double (&acc)[J], const double (&buf
         for (int j = 0; j < J; ++j) acc[j] += buf[k * J + j];
 }
 
-// Stack the (NCH-1)*8 rows of the full chunks of one node (offsets in q[0..NCH-2]); as soon as a
-// chunk's last row has been issued, its registers are refilled with the NEXT node's chunk
-// (`next` points at that node's offsets).  If WITH_EPI, `epi` is interleaved.
+// One batch of the software pipeline (compile-time index I of NB): issue batch I+1, run this
+// batch's share of the previous node's epilogue, then wait for and add batch I.  As soon as a
+// chunk's last row has been issued its offset registers are refilled with the NEXT node's chunk.
+template <int J, bool VOLUME, int NCH, bool WITH_EPI, int I>
+__device__ __forceinline__ void pipeline_batch(double (&acc)[J],
+                                               double (&even)[BatchRows<J>::value * J],
+                                               double (&odd)[BatchRows<J>::value * J],
+                                               uint4 (&q)[NCH], const uint16_t *next,
+                                               unsigned lane_addr, Epilogue<J> &epi,
+                                               Running<J> &run, const StackArgs &a, int t_first,
+                                               int lane) {
+    constexpr int KT = kWave * J;
+    constexpr int RB = BatchRows<J>::value;
+    constexpr int NB = (NCH - 1) * 8 / RB;              // batches per node (full chunks only)
+    constexpr int BPC = 8 / RB;                         // batches per chunk
+    if constexpr (I < NB) {
+        if constexpr (I + 1 < NB) {
+            constexpr int ci = (I + 1) / BPC, bj = (I + 1) % BPC;
+            const unsigned ca = lane_addr + (unsigned)(ci * 8 * KT * 8);
+            issue_rows<J, RB>((I & 1) ? even : odd, q[ci], ca, bj * RB);
+            if constexpr (bj == BPC - 1) q[ci] = load_offsets(next, ci * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WITH_EPI) {
+            constexpr int E = EpiSteps<VOLUME>::value;
+            epi_steps<J, VOLUME, I * E / NB, (I + 1) * E / NB>(epi, run, a, t_first, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        retire_rows<J, RB>(acc, (I & 1) ? odd : even);
+        __builtin_amdgcn_sched_barrier(0);
+        pipeline_batch<J, VOLUME, NCH, WITH_EPI, I + 1>(acc, even, odd, q, next, lane_addr, epi,
+                                                        run, a, t_first, lane);
+    }
+}
+
+// Stack the (NCH-1)*8 rows of the full chunks of one node (offsets in q[0..NCH-2]); if WITH_EPI,
+// the previous node's epilogue `epi` is interleaved.
 template <int J, bool VOLUME, int NCH, bool WITH_EPI>
 __device__ __forceinline__ void stack_full_chunks(double (&acc)[J], uint4 (&q)[NCH],
                                                   const uint16_t *next, unsigned lane_addr,
                                                   Epilogue<J> &epi, Running<J> &run,
                                                   const StackArgs &a, int t_first, int lane) {
-    constexpr int KT = kWave * J;
     constexpr int RB = BatchRows<J>::value;
-    constexpr int NB = (NCH - 1) * 8 / RB;              // batches
-    constexpr int BPC = 8 / RB;                         // batches per chunk
-    if constexpr (NB == 0) {
-        if constexpr (WITH_EPI) epi_steps<J, VOLUME, 0, EpiSteps<VOLUME>::value>(epi, run, a, t_first, lane);
-        return;
+    if constexpr (NCH == 1) {
+        if constexpr (WITH_EPI)
+            epi_steps<J, VOLUME, 0, EpiSteps<VOLUME>::value>(epi, run, a, t_first, lane);
     } else {
-        double b0[RB * J], b1[RB * J];
-        issue_rows<J, RB>(b0, q[0], lane_addr, 0);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            if (i + 1 < NB) {
-                const int ci = (i + 1) / BPC, bj = (i + 1) % BPC;
-                const unsigned ca = lane_addr + (unsigned)(ci * 8 * KT * 8);
-                if (i & 1) issue_rows<J, RB>(b0, q[ci], ca, bj * RB);
-                else issue_rows<J, RB>(b1, q[ci], ca, bj * RB);
-                if (bj == BPC - 1) q[ci] = load_offsets(next, ci * 8);   // chunk ci consumed
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (WITH_EPI) {
-                // this batch's share of the previous node's epilogue
-                switch (i) {
-#define QM_EPI_CASE(I)                                                                       \
-    case I:                                                                                  \
-        epi_steps<J, VOLUME, (I) * EpiSteps<VOLUME>::value / NB,                             \
-                  ((I) + 1) * EpiSteps<VOLUME>::value / NB>(epi, run, a,                      \
-                                                                               t_first, lane); \
-        break;
-                    QM_EPI_CASE(0) QM_EPI_CASE(1) QM_EPI_CASE(2) QM_EPI_CASE(3) QM_EPI_CASE(4)
-                    QM_EPI_CASE(5) QM_EPI_CASE(6) QM_EPI_CASE(7) QM_EPI_CASE(8) QM_EPI_CASE(9)
-                    QM_EPI_CASE(10) QM_EPI_CASE(11) QM_EPI_CASE(12) QM_EPI_CASE(13)
-                    QM_EPI_CASE(14) QM_EPI_CASE(15) QM_EPI_CASE(16) QM_EPI_CASE(17)
-                    QM_EPI_CASE(18) QM_EPI_CASE(19) QM_EPI_CASE(20) QM_EPI_CASE(21)
-                    QM_EPI_CASE(22) QM_EPI_CASE(23) QM_EPI_CASE(24) QM_EPI_CASE(25)
-                    QM_EPI_CASE(26) QM_EPI_CASE(27) QM_EPI_CASE(28) QM_EPI_CASE(29)
-                    QM_EPI_CASE(30) QM_EPI_CASE(31) QM_EPI_CASE(32) QM_EPI_CASE(33)
-                    QM_EPI_CASE(34) QM_EPI_CASE(35) QM_EPI_CASE(36) QM_EPI_CASE(37)
-                    QM_EPI_CASE(38) QM_EPI_CASE(39) QM_EPI_CASE(40) QM_EPI_CASE(41)
-                    QM_EPI_CASE(42) QM_EPI_CASE(43) QM_EPI_CASE(44) QM_EPI_CASE(45)
-                    QM_EPI_CASE(46) QM_EPI_CASE(47) QM_EPI_CASE(48) QM_EPI_CASE(49)
-                    QM_EPI_CASE(50) QM_EPI_CASE(51) QM_EPI_CASE(52) QM_EPI_CASE(53)
-                    QM_EPI_CASE(54) QM_EPI_CASE(55)
-#undef QM_EPI_CASE
-                    default: break;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (i & 1) retire_rows<J, RB>(acc, b1);
-            else retire_rows<J, RB>(acc, b0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        double even[RB * J], odd[RB * J];
+        issue_rows<J, RB>(even, q[0], lane_addr, 0);
+        pipeline_batch<J, VOLUME, NCH, WITH_EPI, 0>(acc, even, odd, q, next, lane_addr, epi, run,
+                                                    a, t_first, lane);
     }
 }
 
