@@ -410,12 +410,15 @@ __device__ __forceinline__ void unpack8(const uint4 &q, unsigned base, unsigned 
     addr[6] = base + (q.w & 0xffffu); addr[7] = base + (q.w >> 16);
 }
 
-// vector (not scalar) 16-byte load of 8 packed offsets: the index is made opaque so the
-// compiler cannot prove the address wave-uniform and turn it into an s_load.
+// vector (not scalar) 16-byte load of 8 packed offsets: a zero made opaque to the compiler is
+// added as the 32-bit vector offset, so the address is "uniform base + VGPR offset" (the saddr
+// form of global_load: no 64-bit address arithmetic in the VALU) and cannot be turned into an
+// s_load.
 __device__ __forceinline__ uint4 load_offsets(const uint16_t *rel, int64_t entry) {
-    int zero = 0;
+    unsigned zero = 0;
     asm volatile("" : "+v"(zero));
-    return *reinterpret_cast<const uint4 *>(rel + entry + zero);
+    const char *base = reinterpret_cast<const char *>(rel + entry);
+    return *reinterpret_cast<const uint4 *>(base + zero);
 }
 
 // ---------------------------------------------------------------------------------------
