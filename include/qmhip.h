@@ -160,6 +160,23 @@ int qm_engine_marginal(qm_engine *e, const double *log_onsets, int onsets_on_dev
                        double *coa_map, int map_on_device, double *max_coa,
                        double *max_norm_coa, int64_t *max_coa_idx, int out_on_device);
 
+/* Onset stage on the device -- the step immediately upstream of the path:
+ * STALTAOnset._onset (quakemigrate/signal/onsets/stalta.py:491-548: signal transform, STA/LTA
+ * per component trace with the arithmetic of core/src/onsetlib.c, taper windows :550-583,
+ * root-mean-square over the components, clip at min_onset_value) and then lib.migrate's
+ * log(clip(., 0.01)) (core/lib.py:93-94).
+ *   signals    f64 [n_traces][t_samples], pre-processed (filtered / resampled) waveforms
+ *   trace_row  [n_traces] onset row each trace feeds (the components of one station/phase)
+ *   nsta/nlta  [n_rows] window lengths in samples;  transform 0 = energy (x*x), 1 = abs
+ *   position   0 = classic / overlapping, 1 = centred;  taper_pad < 0 = no taper windows
+ *   raw_onsets (optional) and log_onsets: f64 [n_rows][t_samples]; log_onsets is what
+ *   qm_engine_detect takes (pass it with onsets_on_device = 1 to keep everything on the GPU). */
+int qm_engine_onsets(qm_engine *e, const double *signals, int signals_on_device,
+                     int32_t n_traces, int32_t t_samples, const int32_t *trace_row,
+                     int32_t n_rows, const int32_t *nsta, const int32_t *nlta, int transform,
+                     int position, int32_t taper_pad, double min_onset_value,
+                     double *raw_onsets, double *log_onsets, int out_on_device);
+
 /* Scan of an existing volume (find_max_coa semantics, no table needed). */
 int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
                            int32_t n_samples, int64_t n_nodes, double *max_coa,

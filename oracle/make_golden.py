@@ -227,6 +227,32 @@ def main():
          served_50=served, decimate=np.array([2, 3, 4]), served_dec_250=served_dec,
          dec_node_count=np.array(dec.node_count))
 
+    # 10. onset stage: reference C STA/LTA (through lib.py) inside the NumPy glue of
+    #     STALTAOnset._onset (stalta.py:515-546, :579-581) and lib.migrate (lib.py:93-94)
+    from oracle import qm_oracle as oq
+
+    rng10 = np.random.default_rng(1010)
+    n_traces, T10 = 9, 1400
+    trace_row = np.array([0, 0, 0, 1, 2, 2, 3, 3, 3], dtype=np.int32)    # 3-, 1-, 2-, 3-component rows
+    nsta10 = np.array([11, 11, 21, 21], dtype=np.int32)
+    nlta10 = np.array([51, 51, 101, 101], dtype=np.int32)
+    sig10 = rng10.standard_normal((n_traces, T10)) * np.exp(rng10.normal(0, 1, (n_traces, 1)))
+    sig10[:, 700:720] *= 12.0                         # an arrival
+    sig10[4, 200:260] = 0.0                           # a dead stretch (lta -> 0 guard)
+    arrays = dict(signals=sig10, trace_row=trace_row, nsta=nsta10, nlta=nlta10,
+                  taper_pad=37, min_onset_value=0.4)
+    for pos in ("classic", "centred"):
+        for tf in ("energy", "abs"):
+            raw, logged = oq.np_onset_stage(
+                sig10, trace_row, nsta10, nlta10, tf, pos, 37, 0.4,
+                stalta=(lib.overlapping_sta_lta, lib.centred_sta_lta))
+            arrays[f"raw_{pos}_{tf}"] = raw
+            arrays[f"log_{pos}_{tf}"] = logged
+    raw, logged = oq.np_onset_stage(sig10, trace_row, nsta10, nlta10, "energy", "classic", -1,
+                                    0.01, stalta=(lib.overlapping_sta_lta, lib.centred_sta_lta))
+    arrays["raw_classic_energy_notaper"] = raw
+    save("onset_stage", **arrays)
+
     # 8. STA/LTA: the reference's own known answers + a random trace ---------
     toy = np.arange(6)
     sig = np.abs(rng.standard_normal(600)) + 0.05

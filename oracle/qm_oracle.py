@@ -244,3 +244,33 @@ def c_centred_sta_lta(signal, nsta, nlta):
 
 def c_recursive_sta_lta(signal, nsta, nlta):
     return _stalta(_port()["recursive"], signal, nsta, nlta, 0.0)
+
+
+# --------------------------------------------------------------------------
+# Onset stage (host-side NumPy around the C STA/LTA in the reference)
+# --------------------------------------------------------------------------
+def np_onset_stage(signals, trace_row, nsta, nlta, transform="energy",
+                   position="classic", taper_pad=-1, min_onset_value=0.4,
+                   stalta=None):
+    """
+    ``STALTAOnset._onset`` (quakemigrate/signal/onsets/stalta.py:515-546) with the taper
+    windows of ``_trim_taper_pad`` (:579-581), then ``lib.migrate``'s clip + log (lib.py:93-94).
+    ``stalta``: ``(overlapping_fn, centred_fn)`` taking (signal, nsta, nlta); defaults to the
+    C port.  Returns ``(raw_onsets, log_onsets)``, shape (n_rows, T).
+    """
+    over, cent = stalta or (c_overlapping_sta_lta, c_centred_sta_lta)
+    fn = over if position == "classic" else cent
+    raw = []
+    for row in range(len(nsta)):
+        comps = []
+        for tr in np.flatnonzero(np.asarray(trace_row) == row):
+            x = signals[tr] ** 2 if transform == "energy" else np.abs(signals[tr])
+            o = fn(x, int(nsta[row]), int(nlta[row]))
+            if taper_pad >= 0:
+                o[: (taper_pad + int(nlta[row]) - 1)] = 1.0
+                o[-(int(nsta[row]) + taper_pad):] = 1.0
+            comps.append(o)
+        onset = np.sqrt(np.sum([c ** 2 for c in comps], axis=0) / len(comps))
+        raw.append(np.clip(onset, min_onset_value, np.inf))
+    raw = np.stack(raw, axis=0)
+    return raw, np.log(np.clip(raw, 0.01, np.inf))

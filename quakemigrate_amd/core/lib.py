@@ -85,6 +85,9 @@ qmlib.qm_engine_migrate.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32,
 qmlib.qm_engine_marginal.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32, c_int32,
                                      c_int32, c_int64, c_int32, c_int32, _vp, ctypes.c_int,
                                      _vp, _vp, _vp, ctypes.c_int]
+qmlib.qm_engine_onsets.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32, c_i32Pt, c_int32,
+                                   c_i32Pt, c_i32Pt, ctypes.c_int, ctypes.c_int, c_int32,
+                                   ctypes.c_double, _vp, _vp, ctypes.c_int]
 qmlib.qm_engine_find_max_coa.argtypes = [_vp, _vp, ctypes.c_int, c_int32,
                                          c_int64, _vp, _vp, _vp, ctypes.c_int]
 qmlib.qm_engine_last_kernel_ms.argtypes = [_vp, ctypes.POINTER(ctypes.c_double)]
@@ -325,6 +328,31 @@ class Engine:
             self._h, po, dev_on, t_samples, int(fsmp), int(lsmp), int(available), total,
             int(first_sample), int(end_sample), pm, dev_map, pa, pb, pc, da))
         return out
+
+    def onsets(self, signals, trace_row, nsta, nlta, transform="energy", position="classic",
+               taper_pad=-1, min_onset_value=0.4, raw_out=None, log_out=None):
+        """
+        Onset stage on the GPU (``STALTAOnset._onset`` + the clip/log of ``lib.migrate``): from
+        pre-processed component waveforms ``signals`` (n_traces, T) to the raw onset rows and
+        ``log(clip(onset, 0.01))`` rows, shape (n_rows, T).  Returns ``(raw, logged)``.
+        """
+        n_traces, t_samples = (int(v) for v in signals.shape)
+        trace_row = np.ascontiguousarray(trace_row, dtype=np.int32)
+        nsta = np.ascontiguousarray(nsta, dtype=np.int32)
+        nlta = np.ascontiguousarray(nlta, dtype=np.int32)
+        n_rows = len(nsta)
+        ps, dev_s = self._ptr(signals, np.float64)
+        if log_out is None:
+            log_out = np.zeros((n_rows, t_samples))
+        if raw_out is None and isinstance(log_out, np.ndarray):
+            raw_out = np.zeros((n_rows, t_samples))
+        pl, dev_o = self._ptr(log_out, np.float64)
+        pr = self._ptr(raw_out, np.float64)[0] if raw_out is not None else _vp(None)
+        _check(qmlib.qm_engine_onsets(
+            self._h, ps, dev_s, n_traces, t_samples, trace_row, n_rows, nsta, nlta,
+            {"energy": 0, "abs": 1}[transform], {"classic": 0, "centred": 1}[position],
+            int(taper_pad), float(min_onset_value), pr, pl, dev_o))
+        return raw_out, log_out
 
     def find_max_coa(self, map4d, n_samples, n_nodes, out=None):
         if out is None:

@@ -103,6 +103,10 @@ struct qm_engine {
     DevBuf<int32_t> d_rows, d_served;
     int gx = 0, gy = 0, gz = 0, g_rows = 0;
 
+    // onset stage scratch
+    DevBuf<double> d_sig, d_sta, d_lta, d_raw;
+    DevBuf<int32_t> d_onset_meta;
+
     // scratch
     DevBuf<double> d_onsets, d_pmax, d_psum, d_out_a, d_out_b, d_chunk, d_marg, d_marg_out;
     DevBuf<int64_t> d_pidx, d_out_i;
@@ -422,6 +426,8 @@ void qm_engine_destroy(qm_engine *e) {
     DeviceGuard guard(e->device);
     (void)hipStreamSynchronize(e->stream);
     e->d_grids.release(); e->d_rows.release(); e->d_served.release();
+    e->d_sig.release(); e->d_sta.release(); e->d_lta.release(); e->d_raw.release();
+    e->d_onset_meta.release();
     e->d_lut.release(); e->d_bmeta.release();
     e->d_btotal.release(); e->d_wide.release(); e->d_scalar.release(); e->d_rel.release();
     e->d_onsets.release(); e->d_pmax.release(); e->d_psum.release(); e->d_out_a.release();
@@ -811,6 +817,78 @@ int qm_engine_marginal(qm_engine *e, const double *log_onsets, int onsets_on_dev
         QM_HIP(hipStreamSynchronize(e->stream));
     }
     if (want_scan) return fetch_out(e, ns, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
+    return 0;
+}
+
+int qm_engine_onsets(qm_engine *e, const double *signals, int signals_on_device,
+                     int32_t n_traces, int32_t t_samples, const int32_t *trace_row, int32_t n_rows,
+                     const int32_t *nsta, const int32_t *nlta, int transform, int position,
+                     int32_t taper_pad, double min_onset_value, double *raw_onsets,
+                     double *log_onsets, int out_on_device) {
+    if (!e || !signals || !trace_row || !nsta || !nlta || !log_onsets)
+        return fail("qm_engine_onsets: NULL argument");
+    if (n_traces < 1 || n_rows < 1 || t_samples < 1) return fail("qm_engine_onsets: empty input");
+    if (transform != 0 && transform != 1) return fail("transform must be 0 (energy) or 1 (abs)");
+    if (position != 0 && position != 1) return fail("position must be 0 (classic) or 1 (centred)");
+    std::vector<int> per_row(n_rows, 0);
+    for (int i = 0; i < n_traces; ++i) {
+        if (trace_row[i] < 0 || trace_row[i] >= n_rows) return fail("trace %d: row out of range", i);
+        ++per_row[trace_row[i]];
+    }
+    for (int r = 0; r < n_rows; ++r)
+        if (per_row[r] == 0) return fail("onset row %d has no trace", r);
+    DeviceGuard guard(e->device);
+    const size_t sig = (size_t)n_traces * t_samples, out = (size_t)n_rows * t_samples;
+    const double *d_sig = signals;
+    if (!signals_on_device) {
+        if (e->d_sig.ensure(sig)) return 1;
+        QM_HIP(hipMemcpyAsync(e->d_sig.p, signals, sig * sizeof(double), hipMemcpyHostToDevice,
+                              e->stream));
+        d_sig = e->d_sig.p;
+    }
+    if (e->d_sta.ensure(sig) || e->d_lta.ensure(sig) ||
+        e->d_onset_meta.ensure((size_t)n_traces + 2 * n_rows))
+        return 1;
+    std::vector<int32_t> meta(trace_row, trace_row + n_traces);
+    meta.insert(meta.end(), nsta, nsta + n_rows);
+    meta.insert(meta.end(), nlta, nlta + n_rows);
+    QM_HIP(hipMemcpyAsync(e->d_onset_meta.p, meta.data(), meta.size() * sizeof(int32_t),
+                          hipMemcpyHostToDevice, e->stream));
+    QM_HIP(hipStreamSynchronize(e->stream));            // `meta` is a stack-lifetime buffer
+    qm::OnsetArgs a{};
+    a.signals = d_sig;
+    a.trace_row = e->d_onset_meta.p;
+    a.nsta = e->d_onset_meta.p + n_traces;
+    a.nlta = e->d_onset_meta.p + n_traces + n_rows;
+    a.sta = e->d_sta.p;
+    a.lta = e->d_lta.p;
+    a.n_traces = n_traces; a.n_rows = n_rows; a.T = t_samples;
+    a.transform = transform; a.position = position; a.taper_pad = taper_pad;
+    a.min_onset_value = min_onset_value;
+    double *d_log = log_onsets, *d_raw = raw_onsets;
+    if (!out_on_device) {
+        if (e->d_onsets.ensure(out)) return 1;
+        d_log = e->d_onsets.p;
+        if (raw_onsets) {
+            if (e->d_raw.ensure(out)) return 1;
+            d_raw = e->d_raw.p;
+        }
+    }
+    a.raw = d_raw;
+    a.logged = d_log;
+    hipLaunchKernelGGL(qm::stalta_sums_kernel, dim3((n_traces + 63) / 64), dim3(64), 0, e->stream, a);
+    QM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(qm::onset_rows_kernel, dim3((unsigned)((out + 255) / 256)), dim3(256), 0,
+                       e->stream, a);
+    QM_HIP(hipGetLastError());
+    if (!out_on_device) {
+        QM_HIP(hipMemcpyAsync(log_onsets, d_log, out * sizeof(double), hipMemcpyDeviceToHost,
+                              e->stream));
+        if (raw_onsets)
+            QM_HIP(hipMemcpyAsync(raw_onsets, d_raw, out * sizeof(double), hipMemcpyDeviceToHost,
+                                  e->stream));
+        QM_HIP(hipStreamSynchronize(e->stream));
+    }
     return 0;
 }
 

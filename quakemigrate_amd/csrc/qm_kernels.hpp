@@ -159,6 +159,106 @@ __global__ void brick_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
 }
 
 // ---------------------------------------------------------------------------------------
+// Onset stage on the device: STALTAOnset._onset (quakemigrate/signal/onsets/stalta.py:491-548,
+// trim/taper :550-583) followed by lib.migrate's clip + log (core/lib.py:93-94).
+//   pass 1  one thread per trace, sequential: the running short / long sums of the transformed
+//           signal in exactly the operation order of onsetlib.c:35-59 / :79-108 (the order fixes
+//           their rounding), stored per sample;
+//   pass 2  parallel: ratio * nlta/nsta, the 1.0 fill outside the valid range, the taper
+//           windows, then per onset row the root-mean-square over its component traces,
+//           clip at min_onset_value (raw onset) and log(clip(., 0.01)) (what the stack reads).
+// ---------------------------------------------------------------------------------------
+struct OnsetArgs {
+    const double *signals;     // [n_traces][T] pre-processed waveforms
+    const int32_t *trace_row;  // [n_traces] onset row of each trace (ascending)
+    const int32_t *nsta;       // [n_rows]
+    const int32_t *nlta;       // [n_rows]
+    double *sta, *lta;         // [n_traces][T] scratch
+    double *raw;               // [n_rows][T] or nullptr
+    double *logged;            // [n_rows][T]
+    int n_traces, n_rows, T;
+    int transform;             // 0: energy x*x, 1: abs
+    int position;              // 0: classic (overlapping windows), 1: centred
+    int taper_pad;             // samples; < 0: no taper windows
+    double min_onset_value;
+};
+
+__device__ __forceinline__ double onset_transform(double x, int transform) {
+    return transform == 0 ? x * x : __builtin_fabs(x);
+}
+
+__global__ void stalta_sums_kernel(OnsetArgs a) {
+    const int tr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tr >= a.n_traces) return;
+    const int row = a.trace_row[tr];
+    const int ns = a.nsta[row], nl = a.nlta[row], n = a.T;
+    const double *x = a.signals + (int64_t)tr * n;
+    double *S = a.sta + (int64_t)tr * n, *L = a.lta + (int64_t)tr * n;
+    const int f = a.transform;
+    if (nl > n || ns > nl || ns < 1) return;            // pass 2 leaves such a trace at 1.0
+    double s_short = 0.0, s_long = 0.0;
+    if (a.position == 0) {                              // onsetlib.c:35-59
+        for (int i = 0; i < ns; ++i) s_short += onset_transform(x[i], f);
+        s_long = s_short;
+        for (int i = ns; i < nl; ++i) {
+            const double in = onset_transform(x[i], f);
+            s_long += in;
+            s_short += in - onset_transform(x[i - ns], f);
+        }
+        S[nl - 1] = s_short;
+        L[nl - 1] = s_long;
+        for (int i = nl; i < n; ++i) {
+            const double in = onset_transform(x[i], f);
+            s_short += in - onset_transform(x[i - ns], f);
+            s_long += in - onset_transform(x[i - nl], f);
+            S[i] = s_short;
+            L[i] = s_long;
+        }
+    } else {                                            // onsetlib.c:79-108
+        if (nl + ns > n) return;
+        for (int i = 0; i < nl; ++i) s_long += onset_transform(x[i], f);
+        for (int i = nl; i < nl + ns; ++i) s_short += onset_transform(x[i], f);
+        S[nl - 1] = s_short;
+        L[nl - 1] = s_long;
+        for (int i = nl; i < n - ns; ++i) {
+            s_short += onset_transform(x[i + ns], f) - onset_transform(x[i], f);
+            s_long += onset_transform(x[i], f) - onset_transform(x[i - nl], f);
+            S[i] = s_short;
+            L[i] = s_long;
+        }
+    }
+}
+
+// thread <-> (row, sample); the components of a row are consecutive traces
+__global__ void onset_rows_kernel(OnsetArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)a.n_rows * a.T) return;
+    const int row = (int)(i / a.T), t = (int)(i % a.T);
+    const int ns = a.nsta[row], nl = a.nlta[row], n = a.T;
+    const double frac = (double)nl / (double)ns;
+    double sumsq = 0.0;
+    int count = 0;
+    for (int tr = 0; tr < a.n_traces; ++tr) {
+        if (a.trace_row[tr] != row) continue;
+        double v = 1.0;                                  // lib.py pre-fills with ones
+        const bool sane = !(nl > n || ns > nl || ns < 1) && (a.position == 0 || nl + ns <= n);
+        const int last = a.position == 0 ? n - 1 : n - ns - 1;
+        if (sane && t >= nl - 1 && t <= last) {
+            const double s = a.sta[(int64_t)tr * n + t], l = a.lta[(int64_t)tr * n + t];
+            if (a.position == 0 || t == nl - 1 || l > 0.0) v = s / l * frac;
+        }
+        if (a.taper_pad >= 0 && (t < a.taper_pad + nl - 1 || t >= n - (ns + a.taper_pad)))
+            v = 1.0;                                     // stalta.py:579-581
+        sumsq += v * v;
+        ++count;
+    }
+    double onset = __builtin_sqrt(sumsq / (double)count);             // stalta.py:544
+    onset = onset < a.min_onset_value ? a.min_onset_value : onset;     // :546
+    if (a.raw) a.raw[i] = onset;
+    a.logged[i] = log(onset < 0.01 ? 0.01 : onset);                    // lib.py:93-94
+}
+
+// ---------------------------------------------------------------------------------------
 // Table serving on the device (what LUT.serve_traveltimes does on the host every timestep,
 // quakemigrate/lut/lut.py:502-538): from float64 travel-time grids in seconds, one [N_full] grid
 // per station/phase, build the int32 [N][S] table of the selected rows as rint(tt * rate)

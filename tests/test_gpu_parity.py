@@ -471,3 +471,36 @@ def test_marginal_map_equals_time_sum_of_the_volume(lib, oracle, cfg):
     with pytest.raises(lib.QMHipError, match="window"):
         eng.marginal_map(lon, case.fsmp, case.lsmp, case.available, 10, 500)
     eng.close()
+
+
+def test_onset_stage_on_device_matches_reference_fixture(lib, oracle):
+    """qm_engine_onsets vs STALTAOnset._onset arithmetic (reference C STA/LTA inside the
+    reference's NumPy glue, oracle/make_golden.py section 10), then straight into detect."""
+    import torch
+
+    g = load_golden("onset_stage")
+    eng = lib.Engine(0)
+    args = (g["signals"], g["trace_row"], g["nsta"], g["nlta"])
+    for pos in ("classic", "centred"):
+        for tf in ("energy", "abs"):
+            raw, logged = eng.onsets(*args, transform=tf, position=pos,
+                                     taper_pad=int(g["taper_pad"]),
+                                     min_onset_value=float(g["min_onset_value"]))
+            np.testing.assert_allclose(raw, g[f"raw_{pos}_{tf}"], rtol=1e-12)
+            np.testing.assert_allclose(logged, g[f"log_{pos}_{tf}"], rtol=1e-12, atol=1e-14)
+    raw, _ = eng.onsets(*args, taper_pad=-1, min_onset_value=0.01)
+    np.testing.assert_allclose(raw, g["raw_classic_energy_notaper"], rtol=1e-12)
+    # device-resident chain: signals -> log-onsets (stay on the GPU) -> fused detect
+    rng = np.random.default_rng(8)
+    grid, lsmp, fsmp = (9, 8, 7), 160, 120
+    tt = rng.integers(0, lsmp + 1, size=grid + (4,), dtype=np.int32)
+    d_log = torch.empty((4, g["signals"].shape[1]), dtype=torch.float64, device="cuda")
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.onsets(*args, position="centred", taper_pad=int(g["taper_pad"]), log_out=d_log)
+    eng.load_lut(tt)
+    got = eng.detect(d_log, fsmp, lsmp, 4)
+    want = oracle.detect(g["raw_centred_energy"], tt, fsmp, lsmp, 4, threads=2)
+    assert np.array_equal(got[2], want[2])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-11)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-11)
+    eng.close()

@@ -145,3 +145,15 @@ def test_table_serving_restatement_matches_reference_lut_class(oracle):
     dec = [oracle.np_decimate(p, g["decimate"]) for p in picked]
     assert dec[0].shape == tuple(int(v) for v in g["dec_node_count"])
     assert np.array_equal(oracle.np_serve_traveltimes(dec, 250), g["served_dec_250"])
+
+
+def test_onset_stage_restatement_with_the_c_port(oracle):
+    """np_onset_stage on the oracle's C STA/LTA port == the fixture made with the reference's."""
+    g = load_golden("onset_stage")
+    for pos in ("classic", "centred"):
+        for tf in ("energy", "abs"):
+            raw, logged = oracle.np_onset_stage(g["signals"], g["trace_row"], g["nsta"], g["nlta"],
+                                                tf, pos, int(g["taper_pad"]),
+                                                float(g["min_onset_value"]))
+            np.testing.assert_allclose(raw, g[f"raw_{pos}_{tf}"], rtol=1e-12)
+            np.testing.assert_allclose(logged, g[f"log_{pos}_{tf}"], rtol=1e-12, atol=1e-14)
