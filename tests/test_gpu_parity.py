@@ -504,3 +504,57 @@ def test_onset_stage_on_device_matches_reference_fixture(lib, oracle):
     np.testing.assert_allclose(got[0], want[0], rtol=1e-11)
     np.testing.assert_allclose(got[1], want[1], rtol=1e-11)
     eng.close()
+
+
+def test_randomised_differential_with_many_exact_ties(lib, oracle):
+    """
+    40 random shapes / engine configurations against the oracle.  The LOG-onsets are small
+    multiples of 2^-6, so every partial sum is exact in float64 whatever the row order: nodes
+    that stack the same multiset of values reach EXACTLY the same sum, there are many exact
+    ties at the maximum, and the argmax must be the lowest flat index whichever wave / brick /
+    workgroup / partial set saw it first (migratelib.c:102 strict '>').  (Sums that are equal
+    in exact arithmetic but differ in the last bits are a different matter: the reference then
+    compares libmvec exp values, which merge such neighbours unpredictably -- DESIGN.md section 1.)
+    """
+    rng = np.random.default_rng(20260927)
+    n_ties = 0
+    for trial in range(40):
+        grid = tuple(int(v) for v in rng.integers(1, 12, size=3))
+        S = int(rng.integers(1, 40))
+        ns = int(rng.integers(1, 400))
+        fsmp = int(rng.integers(0, 20))
+        lsmp = int(rng.integers(1, 60))
+        if trial % 2 == 0:                                 # coherent table (LDS-tiled path)
+            base = rng.integers(0, max(1, lsmp // 2), size=S)
+            ijk = np.indices(grid).sum(axis=0)[..., None]
+            tt = np.minimum(base[None, None, None, :] + ijk // 2, lsmp).astype(np.int32)
+        else:                                              # incoherent table, negatives too
+            tt = rng.integers(-3, lsmp + 1, size=grid + (S,), dtype=np.int32)
+        lon = rng.choice([-48, -16, 0, 16, 80], size=(S, fsmp + ns + lsmp),
+                         p=[0.45, 0.25, 0.15, 0.1, 0.05]) / 64.0
+        avail = int(2 ** rng.integers(0, 5))               # power of two: sum/avail is exact too
+        cfg = dict(samples_per_lane=int(rng.choice([0, 1, 2, 4])),
+                   waves=int(rng.choice([1, 2, 4, 8, 16])),
+                   groups=int(rng.choice([0, 1, 3, 7])))
+        if rng.random() < 0.4:
+            cfg.update(brick_x=int(rng.integers(1, 9)), brick_y=int(rng.integers(1, 9)),
+                       brick_z=int(rng.integers(1, 9)))
+        if rng.random() < 0.2:
+            cfg["generic"] = 1
+        want = oracle.detect(lon, tt, fsmp, lsmp, avail, threads=2, prelogged=True)
+        ref = oracle.c_migrate(lon, tt, fsmp, lsmp, avail, threads=2, prelogged=True)
+        flat = ref.reshape(-1, ns)
+        n_ties += int((np.sum(flat == flat.max(axis=0)[None, :], axis=0) > 1).sum())
+        eng = lib.Engine(0, **cfg)
+        eng.load_lut(tt)
+        got = eng.detect(lon, fsmp, lsmp, avail)
+        assert np.array_equal(got[2], want[2]), (trial, grid, S, ns, cfg)
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-13, err_msg=str((trial, cfg)))
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-12, err_msg=str((trial, cfg)))
+        vol = np.zeros(grid + (ns,))
+        series = (np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64))
+        eng.migrate(lon, fsmp, lsmp, avail, vol, scan_out=series)
+        np.testing.assert_allclose(vol, ref, rtol=1e-13, err_msg=str((trial, cfg)))
+        assert np.array_equal(series[2], want[2]), (trial, cfg)
+        eng.close()
+    assert n_ties > 1000                                   # the test does exercise ties
