@@ -1,0 +1,73 @@
+# -*- coding: utf-8 -*-
+"""
+Row f4: the ``.scanmseed`` wire format (quakemigrate/io/scanmseed.py:74-150, 222-240, 244-325)
+read and written without obspy.  The fixture is the reference's own benchmark output,
+examples/benchmarks/Icequake_Iceland/2014_180.scanmseed (a data file its test-suite compares
+against, tests/test_benchmarks.py:80-111).
+"""
+
+import datetime as dt
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from quakemigrate_amd import scanmseed as sm
+
+FIXTURE = GOLDEN / "icequake_iceland_2014_180.scanmseed"
+
+
+def test_decode_reference_benchmark_file():
+    t0, rate, cols = sm.read_scanmseed(FIXTURE)
+    assert t0 == dt.datetime(2014, 6, 29, 18, 42, 5) and rate == 250.0
+    ints = cols["int"]
+    assert set(ints) == set(sm.CHANNELS) and all(len(v) == 2500 for v in ints.values())
+    # 4 timesteps of 2.5 s at 250 Hz (iceland_detect.py:45,62); plausible physical ranges
+    assert 1.0 < cols["COA"].min() and cols["COA"].max() < 10.0
+    assert (cols["COA_N"] >= 1.0).all()
+    assert -17.3 < cols["X"].min() and cols["X"].max() < -17.1      # degrees east
+    assert 64.3 < cols["Y"].min() and cols["Y"].max() < 64.4        # degrees north
+    # every record's reverse integration constant was verified by the decoder
+    blob = FIXTURE.read_bytes()
+    assert len(blob) % sm.RECLEN == 0 and len(list(sm.read_records(blob))) == 11
+
+
+def test_encoder_reproduces_the_reference_file_byte_for_byte():
+    t0, rate, cols = sm.read_scanmseed(FIXTURE)
+    blob = b"".join(sm.write_trace(sm.Trace(ch, "NW", t0, rate, cols["int"][ch]))
+                    for ch in sm.CHANNELS)
+    assert blob == FIXTURE.read_bytes()
+
+
+def test_round_trip_all_packings(tmp_path):
+    rng = np.random.default_rng(5)
+    n = 9000
+    scales = rng.choice([3, 12, 25, 100, 400, 12000, 5.0e7], size=n)   # every STEIM2 width
+    steps = np.clip(rng.standard_normal(n) * scales, -2.0e8, 2.0e8).astype(np.int64)
+    x = np.cumsum(steps)
+    x = (x - (x.max() + x.min()) // 2).astype(np.int64)
+    x = (x % (2 ** 28) - 2 ** 27 if np.abs(x).max() >= 2 ** 30 else x).astype(np.int32)
+    assert np.abs(np.diff(x.astype(np.int64))).max() < 2 ** 29
+    series = {ch: np.roll(x, i * 7) for i, ch in enumerate(sm.CHANNELS)}
+    series["Z"] = np.zeros(n, dtype=np.int32)                             # an "empty" timestep
+    path = tmp_path / "2020_001.scanmseed"
+    t0 = dt.datetime(2020, 1, 1, 0, 0, 0, 120000)
+    sm.write_scanmseed(path, t0, 50.0, series)
+    t1, rate, cols = sm.read_scanmseed(path)
+    assert t1 == t0 and rate == 50.0
+    for ch in sm.CHANNELS:
+        assert np.array_equal(cols["int"][ch], series[ch])
+    with pytest.raises(OverflowError):
+        sm.steim2_encode(np.array([0, 2 ** 30 + 5], dtype=np.int64), 0)
+
+
+def test_quantisation_follows_data2int():
+    """clip at 21474, scale, round half to even, int32 (scanmseed.py:103-130, 222-240)."""
+    coa = np.array([0.000005, 0.000015, 1.234565, 30000.0])
+    q = sm.quantise(coa, coa * 2, np.array([[1.25, 2.0, 0.0015]] * 4), ucf=1000.0)
+    assert q["COA"].tolist() == [0, 2, 123456, 2147400000]
+    assert q["COA"].dtype == np.int32 and q["COA_N"][3] == 2147400000
+    assert q["X"][0] == 1250000 and q["Z"][0] == 1500
+    # what Trigger reads back (scanmseed.py:300-305)
+    f = sm.scale_factors(1000.0)
+    np.testing.assert_allclose(q["COA"][:3] / f["COA"], coa[:3], atol=5e-6)
