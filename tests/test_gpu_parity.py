@@ -558,3 +558,28 @@ def test_randomised_differential_with_many_exact_ties(lib, oracle):
         assert np.array_equal(series[2], want[2]), (trial, cfg)
         eng.close()
     assert n_ties > 1000                                   # the test does exercise ties
+
+
+def test_end_to_end_synthetic_detect_example(lib, tmp_path):
+    """examples/synthetic_detect.py: signals -> onsets (GPU) -> served table (GPU) -> fused
+    detect -> .scanmseed; the injected events are located and the file reads back."""
+    import importlib.util
+
+    from conftest import ROOT
+    from quakemigrate_amd import scanmseed as sm
+
+    spec = importlib.util.spec_from_file_location("synthetic_detect",
+                                                  ROOT / "examples" / "synthetic_detect.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run(tmp_path)
+    for node, t in res["truth"]:                      # t: sample in the concatenated series
+        lo, hi = max(0, t - 12), t + 12
+        peak = lo + int(np.argmax(res["coa"][lo:hi]))
+        found = np.unravel_index(res["idx"][peak], res["grid"])
+        assert max(abs(a - b) for a, b in zip(found, node)) <= 1, (node, found)
+        assert res["coa"][peak] > 2.0 * np.median(res["coa"])
+    t0, rate, cols = sm.read_scanmseed(res["path"], ucf=1000.0)
+    assert rate == 50.0 and len(cols["COA"]) == len(res["coa"])
+    np.testing.assert_allclose(cols["COA"], np.minimum(res["coa"], 21474.0), atol=5.1e-6)
+    np.testing.assert_allclose(cols["X"], res["coord"][:, 0], atol=5.1e-7)
