@@ -114,15 +114,18 @@ def test_engine_configurations_against_oracle(lib, oracle, cfg):
     eng = lib.Engine(0, **cfg)
     eng.load_lut(case.traveltimes)
     assert eng.lut_max <= case.lsmp
+    # outputs pre-filled with NaN / -1: every element must be written by the engine
+    poisoned = (np.full(case.n_samples, np.nan), np.full(case.n_samples, np.nan),
+                np.full(case.n_samples, -1, dtype=np.int64))
     got = eng.detect(oracle.log_onsets(case.onsets), case.fsmp, case.lsmp,
-                     case.available)
+                     case.available, out=poisoned)
     _assert_series(got, want)
     for (ijk, t0) in case.event_nodes:
         assert got[2][t0] == np.ravel_multi_index(ijk, case.grid)
     # the same through the materialising path, volume on the host
-    vol = np.zeros((case.n_nodes_total, case.n_samples))
-    series = (np.zeros(case.n_samples), np.zeros(case.n_samples),
-              np.zeros(case.n_samples, dtype=np.int64))
+    vol = np.full((case.n_nodes_total, case.n_samples), np.nan)     # poisoned, not accumulated
+    series = (np.full(case.n_samples, np.nan), np.full(case.n_samples, np.nan),
+              np.full(case.n_samples, -1, dtype=np.int64))
     eng.config("chunk_bytes", 1 << 20)                     # forces several time chunks
     eng.migrate(oracle.log_onsets(case.onsets), case.fsmp, case.lsmp, case.available,
                 vol, scan_out=series)
