@@ -140,11 +140,29 @@ int eff_j(const qm_engine *e) {
     return 1;
 }
 
-// bricks whose windows do not fit the LDS budget for the current tile length
-int plan_wide(qm_engine *e) {
-    const int KT = qm::kWave * eff_j(e);
+// Samples per lane for one launch over n_chunk samples: never more than eff_j (the brick shape
+// was chosen for it), but fewer when the padding of the last time tile costs more than the
+// smaller tile's overhead (measured on C3/C4: J = 2 is ~1.12x, J = 1 ~1.4x the work of J = 4 per
+// sample) -- e.g. the Icequake example's 625-sample timestep runs 5 tiles of 128, not 3 of 256.
+int run_j(const qm_engine *e, int n_chunk) {
+    const int jmax = eff_j(e);
+    if (e->cfg_j > 0) return jmax;
+    int best = jmax;
+    double best_cost = 1e300;
+    for (int j : {4, 2, 1}) {
+        if (j > jmax) continue;
+        const int kt = qm::kWave * j;
+        const double cost = (double)((n_chunk + kt - 1) / kt) * kt * (j == 4 ? 1.0 : j == 2 ? 1.12 : 1.4);
+        if (cost < best_cost * 0.999) { best_cost = cost; best = j; }
+    }
+    return best;
+}
+
+// bricks whose windows do not fit the LDS budget for tile length 64*J
+int plan_wide(qm_engine *e, int J) {
+    const int KT = qm::kWave * J;
     const int cap = lds_cap_doubles(e);
-    if (e->plan_j == eff_j(e) && e->plan_cap == cap) return 0;
+    if (e->plan_j == J && e->plan_cap == cap) return 0;
     std::vector<int32_t> wide;
     for (int b = 0; b < e->g.nbricks; ++b) {
         if (!qm::brick_fits(e->h_btotal[b], e->g.n_rows, KT, cap)) wide.push_back(b);
@@ -156,7 +174,7 @@ int plan_wide(qm_engine *e) {
                               hipMemcpyHostToDevice, e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
     }
-    e->plan_j = eff_j(e);
+    e->plan_j = J;
     e->plan_cap = cap;
     return 0;
 }
@@ -240,8 +258,8 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
               int available, int sample0, int n_chunk, double *volume, int64_t vol_stride,
               int accumulate, bool want_scan, int *n_sets, double *marginal = nullptr,
               int m0 = 0, int m1 = 0) {
-    if (plan_wide(e)) return 1;
-    const int J = eff_j(e);
+    const int J = run_j(e, n_chunk);
+    if (plan_wide(e, J)) return 1;
     const int KT = qm::kWave * J;
     qm::StackArgs a{};
     a.g = e->g;
@@ -509,7 +527,7 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "n_wide_bricks") {
         if (e->have_lut) {
             DeviceGuard guard(e->device);
-            if (plan_wide(e)) return 1;
+            if (plan_wide(e, eff_j(e))) return 1;
         }
         *v = e->n_wide;
     } else if (k == "n_cu") *v = e->n_cu;
@@ -591,7 +609,7 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     e->node_offset = node_offset;
     e->plan_j = -1;
     e->have_lut = true;
-    return plan_wide(e);
+    return plan_wide(e, eff_j(e));
 }
 
 int qm_engine_grids_begin(qm_engine *e, int32_t nx, int32_t ny, int32_t nz, int32_t n_grids) {
@@ -794,7 +812,7 @@ int qm_engine_marginal(qm_engine *e, const double *log_onsets, int onsets_on_dev
     OutStage st{nullptr, nullptr, nullptr};
     if (want_scan && stage_out(e, ns, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st))
         return 1;
-    const int KT = qm::kWave * eff_j(e);
+    const int KT = qm::kWave * run_j(e, ns);            // the tile length run_stack will use
     const int ntiles = (ns + KT - 1) / KT;
     if (e->d_marg.ensure((size_t)ntiles * e->n_nodes)) return 1;
     double *d_map = coa_map;
