@@ -184,7 +184,8 @@ int launch_lds(qm_engine *e, qm::StackArgs &a, int groups_lds, int threads, size
     QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_lds_kernel<J, VOLUME, NCH>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((qm::stack_lds_kernel<J, VOLUME, NCH>),
-                       dim3((unsigned)(a.ntiles * groups_lds)), dim3(threads), lds, e->stream, a);
+                       dim3((unsigned)(a.ntiles * ((groups_lds + 7) / 8 * 8))), dim3(threads), lds,
+                       e->stream, a);
     QM_HIP(hipGetLastError());
     return 0;
 }
@@ -231,7 +232,7 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
             a.n_list = e->n_wide;
         }
         hipLaunchKernelGGL((qm::stack_direct_kernel<J, VOLUME>),
-                           dim3((unsigned)(a.ntiles * groups_direct)), dim3(threads),
+                           dim3((unsigned)(a.ntiles * ((groups_direct + 7) / 8 * 8))), dim3(threads),
                            publish_bytes, e->stream, a);
         QM_HIP(hipGetLastError());
         a.set0 += groups_direct;

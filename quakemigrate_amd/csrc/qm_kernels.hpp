@@ -713,8 +713,14 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
-    const int tile = blockIdx.x % a.ntiles;
-    const int group = blockIdx.x / a.ntiles;
+    // XCD-aware workgroup -> (time tile, brick group) map: workgroup b is observed to run on XCD
+    // b % 8, each XCD has its own L2; all time tiles of one brick group read the same slice of the
+    // offset table, so whole groups are dealt to XCDs (group = xcd + 8 * k) and a slice is fetched
+    // into one L2 instead of eight.  Purely a placement hint: any mapping gives the same result.
+    const int slot = blockIdx.x >> 3;
+    const int tile = slot % a.ntiles;
+    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
     const int t_first = tile * KT;                    // relative to sample0
     const int S = g.n_rows;
     const int nfull = S >> 3, ntail = S & 7;
@@ -868,8 +874,14 @@ __global__ __launch_bounds__(1024) void stack_direct_kernel(StackArgs a) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
-    const int tile = blockIdx.x % a.ntiles;
-    const int group = blockIdx.x / a.ntiles;
+    // XCD-aware workgroup -> (time tile, brick group) map: workgroup b is observed to run on XCD
+    // b % 8, each XCD has its own L2; all time tiles of one brick group read the same slice of the
+    // offset table, so whole groups are dealt to XCDs (group = xcd + 8 * k) and a slice is fetched
+    // into one L2 instead of eight.  Purely a placement hint: any mapping gives the same result.
+    const int slot = blockIdx.x >> 3;
+    const int tile = slot % a.ntiles;
+    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
     const int t_first = tile * KT;
     const int S = g.n_rows;
     const int n_list = a.brick_list ? a.n_list : g.nbricks;
