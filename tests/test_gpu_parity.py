@@ -586,3 +586,35 @@ def test_end_to_end_synthetic_detect_example(lib, tmp_path):
     assert rate == 50.0 and len(cols["COA"]) == len(res["coa"])
     np.testing.assert_allclose(cols["COA"], np.minimum(res["coa"], 21474.0), atol=5.1e-6)
     np.testing.assert_allclose(cols["X"], res["coord"][:, 0], atol=5.1e-7)
+
+
+def test_empty_scan_and_nan_onsets(lib, oracle):
+    """No samples to scan is an error (the reference would allocate an empty map).  NaN onsets:
+    the reference is built with -Ofast (-ffinite-math-only), so what it does with a NaN is
+    unspecified; the engine's behaviour is defined: a NaN stack never wins the maximum and
+    turns that sample's sum -- hence max_norm_coa -- to NaN; all other samples are untouched."""
+    g = load_golden("small_random")
+    tt, fsmp, lsmp = g["traveltimes"], int(g["fsmp"]), int(g["lsmp"])
+    eng = lib.Engine(0)
+    eng.load_lut(tt)
+    with pytest.raises(lib.QMHipError, match="no samples"):
+        eng.detect(np.zeros((6, fsmp + lsmp)), fsmp, lsmp, 6)
+    with pytest.raises(lib.QMHipError, match="available"):
+        eng.detect(np.zeros((6, fsmp + lsmp + 5)), fsmp, lsmp, 0)
+    on = g["onsets"].copy()
+    flat = tt.reshape(-1, 6)
+    on[3, fsmp + 60 + int(flat[200, 3])] = np.nan          # node 200 reads it at sample 60
+    clean = eng.detect(oracle.log_onsets(g["onsets"]), fsmp, lsmp, 6)
+    got = eng.detect(oracle.log_onsets(on), fsmp, lsmp, 6)
+    hit = np.isnan(got[1])
+    assert hit[60] and not np.isnan(got[0]).any()
+    # samples whose stacks never read the NaN are bit-identical to the clean run
+    for a, b in zip(got, clean):
+        assert np.array_equal(a[~hit], b[~hit])
+    # at a poisoned sample the winner is the best node among those that did not read it
+    vol = oracle.c_migrate(g["onsets"], tt, fsmp, lsmp, 6, threads=2).reshape(-1, got[0].size)
+    reads_nan = np.array([fsmp + 60 + int(flat[n, 3]) == fsmp + 60 + int(flat[200, 3])
+                          for n in range(vol.shape[0])])
+    col = np.where(reads_nan, -np.inf, vol[:, 60])
+    assert got[2][60] == int(np.argmax(col))
+    eng.close()

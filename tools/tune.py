@@ -21,10 +21,11 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--sweep", default="default")
     ap.add_argument("--ns", type=int, default=0, help="override n_samples")
+    ap.add_argument("--rows", type=int, default=0, help="override the number of table rows")
     ap.add_argument("--volume", action="store_true", help="materialising path (device volume)")
     args = ap.parse_args()
     t0 = time.time()
-    case = synth.make_case(args.config, n_samples=args.ns or None)
+    case = synth.make_case(args.config, n_samples=args.ns or None, rows=args.rows or None)
     vol = None
     if args.volume:
         import torch
