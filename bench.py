@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--no-materialised", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--engine", default="{}", help="json dict of engine tunables")
+    ap.add_argument("--materialise-full", action="store_true",
+                    help="also run configs[2] literally: the whole n_samples volume (196 GB at "
+                         "C3) written to HBM with the scan outputs (needs the memory)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single process: build and time the slab rank --emulate-rank of an "
                          "N-GPU partition would hold (no exchange); for measuring C4 on 1 GPU")
@@ -341,6 +344,32 @@ def main():
             "bound": "hbm", "achieved": 8.0 * n_local * ns_loc / sec / 1e9, "peak": HBM_PEAK / 1e9,
             "unit": "GB/s", "frac": 8.0 * n_local * ns_loc / sec / HBM_PEAK, "avg_ms": sec * 1e3,
             "workload": "find_max_coa of the resident locate volume (scan + combine kernels)"}
+        del vol
+
+    if args.materialise_full and world == 1 and not streaming:
+        vol = torch.empty((n_local, ns), dtype=torch.float64, device=dev)
+        o3 = tuple(torch.empty(ns, dtype=d, device=dev)
+                   for d in (torch.float64, torch.float64, torch.int64))
+        eng.migrate(onsets_dev[0], case.fsmp, case.lsmp, case.available, vol, scan_out=o3)
+        torch.cuda.synchronize()
+        eng.config("log_timing", 1)
+        for _ in range(3):
+            eng.migrate(onsets_dev[0], case.fsmp, case.lsmp, case.available, vol, scan_out=o3)
+        torch.cuda.synchronize()
+        ms, calls = eng.kernel_log()
+        eng.config("log_timing", 0)
+        sec = ms / 1e3 / calls
+        b_full = 8.0 * n_local * ns + b_fused
+        eng.detect(onsets_dev[0], case.fsmp, case.lsmp, case.available, n_nodes_total=n_total,
+                   out=out)
+        torch.cuda.synchronize()
+        result["roofline_materialised_full"] = {
+            "bound": "hbm", "achieved": b_full / sec / 1e9, "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s", "frac": b_full / sec / HBM_PEAK, "avg_ms": sec * 1e3,
+            "node_samples_per_s": n_local * ns / sec,
+            "scan_equals_fused_detect": bool(torch.equal(o3[2], out[2])
+                                             and torch.equal(o3[0], out[0])),
+            "workload": f"whole step materialised: {8.0 * n_local * ns / 1e9:.0f} GB volume + scan"}
         del vol
 
     if not args.no_cpu_baseline and world == 1 and not streaming:
