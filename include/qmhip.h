@@ -160,6 +160,31 @@ int qm_engine_marginal(qm_engine *e, const double *log_onsets, int onsets_on_dev
                        double *coa_map, int map_on_device, double *max_coa,
                        double *max_norm_coa, int64_t *max_coa_idx, int out_on_device);
 
+/* Locate post-reductions of a marginalised 3-D coalescence map f64 [nx][ny][nz] (the output of
+ * qm_engine_marginal), on the device -- QuakeScan._calculate_location's array work
+ * (quakemigrate/signal/scan.py:696-733):
+ *   - coa_map / nanmax(coa_map)                                       (scan.py:721)
+ *   - _gaufilt3d: fftconvolve with util.gaussian_3d(nx, ny, nz, sgm), mode "same", twice, the
+ *     second time mirrored, each normalised by its maximum           (scan.py:1008-1043,
+ *     util.py:76-116), evaluated as a separable direct convolution
+ *   - _covfit3d: weights = map where map > cov_thresh; expectation and 3x3 covariance of the
+ *     node positions ix*node_spacing[0], ...                          (scan.py:939-1005)
+ *   - the 7x7x7 window of the smoothed map around its maximum that _gaufit3d fits and the
+ *     5x5x5 window of the normalised map that _splineloc interpolates (scan.py:736-936);
+ *     nodes outside the grid are NaN.  The 10-parameter least squares / RBF solves on those
+ *     few hundred values stay with the caller.
+ * norm_map / smoothed_map: optional f64 [nx*ny*nz] outputs (host or device per out_on_device).
+ * summary (host, 16 doubles): 0 nanmax of the input; 1 flat index of the first maximum of the
+ * normalised map; 2 mean of the smoothed map; 3 flat index of the first maximum of the
+ * smoothed map; 4 total weight; 5-7 expectation (xe, ye, ze); 8-13 covariance xx, yy, zz, xy,
+ * xz, yz; 14, 15 the maxima the two smoothing passes were normalised by.
+ * gau_window: host f64 [343]; spline_window: host f64 [125]. */
+int qm_engine_locate_fits(qm_engine *e, const double *coa_map, int map_on_device, int32_t nx,
+                          int32_t ny, int32_t nz, double sgm, double cov_thresh,
+                          const double *node_spacing, double *norm_map, double *smoothed_map,
+                          int out_on_device, double *summary, double *gau_window,
+                          double *spline_window);
+
 /* Onset stage on the device -- the step immediately upstream of the path:
  * STALTAOnset._onset (quakemigrate/signal/onsets/stalta.py:491-548: signal transform, STA/LTA
  * per component trace with the arithmetic of core/src/onsetlib.c, taper windows :550-583,

@@ -67,6 +67,95 @@ def load_reference_lut_module():
     return mod
 
 
+def load_reference_scan_module():
+    """
+    The reference's quakemigrate/signal/scan.py and util.py, imported as plain modules.  The
+    location methods recorded in section 11 (QuakeScan._calculate_location and the four fits it
+    calls, scan.py:696-1077) use numpy / scipy and ``self.lut`` only; obspy, the io / plot
+    packages and the onset / picker / magnitude modules the file imports at the top are absent or
+    irrelevant here, so permissive empty modules stand in for those imports.
+    """
+    class Blank(types.ModuleType):
+        __path__ = []
+
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return type(name, (), {})
+
+    saved = dict(sys.modules)
+    for name in ("obspy", "quakemigrate", "quakemigrate.core", "quakemigrate.io",
+                 "quakemigrate.plot", "quakemigrate.plot.event", "quakemigrate.signal",
+                 "quakemigrate.signal.onsets", "quakemigrate.signal.pickers",
+                 "quakemigrate.signal.local_mag"):
+        sys.modules[name] = Blank(name)
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "quakemigrate.util", REF / "quakemigrate" / "util.py")
+        util = importlib.util.module_from_spec(spec)
+        sys.modules["quakemigrate.util"] = util
+        spec.loader.exec_module(util)
+        sys.modules["quakemigrate"].util = util
+        spec = importlib.util.spec_from_file_location(
+            "quakemigrate.signal.scan", REF / "quakemigrate" / "signal" / "scan.py")
+        scan = importlib.util.module_from_spec(spec)
+        sys.modules["quakemigrate.signal.scan"] = scan
+        spec.loader.exec_module(scan)
+    finally:
+        for name in list(sys.modules):
+            if name not in saved and (name == "obspy" or name.startswith("quakemigrate")):
+                del sys.modules[name]
+        sys.modules.update({k: v for k, v in saved.items()
+                            if k == "obspy" or k.startswith("quakemigrate")})
+    return scan
+
+
+def reference_location(scan_mod, map4d, node_spacing):
+    """
+    Run the reference's QuakeScan._calculate_location on ``map4d`` with a stand-in ``self``
+    whose LUT has the identity coordinate transform (pyproj is absent: locations come back in
+    grid-index / grid-xyz space, which is the parity point).
+    """
+    class GridOnlyLUT:
+        def __init__(self, shape, spacing):
+            self.node_count = np.array(shape)
+            self.node_spacing = np.array(spacing, dtype=np.float64)
+            self.ll_corner = np.zeros(3)
+
+        def index2coord(self, loc):
+            return np.array(loc, dtype=np.float64)
+
+        def coord2grid(self, loc, inverse=False):
+            return np.atleast_2d(np.array(loc, dtype=np.float64))
+
+    class Recorder:
+        def __init__(self, map4d):
+            self.map4d = map4d
+            self.out = {}
+
+        def add_spline_location(self, loc):
+            self.out["spline"] = np.array(loc, dtype=np.float64)
+
+        def add_gaussian_location(self, loc, unc):
+            self.out["gaussian"] = np.array(loc, dtype=np.float64)
+            self.out["gaussian_uncertainty"] = np.array(unc, dtype=np.float64)
+
+        def add_covariance_location(self, loc, unc):
+            self.out["covariance"] = np.array(loc, dtype=np.float64)
+            self.out["covariance_uncertainty"] = np.array(unc, dtype=np.float64)
+
+    qs = scan_mod.QuakeScan
+    me = types.SimpleNamespace(lut=GridOnlyLUT(map4d.shape[:3], node_spacing))
+    for name in ("_splineloc", "_gaufilt3d", "_gaufit3d", "_covfit3d", "_mask3d"):
+        setattr(me, name, types.MethodType(getattr(qs, name), me))
+    event = Recorder(map4d)
+    coa_map = qs._calculate_location(me, event)
+    out = dict(event.out)
+    out["coa_map"] = coa_map
+    out["smoothed"] = me._gaufilt3d(np.copy(coa_map))
+    return out
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -86,7 +175,12 @@ def run(lib, onsets, tt, fsmp, lsmp, avail, threads=4):
     return m, a, b, c
 
 
+ONLY = set(sys.argv[1:])        # `make_golden.py locate_fits ...` rewrites just those fixtures
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     arrays["meta"] = np.array(repr(meta()))
     path = OUT / f"{name}.npz"
     np.savez_compressed(path, **arrays)
@@ -252,6 +346,40 @@ def main():
                                     0.01, stalta=(lib.overlapping_sta_lta, lib.centred_sta_lta))
     arrays["raw_classic_energy_notaper"] = raw
     save("onset_stage", **arrays)
+
+    # 11. locate post-reductions: QuakeScan._calculate_location (scan.py:696-733) and the fits it
+    #     calls, run from the reference's own scan.py on synthetic 4-D maps --------------------
+    scan_mod = load_reference_scan_module()
+    rng11 = np.random.default_rng(1111)
+
+    def blob_map4d(shape, centre, widths, nt=7, noise=0.02):
+        idx = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+        r2 = sum(((g - c) / w) ** 2 for g, c, w in zip(idx, centre, widths))
+        base = 1.2 + 2.5 * np.exp(-0.5 * r2) + noise * rng11.standard_normal(shape)
+        profile = 1.0 + 0.5 * np.exp(-0.5 * ((np.arange(nt) - nt // 2) / 1.5) ** 2)
+        return base[..., None] * profile + 0.01 * rng11.random(shape + (nt,))
+
+    locate_cases = {
+        # odd grid, interior peak between nodes
+        "interior_odd": ((21, 19, 15), (9.3, 10.6, 6.2), (2.0, 2.6, 1.7), (0.5, 0.5, 0.25)),
+        # even sizes on every axis: the half-node shift of the "same"-mode filter
+        "interior_even": ((20, 18, 16), (11.4, 7.7, 8.5), (2.4, 1.9, 2.2), (1.0, 1.0, 1.0)),
+        # mixed parity, peak two nodes from a face: both fit windows are clipped
+        "near_face": ((17, 14, 12), (1.2, 6.8, 9.9), (2.2, 2.0, 2.1), (0.4, 0.5, 0.6)),
+        # peak one node from a corner: the clipped spline window is still a cube (4x4x4)
+        "corner": ((13, 12, 11), (1.0, 1.0, 1.0), (1.6, 1.6, 1.6), (0.5, 0.5, 0.5)),
+        # smaller than the filter's reach on one axis
+        "thin": ((15, 16, 5), (7.2, 8.1, 2.4), (2.0, 2.0, 1.2), (0.5, 0.5, 0.5)),
+    }
+    arrays = {"cases": np.array(sorted(locate_cases))}
+    for name, (shape, centre, widths, spacing) in locate_cases.items():
+        m4 = blob_map4d(shape, centre, widths)
+        out = reference_location(scan_mod, m4, spacing)
+        arrays[f"{name}_map4d"] = m4
+        arrays[f"{name}_node_spacing"] = np.array(spacing)
+        for k, v in out.items():
+            arrays[f"{name}_{k}"] = v
+    save("locate_fits", **arrays)
 
     # 8. STA/LTA: the reference's own known answers + a random trace ---------
     toy = np.arange(6)

@@ -274,3 +274,113 @@ def np_onset_stage(signals, trace_row, nsta, nlta, transform="energy",
         raw.append(np.clip(onset, min_onset_value, np.inf))
     raw = np.stack(raw, axis=0)
     return raw, np.log(np.clip(raw, 0.01, np.inf))
+
+
+# --------------------------------------------------------------------------------------
+# locate post-reductions: QuakeScan._calculate_location's array work
+# --------------------------------------------------------------------------------------
+def np_window_bounds(shape, centre, window):
+    """``QuakeScan._mask3d`` bounds (scan.py:1066-1072): ``[lo, hi)`` per axis, clipped."""
+    n = np.asarray(shape)
+    c = np.asarray(centre)
+    half = (window - 1) // 2
+    return np.clip(c - half, 0, n), np.clip(c + half + 1, 0, n)
+
+
+def np_gaufilt3d(map3d, sgm=0.8):
+    """
+    ``QuakeScan._gaufilt3d`` (scan.py:1008-1043) with ``util.gaussian_3d`` (util.py:76-116): a
+    map-sized Gaussian, FFT-convolved in "same" mode, normalised; mirrored, convolved and
+    normalised again.
+    """
+    from scipy.signal import fftconvolve
+
+    map3d = np.asarray(map3d, dtype=np.float64)
+    axes = [np.linspace(-(n - 1) / 2, (n - 1) / 2, n) for n in map3d.shape]
+    gx, gy, gz = np.meshgrid(*axes, indexing="ij")
+    flt = np.exp(-(gx * gx) / (2 * sgm * sgm) - (gy * gy) / (2 * sgm * sgm)
+                 - (gz * gz) / (2 * sgm * sgm))
+    out = map3d
+    for _ in range(2):
+        out = fftconvolve(out, flt, mode="same")
+        out = out[::-1, ::-1, ::-1] / np.nanmax(out)
+    return out
+
+
+def np_covfit3d(coa_map, node_spacing, thresh=0.90):
+    """
+    ``QuakeScan._covfit3d`` (scan.py:939-1005) without the coordinate transform: returns
+    ``(expectation xyz relative to the grid's lower-left corner, 3x3 covariance)``; the
+    reference's uncertainty is ``sqrt(abs(diag(cov)))``.
+    """
+    coa_map = np.asarray(coa_map, dtype=np.float64)
+    w = np.where(coa_map > thresh, coa_map, np.nan).ravel()
+    total = np.nansum(w)
+    idx = np.meshgrid(*[np.arange(n) for n in coa_map.shape], indexing="ij")
+    pos = [g.ravel() * s for g, s in zip(idx, node_spacing)]
+    mean = np.array([np.nansum(w * p) / total for p in pos])
+    cov = np.zeros((3, 3))
+    for a in range(3):
+        for b in range(a, 3):
+            if a == b:
+                cov[a, a] = np.nansum(w * (pos[a] - mean[a]) ** 2) / total
+            else:
+                cov[a, b] = cov[b, a] = np.nansum(w * (pos[a] - mean[a]) * (pos[b] - mean[b])) / total
+    return mean, cov
+
+
+def np_gaufit3d(smoothed, thresh=0.0, win=7):
+    """
+    ``QuakeScan._gaufit3d`` (scan.py:844-936) in grid-index space: returns ``(location ijk
+    (fractional), sigma in nodes (from the eigenvalues, scan.py:922-923), peak value)``; the
+    reference's uncertainty is ``sigma * node_spacing``.
+    """
+    smoothed = np.asarray(smoothed, dtype=np.float64)
+    peak = np.unravel_index(np.nanargmax(smoothed), smoothed.shape)
+    lo, hi = np_window_bounds(smoothed.shape, peak, win)
+    mask = np.zeros(smoothed.shape, dtype=bool)
+    mask[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = True
+    ix, iy, iz = np.where(mask & (smoothed > thresh))
+    centred = smoothed - np.nanmean(smoothed)
+    x, y, z = ix - peak[0], iy - peak[1], iz - peak[2]
+    design = np.stack([x * x, y * y, z * z, x * y, x * z, y * z, x, y, z, np.ones(len(x))])
+    rhs = -np.log(np.clip(centred[ix, iy, iz], 1e-300, np.inf))
+    p = rhs @ np.linalg.pinv(design)
+    g = -np.array([[2 * p[0], p[3], p[4]], [p[3], 2 * p[1], p[5]], [p[4], p[5], 2 * p[2]]])
+    loc = np.linalg.inv(g) @ p[6:9]
+    k = (p[9] - p[0] * loc[0] ** 2 - p[1] * loc[1] ** 2 - p[2] * loc[2] ** 2
+         - p[3] * loc[0] * loc[1] - p[4] * loc[0] * loc[2] - p[5] * loc[1] * loc[2])
+    m = np.array([[p[0], p[3] / 2, p[4] / 2], [p[3] / 2, p[1], p[5] / 2],
+                  [p[4] / 2, p[5] / 2, p[2]]])
+    egv, _ = np.linalg.eig(m)
+    sigma = np.sqrt(0.5 / np.clip(np.abs(egv), 1e-10, np.inf)) / 2
+    return loc + np.array(peak), sigma, np.exp(-k)
+
+
+def np_splineloc(coa_map, win=5, upscale=10):
+    """
+    ``QuakeScan._splineloc`` (scan.py:736-841) in grid-index space: cubic RBF through the
+    ``win``^3 nodes around the maximum, evaluated ``upscale`` times finer; the gridded maximum
+    if the window crosses the edge of the grid or the interpolated peak leaves the window.
+    """
+    from scipy.interpolate import Rbf
+
+    coa_map = np.asarray(coa_map, dtype=np.float64)
+    peak = np.array(np.unravel_index(np.nanargmax(coa_map), coa_map.shape))
+    lo, hi = np_window_bounds(coa_map.shape, peak, win)
+    ext = hi - lo
+    if not (ext[0] == ext[1] == ext[2]):
+        return peak.astype(np.float64)
+    sub = coa_map[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+    # the reference's meshgrid is "xy"-indexed, so its axis-0 coordinate runs along axis 1 of
+    # the window (scan.py:780-787): reproduce that pairing, not the natural one
+    coarse = [np.linspace(0, n - 1, n) for n in sub.shape]
+    cx, cy, cz = np.meshgrid(*coarse)
+    rbf = Rbf(cx.ravel(), cy.ravel(), cz.ravel(), sub.ravel(), function="cubic")
+    fine = [np.linspace(0, n - 1, (n - 1) * upscale + 1) for n in sub.shape]
+    fx, fy, fz = np.meshgrid(*fine)
+    dense = rbf(fx.ravel(), fy.ravel(), fz.ravel()).reshape(fx.shape)
+    best = np.array(np.unravel_index(np.nanargmax(dense), dense.shape)) / upscale + lo
+    if np.any(np.abs(peak - best) > (win - 1) // 2):
+        return peak.astype(np.float64)
+    return best

@@ -85,6 +85,12 @@ qmlib.qm_engine_migrate.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32,
 qmlib.qm_engine_marginal.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32, c_int32,
                                      c_int32, c_int64, c_int32, c_int32, _vp, ctypes.c_int,
                                      _vp, _vp, _vp, ctypes.c_int]
+qmlib.qm_engine_locate_fits.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32, c_int32,
+                                        ctypes.c_double, ctypes.c_double,
+                                        ctypes.POINTER(ctypes.c_double), _vp, _vp, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_double)]
 qmlib.qm_engine_onsets.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32, c_i32Pt, c_int32,
                                    c_i32Pt, c_i32Pt, ctypes.c_int, ctypes.c_int, c_int32,
                                    ctypes.c_double, _vp, _vp, ctypes.c_int]
@@ -328,6 +334,45 @@ class Engine:
             self._h, po, dev_on, t_samples, int(fsmp), int(lsmp), int(available), total,
             int(first_sample), int(end_sample), pm, dev_map, pa, pb, pc, da))
         return out
+
+    def locate_fits(self, coa_map, node_spacing, sgm=0.8, cov_thresh=0.90, norm_out=None,
+                    smoothed_out=None):
+        """
+        Device part of ``QuakeScan._calculate_location`` (scan.py:696-733) on a marginalised
+        map ``coa_map`` (nx, ny, nz), host array or device tensor: normalisation, the two-pass
+        Gaussian smoothing, the covariance moments and the two fit windows.  Returns a dict;
+        ``norm_out`` / ``smoothed_out`` (both host or both device) receive the maps.
+        """
+        nx, ny, nz = (int(v) for v in coa_map.shape)
+        pm, dev_map = self._ptr(coa_map, np.float64)
+        outs = [o for o in (norm_out, smoothed_out) if o is not None]
+        pn = ps = _vp(None)
+        dev_out = 0
+        if norm_out is not None:
+            pn, dev_out = self._ptr(norm_out, np.float64)
+        if smoothed_out is not None:
+            ps, dev_s = self._ptr(smoothed_out, np.float64)
+            if len(outs) == 2 and dev_s != dev_out:
+                raise ValueError("norm_out and smoothed_out must both be host or both device")
+            dev_out = dev_s
+        spacing = (ctypes.c_double * 3)(*[float(v) for v in node_spacing])
+        summary = (ctypes.c_double * 16)()
+        gau = np.zeros((7, 7, 7))
+        spl = np.zeros((5, 5, 5))
+        dp = ctypes.POINTER(ctypes.c_double)
+        _check(qmlib.qm_engine_locate_fits(
+            self._h, pm, dev_map, nx, ny, nz, float(sgm), float(cov_thresh), spacing, pn, ps,
+            dev_out, summary, gau.ctypes.data_as(dp), spl.ctypes.data_as(dp)))
+        sm = np.array(summary[:])
+        cov = np.array([[sm[8], sm[11], sm[12]], [sm[11], sm[9], sm[13]],
+                        [sm[12], sm[13], sm[10]]])
+        return {"map_max": sm[0],
+                "peak": np.array(np.unravel_index(int(sm[1]), (nx, ny, nz))),
+                "smoothed_mean": sm[2],
+                "smoothed_peak": np.array(np.unravel_index(int(sm[3]), (nx, ny, nz))),
+                "weight": sm[4], "expectation": sm[5:8].copy(), "covariance": cov,
+                "pass_maxima": sm[14:16].copy(), "gaussian_window": gau,
+                "spline_window": spl}
 
     def onsets(self, signals, trace_row, nsta, nlta, transform="energy", position="classic",
                taper_pad=-1, min_onset_value=0.4, raw_out=None, log_out=None):

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,7 @@
 #include <vector>
 
 #include "qm_kernels.hpp"
+#include "qm_locate.hpp"
 
 namespace {
 
@@ -110,6 +112,9 @@ struct qm_engine {
     // scratch
     DevBuf<double> d_onsets, d_pmax, d_psum, d_out_a, d_out_b, d_chunk, d_marg, d_marg_out;
     DevBuf<int64_t> d_pidx, d_out_i;
+    // locate fits: three map-sized work buffers, reduction partials, device-side scalars
+    DevBuf<double> d_fit_a, d_fit_b, d_fit_c, d_fit_part, d_fit_val, d_fit_win;
+    DevBuf<int64_t> d_fit_pidx;
 };
 
 namespace {
@@ -451,6 +456,8 @@ void qm_engine_destroy(qm_engine *e) {
     e->d_btotal.release(); e->d_wide.release(); e->d_scalar.release(); e->d_rel.release();
     e->d_onsets.release(); e->d_pmax.release(); e->d_psum.release(); e->d_out_a.release();
     e->d_out_b.release(); e->d_chunk.release(); e->d_marg.release(); e->d_marg_out.release(); e->d_pidx.release(); e->d_out_i.release();
+    e->d_fit_a.release(); e->d_fit_b.release(); e->d_fit_c.release(); e->d_fit_part.release();
+    e->d_fit_val.release(); e->d_fit_win.release(); e->d_fit_pidx.release();
     for (hipEvent_t ev : e->ev_log) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -953,6 +960,181 @@ int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
         }
     }
     return fetch_out(e, n_samples, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
+}
+
+namespace {
+
+// Weights of one axis of the reference's filter as a function of d = i - j.
+// util.gaussian_3d (util.py:76-116) samples exp(-x^2 / (2 sgm^2)) at x = k - (n-1)/2,
+// k = 0..n-1; fftconvolve(..., mode="same") centres the full convolution at (n-1)//2, so
+// out[i] = sum_j in[j] * flt[i - j + (n-1)//2]: symmetric for odd n, shifted by half a node
+// for even n (which is why the reference filters twice, mirrored).  `mirror` gives the second
+// pass, w(d) -> w(-d).  Weights below 1e-40 of the peak are dropped: the reference's own FFT
+// round-off is 24 orders of magnitude above that.
+int axis_taps(int n, double sgm, bool mirror, qm::Taps *t) {
+    const int c = (n - 1) / 2;
+    const double half = 0.5 * (n - 1);
+    int R = (int)std::ceil(sgm * 13.6) + 1;             // exp(-(13.6)^2 / 2) = 7e-41
+    int lo = 0, hi = -1;
+    bool any = false;
+    for (int d = -R; d <= R; ++d) {
+        const int k = (mirror ? -d : d) + c;
+        if (k < 0 || k > n - 1) continue;
+        if (!any) lo = d;
+        hi = d;
+        any = true;
+    }
+    if (!any) return fail("gaussian filter: empty support");
+    if (hi - lo + 1 > qm::kMaxTaps)
+        return fail("gaussian filter: sgm %.3g needs %d taps, more than %d", sgm, hi - lo + 1,
+                    qm::kMaxTaps);
+    t->lo = lo;
+    t->n = hi - lo + 1;
+    for (int d = lo; d <= hi; ++d) {
+        const double x = (double)((mirror ? -d : d) + c) - half;
+        t->w[d - lo] = std::exp(-(x * x) / (2.0 * sgm * sgm));
+    }
+    return 0;
+}
+
+}  // namespace
+
+int qm_engine_locate_fits(qm_engine *e, const double *coa_map, int map_on_device, int32_t nx,
+                          int32_t ny, int32_t nz, double sgm, double cov_thresh,
+                          const double *node_spacing, double *norm_map, double *smoothed_map,
+                          int out_on_device, double *summary, double *gau_window,
+                          double *spline_window) {
+    if (!e || !coa_map || !node_spacing || !summary || !gau_window || !spline_window)
+        return fail("qm_engine_locate_fits: NULL argument");
+    if (nx < 1 || ny < 1 || nz < 1) return fail("qm_engine_locate_fits: empty grid");
+    if (!(sgm > 0.0)) return fail("qm_engine_locate_fits: sgm must be positive");
+    DeviceGuard guard(e->device);
+    const int64_t n = (int64_t)nx * ny * nz;
+    constexpr int NB = qm::kFitBlocks, BS = qm::kFitBlock;
+    if (e->d_fit_a.ensure((size_t)n) || e->d_fit_b.ensure((size_t)n) ||
+        e->d_fit_c.ensure((size_t)n) || e->d_fit_part.ensure((size_t)NB * 6) ||
+        e->d_fit_pidx.ensure(NB) || e->d_fit_val.ensure(32) || e->d_fit_win.ensure(343 + 125))
+        return 1;
+    hipStream_t s = e->stream;
+    const double *d_in = coa_map;
+    if (!map_on_device) {
+        QM_HIP(hipMemcpyAsync(e->d_fit_c.p, coa_map, (size_t)n * sizeof(double),
+                              hipMemcpyHostToDevice, s));
+        d_in = e->d_fit_c.p;
+    }
+    double *val = e->d_fit_val.p;
+    // device scalars: 0 map max, 1 map argmax, 2 pass-1 max, 3 -, 4 pass-2 max, 5 -,
+    // 6 smoothed mean, 7 smoothed argmax, 8..11 first moments, 12..17 second moments, 18 -
+    auto argmax = [&](const double *m, double *out_v, double *out_i) -> int {
+        hipLaunchKernelGGL(qm::argmax_partial_kernel, dim3(NB), dim3(BS), 0, s, m, n,
+                           e->d_fit_part.p, e->d_fit_pidx.p);
+        hipLaunchKernelGGL(qm::argmax_final_kernel, dim3(1), dim3(BS), 0, s, e->d_fit_part.p,
+                           e->d_fit_pidx.p, NB, out_v, out_i);
+        QM_HIP(hipGetLastError());
+        return 0;
+    };
+    const unsigned node_blocks = (unsigned)((n + BS - 1) / BS);
+    auto smooth = [&](const double *in, double *tmp, double *out, bool mirror,
+                      const double *div) -> int {
+        qm::Taps tx, ty, tz;
+        if (axis_taps(nx, sgm, mirror, &tx) || axis_taps(ny, sgm, mirror, &ty) ||
+            axis_taps(nz, sgm, mirror, &tz))
+            return 1;
+        hipLaunchKernelGGL(qm::smooth_axis_kernel, dim3(node_blocks), dim3(BS), 0, s, in, out,
+                           nx, ny, nz, 0, tx, div);
+        hipLaunchKernelGGL(qm::smooth_axis_kernel, dim3(node_blocks), dim3(BS), 0, s,
+                           (const double *)out, tmp, nx, ny, nz, 1, ty, (const double *)nullptr);
+        hipLaunchKernelGGL(qm::smooth_axis_kernel, dim3(node_blocks), dim3(BS), 0, s,
+                           (const double *)tmp, out, nx, ny, nz, 2, tz, (const double *)nullptr);
+        QM_HIP(hipGetLastError());
+        return 0;
+    };
+
+    // (1) coa_map / nanmax(coa_map)                                       scan.py:721
+    double *d_norm = (norm_map && out_on_device) ? norm_map : e->d_fit_a.p;
+    if (argmax(d_in, val + 0, val + 1)) return 1;
+    hipLaunchKernelGGL(qm::divide_kernel, dim3(NB), dim3(BS), 0, s, d_in, (const double *)val, n,
+                       d_norm);
+    if (argmax(d_norm, val + 18, val + 1)) return 1;
+
+    // (2) _gaufilt3d: filter, normalise, filter mirrored, normalise        scan.py:1033-1041
+    double *d_smooth = (smoothed_map && out_on_device) ? smoothed_map : e->d_fit_b.p;
+    double *d_tmp = e->d_fit_c.p;           // the staged input is dead once d_norm exists
+    if (smooth(d_norm, d_tmp, d_smooth, false, nullptr)) return 1;
+    if (argmax(d_smooth, val + 2, val + 3)) return 1;
+    // second pass: its first axis divides by the pass-1 maximum (the filter is linear)
+    {
+        // no axis may filter in place: x -> d_tmp, y -> d_smooth, z -> d_tmp
+        qm::Taps tx, ty, tz;
+        if (axis_taps(nx, sgm, true, &tx) || axis_taps(ny, sgm, true, &ty) ||
+            axis_taps(nz, sgm, true, &tz))
+            return 1;
+        hipLaunchKernelGGL(qm::smooth_axis_kernel, dim3(node_blocks), dim3(BS), 0, s,
+                           (const double *)d_smooth, d_tmp, nx, ny, nz, 0, tx,
+                           (const double *)(val + 2));
+        hipLaunchKernelGGL(qm::smooth_axis_kernel, dim3(node_blocks), dim3(BS), 0, s,
+                           (const double *)d_tmp, d_smooth, nx, ny, nz, 1, ty,
+                           (const double *)nullptr);
+        hipLaunchKernelGGL(qm::smooth_axis_kernel, dim3(node_blocks), dim3(BS), 0, s,
+                           (const double *)d_smooth, d_tmp, nx, ny, nz, 2, tz,
+                           (const double *)nullptr);
+        QM_HIP(hipGetLastError());
+    }
+    if (argmax(d_tmp, val + 4, val + 5)) return 1;
+    hipLaunchKernelGGL(qm::divide_kernel, dim3(NB), dim3(BS), 0, s, (const double *)d_tmp,
+                       (const double *)(val + 4), n, d_smooth);
+    if (argmax(d_smooth, val + 18, val + 7)) return 1;
+    hipLaunchKernelGGL(qm::sum_partial_kernel, dim3(NB), dim3(BS), 0, s,
+                       (const double *)d_smooth, n, e->d_fit_part.p);
+    hipLaunchKernelGGL(qm::sums_final_kernel, dim3(1), dim3(BS), 0, s,
+                       (const double *)e->d_fit_part.p, NB, 1, 1.0 / (double)n, val + 6);
+
+    // (3) _covfit3d on the normalised (unsmoothed) map                     scan.py:973-999
+    hipLaunchKernelGGL(qm::moments_partial_kernel<0>, dim3(NB), dim3(BS), 0, s,
+                       (const double *)d_norm, nx, ny, nz, cov_thresh, node_spacing[0],
+                       node_spacing[1], node_spacing[2], (const double *)nullptr,
+                       e->d_fit_part.p);
+    hipLaunchKernelGGL(qm::sums_final_kernel, dim3(4), dim3(BS), 0, s,
+                       (const double *)e->d_fit_part.p, NB, 4, 1.0, val + 8);
+    hipLaunchKernelGGL(qm::moments_partial_kernel<1>, dim3(NB), dim3(BS), 0, s,
+                       (const double *)d_norm, nx, ny, nz, cov_thresh, node_spacing[0],
+                       node_spacing[1], node_spacing[2], (const double *)(val + 8),
+                       e->d_fit_part.p);
+    hipLaunchKernelGGL(qm::sums_final_kernel, dim3(6), dim3(BS), 0, s,
+                       (const double *)e->d_fit_part.p, NB, 6, 1.0, val + 12);
+    hipLaunchKernelGGL(qm::moments_scale_kernel, dim3(1), dim3(64), 0, s, val + 12,
+                       (const double *)(val + 8));
+
+    // (4) the windows the Gaussian (7^3, smoothed map) and spline (5^3, normalised map) fits use
+    hipLaunchKernelGGL(qm::window_kernel, dim3(2), dim3(256), 0, s, (const double *)d_smooth, nx,
+                       ny, nz, 7, (const double *)(val + 7), e->d_fit_win.p);
+    hipLaunchKernelGGL(qm::window_kernel, dim3(1), dim3(128), 0, s, (const double *)d_norm, nx,
+                       ny, nz, 5, (const double *)(val + 1), e->d_fit_win.p + 343);
+    QM_HIP(hipGetLastError());
+
+    double h[32], w[343 + 125];
+    QM_HIP(hipMemcpyAsync(h, val, sizeof(h), hipMemcpyDeviceToHost, s));
+    QM_HIP(hipMemcpyAsync(w, e->d_fit_win.p, sizeof(w), hipMemcpyDeviceToHost, s));
+    if (norm_map && !out_on_device)
+        QM_HIP(hipMemcpyAsync(norm_map, d_norm, (size_t)n * sizeof(double),
+                              hipMemcpyDeviceToHost, s));
+    if (smoothed_map && !out_on_device)
+        QM_HIP(hipMemcpyAsync(smoothed_map, d_smooth, (size_t)n * sizeof(double),
+                              hipMemcpyDeviceToHost, s));
+    QM_HIP(hipStreamSynchronize(s));
+    if (h[1] < 0) return fail("qm_engine_locate_fits: the map holds no finite value");
+    summary[0] = h[0];                      // nanmax of the input map
+    summary[1] = h[1];                      // first argmax of the normalised map (flat index)
+    summary[2] = h[6];                      // mean of the smoothed map
+    summary[3] = h[7];                      // first argmax of the smoothed map
+    summary[4] = h[8];                      // total weight above the threshold
+    for (int k = 0; k < 3; ++k) summary[5 + k] = h[9 + k] / h[8];     // xe, ye, ze
+    for (int k = 0; k < 6; ++k) summary[8 + k] = h[12 + k];
+    summary[14] = h[2];
+    summary[15] = h[4];
+    std::memcpy(gau_window, w, 343 * sizeof(double));
+    std::memcpy(spline_window, w + 343, 125 * sizeof(double));
+    return 0;
 }
 
 int qm_engine_kernel_log(qm_engine *e, double *total_ms, int32_t *n_calls) {

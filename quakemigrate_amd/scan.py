@@ -187,3 +187,23 @@ class MigrationScan:
         coa_map = eng.marginal_map(onsets, fsmp, lsmp, avail, first_sample, end_sample,
                                    scan_out=series)
         return (coa_map,) + series + (onset_data,)
+
+    def calculate_location(self, data, first_sample, end_sample, sgm=0.8, cov_thresh=0.90):
+        """
+        ``QuakeScan._calculate_location`` (scan.py:696-733) for the marginal window
+        ``[first_sample, end_sample)`` without the 4-D map ever existing: the marginalised map is
+        summed inside the stacking kernel, normalised / smoothed / reduced on the GPU, and only
+        the two fit windows come back for the Gaussian and spline algebra.
+
+        Returns ``(coa_map, fits, max_coa, max_coa_n, max_idx, onset_data)``: ``coa_map`` is the
+        normalised map the reference returns; ``fits`` a :class:`locate.LocationFits` (use
+        ``fits.coordinates(self.lut)`` for the reference's lon / lat / depth triplets).
+        """
+        from quakemigrate_amd import locate
+
+        marginal, max_coa, max_coa_n, max_idx, onset_data = self.marginal_coalescence(
+            data, first_sample, end_sample)
+        coa_map = np.zeros_like(marginal)
+        fits = locate.calculate_location(self.engine, marginal, self.lut.node_spacing, sgm=sgm,
+                                         cov_thresh=cov_thresh, norm_out=coa_map)
+        return coa_map, fits, max_coa, max_coa_n, max_idx, onset_data

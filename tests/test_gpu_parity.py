@@ -326,6 +326,23 @@ def test_migration_scan_compute_mirrors_reference_glue(lib, oracle):
     _assert_series((a, b, np.ravel_multi_index(coord.astype(int).T, case.grid)), want)
     ref = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp, 6, threads=4)
     np.testing.assert_allclose(map4d, ref, rtol=TIGHT)
+
+    # _calculate_location for a marginal window, without the volume (scan.py:696-733)
+    Lut.node_spacing = np.array([0.5, 0.5, 0.25])
+    i0, i1 = 40, 210
+    coa_map, fits, a, b, idx, od = loc.calculate_location(Data(), i0, i1)
+    want_map = ref[..., i0:i1].sum(axis=-1)
+    want_map = want_map / np.nanmax(want_map)
+    np.testing.assert_allclose(coa_map, want_map, rtol=1e-12)
+    gau, sigma, _ = oracle.np_gaufit3d(oracle.np_gaufilt3d(coa_map))
+    np.testing.assert_allclose(fits.gaussian, gau, rtol=1e-8)
+    np.testing.assert_allclose(fits.gaussian_uncertainty, sigma * Lut.node_spacing, rtol=1e-7)
+    mean, cov = oracle.np_covfit3d(coa_map, Lut.node_spacing)
+    np.testing.assert_allclose(fits.expectation, mean, rtol=1e-12)
+    np.testing.assert_allclose(fits.covariance_uncertainty, np.diag(np.sqrt(np.abs(cov))),
+                               rtol=1e-10, atol=1e-300)
+    assert np.array_equal(fits.spline, oracle.np_splineloc(coa_map))
+    _assert_series((a, b, idx), want)
     eng.close()
 
 
@@ -617,4 +634,76 @@ def test_empty_scan_and_nan_onsets(lib, oracle):
                           for n in range(vol.shape[0])])
     col = np.where(reads_nan, -np.inf, vol[:, 60])
     assert got[2][60] == int(np.argmax(col))
+    eng.close()
+
+
+LOCATE_CASES = ["corner", "interior_even", "interior_odd", "near_face", "thin"]
+
+
+@pytest.mark.parametrize("name", LOCATE_CASES)
+def test_locate_fits_match_reference_calculate_location(lib, oracle, name):
+    """qm_engine_locate_fits + the window algebra vs QuakeScan._calculate_location run from the
+    reference's scan.py (fixture locate_fits): normalised map bit-exact, smoothed map to 1e-14
+    absolute (direct separable convolution vs the reference's FFT), covariance moments to
+    1e-12, Gaussian fit to 1e-8, spline location exact."""
+    from quakemigrate_amd import locate
+
+    g = load_golden("locate_fits")
+    spacing = g[f"{name}_node_spacing"]
+    marginal = g[f"{name}_map4d"].sum(axis=-1)                       # scan.py:720
+    eng = lib.Engine(0)
+    norm, smoothed = np.zeros_like(marginal), np.zeros_like(marginal)
+    fits = locate.calculate_location(eng, marginal, spacing, norm_out=norm,
+                                     smoothed_out=smoothed)
+    assert fits.map_max == np.nanmax(marginal)
+    assert np.array_equal(norm, g[f"{name}_coa_map"])
+    np.testing.assert_allclose(smoothed, g[f"{name}_smoothed"], rtol=0, atol=1e-14)
+    assert np.array_equal(fits.peak, np.unravel_index(np.nanargmax(norm), norm.shape))
+    np.testing.assert_allclose(fits.expectation, g[f"{name}_covariance"], rtol=1e-12)
+    np.testing.assert_allclose(fits.covariance_uncertainty,
+                               g[f"{name}_covariance_uncertainty"], rtol=1e-11, atol=1e-300)
+    want_mean, want_cov = oracle.np_covfit3d(norm, spacing)
+    np.testing.assert_allclose(fits.covariance, want_cov, rtol=1e-10, atol=1e-18)
+    np.testing.assert_allclose(fits.gaussian, g[f"{name}_gaussian"], rtol=1e-8)
+    np.testing.assert_allclose(fits.gaussian_uncertainty, g[f"{name}_gaussian_uncertainty"],
+                               rtol=1e-7)
+    assert np.array_equal(fits.spline, g[f"{name}_spline"])
+    eng.close()
+
+
+def test_locate_chain_marginal_map_to_location_stays_on_device(lib, oracle):
+    """Locate without the volume: marginal map (device tensor) -> locate_fits (device in, device
+    maps out) vs the oracle's migrate -> sum -> fits on the host."""
+    import torch
+
+    from quakemigrate_amd import locate
+
+    case = synth.make_case("C2", step=3, grid=(24, 21, 14), rows=10, n_samples=301, n_events=1)
+    ref = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
+                           case.available, threads=4)
+    i0, i1 = 60, 260
+    want = ref[..., i0:i1].sum(axis=-1)
+    want = want / np.nanmax(want)
+    eng = lib.Engine(0)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.load_lut(case.traveltimes)
+    lon = torch.from_numpy(oracle.log_onsets(case.onsets)).cuda()
+    dmap = torch.zeros(case.traveltimes.shape[:3], dtype=torch.float64, device="cuda")
+    eng.marginal_map(lon, case.fsmp, case.lsmp, case.available, i0, i1, out=dmap)
+    dnorm, dsmooth = torch.zeros_like(dmap), torch.zeros_like(dmap)
+    spacing = np.array([1.0, 1.0, 1.0])
+    fits = locate.calculate_location(eng, dmap, spacing, norm_out=dnorm, smoothed_out=dsmooth)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dnorm.cpu().numpy(), want, rtol=1e-12)
+    smooth_want = oracle.np_gaufilt3d(dnorm.cpu().numpy())
+    np.testing.assert_allclose(dsmooth.cpu().numpy(), smooth_want, rtol=0, atol=1e-14)
+    loc, sigma, _ = oracle.np_gaufit3d(smooth_want)
+    np.testing.assert_allclose(fits.gaussian, loc, rtol=1e-8)
+    np.testing.assert_allclose(fits.gaussian_sigma, sigma, rtol=1e-7)
+    mean, cov = oracle.np_covfit3d(dnorm.cpu().numpy(), spacing)
+    np.testing.assert_allclose(fits.expectation, mean, rtol=1e-12)
+    np.testing.assert_allclose(fits.covariance, cov, rtol=1e-10, atol=1e-18)
+    assert np.array_equal(fits.spline, oracle.np_splineloc(dnorm.cpu().numpy()))
+    with pytest.raises(lib.QMHipError, match="sgm"):
+        eng.locate_fits(dmap, spacing, sgm=0.0)
     eng.close()

@@ -157,3 +157,28 @@ def test_onset_stage_restatement_with_the_c_port(oracle):
                                                 float(g["min_onset_value"]))
             np.testing.assert_allclose(raw, g[f"raw_{pos}_{tf}"], rtol=1e-12)
             np.testing.assert_allclose(logged, g[f"log_{pos}_{tf}"], rtol=1e-12, atol=1e-14)
+
+
+LOCATE_CASES = ["corner", "interior_even", "interior_odd", "near_face", "thin"]
+
+
+@pytest.mark.parametrize("name", LOCATE_CASES)
+def test_locate_fit_restatements_match_reference_calculate_location(oracle, name):
+    """np_gaufilt3d / np_gaufit3d / np_covfit3d / np_splineloc vs QuakeScan._calculate_location
+    run from the reference's scan.py (fixture locate_fits, make_golden.py section 11)."""
+    g = load_golden("locate_fits")
+    assert list(g["cases"]) == LOCATE_CASES
+    spacing = g[f"{name}_node_spacing"]
+    coa = g[f"{name}_map4d"].sum(axis=-1)
+    coa = coa / np.nanmax(coa)
+    assert np.array_equal(coa, g[f"{name}_coa_map"])
+    smoothed = oracle.np_gaufilt3d(coa)
+    np.testing.assert_allclose(smoothed, g[f"{name}_smoothed"], rtol=0, atol=1e-14)
+    loc, sigma, _ = oracle.np_gaufit3d(smoothed)
+    np.testing.assert_allclose(loc, g[f"{name}_gaussian"], rtol=1e-9)
+    np.testing.assert_allclose(sigma * spacing, g[f"{name}_gaussian_uncertainty"], rtol=1e-9)
+    mean, cov = oracle.np_covfit3d(coa, spacing)
+    np.testing.assert_allclose(mean, g[f"{name}_covariance"], rtol=1e-13)
+    np.testing.assert_allclose(np.diag(np.sqrt(np.abs(cov))),
+                               g[f"{name}_covariance_uncertainty"], rtol=1e-13, atol=1e-300)
+    assert np.array_equal(oracle.np_splineloc(coa), g[f"{name}_spline"])
