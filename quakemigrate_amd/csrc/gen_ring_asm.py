@@ -61,6 +61,73 @@ def variant(J, rows):
             f'                     : "memory");')
 
 
+def variant32(JP, rows):
+    """
+    The float32 screening pass (qm_screen.hpp): a lane owns JP pairs of consecutive samples, one
+    ds_read_b64 fetches a pair (two floats) and one v_pk_add_f32 adds both.  Row r of a chunk
+    starts r * (8 * 128*JP - 8) bytes after the chunk base (two staggered copies of every window,
+    see qm_screen.hpp); pair j is 512*j bytes further.  Same ring discipline as above.
+    """
+    stride = 8 * 128 * JP - 8
+    n = rows * JP
+    F = IN_FLIGHT
+    lines = []
+
+    def read(k):
+        row, j = divmod(k, JP)
+        lines.append(f"ds_read_b64 %[t{k % SLOTS}], %[a{row}] offset:{row * stride + 512 * j}")
+
+    for k in range(min(F, n)):
+        read(k)
+    for k in range(n):
+        issued_after = min(k + F, n) - 1 - k
+        lines.append(f"s_waitcnt lgkmcnt({issued_after})")
+        if k + F < n:
+            read(k + F)
+        lines.append(f"v_pk_add_f32 %[c{k % JP}], %[c{k % JP}], %[t{k % SLOTS}]")
+    body = "\\n\\t".join(lines)
+    outs = [f'[c{j}] "+v"(acc[{j}])' for j in range(JP)]
+    outs += [f'[t{s}] "=&v"(t[{s}])' for s in range(SLOTS)]
+    ins = [f'[a{r}] "v"(addr[{r}])' for r in range(rows)]
+    return (f'        asm volatile("{body}"\n'
+            f'                     : {", ".join(outs)}\n'
+            f'                     : {", ".join(ins)}\n'
+            f'                     : "memory");')
+
+
+def main32():
+    print()
+    print("// ---- float32 screening pass: ring32_full<JP> / ring32_tail<JP> (pairs of samples) ----")
+    print("typedef float qm_v2f __attribute__((ext_vector_type(2)));")
+    print("template <int JP>")
+    print("__device__ __forceinline__ void ring32_full(qm_v2f (&acc)[JP], const unsigned (&addr)[8]);")
+    print("template <int JP>")
+    print("__device__ __forceinline__ void ring32_tail(qm_v2f (&acc)[JP], const unsigned (&addr)[8],"
+          " int rows);")
+    for JP in (1, 2):
+        print()
+        print("template <>")
+        print(f"__device__ __forceinline__ void ring32_full<{JP}>(qm_v2f (&acc)[{JP}], "
+              "const unsigned (&addr)[8]) {")
+        print(f"    qm_v2f t[{SLOTS}];")
+        print(variant32(JP, 8).replace("        asm", "    asm").replace("                     :", "                 :"))
+        print("}")
+        print()
+        print("template <>")
+        print(f"__device__ __forceinline__ void ring32_tail<{JP}>(qm_v2f (&acc)[{JP}], "
+              "const unsigned (&addr)[8], int rows) {")
+        print(f"    qm_v2f t[{SLOTS}];")
+        print("    switch (rows) {")
+        for rows in range(7, 0, -1):
+            print(f"    case {rows}:")
+            print(variant32(JP, rows))
+            print("        break;")
+        print("    default:")
+        print("        break;")
+        print("    }")
+        print("}")
+
+
 def main():
     print("// GENERATED by gen_ring_asm.py -- do not edit.  See that file for the schedule.")
     print("// ring_chunk<J>(acc, addr, rows): acc[j] += LDS[addr[r] + (r*64*J + 64*j)*8] for")
@@ -98,3 +165,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main32()

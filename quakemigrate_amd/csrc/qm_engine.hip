@@ -20,6 +20,7 @@
 
 #include "qm_kernels.hpp"
 #include "qm_locate.hpp"
+#include "qm_screen.hpp"
 
 namespace {
 
@@ -87,6 +88,7 @@ struct qm_engine {
     int cfg_force_direct = 0;
     int cfg_generic = 0;            // 1 = always the generic (any row count) LDS kernel
     int64_t cfg_chunk_bytes = (int64_t)4 << 30;
+    int cfg_screen = 0;             // detect: float32 screening sweep + exact float64 refinement
 
     // resident table
     bool have_lut = false;
@@ -99,6 +101,16 @@ struct qm_engine {
     std::vector<int32_t> h_btotal;
     int n_wide = 0;
     int plan_j = -1, plan_cap = -1;
+
+    // float32 screening (qm_screen.hpp): staggered-copy offset table and per-step scratch
+    DevBuf<int32_t> d_smeta, d_stotal, d_swide, d_counts, d_cells, d_work, d_flags;
+    DevBuf<uint16_t> d_srel;
+    DevBuf<float> d_on32, d_cell, d_pm;
+    DevBuf<double> d_rowmax, d_ssum, d_cand_z;
+    DevBuf<int64_t> d_cand_idx;
+    int n_swide = 0;
+    int screen_kt = 0, screen_wb = 0;       // what the screening table was built for
+    int64_t screened_steps = 0, fallback_steps = 0, last_candidates = 0;
 
     // float64 travel-time grids in seconds (optional; on-device table serving)
     DevBuf<double> d_grids;
@@ -349,6 +361,244 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     return 0;
 }
 
+// ---- float32 screening path (qm_screen.hpp) ---------------------------------------------------
+// pairs of samples per lane: time tile = 128 * JP; 0 = this table is not screened
+int screen_jp_rows(const qm_engine *e, int S) {
+    if (!e->cfg_screen || e->cfg_force_direct || e->cfg_waves != 8) return 0;
+    for (int jp : {2, 1}) {
+        const int64_t rows_bytes = (int64_t)S * (8 * 128 * jp - 8);
+        if (S <= 64 && rows_bytes * 5 <= (int64_t)e->cfg_lds_bytes * 4) return jp;
+    }
+    return 0;
+}
+int screen_jp(const qm_engine *e) { return screen_jp_rows(e, e->g.n_rows); }
+int screen_window_bytes(const qm_engine *e, int JP) {
+    return (e->cfg_lds_bytes - 128 * JP * 4) / 16 * 16;     // minus the cell-maximum row
+}
+
+int ensure_screen_tables(qm_engine *e, int JP) {
+    const int KT = 128 * JP;
+    const int wb = screen_window_bytes(e, JP);
+    if (e->screen_kt == KT && e->screen_wb == wb) return 0;
+    const qm::GridDesc &g = e->g;
+    const size_t br = (size_t)g.nbricks * g.n_rows;
+    if (e->d_smeta.ensure(4 * br) || e->d_stotal.ensure(g.nbricks) ||
+        e->d_srel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad))
+        return 1;
+    hipLaunchKernelGGL(qm::screen_prefix_kernel, dim3((g.nbricks + 255) / 256), dim3(256), 0,
+                       e->stream, g, reinterpret_cast<const int4 *>(e->d_bmeta.p),
+                       reinterpret_cast<int4 *>(e->d_smeta.p), e->d_stotal.p);
+    QM_HIP(hipGetLastError());
+    std::vector<int32_t> total(g.nbricks), wide;
+    QM_HIP(hipMemcpyAsync(total.data(), e->d_stotal.p, (size_t)g.nbricks * sizeof(int32_t),
+                          hipMemcpyDeviceToHost, e->stream));
+    QM_HIP(hipStreamSynchronize(e->stream));
+    for (int b = 0; b < g.nbricks; ++b)
+        if (!qm::screen_fits(total[b], g.n_rows, KT, wb)) wide.push_back(b);
+    e->n_swide = (int)wide.size();
+    if (e->n_swide) {
+        if (e->d_swide.ensure(wide.size())) return 1;
+        QM_HIP(hipMemcpyAsync(e->d_swide.p, wide.data(), wide.size() * sizeof(int32_t),
+                              hipMemcpyHostToDevice, e->stream));
+    }
+    hipLaunchKernelGGL(qm::screen_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
+                       e->d_lut.p, reinterpret_cast<const int4 *>(e->d_smeta.p), e->d_stotal.p, KT,
+                       wb, e->d_srel.p);
+    QM_HIP(hipGetLastError());
+    QM_HIP(hipStreamSynchronize(e->stream));           // `wide` is a stack-lifetime buffer
+    e->screen_kt = KT;
+    e->screen_wb = wb;
+    return 0;
+}
+
+template <int JP, int NCH>
+int launch_screen(qm_engine *e, qm::ScreenArgs &a, size_t lds) {
+    QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::screen_lds_kernel<JP, NCH>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((qm::screen_lds_kernel<JP, NCH>),
+                       dim3((unsigned)(a.ntiles * ((a.ngroups + 7) / 8 * 8))), dim3(512), lds,
+                       e->stream, a);
+    QM_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int JP>
+int launch_screen_jp(qm_engine *e, qm::ScreenArgs &a, size_t lds) {
+    switch (e->g.row_pad / 8) {
+        case 1: return launch_screen<JP, 1>(e, a, lds);
+        case 2: return launch_screen<JP, 2>(e, a, lds);
+        case 3: return launch_screen<JP, 3>(e, a, lds);
+        case 4: return launch_screen<JP, 4>(e, a, lds);
+        case 5: return launch_screen<JP, 5>(e, a, lds);
+        case 6: return launch_screen<JP, 6>(e, a, lds);
+        case 7: return launch_screen<JP, 7>(e, a, lds);
+        case 8: return launch_screen<JP, 8>(e, a, lds);
+        default: return fail("screening supports at most 64 table rows");
+    }
+}
+
+// Whole-scan detect through the screening path.  On success with *screened = true the partial
+// sets [*n_sets][ns] are in e->d_pmax/d_pidx/d_psum exactly as run_stack leaves them.  *screened =
+// false (nothing usable was produced) if some sample had more candidate cells than slots or the
+// onsets hold a non-finite value: the caller then runs the float64 kernel.
+int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, int available,
+               int *n_sets, bool *screened) {
+    *screened = false;
+    const int JP = screen_jp(e);
+    if (JP == 0) return 0;
+    if (ensure_screen_tables(e, JP)) return 1;
+    const qm::GridDesc &g = e->g;
+    const int KT = 128 * JP;
+    const int ntiles = (ns + KT - 1) / KT;
+    const int64_t ns_pad = (int64_t)ntiles * KT;
+    const int S = g.n_rows;
+    const int n_fit = g.nbricks - e->n_swide;
+    const int groups = n_fit > 0 ? (e->cfg_groups > 0 ? std::min(e->cfg_groups, g.nbricks)
+                                                       : auto_groups(e, ntiles, g.nbricks, 2))
+                                 : 0;
+    const int groups_direct =
+        e->n_swide > 0 ? (e->cfg_groups > 0 ? std::min(e->cfg_groups, e->n_swide)
+                                            : auto_groups(e, (ns + 63) / 64, e->n_swide, 4))
+                       : 0;
+    const int sets = groups_direct + 1;
+    constexpr int kPeakChunks = 16;
+    const int per_chunk = (g.nbricks + kPeakChunks - 1) / kPeakChunks;
+    if (e->d_on32.ensure((size_t)S * T) || e->d_rowmax.ensure(S) ||
+        e->d_cell.ensure((size_t)g.nbricks * ns_pad) ||
+        e->d_pm.ensure((size_t)kPeakChunks * ns) || e->d_ssum.ensure((size_t)std::max(1, groups) * ns) ||
+        e->d_counts.ensure(ns) || e->d_cells.ensure((size_t)ns * qm::kScreenSlots) ||
+        e->d_work.ensure((size_t)ns * qm::kScreenSlots) ||
+        e->d_flags.ensure(4) || e->d_cand_z.ensure((size_t)ns * qm::kScreenSlots) ||
+        e->d_cand_idx.ensure((size_t)ns * qm::kScreenSlots))
+        return 1;
+    const size_t need = (size_t)sets * ns;
+    if (e->d_pmax.ensure(need) || e->d_psum.ensure(need) || e->d_pidx.ensure(need)) return 1;
+
+    hipEvent_t ev_begin = e->ev0, ev_end = e->ev1;
+    if (e->log_timing) {
+        if (e->ev_used + 2 > e->ev_log.size()) {
+            for (int i = 0; i < 2; ++i) {
+                hipEvent_t ev;
+                QM_HIP(hipEventCreate(&ev));
+                e->ev_log.push_back(ev);
+            }
+        }
+        ev_begin = e->ev_log[e->ev_used];
+        ev_end = e->ev_log[e->ev_used + 1];
+        e->ev_used += 2;
+    }
+    hipStream_t s = e->stream;
+    QM_HIP(hipEventRecord(ev_begin, s));
+    QM_HIP(hipMemsetAsync(e->d_counts.p, 0, (size_t)ns * sizeof(int32_t), s));
+    QM_HIP(hipMemsetAsync(e->d_flags.p, 0, 4 * sizeof(int32_t), s));
+    hipLaunchKernelGGL(qm::screen_prepare_kernel, dim3(S), dim3(256), 0, s, d_onsets, T,
+                       e->d_on32.p, e->d_rowmax.p);
+    QM_HIP(hipGetLastError());
+
+    qm::ScreenArgs a{};
+    a.g = g;
+    a.onsets32 = e->d_on32.p;
+    a.rel = e->d_srel.p;
+    a.brick_meta = e->d_smeta.p;
+    a.brick_total = e->d_stotal.p;
+    a.T = T;
+    a.fsmp = fsmp;
+    a.n_samples = ns;
+    a.ntiles = ntiles;
+    a.ngroups = groups;
+    a.window_bytes = e->screen_wb;
+    a.z_scale = (float)(1.4426950408889634074 / (double)available);
+    a.cell_max = e->d_cell.p;
+    a.ns_pad = ns_pad;
+    a.part_sum = e->d_ssum.p;
+    if (groups > 0) {
+        const size_t lds = (size_t)e->cfg_lds_bytes;
+        if (JP == 2 ? launch_screen_jp<2>(e, a, lds) : launch_screen_jp<1>(e, a, lds)) return 1;
+    }
+    if (groups_direct > 0) {
+        // bricks whose windows do not fit: exact float64 partial sets from the direct kernel
+        qm::StackArgs d{};
+        d.g = g;
+        d.onsets = d_onsets;
+        d.lut = e->d_lut.p;
+        d.T = T;
+        d.fsmp = fsmp;
+        d.n_samples = ns;
+        d.sample0 = 0;
+        d.n_chunk = ns;
+        d.ntiles = (ns + 63) / 64;
+        d.ngroups = groups_direct;
+        d.z_scale = 1.4426950408889634074 / (double)available;
+        d.want_scan = 1;
+        d.set0 = 0;
+        d.part_max = e->d_pmax.p;
+        d.part_idx = e->d_pidx.p;
+        d.part_sum = e->d_psum.p;
+        d.brick_list = e->d_swide.p;
+        d.n_list = e->n_swide;
+        d.n_nodes = e->n_nodes;
+        const size_t publish_bytes = (size_t)3 * 8 * 64 * sizeof(double);
+        QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_direct_kernel<1, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)publish_bytes));
+        hipLaunchKernelGGL((qm::stack_direct_kernel<1, false>),
+                           dim3((unsigned)(d.ntiles * ((groups_direct + 7) / 8 * 8))), dim3(512),
+                           publish_bytes, s, d);
+        QM_HIP(hipGetLastError());
+    }
+    const unsigned tcols = (unsigned)((ns + 63) / 64);
+    hipLaunchKernelGGL(qm::screen_peak_kernel, dim3(tcols, kPeakChunks), dim3(256), 0, s,
+                       (const float *)e->d_cell.p, ns_pad, ns, g.nbricks, per_chunk, e->d_pm.p);
+    hipLaunchKernelGGL(qm::screen_candidates_kernel, dim3(tcols, kPeakChunks), dim3(256), 0, s,
+                       (const float *)e->d_cell.p, ns_pad, ns, g.nbricks, per_chunk,
+                       (const float *)e->d_pm.p, kPeakChunks, (const double *)e->d_rowmax.p, S,
+                       e->d_counts.p, e->d_cells.p, e->d_work.p, e->d_flags.p);
+    QM_HIP(hipGetLastError());
+    qm::RefineArgs r{};
+    r.g = g;
+    r.onsets = d_onsets;
+    r.lut = e->d_lut.p;
+    r.T = T;
+    r.fsmp = fsmp;
+    r.n_samples = ns;
+    r.z_scale = 1.4426950408889634074 / (double)available;
+    r.cells = e->d_cells.p;
+    r.work = e->d_work.p;
+    r.flags = e->d_flags.p;
+    r.cand_z = e->d_cand_z.p;
+    r.cand_idx = e->d_cand_idx.p;
+    hipLaunchKernelGGL(qm::screen_refine_kernel, dim3((unsigned)(8 * e->n_cu)), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(qm::screen_collect_kernel, dim3((ns + 255) / 256), dim3(256), 0, s,
+                       (const int32_t *)e->d_counts.p, (const double *)e->d_cand_z.p,
+                       (const int64_t *)e->d_cand_idx.p, (const double *)e->d_ssum.p, groups, ns,
+                       e->d_pmax.p + (size_t)groups_direct * ns,
+                       e->d_pidx.p + (size_t)groups_direct * ns,
+                       e->d_psum.p + (size_t)groups_direct * ns);
+    QM_HIP(hipGetLastError());
+    QM_HIP(hipEventRecord(ev_end, s));
+    e->timed = !e->log_timing;
+    int32_t flags[2] = {0, 0};
+    QM_HIP(hipMemcpyAsync(flags, e->d_flags.p, sizeof(flags), hipMemcpyDeviceToHost, s));
+    QM_HIP(hipStreamSynchronize(s));
+    e->last_candidates = flags[1];
+    if (flags[0] != 0) {
+        ++e->fallback_steps;
+        return 0;
+    }
+    ++e->screened_steps;
+    *n_sets = sets;
+    *screened = true;
+    return 0;
+}
+
+// detect-type stacking of the whole scan: screening when enabled and applicable, else float64
+int run_detect(qm_engine *e, const double *d_on, int T, int fsmp, int ns, int available,
+               int *n_sets) {
+    bool screened = false;
+    if (run_screen(e, d_on, T, fsmp, ns, available, n_sets, &screened)) return 1;
+    if (screened) return 0;
+    return run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, n_sets);
+}
+
 int combine(qm_engine *e, const double *pmax, const int64_t *pidx, const double *psum, int sets,
             int n, int mode, int64_t node_offset, int64_t n_nodes_total, double *o_max,
             double *o_second, int64_t *o_idx) {
@@ -458,6 +708,10 @@ void qm_engine_destroy(qm_engine *e) {
     e->d_out_b.release(); e->d_chunk.release(); e->d_marg.release(); e->d_marg_out.release(); e->d_pidx.release(); e->d_out_i.release();
     e->d_fit_a.release(); e->d_fit_b.release(); e->d_fit_c.release(); e->d_fit_part.release();
     e->d_fit_val.release(); e->d_fit_win.release(); e->d_fit_pidx.release();
+    e->d_smeta.release(); e->d_stotal.release(); e->d_swide.release(); e->d_counts.release();
+    e->d_cells.release(); e->d_work.release(); e->d_flags.release(); e->d_srel.release(); e->d_on32.release();
+    e->d_cell.release(); e->d_pm.release(); e->d_rowmax.release(); e->d_ssum.release();
+    e->d_cand_z.release(); e->d_cand_idx.release();
     for (hipEvent_t ev : e->ev_log) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -507,6 +761,8 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
         e->cfg_force_direct = v ? 1 : 0;
     } else if (k == "generic") {
         e->cfg_generic = v ? 1 : 0;
+    } else if (k == "screen") {
+        e->cfg_screen = v ? 1 : 0;
     } else if (k == "log_timing") {
         e->log_timing = v != 0;
         e->ev_used = 0;
@@ -531,6 +787,10 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "lds_bytes") *v = e->cfg_lds_bytes;
     else if (k == "force_direct") *v = e->cfg_force_direct;
     else if (k == "chunk_bytes") *v = e->cfg_chunk_bytes;
+    else if (k == "screen") *v = e->cfg_screen;
+    else if (k == "screened_steps") *v = e->screened_steps;
+    else if (k == "fallback_steps") *v = e->fallback_steps;
+    else if (k == "last_candidates") *v = e->last_candidates;
     else if (k == "n_bricks") *v = e->g.nbricks;
     else if (k == "n_wide_bricks") {
         if (e->have_lut) {
@@ -601,9 +861,15 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
         QM_HIP(hipMemcpyAsync(&e->lut_max, e->d_scalar.p, sizeof(int32_t), hipMemcpyDeviceToHost,
                               e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
+        // with screening on, a brick must also fit the float32 sweep's staggered-copy windows
+        // (every span rounded up to even: at most one word per row more than the total here)
+        const int sjp = screen_jp_rows(e, n_rows);
         int64_t wide = 0;
         for (int64_t b = 0; b < nbricks; ++b)
-            if (!qm::brick_fits(e->h_btotal[b], n_rows, KT, lds_cap_doubles(e))) ++wide;
+            if (!qm::brick_fits(e->h_btotal[b], n_rows, KT, lds_cap_doubles(e)) ||
+                (sjp && !qm::screen_fits((int64_t)e->h_btotal[b] + n_rows, n_rows, 128 * sjp,
+                                         screen_window_bytes(e, sjp))))
+                ++wide;
         if (wide * 200 <= nbricks) break;              // <= 0.5 % of the bricks on the slow path
     }
     if (e->d_rel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;
@@ -616,6 +882,7 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     e->n_nodes = n_nodes;
     e->node_offset = node_offset;
     e->plan_j = -1;
+    e->screen_kt = 0;
     e->have_lut = true;
     return plan_wide(e, eff_j(e));
 }
@@ -702,7 +969,7 @@ int qm_engine_detect_partial(qm_engine *e, const double *log_onsets, int onsets_
     if (check_step(e, T, fsmp, lsmp, available, &ns)) return 1;
     const double *d_on = nullptr;
     if (stage_onsets(e, log_onsets, onsets_on_device, T, &d_on)) return 1;
-    if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, &sets)) return 1;
+    if (run_detect(e, d_on, T, fsmp, ns, available, &sets)) return 1;
     return combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, 0, e->node_offset, 0,
                    d_part_max, d_part_sum, d_part_idx);
 }
@@ -737,7 +1004,7 @@ int qm_engine_detect(qm_engine *e, const double *log_onsets, int onsets_on_devic
     if (stage_onsets(e, log_onsets, onsets_on_device, T, &d_on)) return 1;
     OutStage st;
     if (stage_out(e, ns, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st)) return 1;
-    if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, &sets)) return 1;
+    if (run_detect(e, d_on, T, fsmp, ns, available, &sets)) return 1;
     if (combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, 1, e->node_offset,
                 n_nodes_total, st.a, st.b, st.i))
         return 1;

@@ -27,7 +27,7 @@ struct Taps {
 };
 
 // ---- max / first argmax (NaN never wins: numpy nanmax / nanargmax) ----------------------------
-__device__ inline void better(double &v, int64_t &i, double ov, int64_t oi) {
+__device__ inline void take_better(double &v, int64_t &i, double ov, int64_t oi) {
     if (oi >= 0 && (i < 0 || ov > v || (ov == v && oi < i))) {
         v = ov;
         i = oi;
@@ -41,7 +41,7 @@ __device__ inline void block_argmax(double v, int64_t i, double *out_v, int64_t 
     si[threadIdx.x] = i;
     __syncthreads();
     for (int s = kFitBlock / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) better(sv[threadIdx.x], si[threadIdx.x], sv[threadIdx.x + s],
+        if ((int)threadIdx.x < s) take_better(sv[threadIdx.x], si[threadIdx.x], sv[threadIdx.x + s],
                                          si[threadIdx.x + s]);
         __syncthreads();
     }
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kFitBlock) void argmax_final_kernel(
     double *__restrict__ out_v, double *__restrict__ out_i) {
     double v = 0.0;
     int64_t idx = -1;
-    for (int k = threadIdx.x; k < np; k += kFitBlock) better(v, idx, pv[k], pi[k]);
+    for (int k = threadIdx.x; k < np; k += kFitBlock) take_better(v, idx, pv[k], pi[k]);
     __shared__ double rv;
     __shared__ int64_t ri;
     block_argmax(v, idx, &rv, &ri);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kFitBlock) void moments_partial_kernel(
         const double x = (double)(i / ((int64_t)nz * ny)) * sx;
         const double y = (double)((i / nz) % ny) * sy;
         const double z = (double)(i % nz) * sz;
-        if (STAGE == 0) {
+        if constexpr (STAGE == 0) {
             v[0] += w;
             v[1] += w * x;
             v[2] += w * y;

@@ -707,3 +707,65 @@ def test_locate_chain_marginal_map_to_location_stays_on_device(lib, oracle):
     with pytest.raises(lib.QMHipError, match="sgm"):
         eng.locate_fits(dmap, spacing, sgm=0.0)
     eng.close()
+
+
+def _screen_vs_exact(lib, case, expect_screened=True, **cfg):
+    lon = np.ascontiguousarray(np.log(np.clip(case.onsets, 0.01, np.inf)))
+    exact = lib.Engine(0, **cfg)
+    exact.load_lut(case.traveltimes)
+    want = exact.detect(lon, case.fsmp, case.lsmp, case.available)
+    exact.close()
+    eng = lib.Engine(0, screen=1, **cfg)
+    eng.load_lut(case.traveltimes)
+    got = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+    screened, fallback = eng.get("screened_steps"), eng.get("fallback_steps")
+    eng.close()
+    assert np.array_equal(got[2], want[2]), f"argmax differs at {np.flatnonzero(got[2] != want[2])[:8]}"
+    assert np.array_equal(got[0], want[0])              # the peak is the same float64 evaluation
+    np.testing.assert_allclose(got[1], want[1], rtol=RTOL)
+    np.testing.assert_allclose(got[1], want[1], rtol=2e-7)   # observed: float32 terms in the sum
+    assert (screened, fallback) == ((1, 0) if expect_screened else (0, 1))
+    return got
+
+
+@pytest.mark.parametrize("rows,grid,ns", [(30, (24, 22, 18), 700), (20, (17, 19, 23), 300),
+                                          (6, (9, 8, 7), 150), (47, (16, 16, 12), 260),
+                                          (60, (12, 10, 9), 130), (33, (13, 9, 11), 129)])
+def test_screened_detect_equals_float64_detect(lib, oracle, rows, grid, ns):
+    """float32 screening sweep + exact refinement: same max_coa / argmax as the float64 kernel
+    (bit for bit), max_norm_coa within the contract; also against the CPU oracle."""
+    case = synth.make_case("C3", step=2, grid=grid, rows=rows, n_samples=ns)
+    got = _screen_vs_exact(lib, case)
+    want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
+                         threads=4)
+    assert np.array_equal(got[2], want[2])
+    np.testing.assert_allclose(got[0], want[0], rtol=TIGHT)
+    np.testing.assert_allclose(got[1], want[1], rtol=RTOL)
+
+
+def test_screened_detect_falls_back_on_flat_data(lib, oracle):
+    """All-ties data (every onset on the clip floor): every cell is a candidate, the step is
+    re-run by the float64 kernel and the lowest-index rule still holds."""
+    case = synth.make_case("C2", step=1, grid=(20, 18, 16), rows=12, n_samples=300, quiet=True)
+    got = _screen_vs_exact(lib, case, expect_screened=False)
+    assert np.all(got[2] == 0)
+
+
+def test_screened_detect_with_wide_bricks_and_rows_over_64(lib, oracle):
+    """Bricks whose windows do not fit go through the float64 direct kernel inside the screened
+    step; more than 64 rows are not screened at all."""
+    rng = np.random.default_rng(77)
+    case = synth.make_case("C2", step=5, grid=(16, 16, 16), rows=10, n_samples=280)
+    tt = case.traveltimes.copy()
+    tt[:8, :8, :8, :] = rng.integers(0, case.lsmp, size=(8, 8, 8, 10))     # one incoherent brick
+    case.traveltimes = np.ascontiguousarray(tt)
+    _screen_vs_exact(lib, case, brick_x=8, brick_y=8, brick_z=8)
+    big = synth.make_case("C2", step=5, grid=(8, 8, 8), rows=70, n_samples=130)
+    lon = np.ascontiguousarray(np.log(np.clip(big.onsets, 0.01, np.inf)))
+    eng = lib.Engine(0, screen=1)
+    eng.load_lut(big.traveltimes)
+    got = eng.detect(lon, big.fsmp, big.lsmp, big.available)
+    assert eng.get("screened_steps") == 0 and eng.get("fallback_steps") == 0
+    want = oracle.detect(big.onsets, big.traveltimes, big.fsmp, big.lsmp, big.available, threads=4)
+    _assert_series(got, want)
+    eng.close()
