@@ -20,6 +20,8 @@ import os
 IN_FLIGHT = int(os.environ.get("QM_RING_IN_FLIGHT", "8"))     # ds_read_b64 in flight per wave
 SETPRIO = int(os.environ.get("QM_RING_SETPRIO", "0"))          # s_setprio level inside the ring
 SLOTS = IN_FLIGHT + 1                                          # landing registers (doubles)
+IN_FLIGHT32 = int(os.environ.get("QM_RING32_IN_FLIGHT", "8"))  # float32 screening ring
+SETPRIO32 = int(os.environ.get("QM_RING32_SETPRIO", "0"))
 
 
 def variant(J, rows):
@@ -70,8 +72,11 @@ def variant32(JP, rows):
     """
     stride = 8 * 128 * JP - 8
     n = rows * JP
-    F = IN_FLIGHT
+    F = IN_FLIGHT32
+    SLOTS = F + 1
     lines = []
+    if SETPRIO32:
+        lines.append(f"s_setprio {SETPRIO32}")
 
     def read(k):
         row, j = divmod(k, JP)
@@ -85,6 +90,8 @@ def variant32(JP, rows):
         if k + F < n:
             read(k + F)
         lines.append(f"v_pk_add_f32 %[c{k % JP}], %[c{k % JP}], %[t{k % SLOTS}]")
+    if SETPRIO32:
+        lines.append("s_setprio 0")
     body = "\\n\\t".join(lines)
     outs = [f'[c{j}] "+v"(acc[{j}])' for j in range(JP)]
     outs += [f'[t{s}] "=&v"(t[{s}])' for s in range(SLOTS)]
@@ -109,14 +116,14 @@ def main32():
         print("template <>")
         print(f"__device__ __forceinline__ void ring32_full<{JP}>(qm_v2f (&acc)[{JP}], "
               "const unsigned (&addr)[8]) {")
-        print(f"    qm_v2f t[{SLOTS}];")
+        print(f"    qm_v2f t[{IN_FLIGHT32 + 1}];")
         print(variant32(JP, 8).replace("        asm", "    asm").replace("                     :", "                 :"))
         print("}")
         print()
         print("template <>")
         print(f"__device__ __forceinline__ void ring32_tail<{JP}>(qm_v2f (&acc)[{JP}], "
               "const unsigned (&addr)[8], int rows) {")
-        print(f"    qm_v2f t[{SLOTS}];")
+        print(f"    qm_v2f t[{IN_FLIGHT32 + 1}];")
         print("    switch (rows) {")
         for rows in range(7, 0, -1):
             print(f"    case {rows}:")

@@ -105,7 +105,7 @@ struct qm_engine {
     // float32 screening (qm_screen.hpp): staggered-copy offset table and per-step scratch
     DevBuf<int32_t> d_smeta, d_stotal, d_swide, d_counts, d_cells, d_work, d_flags;
     DevBuf<uint16_t> d_srel;
-    DevBuf<float> d_on32, d_cell, d_pm;
+    DevBuf<float> d_on32, d_cell, d_gmax, d_pm;
     DevBuf<double> d_rowmax, d_ssum, d_cand_z;
     DevBuf<int64_t> d_cand_idx;
     int n_swide = 0;
@@ -461,11 +461,10 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
                                             : auto_groups(e, (ns + 63) / 64, e->n_swide, 4))
                        : 0;
     const int sets = groups_direct + 1;
-    constexpr int kPeakChunks = 16;
-    const int per_chunk = (g.nbricks + kPeakChunks - 1) / kPeakChunks;
+    constexpr int kGroupsPerBlock = 32;
     if (e->d_on32.ensure((size_t)S * T) || e->d_rowmax.ensure(S) ||
         e->d_cell.ensure((size_t)g.nbricks * ns_pad) ||
-        e->d_pm.ensure((size_t)kPeakChunks * ns) || e->d_ssum.ensure((size_t)std::max(1, groups) * ns) ||
+        e->d_gmax.ensure((size_t)std::max(1, groups) * ns_pad) || e->d_pm.ensure(ns) || e->d_ssum.ensure((size_t)std::max(1, groups) * ns) ||
         e->d_counts.ensure(ns) || e->d_cells.ensure((size_t)ns * qm::kScreenSlots) ||
         e->d_work.ensure((size_t)ns * qm::kScreenSlots) ||
         e->d_flags.ensure(4) || e->d_cand_z.ensure((size_t)ns * qm::kScreenSlots) ||
@@ -509,6 +508,7 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
     a.window_bytes = e->screen_wb;
     a.z_scale = (float)(1.4426950408889634074 / (double)available);
     a.cell_max = e->d_cell.p;
+    a.group_max = e->d_gmax.p;
     a.ns_pad = ns_pad;
     a.part_sum = e->d_ssum.p;
     if (groups > 0) {
@@ -546,12 +546,14 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
         QM_HIP(hipGetLastError());
     }
     const unsigned tcols = (unsigned)((ns + 63) / 64);
-    hipLaunchKernelGGL(qm::screen_peak_kernel, dim3(tcols, kPeakChunks), dim3(256), 0, s,
-                       (const float *)e->d_cell.p, ns_pad, ns, g.nbricks, per_chunk, e->d_pm.p);
-    hipLaunchKernelGGL(qm::screen_candidates_kernel, dim3(tcols, kPeakChunks), dim3(256), 0, s,
-                       (const float *)e->d_cell.p, ns_pad, ns, g.nbricks, per_chunk,
-                       (const float *)e->d_pm.p, kPeakChunks, (const double *)e->d_rowmax.p, S,
-                       e->d_counts.p, e->d_cells.p, e->d_work.p, e->d_flags.p);
+    hipLaunchKernelGGL(qm::screen_peak_kernel, dim3(tcols), dim3(256), 0, s,
+                       (const float *)e->d_gmax.p, ns_pad, ns, groups, e->d_pm.p);
+    hipLaunchKernelGGL(qm::screen_candidates_kernel,
+                       dim3(tcols, (unsigned)std::max(1, (groups + kGroupsPerBlock - 1) / kGroupsPerBlock)),
+                       dim3(256), 0, s, (const float *)e->d_cell.p, (const float *)e->d_gmax.p,
+                       ns_pad, ns, g.nbricks, groups, kGroupsPerBlock, (const float *)e->d_pm.p,
+                       (const double *)e->d_rowmax.p, S, e->d_counts.p, e->d_cells.p, e->d_work.p,
+                       e->d_flags.p);
     QM_HIP(hipGetLastError());
     qm::RefineArgs r{};
     r.g = g;
@@ -567,7 +569,7 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
     r.cand_z = e->d_cand_z.p;
     r.cand_idx = e->d_cand_idx.p;
     hipLaunchKernelGGL(qm::screen_refine_kernel, dim3((unsigned)(8 * e->n_cu)), dim3(256), 0, s, r);
-    hipLaunchKernelGGL(qm::screen_collect_kernel, dim3((ns + 255) / 256), dim3(256), 0, s,
+    hipLaunchKernelGGL(qm::screen_collect_kernel, dim3((ns + 63) / 64), dim3(256), 0, s,
                        (const int32_t *)e->d_counts.p, (const double *)e->d_cand_z.p,
                        (const int64_t *)e->d_cand_idx.p, (const double *)e->d_ssum.p, groups, ns,
                        e->d_pmax.p + (size_t)groups_direct * ns,
@@ -710,7 +712,7 @@ void qm_engine_destroy(qm_engine *e) {
     e->d_fit_val.release(); e->d_fit_win.release(); e->d_fit_pidx.release();
     e->d_smeta.release(); e->d_stotal.release(); e->d_swide.release(); e->d_counts.release();
     e->d_cells.release(); e->d_work.release(); e->d_flags.release(); e->d_srel.release(); e->d_on32.release();
-    e->d_cell.release(); e->d_pm.release(); e->d_rowmax.release(); e->d_ssum.release();
+    e->d_cell.release(); e->d_gmax.release(); e->d_pm.release(); e->d_rowmax.release(); e->d_ssum.release();
     e->d_cand_z.release(); e->d_cand_idx.release();
     for (hipEvent_t ev : e->ev_log) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);

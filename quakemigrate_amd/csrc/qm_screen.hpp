@@ -46,6 +46,7 @@ struct ScreenArgs {
     int window_bytes;              // LDS bytes available to the windows
     float z_scale;                 // log2(e) / available
     float *cell_max;               // [nbricks][ns_pad] float32 stack maxima (not scaled)
+    float *group_max;              // [ngroups][ns_pad] maxima over the cells of a workgroup
     int64_t ns_pad;                // ntiles * KT
     double *part_sum;              // [ngroups][n_samples]
 };
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(1024) void screen_lds_kernel(ScreenArgs a) {
 #pragma unroll
     for (int i = 0; i < 2 * JP; ++i) vsum[i] = 0.0;
     int prev_b = -1;
+    float group_best = -__builtin_inff();              // threads k < KT: maximum of sample k
 
     for (int b = group; b < g.nbricks; b += a.ngroups) {
         if (!screen_fits(a.brick_total[b], S, KT, a.window_bytes)) {
@@ -207,9 +209,11 @@ __global__ __launch_bounds__(1024) void screen_lds_kernel(ScreenArgs a) {
         }
         __syncthreads();                                // previous brick consumed and merged
         if (prev_b >= 0) {
-            for (int k = threadIdx.x; k < KT; k += blockDim.x) {
-                a.cell_max[(int64_t)prev_b * a.ns_pad + t_first + k] = cellbuf[k];
-                cellbuf[k] = -__builtin_inff();
+            if ((int)threadIdx.x < KT) {
+                const float v = cellbuf[threadIdx.x];
+                a.cell_max[(int64_t)prev_b * a.ns_pad + t_first + threadIdx.x] = v;
+                group_best = fmaxf(group_best, v);
+                cellbuf[threadIdx.x] = -__builtin_inff();
             }
         }
         stage_windows32<JP>(a, swin, b, wave, nwaves, lane, t_first);
@@ -288,9 +292,13 @@ __global__ __launch_bounds__(1024) void screen_lds_kernel(ScreenArgs a) {
         prev_b = b;
     }
     __syncthreads();
-    if (prev_b >= 0) {
-        for (int k = threadIdx.x; k < KT; k += blockDim.x)
-            a.cell_max[(int64_t)prev_b * a.ns_pad + t_first + k] = cellbuf[k];
+    if ((int)threadIdx.x < KT) {
+        if (prev_b >= 0) {
+            const float v = cellbuf[threadIdx.x];
+            a.cell_max[(int64_t)prev_b * a.ns_pad + t_first + threadIdx.x] = v;
+            group_best = fmaxf(group_best, v);
+        }
+        a.group_max[(int64_t)group * a.ns_pad + t_first + threadIdx.x] = group_best;
     }
     // partial sums of this workgroup: cross-wave through LDS (the windows are dead)
     double *red = reinterpret_cast<double *>(swin);
@@ -309,37 +317,35 @@ __global__ __launch_bounds__(1024) void screen_lds_kernel(ScreenArgs a) {
 }
 
 // ---- candidates --------------------------------------------------------------------------------
-// partial maxima over brick chunks: pm[chunk][t]
-__global__ __launch_bounds__(256) void screen_peak_kernel(const float *__restrict__ cell_max,
+// float32 maximum of every sample over the workgroups: peak[t]
+__global__ __launch_bounds__(256) void screen_peak_kernel(const float *__restrict__ group_max,
                                                           int64_t ns_pad, int n_samples,
-                                                          int nbricks, int per_chunk,
-                                                          float *__restrict__ pm) {
+                                                          int ngroups, float *__restrict__ peak) {
     __shared__ float red[4][kWave];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * kWave + lane;
     const int tc = t < n_samples ? t : n_samples - 1;
-    const int b0 = blockIdx.y * per_chunk;
-    const int b1 = min(nbricks, b0 + per_chunk);
     float m = -__builtin_inff();
-    for (int b = b0 + wave; b < b1; b += 4) m = fmaxf(m, cell_max[(int64_t)b * ns_pad + tc]);
+    for (int gsel = wave; gsel < ngroups; gsel += 4) m = fmaxf(m, group_max[(int64_t)gsel * ns_pad + tc]);
     red[wave][lane] = m;
     __syncthreads();
     if (wave == 0 && t < n_samples)
-        pm[(int64_t)blockIdx.y * n_samples + t] =
-            fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
+        peak[t] = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
 }
 
 // every cell within 2 D of the sample's float32 maximum becomes a candidate: a slot in the
 // sample's list (for the final pick) and an entry in the flat work list (for the refinement).
+// Only the cells of workgroups whose own maximum reaches the bar are looked at (workgroup g owns
+// bricks g, g + ngroups, ...).
 // flags[0]: bit 0 = some sample overflowed its slots, bit 1 = non-finite onsets; flags[1]: entries.
 __global__ __launch_bounds__(256) void screen_candidates_kernel(
-    const float *__restrict__ cell_max, int64_t ns_pad, int n_samples, int nbricks, int per_chunk,
-    const float *__restrict__ pm, int nchunks, const double *__restrict__ row_absmax, int n_rows,
-    int32_t *__restrict__ counts, int32_t *__restrict__ cells, int32_t *__restrict__ work,
-    int32_t *__restrict__ flags) {
+    const float *__restrict__ cell_max, const float *__restrict__ group_max, int64_t ns_pad,
+    int n_samples, int nbricks, int ngroups, int groups_per_block, const float *__restrict__ peak,
+    const double *__restrict__ row_absmax, int n_rows, int32_t *__restrict__ counts,
+    int32_t *__restrict__ cells, int32_t *__restrict__ work, int32_t *__restrict__ flags) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * kWave + lane;
-    const int tc = t < n_samples ? t : n_samples - 1;
+    if (t >= n_samples) return;
     double A = 0.0;
     for (int r = 0; r < n_rows; ++r) A += row_absmax[r];
     const double D = 1.001 * (double)n_rows * 5.9604644775390625e-08 * A;     // S * 2^-24 * A
@@ -347,14 +353,13 @@ __global__ __launch_bounds__(256) void screen_candidates_kernel(
         if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) atomicOr(flags, 2);
         return;
     }
-    float m = -__builtin_inff();
-    for (int c = 0; c < nchunks; ++c) m = fmaxf(m, pm[(int64_t)c * n_samples + tc]);
-    const double bar = (double)m - 2.0 * D;
-    const int b0 = blockIdx.y * per_chunk;
-    const int b1 = min(nbricks, b0 + per_chunk);
-    for (int b = b0 + wave; b < b1; b += 4) {
-        const float v = cell_max[(int64_t)b * ns_pad + tc];
-        if (t < n_samples && (double)v >= bar) {
+    const double bar = (double)peak[t] - 2.0 * D;
+    const int g0 = blockIdx.y * groups_per_block;
+    const int g1 = min(ngroups, g0 + groups_per_block);
+    for (int gsel = g0 + wave; gsel < g1; gsel += 4) {
+        if (!((double)group_max[(int64_t)gsel * ns_pad + t] >= bar)) continue;
+        for (int b = gsel; b < nbricks; b += ngroups) {
+            if (!((double)cell_max[(int64_t)b * ns_pad + t] >= bar)) continue;
             const int k = atomicAdd(&counts[t], 1);
             if (k < kScreenSlots) {
                 cells[(int64_t)t * kScreenSlots + k] = b;
@@ -398,11 +403,23 @@ __global__ __launch_bounds__(256) void screen_refine_kernel(RefineArgs a) {
         for (int m = threadIdx.x; m < nvalid; m += 256) {   // ascending node index per thread
             const int node = brick_walk_node(g, x0, y0, z0, vy, vz, m);
             const int32_t *row = a.lut + (int64_t)node * g.n_rows;
+            const double *col = a.onsets + a.fsmp + t;
             double s = 0.0;
-            for (int r = 0; r < g.n_rows; ++r) {            // ascending rows: migratelib.c:54-59
-                int d = row[r];
-                d = d < 0 ? 0 : d;
-                s += a.onsets[(int64_t)r * a.T + d + a.fsmp + t];
+            int r = 0;
+            for (; r + 8 <= g.n_rows; r += 8) {             // 8 delays, then 8 gathers, in flight
+                int d[8];
+                double v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[k] = row[r + k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    v[k] = col[(int64_t)(r + k) * a.T + (d[k] < 0 ? 0 : d[k])];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += v[k];      // ascending rows: migratelib.c:54-59
+            }
+            for (; r < g.n_rows; ++r) {
+                const int d = row[r];
+                s += col[(int64_t)r * a.T + (d < 0 ? 0 : d)];
             }
             const double z = s * a.z_scale;
             if (z > best) {                                 // strict: first node wins
@@ -439,14 +456,21 @@ __global__ __launch_bounds__(256) void screen_refine_kernel(RefineArgs a) {
 
 // one partial set (log2-domain maximum, local node index, sum) from the candidates and the
 // workgroups' sums -- the same form stack_lds_kernel publishes, so combine_kernel finishes it.
-__global__ void screen_collect_kernel(const int32_t *__restrict__ counts,
-                                      const double *__restrict__ cand_z,
-                                      const int64_t *__restrict__ cand_idx,
-                                      const double *__restrict__ part_sum, int ngroups,
-                                      int n_samples, double *__restrict__ out_max,
-                                      int64_t *__restrict__ out_idx, double *__restrict__ out_sum) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_samples) return;
+__global__ __launch_bounds__(256) void screen_collect_kernel(
+    const int32_t *__restrict__ counts, const double *__restrict__ cand_z,
+    const int64_t *__restrict__ cand_idx, const double *__restrict__ part_sum, int ngroups,
+    int n_samples, double *__restrict__ out_max, int64_t *__restrict__ out_idx,
+    double *__restrict__ out_sum) {
+    __shared__ double ssum[4][kWave];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * kWave + lane;
+    const int tc = t < n_samples ? t : n_samples - 1;
+    double total = 0.0;
+    for (int gsel = wave; gsel < ngroups; gsel += 4) total += part_sum[(int64_t)gsel * n_samples + tc];
+    ssum[wave][lane] = total;
+    __syncthreads();
+    if (wave != 0 || t >= n_samples) return;
+    total = ((ssum[0][lane] + ssum[1][lane]) + ssum[2][lane]) + ssum[3][lane];
     double best = -__builtin_inf();
     int64_t bi = kNoIndex;
     const int n = min(counts[t], kScreenSlots);
@@ -458,8 +482,6 @@ __global__ void screen_collect_kernel(const int32_t *__restrict__ counts,
             bi = i;
         }
     }
-    double total = 0.0;
-    for (int gsel = 0; gsel < ngroups; ++gsel) total += part_sum[(int64_t)gsel * n_samples + t];
     out_max[t] = best;
     out_idx[t] = bi;
     out_sum[t] = total;
