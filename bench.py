@@ -43,6 +43,7 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12           # B/s  (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 LDS_PEAK = 150.0e12         # B/s  aggregate ds_read_b64/b128
 FP64_PEAK = 39.3e12         # vector FP64 instructions-lanes / s (78.6 TFLOP/s FMA)
+EXP_F32_OPS = 8             # float32 ops per node-sample besides the S adds in the screening sweep
 EXP_FP64_OPS = 18           # FP64-rate VALU ops per node-sample besides the S adds (2^z, sum, max)
 
 
@@ -59,6 +60,8 @@ def parse():
     ap.add_argument("--no-materialised", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--engine", default="{}", help="json dict of engine tunables")
+    ap.add_argument("--no-exact", action="store_true",
+                    help="skip the float64-kernel comparison run (exact_f64)")
     ap.add_argument("--materialise-full", action="store_true",
                     help="also run configs[2] literally: the whole n_samples volume (196 GB at "
                          "C3) written to HBM with the scan outputs (needs the memory)")
@@ -118,6 +121,25 @@ def cpu_baseline(case, budget_s):
         "migrate_s": warm[0], "find_max_coa_s": warm[1],
         "cold_value": work / sum(cold),
     }
+
+
+def onchip(screened, local_ns, S, kern_s):
+    """The ceilings that bind the stacking kernel: LDS operand bytes and VALU issue."""
+    if screened:
+        # 4 operand bytes per add; packed float32: two adds per lane-instruction
+        ops = S + EXP_F32_OPS
+        return {"lds": {"achieved": 4.0 * local_ns * S / kern_s / 1e12, "peak": LDS_PEAK / 1e12,
+                        "unit": "TB/s", "frac": 4.0 * local_ns * S / kern_s / LDS_PEAK},
+                "fp32_packed_valu": {"achieved": local_ns * ops / kern_s / 1e12,
+                                     "peak": 2 * FP64_PEAK / 1e12, "unit": "Tops/s",
+                                     "frac": local_ns * ops / kern_s / (2 * FP64_PEAK),
+                                     "ops_per_node_sample": ops}}
+    return {"lds": {"achieved": 8.0 * local_ns * S / kern_s / 1e12, "peak": LDS_PEAK / 1e12,
+                    "unit": "TB/s", "frac": 8.0 * local_ns * S / kern_s / LDS_PEAK},
+            "fp64_valu": {"achieved": local_ns * (S + EXP_FP64_OPS) / kern_s / 1e12,
+                          "peak": FP64_PEAK / 1e12, "unit": "Tinstr-lanes/s",
+                          "frac": local_ns * (S + EXP_FP64_OPS) / kern_s / FP64_PEAK,
+                          "ops_per_node_sample": S + EXP_FP64_OPS}}
 
 
 def main():
@@ -222,6 +244,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms, kern_calls = eng.kernel_log()
     eng.config("log_timing", 0)
+    screened = eng.get("screened_steps") > 0 and eng.get("fallback_steps") == 0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -257,7 +280,7 @@ def main():
         "value": value, "unit": "node-samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f32 sweep + f64 refinement" if screened else "f64", "data": "synthetic",
         "config": {"workload": f"{args.config} detect sweep: {x_range[1] - x_range[0]}x{ny}x{nz} "
                                f"nodes on rank 0 (grid {grid[0]}x{ny}x{nz}), {S} onset rows, "
                                f"{ns} samples per step, fused migrate+find_max_coa, table "
@@ -271,8 +294,9 @@ def main():
                                                                    eng.get("brick_y"),
                                                                    eng.get("brick_z")],
                                                samples_per_lane=eng.get("samples_per_lane"))},
-        "kernel": {"name": f"qm::stack_lds_kernel<{eng.get('samples_per_lane')},false,"
-                           f"{(S + 7) // 8}>", "avg_ms": kern_s * 1e3,
+        "kernel": {"name": (f"qm::screen_lds_kernel<{2 if S <= 32 else 1},{(S + 7) // 8}>" if screened
+                            else f"qm::stack_lds_kernel<{eng.get('samples_per_lane')},false,"
+                                 f"{(S + 7) // 8}>"), "avg_ms": kern_s * 1e3,
                    "launches": kern_calls, "timing": "HIP events on the launch stream"},
         "roofline": {"bound": "hbm", "achieved": b_fused / kern_s / 1e9,
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -280,15 +304,53 @@ def main():
                      "algorithmic_bytes_per_launch": b_fused,
                      "note": "fused detect never writes the volume: compulsory HBM bytes "
                              "are the table, the onsets and the outputs only; the kernel "
-                             "is LDS-gather / FP64-VALU bound (see roofline_onchip)"},
-        "roofline_onchip": {
-            "lds": {"achieved": 8.0 * local_ns * S / kern_s / 1e12, "peak": LDS_PEAK / 1e12,
-                    "unit": "TB/s", "frac": 8.0 * local_ns * S / kern_s / LDS_PEAK},
-            "fp64_valu": {"achieved": local_ns * (S + EXP_FP64_OPS) / kern_s / 1e12,
-                          "peak": FP64_PEAK / 1e12, "unit": "Tinstr-lanes/s",
-                          "frac": local_ns * (S + EXP_FP64_OPS) / kern_s / FP64_PEAK,
-                          "ops_per_node_sample": S + EXP_FP64_OPS}},
+                             "is LDS-gather / VALU bound (see roofline_onchip)"},
+        "roofline_onchip": onchip(screened, local_ns, S, kern_s),
     }
+    if screened:
+        result["screening"] = {
+            "what": "every node-sample is stacked in float32 (pairs of samples: ds_read_b64 + "
+                    "v_pk_add_f32); every (brick, sample) cell within the rigorous float32 "
+                    "error bound of the sample's maximum is re-evaluated node by node in "
+                    "float64: max_coa and max_coa_idx are those of the float64 kernel, "
+                    "max_norm_coa's sum over nodes has float32 terms",
+            "candidate_cells_last_step": eng.get("last_candidates"),
+            "steps_screened": eng.get("screened_steps"),
+            "steps_fallen_back_to_float64": eng.get("fallback_steps")}
+
+    # ---- the float64 kernel on the same steps, and the two paths side by side --------
+    if screened and world == 1 and not streaming and not args.no_exact:
+        ex = lib.Engine(local_rank, **dict(tunables, screen=0))
+        ex.set_stream(torch.cuda.current_stream().cuda_stream)
+        ex.load_lut(case.traveltimes, node_offset=x_range[0] * ny * nz)
+        out_x = tuple(torch.empty_like(o) for o in out)
+        n_x = max(2, min(args.steps, 10))
+        ex.detect(onsets_dev[last], case.fsmp, case.lsmp, case.available, n_nodes_total=n_total,
+                  out=out_x)
+        torch.cuda.synchronize()
+        same_idx = bool(torch.equal(out_x[2], res[2]))
+        same_coa = bool(torch.equal(out_x[0], res[0]))
+        norm_rel = float(((out_x[1] - res[1]).abs() / out_x[1]).max().item())
+        assert same_idx and same_coa and norm_rel < 1e-6, (same_idx, same_coa, norm_rel)
+        ex.config("log_timing", 1)
+        t0 = time.perf_counter()
+        for i in range(n_x):
+            ex.detect(onsets_dev[i % n_pool], case.fsmp, case.lsmp, case.available,
+                      n_nodes_total=n_total, out=out_x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_x
+        xk_ms, xk_calls = ex.kernel_log()
+        xk_s = xk_ms / 1e3 / max(xk_calls, 1)
+        result["exact_f64"] = {
+            "ms_per_step": dt * 1e3, "value": work_step / dt, "unit": "node-samples/s",
+            "steps": n_x,
+            "kernel": {"name": f"qm::stack_lds_kernel<{ex.get('samples_per_lane')},false,"
+                               f"{(S + 7) // 8}>", "avg_ms": xk_s * 1e3, "launches": xk_calls},
+            "roofline_onchip": onchip(False, local_ns, S, xk_s),
+            "screened_vs_float64": {"max_coa_idx_identical": same_idx,
+                                    "max_coa_identical": same_coa,
+                                    "max_norm_coa_max_rel_diff": norm_rel}}
+        ex.close()
 
     # ---- locate-style materialising variant on the same grid (HBM-write bound) ------
     if not args.no_materialised and world == 1 and cfg_name == "C3" and not streaming:

@@ -19,6 +19,10 @@ from quakemigrate_amd import synth
 
 pytestmark = pytest.mark.gpu
 TIGHT = 1e-13
+# max_norm_coa of a screened detect: the sum over nodes is made of float32 terms (observed <= 2e-7
+# on grids of a few hundred nodes, ~2e-9 at BASELINE sizes; contract RTOL = 1e-6).  The float64
+# engine (screen=0) is held to 1e-12 in test_float64_engine_keeps_max_norm_coa_tight.
+NORM = 5e-7
 
 
 @pytest.fixture(scope="module")
@@ -36,7 +40,7 @@ def _assert_series(got, want, tight=TIGHT):
     np.testing.assert_allclose(a, ra, rtol=RTOL)          # the contract
     np.testing.assert_allclose(b, rb, rtol=RTOL)
     np.testing.assert_allclose(a, ra, rtol=tight)         # what we actually get
-    np.testing.assert_allclose(b, rb, rtol=max(tight, 1e-12))
+    np.testing.assert_allclose(b, rb, rtol=max(tight, NORM))
 
 
 FULL = ["small_random", "ties_floor", "ties_twins", "edges"]
@@ -201,14 +205,14 @@ def test_sharded_partials_combine_to_single_gpu_result(lib, oracle):
     got = eng.finalize(pmax, pidx, psum, 4, ns, case.n_nodes_total)
     assert np.array_equal(got[2], want[2])
     np.testing.assert_allclose(got[0], want[0], rtol=TIGHT)
-    np.testing.assert_allclose(got[1], want[1], rtol=1e-12)
+    np.testing.assert_allclose(got[1], want[1], rtol=NORM)
     # the torch-level exchange used across ranks gives the same answer
     from quakemigrate_amd import distributed as qd
 
     a, b, c = qd.combine_partials_local(pmax, pidx, psum, case.n_nodes_total)
     assert np.array_equal(c.cpu().numpy(), want[2])
     np.testing.assert_allclose(a.cpu().numpy(), want[0], rtol=TIGHT)
-    np.testing.assert_allclose(b.cpu().numpy(), want[1], rtol=1e-12)
+    np.testing.assert_allclose(b.cpu().numpy(), want[1], rtol=NORM)
 
 
 # ---------------------------------------------------------------------------------
@@ -263,7 +267,7 @@ def test_full_size_configs_chunk_oracle_and_properties(lib, oracle, name, nk):
     eng.synchronize()
     both = eng.finalize(pmax, pidx, psum, 2, ns, case.n_nodes_total)
     assert np.array_equal(both[2], got[2]) and np.array_equal(both[0], got[0])
-    np.testing.assert_allclose(both[1], got[1], rtol=1e-12)
+    np.testing.assert_allclose(both[1], got[1], rtol=NORM)
     # (e) a quiet step (all onsets on the clip floor): every node ties -> index 0
     quiet = synth.make_case(name, step=1, quiet=True, n_samples=300,
                             grid=(case.grid[0] // 4, case.grid[1], case.grid[2]))
@@ -522,7 +526,7 @@ def test_onset_stage_on_device_matches_reference_fixture(lib, oracle):
     want = oracle.detect(g["raw_centred_energy"], tt, fsmp, lsmp, 4, threads=2)
     assert np.array_equal(got[2], want[2])
     np.testing.assert_allclose(got[0], want[0], rtol=1e-11)
-    np.testing.assert_allclose(got[1], want[1], rtol=1e-11)
+    np.testing.assert_allclose(got[1], want[1], rtol=NORM)
     eng.close()
 
 
@@ -570,7 +574,7 @@ def test_randomised_differential_with_many_exact_ties(lib, oracle):
         got = eng.detect(lon, fsmp, lsmp, avail)
         assert np.array_equal(got[2], want[2]), (trial, grid, S, ns, cfg)
         np.testing.assert_allclose(got[0], want[0], rtol=1e-13, err_msg=str((trial, cfg)))
-        np.testing.assert_allclose(got[1], want[1], rtol=1e-12, err_msg=str((trial, cfg)))
+        np.testing.assert_allclose(got[1], want[1], rtol=NORM, err_msg=str((trial, cfg)))
         vol = np.zeros(grid + (ns,))
         series = (np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64))
         eng.migrate(lon, fsmp, lsmp, avail, vol, scan_out=series)
@@ -625,9 +629,12 @@ def test_empty_scan_and_nan_onsets(lib, oracle):
     got = eng.detect(oracle.log_onsets(on), fsmp, lsmp, 6)
     hit = np.isnan(got[1])
     assert hit[60] and not np.isnan(got[0]).any()
-    # samples whose stacks never read the NaN are bit-identical to the clean run
-    for a, b in zip(got, clean):
-        assert np.array_equal(a[~hit], b[~hit])
+    # a non-finite onset is not screened: that step runs on the float64 kernel
+    assert (eng.get("screened_steps"), eng.get("fallback_steps")) == (1, 1)
+    # samples whose stacks never read the NaN agree with the clean (screened) run
+    assert np.array_equal(got[0][~hit], clean[0][~hit])
+    assert np.array_equal(got[2][~hit], clean[2][~hit])
+    np.testing.assert_allclose(got[1][~hit], clean[1][~hit], rtol=NORM)
     # at a poisoned sample the winner is the best node among those that did not read it
     vol = oracle.c_migrate(g["onsets"], tt, fsmp, lsmp, 6, threads=2).reshape(-1, got[0].size)
     reads_nan = np.array([fsmp + 60 + int(flat[n, 3]) == fsmp + 60 + int(flat[200, 3])
@@ -709,9 +716,24 @@ def test_locate_chain_marginal_map_to_location_stays_on_device(lib, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("name", FULL + ["ragged"])
+def test_float64_engine_keeps_max_norm_coa_tight(lib, name):
+    """screen=0: every node-sample in float64; max_norm_coa to 1e-12 of the reference."""
+    g = load_golden(name)
+    eng = lib.Engine(0, screen=0)
+    eng.load_lut(g["traveltimes"])
+    lon = np.ascontiguousarray(np.log(np.clip(g["onsets"], 0.01, np.inf)))
+    got = eng.detect(lon, int(g["fsmp"]), int(g["lsmp"]), int(g["available"]))
+    assert eng.get("screened_steps") == 0
+    eng.close()
+    assert np.array_equal(got[2], g["max_coa_idx"])
+    np.testing.assert_allclose(got[0], g["max_coa"], rtol=TIGHT)
+    np.testing.assert_allclose(got[1], g["max_norm_coa"], rtol=1e-12)
+
+
 def _screen_vs_exact(lib, case, expect_screened=True, **cfg):
     lon = np.ascontiguousarray(np.log(np.clip(case.onsets, 0.01, np.inf)))
-    exact = lib.Engine(0, **cfg)
+    exact = lib.Engine(0, screen=0, **cfg)
     exact.load_lut(case.traveltimes)
     want = exact.detect(lon, case.fsmp, case.lsmp, case.available)
     exact.close()
