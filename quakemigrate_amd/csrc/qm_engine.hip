@@ -111,6 +111,8 @@ struct qm_engine {
     int n_swide = 0;
     int screen_kt = 0, screen_wb = 0;       // what the screening table was built for
     int64_t screened_steps = 0, fallback_steps = 0, last_candidates = 0;
+    int32_t *h_flags = nullptr;             // pinned ring of per-step (flags, candidates) pairs
+    int flags_pending = 0, flags_head = 0;  // not yet folded into the counters
 
     // float64 travel-time grids in seconds (optional; on-device table serving)
     DevBuf<double> d_grids;
@@ -275,7 +277,7 @@ int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu) {
 int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_samples,
               int available, int sample0, int n_chunk, double *volume, int64_t vol_stride,
               int accumulate, bool want_scan, int *n_sets, double *marginal = nullptr,
-              int m0 = 0, int m1 = 0) {
+              int m0 = 0, int m1 = 0, const int32_t *run_if = nullptr) {
     const int J = run_j(e, n_chunk);
     if (plan_wide(e, J)) return 1;
     const int KT = qm::kWave * J;
@@ -304,6 +306,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     a.m0 = m0;
     a.m1 = m1;
     a.n_nodes = e->n_nodes;
+    a.run_if = run_if;
 
     const bool use_direct = e->cfg_force_direct || e->n_wide > 0;
     const bool use_lds = !e->cfg_force_direct && e->n_wide < e->g.nbricks;
@@ -329,8 +332,11 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     a.part_sum = e->d_psum.p;
     *n_sets = sets;
 
+    // a conditional launch (the fallback of a screened step) is not part of the timing log: it
+    // returns at once unless the step has to be redone
+    const bool logged = run_if == nullptr;
     hipEvent_t ev_begin = e->ev0, ev_end = e->ev1;
-    if (e->log_timing) {
+    if (e->log_timing && logged) {
         if (e->ev_used + 2 > e->ev_log.size()) {
             for (int i = 0; i < 2; ++i) {
                 hipEvent_t ev;
@@ -342,7 +348,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         ev_end = e->ev_log[e->ev_used + 1];
         e->ev_used += 2;
     }
-    QM_HIP(hipEventRecord(ev_begin, e->stream));
+    if (logged) QM_HIP(hipEventRecord(ev_begin, e->stream));
     int rc = 0;
 #define QM_LAUNCH(JJ)                                                                        \
     rc = (volume || marginal)                                                                 \
@@ -356,12 +362,30 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     }
 #undef QM_LAUNCH
     if (rc) return rc;
-    QM_HIP(hipEventRecord(ev_end, e->stream));
-    e->timed = !e->log_timing;
+    if (logged) {
+        QM_HIP(hipEventRecord(ev_end, e->stream));
+        e->timed = !e->log_timing;
+    }
     return 0;
 }
 
 // ---- float32 screening path (qm_screen.hpp) ---------------------------------------------------
+constexpr int kFlagRing = 1024;
+
+// fold the per-step outcomes that have reached the host into the counters (synchronises)
+int drain_flags(qm_engine *e) {
+    if (e->flags_pending == 0) return 0;
+    QM_HIP(hipStreamSynchronize(e->stream));
+    for (; e->flags_pending > 0; --e->flags_pending) {
+        const int32_t *f = e->h_flags + 2 * e->flags_head;
+        if (f[0] != 0) ++e->fallback_steps;
+        else ++e->screened_steps;
+        e->last_candidates = f[1];
+        e->flags_head = (e->flags_head + 1) % kFlagRing;
+    }
+    return 0;
+}
+
 // pairs of samples per lane: time tile = 128 * JP; 0 = this table is not screened
 int screen_jp_rows(const qm_engine *e, int S) {
     if (!e->cfg_screen || e->cfg_force_direct || e->cfg_waves != 8) return 0;
@@ -447,6 +471,9 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
     const int JP = screen_jp(e);
     if (JP == 0) return 0;
     if (ensure_screen_tables(e, JP)) return 1;
+    if (!e->h_flags)
+        QM_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->h_flags),
+                             2 * kFlagRing * sizeof(int32_t), hipHostMallocDefault));
     const qm::GridDesc &g = e->g;
     const int KT = 128 * JP;
     const int ntiles = (ns + KT - 1) / KT;
@@ -578,37 +605,49 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
                        e->d_psum.p + (size_t)groups_direct * ns);
     QM_HIP(hipGetLastError());
     e->timed = !e->log_timing;
-    int32_t flags[2] = {0, 0};
-    QM_HIP(hipMemcpyAsync(flags, e->d_flags.p, sizeof(flags), hipMemcpyDeviceToHost, s));
-    QM_HIP(hipStreamSynchronize(s));
-    e->last_candidates = flags[1];
-    if (flags[0] != 0) {
-        ++e->fallback_steps;
-        return 0;
-    }
-    ++e->screened_steps;
+    // the outcome travels to the host asynchronously (statistics only: the decision to redo the
+    // step in float64 is taken on the device, see detect_core)
+    if (e->flags_pending == kFlagRing && drain_flags(e)) return 1;
+    QM_HIP(hipMemcpyAsync(e->h_flags + 2 * ((e->flags_head + e->flags_pending) % kFlagRing),
+                          e->d_flags.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ++e->flags_pending;
     *n_sets = sets;
     *screened = true;
     return 0;
 }
 
-// detect-type stacking of the whole scan: screening when enabled and applicable, else float64
-int run_detect(qm_engine *e, const double *d_on, int T, int fsmp, int ns, int available,
-               int *n_sets) {
-    bool screened = false;
-    if (run_screen(e, d_on, T, fsmp, ns, available, n_sets, &screened)) return 1;
-    if (screened) return 0;
-    return run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, n_sets);
-}
-
 int combine(qm_engine *e, const double *pmax, const int64_t *pidx, const double *psum, int sets,
             int n, int mode, int64_t node_offset, int64_t n_nodes_total, double *o_max,
-            double *o_second, int64_t *o_idx) {
+            double *o_second, int64_t *o_idx, const int32_t *run_if = nullptr) {
     hipLaunchKernelGGL(qm::combine_kernel, dim3((n + qm::kWave - 1) / qm::kWave), dim3(256), 0,
                        e->stream, pmax, pidx, psum, sets, n, mode, node_offset,
-                       (double)n_nodes_total, o_max, o_second, o_idx);
+                       (double)n_nodes_total, o_max, o_second, o_idx, run_if);
     QM_HIP(hipGetLastError());
     return 0;
+}
+
+// Detect-type stacking of the whole scan plus the combine of its partial sets into the three
+// output series (mode as combine_kernel).  With screening: the screened result is combined first;
+// then the float64 kernel and its combine are enqueued conditionally on the step's flag word, so a
+// step that could not be screened (too many candidate cells, non-finite onsets) is redone on the
+// device without the host ever waiting -- those launches return at once otherwise.
+int detect_core(qm_engine *e, const double *d_on, int T, int fsmp, int ns, int available, int mode,
+                int64_t n_nodes_total, double *o_max, double *o_second, int64_t *o_idx) {
+    int sets = 0;
+    bool screened = false;
+    if (run_screen(e, d_on, T, fsmp, ns, available, &sets, &screened)) return 1;
+    const int32_t *run_if = nullptr;
+    if (screened) {
+        if (combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, mode, e->node_offset,
+                    n_nodes_total, o_max, o_second, o_idx))
+            return 1;
+        run_if = e->d_flags.p;
+    }
+    if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, &sets, nullptr, 0, 0,
+                  run_if))
+        return 1;
+    return combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, mode, e->node_offset,
+                   n_nodes_total, o_max, o_second, o_idx, run_if);
 }
 
 int check_step(qm_engine *e, int T, int fsmp, int lsmp, int available, int *n_samples) {
@@ -714,6 +753,7 @@ void qm_engine_destroy(qm_engine *e) {
     e->d_cells.release(); e->d_work.release(); e->d_flags.release(); e->d_srel.release(); e->d_on32.release();
     e->d_cell.release(); e->d_gmax.release(); e->d_pm.release(); e->d_rowmax.release(); e->d_ssum.release();
     e->d_cand_z.release(); e->d_cand_idx.release();
+    if (e->h_flags) (void)hipHostFree(e->h_flags);
     for (hipEvent_t ev : e->ev_log) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -790,9 +830,12 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "force_direct") *v = e->cfg_force_direct;
     else if (k == "chunk_bytes") *v = e->cfg_chunk_bytes;
     else if (k == "screen") *v = e->cfg_screen;
-    else if (k == "screened_steps") *v = e->screened_steps;
-    else if (k == "fallback_steps") *v = e->fallback_steps;
-    else if (k == "last_candidates") *v = e->last_candidates;
+    else if (k == "screened_steps" || k == "fallback_steps" || k == "last_candidates") {
+        DeviceGuard guard(e->device);
+        if (drain_flags(e)) return 1;
+        *v = k == "screened_steps" ? e->screened_steps
+             : k == "fallback_steps" ? e->fallback_steps : e->last_candidates;
+    }
     else if (k == "n_bricks") *v = e->g.nbricks;
     else if (k == "n_wide_bricks") {
         if (e->have_lut) {
@@ -971,9 +1014,8 @@ int qm_engine_detect_partial(qm_engine *e, const double *log_onsets, int onsets_
     if (check_step(e, T, fsmp, lsmp, available, &ns)) return 1;
     const double *d_on = nullptr;
     if (stage_onsets(e, log_onsets, onsets_on_device, T, &d_on)) return 1;
-    if (run_detect(e, d_on, T, fsmp, ns, available, &sets)) return 1;
-    return combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, 0, e->node_offset, 0,
-                   d_part_max, d_part_sum, d_part_idx);
+    (void)sets;
+    return detect_core(e, d_on, T, fsmp, ns, available, 0, 0, d_part_max, d_part_sum, d_part_idx);
 }
 
 int qm_engine_finalize(qm_engine *e, const double *d_part_max, const int64_t *d_part_idx,
@@ -1006,10 +1048,8 @@ int qm_engine_detect(qm_engine *e, const double *log_onsets, int onsets_on_devic
     if (stage_onsets(e, log_onsets, onsets_on_device, T, &d_on)) return 1;
     OutStage st;
     if (stage_out(e, ns, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st)) return 1;
-    if (run_detect(e, d_on, T, fsmp, ns, available, &sets)) return 1;
-    if (combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, 1, e->node_offset,
-                n_nodes_total, st.a, st.b, st.i))
-        return 1;
+    (void)sets;
+    if (detect_core(e, d_on, T, fsmp, ns, available, 1, n_nodes_total, st.a, st.b, st.i)) return 1;
     return fetch_out(e, ns, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
 }
 

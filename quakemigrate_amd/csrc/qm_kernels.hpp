@@ -60,6 +60,8 @@ struct StackArgs {
     double *marginal;              // [ntiles][n_nodes] per-tile sums over samples [m0, m1) of the
     int m0, m1;                    //   coalescence (VOLUME kernels; replaces the volume store)
     int64_t n_nodes;
+    const int32_t *run_if;         // if set: do nothing unless *run_if != 0 (device-side fallback
+                                   // of a screened step, qm_screen.hpp)
 };
 
 // max of two non-NaN-producing operands without the canonicalising copy clang adds to fmax()
@@ -721,6 +723,7 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
     const int tile = slot % a.ntiles;
     const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
     if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
+    if (a.run_if != nullptr && *a.run_if == 0) return;
     const int t_first = tile * KT;                    // relative to sample0
     const int S = g.n_rows;
     const int nfull = S >> 3, ntail = S & 7;
@@ -882,6 +885,7 @@ __global__ __launch_bounds__(1024) void stack_direct_kernel(StackArgs a) {
     const int tile = slot % a.ntiles;
     const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
     if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
+    if (a.run_if != nullptr && *a.run_if == 0) return;
     const int t_first = tile * KT;
     const int S = g.n_rows;
     const int n_list = a.brick_list ? a.n_list : g.nbricks;
@@ -1010,9 +1014,11 @@ __global__ __launch_bounds__(256) void combine_kernel(const double *__restrict__
                                                       int64_t node_offset, double n_nodes_total,
                                                       double *__restrict__ out_max,
                                                       double *__restrict__ out_norm_or_sum,
-                                                      int64_t *__restrict__ out_idx) {
+                                                      int64_t *__restrict__ out_idx,
+                                                      const int32_t *__restrict__ run_if) {
     __shared__ double smax[4][kWave], ssum[4][kWave];
     __shared__ int64_t sidx[4][kWave];
+    if (run_if != nullptr && *run_if == 0) return;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int t = blockIdx.x * kWave + lane;
     const int tc = t < n ? t : n - 1;
