@@ -296,7 +296,7 @@ def main():
                                                                    eng.get("brick_y"),
                                                                    eng.get("brick_z")],
                                                samples_per_lane=eng.get("samples_per_lane"))},
-        "kernel": {"name": (f"qm::screen_lds_kernel<{2 if S <= 32 else 1},{(S + 7) // 8}>" if screened
+        "kernel": {"name": (f"qm::screen_lds_kernel<{eng.get('screen_pairs')},{(S + 7) // 8}>" if screened
                             else f"qm::stack_lds_kernel<{eng.get('samples_per_lane')},false,"
                                  f"{(S + 7) // 8}>"), "avg_ms": kern_s * 1e3,
                    "launches": kern_calls, "timing": "HIP events on the launch stream"},

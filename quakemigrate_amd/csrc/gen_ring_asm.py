@@ -111,7 +111,7 @@ def main32():
     print("template <int JP>")
     print("__device__ __forceinline__ void ring32_tail(qm_v2f (&acc)[JP], const unsigned (&addr)[8],"
           " int rows);")
-    for JP in (1, 2):
+    for JP in (1, 2, 4):
         print()
         print("template <>")
         print(f"__device__ __forceinline__ void ring32_full<{JP}>(qm_v2f (&acc)[{JP}], "

@@ -89,6 +89,9 @@ struct qm_engine {
     int cfg_generic = 0;            // 1 = always the generic (any row count) LDS kernel
     int64_t cfg_chunk_bytes = (int64_t)4 << 30;
     int cfg_screen = 1;             // detect: float32 screening sweep + exact float64 refinement
+    int cfg_screen_pairs = 0;       // pairs of samples per lane in the sweep (0 = automatic)
+    int cfg_screen_brick16 = 0;     // also try 16x8x8 bricks for the sweep
+    int cfg_screen_big = -1;        // 1: one 16-wave workgroup per CU with 160 KB of LDS; -1 = automatic
 
     // resident table
     bool have_lut = false;
@@ -103,7 +106,8 @@ struct qm_engine {
     int plan_j = -1, plan_cap = -1;
 
     // float32 screening (qm_screen.hpp): staggered-copy offset table and per-step scratch
-    DevBuf<int32_t> d_smeta, d_stotal, d_swide, d_counts, d_cells, d_work, d_flags;
+    DevBuf<int32_t> d_smeta, d_smeta_raw, d_stotal, d_swide, d_counts, d_cells, d_work, d_flags;
+    qm::GridDesc sg{};                      // the sweep's own brick grid
     DevBuf<uint16_t> d_srel;
     DevBuf<float> d_on32, d_cell, d_gmax, d_pm;
     DevBuf<double> d_rowmax, d_ssum, d_cand_z;
@@ -111,6 +115,7 @@ struct qm_engine {
     int n_swide = 0;
     int screen_kt = 0, screen_wb = 0;       // what the screening table was built for
     int64_t screened_steps = 0, fallback_steps = 0, last_candidates = 0;
+    int last_plan_jp = 0, last_plan_big = 0;
     int32_t *h_flags = nullptr;             // pinned ring of per-step (flags, candidates) pairs
     int flags_pending = 0, flags_head = 0;  // not yet folded into the counters
 
@@ -387,76 +392,138 @@ int drain_flags(qm_engine *e) {
 }
 
 // pairs of samples per lane: time tile = 128 * JP; 0 = this table is not screened
-int screen_jp_rows(const qm_engine *e, int S) {
-    if (!e->cfg_screen || e->cfg_force_direct || e->cfg_waves != 8) return 0;
-    for (int jp : {2, 1}) {
-        const int64_t rows_bytes = (int64_t)S * (8 * 128 * jp - 8);
-        if (S <= 64 && rows_bytes * 5 <= (int64_t)e->cfg_lds_bytes * 4) return jp;
+// How the sweep is launched: JP pairs of samples per lane (time tile 128*JP) and either two
+// 8-wave workgroups per CU with 80 KB of LDS each, or ("big") one 16-wave workgroup with all
+// 160 KB -- twice the tile for the same rows, so fewer address / epilogue instructions per sample.
+struct ScreenPlan {
+    int jp = 0;                     // 0 = this table is not screened
+    bool big = false;
+    int kt() const { return 128 * jp; }
+    int lds_bytes(const qm_engine *e) const { return big ? 160 * 1024 : e->cfg_lds_bytes; }
+    int window_bytes(const qm_engine *e) const {       // minus the cell-maximum row
+        return (lds_bytes(e) - kt() * 4) / 16 * 16;
     }
-    return 0;
-}
-int screen_jp(const qm_engine *e) { return screen_jp_rows(e, e->g.n_rows); }
-int screen_window_bytes(const qm_engine *e, int JP) {
-    return (e->cfg_lds_bytes - 128 * JP * 4) / 16 * 16;     // minus the cell-maximum row
+    int threads() const { return big ? 1024 : 512; }
+};
+
+bool screen_plan_feasible(const qm_engine *e, int S, const ScreenPlan &p) {
+    const int64_t rows_bytes = (int64_t)S * (8 * p.kt() - 8);
+    return S <= 64 && (p.big || p.jp < 4) && rows_bytes * 5 <= (int64_t)p.lds_bytes(e) * 4;
 }
 
-int ensure_screen_tables(qm_engine *e, int JP) {
-    const int KT = 128 * JP;
-    const int wb = screen_window_bytes(e, JP);
+// plan for a scan of n_samples (0 = unknown: the most LDS-hungry plan that could be chosen, for
+// the brick-shape decision at load time)
+ScreenPlan screen_plan(const qm_engine *e, int S, int n_samples) {
+    ScreenPlan best;
+    if (!e->cfg_screen || e->cfg_force_direct || e->cfg_waves != 8) return best;
+    double best_cost = 1e300;
+    // relative cost per sample, measured on C3 / C4-sized tables (tools/ab_screen.py)
+    const struct { int jp; bool big; double cost; } options[] = {
+        {4, true, 1.00}, {2, false, 1.045}, {2, true, 1.045}, {1, false, 1.20}, {1, true, 1.20}};
+    for (const auto &o : options) {
+        ScreenPlan p;
+        p.jp = o.jp;
+        p.big = o.big;
+        if (e->cfg_screen_pairs && o.jp != e->cfg_screen_pairs) continue;
+        if (e->cfg_screen_big >= 0 && (int)o.big != e->cfg_screen_big) continue;
+        if (!screen_plan_feasible(e, S, p)) continue;
+        double cost = o.cost;
+        if (n_samples > 0) cost *= (double)((n_samples + p.kt() - 1) / p.kt()) * p.kt();
+        // unknown length: the plan that leaves the least LDS to the delay spans (the binding one)
+        else cost = (double)p.window_bytes(e) - (double)S * (8 * p.kt() - 8);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = p;
+        }
+    }
+    return best;
+}
+
+// The sweep has its own brick grid (e->sg): its LDS budget and window layout differ from the
+// float64 kernel's, so the largest brick shape whose windows fit is chosen for it separately.
+int ensure_screen_tables(qm_engine *e, const ScreenPlan &plan) {
+    const int KT = plan.kt();
+    const int wb = plan.window_bytes(e);
     if (e->screen_kt == KT && e->screen_wb == wb) return 0;
-    const qm::GridDesc &g = e->g;
-    const size_t br = (size_t)g.nbricks * g.n_rows;
-    if (e->d_smeta.ensure(4 * br) || e->d_stotal.ensure(g.nbricks) ||
-        e->d_srel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad))
-        return 1;
-    hipLaunchKernelGGL(qm::screen_prefix_kernel, dim3((g.nbricks + 255) / 256), dim3(256), 0,
-                       e->stream, g, reinterpret_cast<const int4 *>(e->d_bmeta.p),
-                       reinterpret_cast<int4 *>(e->d_smeta.p), e->d_stotal.p);
-    QM_HIP(hipGetLastError());
-    std::vector<int32_t> total(g.nbricks), wide;
-    QM_HIP(hipMemcpyAsync(total.data(), e->d_stotal.p, (size_t)g.nbricks * sizeof(int32_t),
-                          hipMemcpyDeviceToHost, e->stream));
-    QM_HIP(hipStreamSynchronize(e->stream));
-    for (int b = 0; b < g.nbricks; ++b)
-        if (!qm::screen_fits(total[b], g.n_rows, KT, wb)) wide.push_back(b);
+    static const int kShapes[][3] = {{16, 8, 8}, {8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4},
+                                     {2, 4, 4},  {2, 2, 4}, {2, 2, 2}, {1, 1, 2}, {1, 1, 1}};
+    const bool fixed = e->cfg_bx > 0;
+    const int n_shapes = fixed ? 1 : (int)(sizeof(kShapes) / sizeof(kShapes[0]));
+    const int first = fixed ? 0 : (e->cfg_screen_brick16 ? 0 : 1);
+    qm::GridDesc g = e->g;
+    std::vector<int32_t> total, wide;
+    for (int s = first; s < std::max(n_shapes, first + 1); ++s) {
+        g = e->g;
+        if (!fixed) {
+            g.bx = std::min(kShapes[s][0], g.nx);
+            g.by = std::min(kShapes[s][1], g.ny);
+            g.bz = std::min(kShapes[s][2], g.nz);
+            g.nbx = (g.nx + g.bx - 1) / g.bx;
+            g.nby = (g.ny + g.by - 1) / g.by;
+            g.nbz = (g.nz + g.bz - 1) / g.bz;
+            g.nbricks = g.nbx * g.nby * g.nbz;
+            g.brick_nodes = g.bx * g.by * g.bz;
+        }
+        const size_t br = (size_t)g.nbricks * g.n_rows;
+        if (e->d_smeta_raw.ensure(4 * br) || e->d_smeta.ensure(4 * br) ||
+            e->d_stotal.ensure(g.nbricks) || e->d_scalar.ensure(4))
+            return 1;
+        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
+        hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
+                           e->d_lut.p, reinterpret_cast<int4 *>(e->d_smeta_raw.p), e->d_scalar.p);
+        hipLaunchKernelGGL(qm::screen_prefix_kernel, dim3((g.nbricks + 255) / 256), dim3(256), 0,
+                           e->stream, g, reinterpret_cast<const int4 *>(e->d_smeta_raw.p),
+                           reinterpret_cast<int4 *>(e->d_smeta.p), e->d_stotal.p);
+        QM_HIP(hipGetLastError());
+        total.resize(g.nbricks);
+        QM_HIP(hipMemcpyAsync(total.data(), e->d_stotal.p, (size_t)g.nbricks * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, e->stream));
+        QM_HIP(hipStreamSynchronize(e->stream));
+        wide.clear();
+        for (int b = 0; b < g.nbricks; ++b)
+            if (!qm::screen_fits(total[b], g.n_rows, KT, wb)) wide.push_back(b);
+        if ((int64_t)wide.size() * 200 <= g.nbricks) break;    // <= 0.5 % on the slow path
+    }
     e->n_swide = (int)wide.size();
     if (e->n_swide) {
         if (e->d_swide.ensure(wide.size())) return 1;
         QM_HIP(hipMemcpyAsync(e->d_swide.p, wide.data(), wide.size() * sizeof(int32_t),
                               hipMemcpyHostToDevice, e->stream));
     }
+    if (e->d_srel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;
     hipLaunchKernelGGL(qm::screen_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
                        e->d_lut.p, reinterpret_cast<const int4 *>(e->d_smeta.p), e->d_stotal.p, KT,
                        wb, e->d_srel.p);
     QM_HIP(hipGetLastError());
     QM_HIP(hipStreamSynchronize(e->stream));           // `wide` is a stack-lifetime buffer
+    e->sg = g;
     e->screen_kt = KT;
     e->screen_wb = wb;
     return 0;
 }
 
 template <int JP, int NCH>
-int launch_screen(qm_engine *e, qm::ScreenArgs &a, size_t lds) {
+int launch_screen(qm_engine *e, qm::ScreenArgs &a, size_t lds, int threads) {
     QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::screen_lds_kernel<JP, NCH>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((qm::screen_lds_kernel<JP, NCH>),
-                       dim3((unsigned)(a.ntiles * ((a.ngroups + 7) / 8 * 8))), dim3(512), lds,
+                       dim3((unsigned)(a.ntiles * ((a.ngroups + 7) / 8 * 8))), dim3(threads), lds,
                        e->stream, a);
     QM_HIP(hipGetLastError());
     return 0;
 }
 
 template <int JP>
-int launch_screen_jp(qm_engine *e, qm::ScreenArgs &a, size_t lds) {
+int launch_screen_jp(qm_engine *e, qm::ScreenArgs &a, size_t lds, int threads) {
     switch (e->g.row_pad / 8) {
-        case 1: return launch_screen<JP, 1>(e, a, lds);
-        case 2: return launch_screen<JP, 2>(e, a, lds);
-        case 3: return launch_screen<JP, 3>(e, a, lds);
-        case 4: return launch_screen<JP, 4>(e, a, lds);
-        case 5: return launch_screen<JP, 5>(e, a, lds);
-        case 6: return launch_screen<JP, 6>(e, a, lds);
-        case 7: return launch_screen<JP, 7>(e, a, lds);
-        case 8: return launch_screen<JP, 8>(e, a, lds);
+        case 1: return launch_screen<JP, 1>(e, a, lds, threads);
+        case 2: return launch_screen<JP, 2>(e, a, lds, threads);
+        case 3: return launch_screen<JP, 3>(e, a, lds, threads);
+        case 4: return launch_screen<JP, 4>(e, a, lds, threads);
+        case 5: return launch_screen<JP, 5>(e, a, lds, threads);
+        case 6: return launch_screen<JP, 6>(e, a, lds, threads);
+        case 7: return launch_screen<JP, 7>(e, a, lds, threads);
+        case 8: return launch_screen<JP, 8>(e, a, lds, threads);
         default: return fail("screening supports at most 64 table rows");
     }
 }
@@ -468,20 +535,23 @@ int launch_screen_jp(qm_engine *e, qm::ScreenArgs &a, size_t lds) {
 int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, int available,
                int *n_sets, bool *screened) {
     *screened = false;
-    const int JP = screen_jp(e);
+    const ScreenPlan plan = screen_plan(e, e->g.n_rows, ns);
+    const int JP = plan.jp;
     if (JP == 0) return 0;
-    if (ensure_screen_tables(e, JP)) return 1;
+    if (ensure_screen_tables(e, plan)) return 1;
+    e->last_plan_jp = plan.jp;
+    e->last_plan_big = plan.big ? 1 : 0;
+    const qm::GridDesc &g = e->sg;
     if (!e->h_flags)
         QM_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->h_flags),
                              2 * kFlagRing * sizeof(int32_t), hipHostMallocDefault));
-    const qm::GridDesc &g = e->g;
     const int KT = 128 * JP;
     const int ntiles = (ns + KT - 1) / KT;
     const int64_t ns_pad = (int64_t)ntiles * KT;
     const int S = g.n_rows;
     const int n_fit = g.nbricks - e->n_swide;
     const int groups = n_fit > 0 ? (e->cfg_groups > 0 ? std::min(e->cfg_groups, g.nbricks)
-                                                       : auto_groups(e, ntiles, g.nbricks, 2))
+                                                       : auto_groups(e, ntiles, g.nbricks, plan.big ? 1 : 2))
                                  : 0;
     const int groups_direct =
         e->n_swide > 0 ? (e->cfg_groups > 0 ? std::min(e->cfg_groups, e->n_swide)
@@ -531,7 +601,7 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
     a.n_samples = ns;
     a.ntiles = ntiles;
     a.ngroups = groups;
-    a.window_bytes = e->screen_wb;
+    a.window_bytes = plan.window_bytes(e);
     a.z_scale = (float)(1.4426950408889634074 / (double)available);
     a.cell_max = e->d_cell.p;
     a.group_max = e->d_gmax.p;
@@ -539,8 +609,12 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
     a.part_sum = e->d_ssum.p;
     QM_HIP(hipEventRecord(ev_begin, s));               // the timing log brackets the sweep kernel
     if (groups > 0) {
-        const size_t lds = (size_t)e->cfg_lds_bytes;
-        if (JP == 2 ? launch_screen_jp<2>(e, a, lds) : launch_screen_jp<1>(e, a, lds)) return 1;
+        const size_t lds = (size_t)plan.lds_bytes(e);
+        const int threads = plan.threads();
+        if (JP == 4 ? launch_screen_jp<4>(e, a, lds, threads)
+                    : JP == 2 ? launch_screen_jp<2>(e, a, lds, threads)
+                              : launch_screen_jp<1>(e, a, lds, threads))
+            return 1;
     }
     QM_HIP(hipEventRecord(ev_end, s));
     if (groups_direct > 0) {
@@ -749,7 +823,7 @@ void qm_engine_destroy(qm_engine *e) {
     e->d_out_b.release(); e->d_chunk.release(); e->d_marg.release(); e->d_marg_out.release(); e->d_pidx.release(); e->d_out_i.release();
     e->d_fit_a.release(); e->d_fit_b.release(); e->d_fit_c.release(); e->d_fit_part.release();
     e->d_fit_val.release(); e->d_fit_win.release(); e->d_fit_pidx.release();
-    e->d_smeta.release(); e->d_stotal.release(); e->d_swide.release(); e->d_counts.release();
+    e->d_smeta.release(); e->d_smeta_raw.release(); e->d_stotal.release(); e->d_swide.release(); e->d_counts.release();
     e->d_cells.release(); e->d_work.release(); e->d_flags.release(); e->d_srel.release(); e->d_on32.release();
     e->d_cell.release(); e->d_gmax.release(); e->d_pm.release(); e->d_rowmax.release(); e->d_ssum.release();
     e->d_cand_z.release(); e->d_cand_idx.release();
@@ -805,6 +879,17 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
         e->cfg_generic = v ? 1 : 0;
     } else if (k == "screen") {
         e->cfg_screen = v ? 1 : 0;
+    } else if (k == "screen_pairs") {
+        if (v != 0 && v != 1 && v != 2 && v != 4) return fail("screen_pairs must be 0, 1, 2 or 4");
+        e->cfg_screen_pairs = (int)v;
+        e->screen_kt = 0;
+    } else if (k == "screen_brick16") {
+        e->cfg_screen_brick16 = v ? 1 : 0;
+        e->screen_kt = 0;
+    } else if (k == "screen_big") {
+        if (v < -1 || v > 1) return fail("screen_big must be -1 (automatic), 0 or 1");
+        e->cfg_screen_big = (int)v;
+        e->screen_kt = 0;
     } else if (k == "log_timing") {
         e->log_timing = v != 0;
         e->ev_used = 0;
@@ -836,6 +921,9 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
         *v = k == "screened_steps" ? e->screened_steps
              : k == "fallback_steps" ? e->fallback_steps : e->last_candidates;
     }
+    else if (k == "screen_pairs") *v = e->last_plan_jp;
+    else if (k == "screen_big") *v = e->last_plan_big;
+    else if (k == "screen_brick_nodes") *v = e->sg.brick_nodes;
     else if (k == "n_bricks") *v = e->g.nbricks;
     else if (k == "n_wide_bricks") {
         if (e->have_lut) {
@@ -906,15 +994,9 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
         QM_HIP(hipMemcpyAsync(&e->lut_max, e->d_scalar.p, sizeof(int32_t), hipMemcpyDeviceToHost,
                               e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
-        // with screening on, a brick must also fit the float32 sweep's staggered-copy windows
-        // (every span rounded up to even: at most one word per row more than the total here)
-        const int sjp = screen_jp_rows(e, n_rows);
         int64_t wide = 0;
         for (int64_t b = 0; b < nbricks; ++b)
-            if (!qm::brick_fits(e->h_btotal[b], n_rows, KT, lds_cap_doubles(e)) ||
-                (sjp && !qm::screen_fits((int64_t)e->h_btotal[b] + n_rows, n_rows, 128 * sjp,
-                                         screen_window_bytes(e, sjp))))
-                ++wide;
+            if (!qm::brick_fits(e->h_btotal[b], n_rows, KT, lds_cap_doubles(e))) ++wide;
         if (wide * 200 <= nbricks) break;              // <= 0.5 % of the bricks on the slow path
     }
     if (e->d_rel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;

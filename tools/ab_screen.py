@@ -15,7 +15,7 @@ sys.path.insert(0, %(root)r)
 from quakemigrate_amd import synth
 from quakemigrate_amd.core import lib
 cfg = json.loads(%(cfg)r)
-case = synth.make_case(%(config)r, step=0)
+case = synth.make_case(%(config)r, step=0, **json.loads(%(case)r))
 eng = lib.Engine(0, **cfg)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 eng.load_lut(case.traveltimes)
@@ -46,13 +46,14 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--engine", default='{"screen": 1}')
+    ap.add_argument("--case", default="{}", help='make_case kwargs, e.g. {"x_range": [150, 200]}')
     ap.add_argument("libs", nargs="+")
     args = ap.parse_args()
     for lib in args.libs:
         env = dict(os.environ)
         if lib != "-":
             env["QM_HIP_LIB"] = os.path.abspath(lib)
-        code = CHILD % dict(root=ROOT, cfg=args.engine, config=args.config, steps=args.steps)
+        code = CHILD % dict(root=ROOT, cfg=args.engine, config=args.config, steps=args.steps, case=args.case)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
         print(lib, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:], flush=True)
 
