@@ -15,12 +15,19 @@ C3-sized slab of x-planes of a grid N times longer in x, stacks it, and the rank
 exchange their per-sample (max, argmax, sum) partials with three 48 KB RCCL
 all-reduces per step (the path's only exchange).
 
+Detect runs screened by default: a float32 sweep over every
+node-sample plus an exact float64 re-evaluation of the cells that can hold the maximum
+-- max_coa and max_coa_idx are the float64 kernel's bits, max_norm_coa is within ~3e-9
+(contract 1e-6).  The line therefore also carries `exact_f64`: the same steps on the
+float64 kernel (Engine(screen=0)), timed the same way, and the two results compared.
+
 One JSON line on stdout (rank 0).  Besides the contract's keys it carries
-  roofline      : the dominant kernel (fused LDS-tiled stack) against HBM with its
-                  ALGORITHMIC bytes (table + onsets + outputs) -- by construction far
-                  below 1 %: the fused kernel is LDS-gather / FP64-VALU bound, not
-                  HBM bound (SURVEY.md section 8d);
-  roofline_onchip : the ceilings that do bind it (LDS operand bytes, FP64 VALU ops);
+  roofline      : the dominant kernel (the sweep / fused LDS-tiled stack) against HBM
+                  with its ALGORITHMIC bytes (table + onsets + outputs) -- by
+                  construction far below 1 %: the kernel is LDS-gather / VALU bound,
+                  not HBM bound (SURVEY.md section 8d);
+  roofline_onchip : the ceilings that do bind it (LDS operand bytes, VALU ops);
+  screening, exact_f64 : see above;
   roofline_materialised : the locate-style variant that writes the 4-D volume
                   (8 B per node-sample of real HBM traffic), the figure the
                   north-star's ">= 50 % of HBM" maps to;

@@ -83,7 +83,15 @@ int qm_engine_synchronize(qm_engine *e);
  * samples),
  * "waves" (wavefronts per workgroup), "groups" (brick groups per time tile,
  * 0 = auto), "lds_bytes" (window budget per workgroup), "force_direct"
- * (1 = bypass the LDS-tiled kernel; debugging / cross-check). */
+ * (1 = bypass the LDS-tiled kernel; debugging / cross-check),
+ * "screen" (default 1: detect / detect_partial run a float32 sweep over every node-sample and
+ * re-evaluate in float64, in the reference's operation order, every (brick, sample) cell that
+ * a rigorous float32 error bound cannot exclude from holding the maximum -- max_coa and
+ * max_coa_idx are bit-identical to screen = 0, max_norm_coa's sum over nodes has float32 terms,
+ * ~1e-7 relative at worst; 0 = every node-sample in float64), "screen_pairs" / "screen_big"
+ * (sweep launch shape, 0 / -1 = automatic).
+ * qm_engine_get additionally reports "screened_steps", "fallback_steps" (steps redone in
+ * float64 on the device: flat all-ties data, non-finite onsets), "last_candidates". */
 int qm_engine_config(qm_engine *e, const char *key, int64_t value);
 int qm_engine_get(qm_engine *e, const char *key, int64_t *value);
 
@@ -111,7 +119,8 @@ int qm_engine_lut_download(qm_engine *e, int32_t *out);
 int qm_engine_lut_max(qm_engine *e, int32_t *max_delay);
 
 /* Fused detect step == migrate() + find_max_coa() of QuakeScan._compute
- * (quakemigrate/signal/scan.py:635-638) without the volume.
+ * (quakemigrate/signal/scan.py:635-638) without the volume (screened by default, see
+ * qm_engine_config; with device buffers the call never waits on the host).
  * n_nodes_total: node count of the FULL grid (normalisation, migratelib.c:108).
  * Outputs [n_samples]: max_coa f64, max_norm_coa f64, max_coa_idx i64. */
 int qm_engine_detect(qm_engine *e, const double *log_onsets, int onsets_on_device,

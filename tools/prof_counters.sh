@@ -19,7 +19,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in rows:
     k = r.get("Kernel_Name", "?")
-    if "stack_" not in k:
+    if "stack_" not in k and "screen_" not in k:
         continue
     agg[k[:60]][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, v in agg.items():
