@@ -419,7 +419,7 @@ ScreenPlan screen_plan(const qm_engine *e, int S, int n_samples) {
     double best_cost = 1e300;
     // relative cost per sample, measured on C3 / C4-sized tables (tools/ab_screen.py)
     const struct { int jp; bool big; double cost; } options[] = {
-        {4, true, 1.00}, {2, false, 1.045}, {2, true, 1.045}, {1, false, 1.20}, {1, true, 1.20}};
+        {4, true, 1.00}, {2, false, 1.045}, {2, true, 1.045}, {1, false, 1.35}, {1, true, 1.35}};
     for (const auto &o : options) {
         ScreenPlan p;
         p.jp = o.jp;
