@@ -50,6 +50,8 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12           # B/s  (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 LDS_PEAK = 150.0e12         # B/s  aggregate ds_read_b64/b128
 FP64_PEAK = 39.3e12         # vector FP64 instructions-lanes / s (78.6 TFLOP/s FMA)
+PMC_TRAFFIC_C3_SWEEP = (1.694e5 + 2.291e5) * 1024     # bytes per screen_lds_kernel launch at C3
+PMC_TRAFFIC_C3_F64 = (1.60e5 + 3.5e4) * 1024          # bytes per stack_lds_kernel launch at C3
 EXP_F32_OPS = 8             # float32 ops per node-sample besides the S adds in the screening sweep
 EXP_FP64_OPS = 18           # FP64-rate VALU ops per node-sample besides the S adds (2^z, sum, max)
 
@@ -310,7 +312,11 @@ def main():
                    "launches": kern_calls, "timing": "HIP events on the launch stream"},
         "roofline": {"bound": "hbm", "achieved": b_fused / kern_s / 1e9,
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": b_fused / kern_s / HBM_PEAK, "traffic": None,
+                     "frac": b_fused / kern_s / HBM_PEAK,
+                     # PMC FETCH_SIZE + WRITE_SIZE of one launch (separate --pmc passes,
+                     # profiles/r01_pmc_C3_{fetch,write}.csv); other configs: not collected
+                     "traffic": (PMC_TRAFFIC_C3_SWEEP if screened else PMC_TRAFFIC_C3_F64)
+                     if (cfg_name == "C3" and world == 1) else None,
                      "algorithmic_bytes_per_launch": b_fused,
                      "note": "fused detect never writes the volume: compulsory HBM bytes "
                              "are the table, the onsets and the outputs only; the kernel "

@@ -839,6 +839,10 @@ int qm_engine_set_stream(qm_engine *e, void *hip_stream, int use_own) {
     if (!e) return fail("engine is NULL");
     // NULL with use_own == 0 is the device's default (null) stream -- what
     // torch.cuda.current_stream().cuda_stream is unless a stream context is active
+    {
+        DeviceGuard guard(e->device);
+        if (drain_flags(e)) return 1;       // per-step outcomes still travelling on the old stream
+    }
     e->stream = use_own ? e->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
     return 0;
 }
