@@ -765,6 +765,26 @@ def test_screened_detect_equals_float64_detect(lib, oracle, rows, grid, ns):
     np.testing.assert_allclose(got[1], want[1], rtol=RTOL)
 
 
+@pytest.mark.parametrize("plan", [dict(screen_pairs=4), dict(screen_pairs=2, screen_big=1),
+                                  dict(screen_pairs=2, screen_big=0), dict(screen_pairs=1),
+                                  dict(screen_pairs=1, screen_big=1)])
+@pytest.mark.parametrize("rows,grid,ns", [(30, (20, 17, 19), 1100), (9, (11, 12, 13), 515)])
+def test_every_sweep_launch_plan_gives_the_float64_result(lib, oracle, plan, rows, grid, ns):
+    """Pairs per lane x workgroup size (ScreenPlan) only change how the sweep is tiled."""
+    case = synth.make_case("C3", step=4, grid=grid, rows=rows, n_samples=ns)
+    lon = np.ascontiguousarray(np.log(np.clip(case.onsets, 0.01, np.inf)))
+    eng = lib.Engine(0, **plan)
+    eng.load_lut(case.traveltimes)
+    got = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+    assert eng.get("screened_steps") == 1 and eng.get("fallback_steps") == 0
+    assert eng.get("screen_pairs") == plan["screen_pairs"]
+    assert eng.get("screen_big") == plan.get("screen_big", 1 if plan["screen_pairs"] == 4 else eng.get("screen_big"))
+    eng.close()
+    want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
+                         threads=4)
+    _assert_series(got, want)
+
+
 def test_screened_detect_falls_back_on_flat_data(lib, oracle):
     """All-ties data (every onset on the clip floor): every cell is a candidate, the step is
     re-run by the float64 kernel and the lowest-index rule still holds."""
