@@ -214,3 +214,30 @@ def test_location_window_algebra_matches_reference(name):
     np.testing.assert_allclose(sigma * spacing, g[f"{name}_gaussian_uncertainty"], rtol=1e-9)
     got = locate.spline_from_window(_cube(coa, peak, 5), peak, coa.shape)
     assert np.array_equal(got, g[f"{name}_spline"])
+
+
+def test_float32_screening_error_bound_holds_on_cpu():
+    """The bound the screened detect relies on (qm_screen.hpp): with A = sum_r max_t |L_r|, a
+    float32 stack (operands rounded to float32, float32 adds in any order) differs from the
+    float64 stack by at most D = 1.001 * S * 2^-24 * A; so the float64 arg-max node always has a
+    float32 stack within 2 D of the float32 maximum.  NumPy restatement, adversarial scales."""
+    rng = np.random.default_rng(31)
+    for trial in range(40):
+        S = int(rng.integers(2, 65))
+        n_nodes, T = 700, 96
+        scale = 10.0 ** rng.uniform(-3, 3)
+        L = np.log(np.clip(rng.lognormal(0, 1.0, size=(S, T)) * scale, 0.01, np.inf))
+        tt = rng.integers(0, T, size=(n_nodes, S))
+        picked = L[np.arange(S)[None, :], tt]                      # (n_nodes, S) operands
+        s64 = np.zeros(n_nodes)
+        s32 = np.zeros(n_nodes, dtype=np.float32)
+        order = rng.permutation(S) if trial % 2 else np.arange(S)  # the bound is order-free
+        for r in range(S):
+            s64 += picked[:, r]
+        for r in order:
+            s32 = (s32 + picked[:, r].astype(np.float32)).astype(np.float32)
+        A = np.abs(L).max(axis=1).sum()
+        D = 1.001 * S * 2.0 ** -24 * A
+        assert np.abs(s32.astype(np.float64) - s64).max() <= D
+        winner = int(np.argmax(s64))
+        assert float(s32[winner]) >= float(s32.max()) - 2 * D
