@@ -535,6 +535,9 @@ int launch_screen_jp(qm_engine *e, qm::ScreenArgs &a, size_t lds, int threads) {
 int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, int available,
                int *n_sets, bool *screened) {
     *screened = false;
+    // `available` far below the row count (never the case for the reference's caller, where it IS
+    // the row count) would amplify the float32 stack error in exp(stack / available)
+    if (2 * (int64_t)available < e->g.n_rows) return 0;
     const ScreenPlan plan = screen_plan(e, e->g.n_rows, ns);
     const int JP = plan.jp;
     if (JP == 0) return 0;
@@ -550,6 +553,7 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
     const int64_t ns_pad = (int64_t)ntiles * KT;
     const int S = g.n_rows;
     const int n_fit = g.nbricks - e->n_swide;
+    if (n_fit < 2) return 0;                            // a single cell: nothing to screen
     const int groups = n_fit > 0 ? (e->cfg_groups > 0 ? std::min(e->cfg_groups, g.nbricks)
                                                        : auto_groups(e, ntiles, g.nbricks, plan.big ? 1 : 2))
                                  : 0;
@@ -674,7 +678,7 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
     hipLaunchKernelGGL(qm::screen_collect_kernel, dim3((ns + 63) / 64), dim3(256), 0, s,
                        (const int32_t *)e->d_counts.p, (const double *)e->d_cand_z.p,
                        (const int64_t *)e->d_cand_idx.p, (const double *)e->d_ssum.p, groups, ns,
-                       e->d_pmax.p + (size_t)groups_direct * ns,
+                       n_fit, e->d_flags.p, e->d_pmax.p + (size_t)groups_direct * ns,
                        e->d_pidx.p + (size_t)groups_direct * ns,
                        e->d_psum.p + (size_t)groups_direct * ns);
     QM_HIP(hipGetLastError());

@@ -459,8 +459,8 @@ __global__ __launch_bounds__(256) void screen_refine_kernel(RefineArgs a) {
 __global__ __launch_bounds__(256) void screen_collect_kernel(
     const int32_t *__restrict__ counts, const double *__restrict__ cand_z,
     const int64_t *__restrict__ cand_idx, const double *__restrict__ part_sum, int ngroups,
-    int n_samples, double *__restrict__ out_max, int64_t *__restrict__ out_idx,
-    double *__restrict__ out_sum) {
+    int n_samples, int n_cells, int32_t *__restrict__ flags, double *__restrict__ out_max,
+    int64_t *__restrict__ out_idx, double *__restrict__ out_sum) {
     __shared__ double ssum[4][kWave];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * kWave + lane;
@@ -473,6 +473,9 @@ __global__ __launch_bounds__(256) void screen_collect_kernel(
     total = ((ssum[0][lane] + ssum[1][lane]) + ssum[2][lane]) + ssum[3][lane];
     double best = -__builtin_inf();
     int64_t bi = kNoIndex;
+    // every cell of the grid a candidate: the sample is (numerically) flat, the float32 errors of
+    // its terms are then all alike and do not average out of the sum -> redo the step in float64
+    if (counts[t] >= n_cells) atomicOr(flags, 1);
     const int n = min(counts[t], kScreenSlots);
     for (int k = 0; k < n; ++k) {
         const double v = cand_z[(int64_t)t * kScreenSlots + k];

@@ -811,3 +811,47 @@ def test_screened_detect_with_wide_bricks_and_rows_over_64(lib, oracle):
     want = oracle.detect(big.onsets, big.traveltimes, big.fsmp, big.lsmp, big.available, threads=4)
     _assert_series(got, want)
     eng.close()
+
+
+def test_screened_detect_randomised_against_float64_engine(lib):
+    """Random tables / row counts / scan lengths / onset dynamic ranges: the screened detect
+    must reproduce the float64 engine's max_coa and argmax bit for bit, whatever it has to fall
+    back on (wide bricks, candidate overflow), and max_norm_coa within the contract."""
+    import os
+
+    rng = np.random.default_rng(int(os.environ.get("QM_FUZZ_SEED", "2027")))
+    n_fallback = 0
+    for trial in range(int(os.environ.get("QM_FUZZ_TRIALS", "24"))):
+        grid = tuple(int(v) for v in rng.integers(3, 19, size=3))
+        S = int(rng.integers(2, 65))
+        ns = int(rng.integers(1, 700))
+        fsmp, lsmp = int(rng.integers(0, 40)), int(rng.integers(20, 160))
+        coherent = rng.random() < 0.7
+        if coherent:                                        # smooth delays, like a real table
+            ijk = np.stack(np.meshgrid(*[np.arange(n) for n in grid], indexing="ij"), -1)
+            src = rng.uniform(-5, 20, size=(S, 3))
+            dist = np.linalg.norm(ijk[..., None, :] - src, axis=-1)
+            tt = np.minimum(np.rint(dist * rng.uniform(0.5, 4.0)), lsmp).astype(np.int32)
+        else:
+            tt = rng.integers(-3, lsmp + 1, size=grid + (S,), dtype=np.int32)
+        tt = np.ascontiguousarray(tt)
+        sigma = float(rng.choice([0.3, 1.0, 3.0]))          # up to ~9 decades of dynamic range
+        on = np.clip(rng.lognormal(0, sigma, size=(S, fsmp + ns + lsmp)), 0.01, None)
+        if rng.random() < 0.2:
+            on[:] = 0.4                                     # flat: every node ties
+        lon = np.ascontiguousarray(np.log(on))
+        avail = int(rng.integers(1, S + 3))
+        exact = lib.Engine(0, screen=0)
+        exact.load_lut(tt)
+        want = exact.detect(lon, fsmp, lsmp, avail)
+        exact.close()
+        eng = lib.Engine(0)
+        eng.load_lut(tt)
+        got = eng.detect(lon, fsmp, lsmp, avail)
+        n_fallback += eng.get("fallback_steps")
+        eng.close()
+        ctx = str((trial, grid, S, ns, fsmp, lsmp, avail, coherent, sigma))
+        assert np.array_equal(got[2], want[2]), ctx
+        assert np.array_equal(got[0], want[0]), ctx
+        np.testing.assert_allclose(got[1], want[1], rtol=RTOL, err_msg=ctx)
+    assert n_fallback >= 1                                  # the flat cases did fall back
