@@ -1301,8 +1301,17 @@ int qm_engine_onsets(qm_engine *e, const double *signals, int signals_on_device,
     }
     a.raw = d_raw;
     a.logged = d_log;
-    hipLaunchKernelGGL(qm::stalta_sums_kernel, dim3((n_traces + 63) / 64), dim3(64), 0, e->stream, a);
-    QM_HIP(hipGetLastError());
+    {
+        // one workgroup per trace; the transformed trace lives in LDS if it fits (20 480 samples)
+        const size_t lds = (size_t)t_samples * sizeof(double);
+        const int in_lds = lds <= 160 * 1024 ? 1 : 0;
+        if (in_lds)
+            QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stalta_sums_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(qm::stalta_sums_kernel, dim3(n_traces), dim3(256), in_lds ? lds : 0,
+                           e->stream, a, in_lds);
+        QM_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(qm::onset_rows_kernel, dim3((unsigned)((out + 255) / 256)), dim3(256), 0,
                        e->stream, a);
     QM_HIP(hipGetLastError());
@@ -1368,12 +1377,12 @@ namespace {
 // k = 0..n-1; fftconvolve(..., mode="same") centres the full convolution at (n-1)//2, so
 // out[i] = sum_j in[j] * flt[i - j + (n-1)//2]: symmetric for odd n, shifted by half a node
 // for even n (which is why the reference filters twice, mirrored).  `mirror` gives the second
-// pass, w(d) -> w(-d).  Weights below 1e-40 of the peak are dropped: the reference's own FFT
-// round-off is 24 orders of magnitude above that.
+// pass, w(d) -> w(-d).  Weights below 1e-20 of the peak are dropped: the reference's own FFT
+// round-off is four orders of magnitude above that.
 int axis_taps(int n, double sgm, bool mirror, qm::Taps *t) {
     const int c = (n - 1) / 2;
     const double half = 0.5 * (n - 1);
-    int R = (int)std::ceil(sgm * 13.6) + 1;             // exp(-(13.6)^2 / 2) = 7e-41
+    int R = (int)std::ceil(sgm * 9.6) + 1;              // exp(-(9.6)^2 / 2) = 1e-20
     int lo = 0, hi = -1;
     bool any = false;
     for (int d = -R; d <= R; ++d) {

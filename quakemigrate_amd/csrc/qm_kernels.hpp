@@ -189,46 +189,104 @@ __device__ __forceinline__ double onset_transform(double x, int transform) {
     return transform == 0 ? x * x : __builtin_fabs(x);
 }
 
-__global__ void stalta_sums_kernel(OnsetArgs a) {
-    const int tr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tr >= a.n_traces) return;
-    const int row = a.trace_row[tr];
-    const int ns = a.nsta[row], nl = a.nlta[row], n = a.T;
-    const double *x = a.signals + (int64_t)tr * n;
-    double *S = a.sta + (int64_t)tr * n, *L = a.lta + (int64_t)tr * n;
-    const int f = a.transform;
-    if (nl > n || ns > nl || ns < 1) return;            // pass 2 leaves such a trace at 1.0
+// One workgroup per trace.  The transformed signal is staged in LDS by all threads; thread 0 then
+// runs the recurrences from LDS (the sums are a serial chain -- keeping the reference's operation
+// order is what makes degenerate stretches, e.g. a dead trace whose window sums are rounding
+// residue, come out as in the reference), unrolled so that the LDS reads of the next steps are in
+// flight while the current additions retire.  `f` = LDS copy, or the global signal if the trace
+// does not fit (then the transform is applied on the fly).
+template <bool IN_LDS>
+__device__ __forceinline__ double onset_sample(const double *f, const double *x, int i, int tf) {
+    return IN_LDS ? f[i] : onset_transform(x[i], tf);
+}
+
+template <bool IN_LDS>
+__device__ __forceinline__ void stalta_recurrence(const OnsetArgs &a, const double *f,
+                                                  const double *x, double *S, double *L, int ns,
+                                                  int nl, int n) {
+    const int tf = a.transform;
     double s_short = 0.0, s_long = 0.0;
     if (a.position == 0) {                              // onsetlib.c:35-59
-        for (int i = 0; i < ns; ++i) s_short += onset_transform(x[i], f);
+        for (int i = 0; i < ns; ++i) s_short += onset_sample<IN_LDS>(f, x, i, tf);
         s_long = s_short;
         for (int i = ns; i < nl; ++i) {
-            const double in = onset_transform(x[i], f);
+            const double in = onset_sample<IN_LDS>(f, x, i, tf);
             s_long += in;
-            s_short += in - onset_transform(x[i - ns], f);
+            s_short += in - onset_sample<IN_LDS>(f, x, i - ns, tf);
         }
         S[nl - 1] = s_short;
         L[nl - 1] = s_long;
-        for (int i = nl; i < n; ++i) {
-            const double in = onset_transform(x[i], f);
-            s_short += in - onset_transform(x[i - ns], f);
-            s_long += in - onset_transform(x[i - nl], f);
+        int i = nl;
+        for (; i + 4 <= n; i += 4) {
+            double in[4], os[4], ol[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                in[k] = onset_sample<IN_LDS>(f, x, i + k, tf);
+                os[k] = onset_sample<IN_LDS>(f, x, i + k - ns, tf);
+                ol[k] = onset_sample<IN_LDS>(f, x, i + k - nl, tf);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s_short += in[k] - os[k];
+                s_long += in[k] - ol[k];
+                S[i + k] = s_short;
+                L[i + k] = s_long;
+            }
+        }
+        for (; i < n; ++i) {
+            const double in = onset_sample<IN_LDS>(f, x, i, tf);
+            s_short += in - onset_sample<IN_LDS>(f, x, i - ns, tf);
+            s_long += in - onset_sample<IN_LDS>(f, x, i - nl, tf);
             S[i] = s_short;
             L[i] = s_long;
         }
     } else {                                            // onsetlib.c:79-108
         if (nl + ns > n) return;
-        for (int i = 0; i < nl; ++i) s_long += onset_transform(x[i], f);
-        for (int i = nl; i < nl + ns; ++i) s_short += onset_transform(x[i], f);
+        for (int i = 0; i < nl; ++i) s_long += onset_sample<IN_LDS>(f, x, i, tf);
+        for (int i = nl; i < nl + ns; ++i) s_short += onset_sample<IN_LDS>(f, x, i, tf);
         S[nl - 1] = s_short;
         L[nl - 1] = s_long;
-        for (int i = nl; i < n - ns; ++i) {
-            s_short += onset_transform(x[i + ns], f) - onset_transform(x[i], f);
-            s_long += onset_transform(x[i], f) - onset_transform(x[i - nl], f);
+        int i = nl;
+        for (; i + 4 <= n - ns; i += 4) {
+            double ahead[4], here[4], old[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ahead[k] = onset_sample<IN_LDS>(f, x, i + k + ns, tf);
+                here[k] = onset_sample<IN_LDS>(f, x, i + k, tf);
+                old[k] = onset_sample<IN_LDS>(f, x, i + k - nl, tf);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s_short += ahead[k] - here[k];
+                s_long += here[k] - old[k];
+                S[i + k] = s_short;
+                L[i + k] = s_long;
+            }
+        }
+        for (; i < n - ns; ++i) {
+            s_short += onset_sample<IN_LDS>(f, x, i + ns, tf) - onset_sample<IN_LDS>(f, x, i, tf);
+            s_long += onset_sample<IN_LDS>(f, x, i, tf) - onset_sample<IN_LDS>(f, x, i - nl, tf);
             S[i] = s_short;
             L[i] = s_long;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void stalta_sums_kernel(OnsetArgs a, int in_lds) {
+    extern __shared__ double fx[];
+    const int tr = blockIdx.x;
+    const int row = a.trace_row[tr];
+    const int ns = a.nsta[row], nl = a.nlta[row], n = a.T;
+    const double *x = a.signals + (int64_t)tr * n;
+    double *S = a.sta + (int64_t)tr * n, *L = a.lta + (int64_t)tr * n;
+    if (nl > n || ns > nl || ns < 1) return;            // pass 2 leaves such a trace at 1.0
+    if (in_lds) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) fx[i] = onset_transform(x[i], a.transform);
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    if (in_lds) stalta_recurrence<true>(a, fx, x, S, L, ns, nl, n);
+    else stalta_recurrence<false>(a, fx, x, S, L, ns, nl, n);
 }
 
 // thread <-> (row, sample); the components of a row are consecutive traces

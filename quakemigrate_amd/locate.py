@@ -84,14 +84,43 @@ def gaussian_from_window(window, smoothed_mean, peak, shape, thresh=0.0):
     return loc + np.asarray(peak), sigma, float(np.exp(-k))
 
 
+def _cubic_rbf_on_grid(sub, upscale):
+    """
+    ``scipy.interpolate.Rbf(x, y, z, d, function="cubic")`` (smooth = 0, Euclidean norm) through
+    the cube ``sub`` and its evaluation on the ``upscale``-times finer grid, spelled out: weights
+    from ``solve(|ci - cj|^3, d)``, interpolant ``sum_i w_i |p - ci|^3``.  Same algebra and the
+    same (default, "xy") meshgrid pairing as the reference's call (scan.py:777-804: the value
+    ``sub[a, b, c]`` sits at ``(x, y, z) = (b, a, c)`` and ``dense[i, j, k]`` is evaluated at
+    ``(j, i, k) / upscale``), but the point-to-centre distances are built per axis -- both sets
+    are tensor grids -- which makes it ~50x faster than the SciPy class on the 41^3 points.
+    """
+    n = sub.shape[0]
+    c = np.arange(n, dtype=np.float64)
+    a, b, cc = np.meshgrid(c, c, c, indexing="ij")                     # value index (a, b, c)
+    centres = np.stack([b.ravel(), a.ravel(), cc.ravel()], axis=1)     # its (x, y, z)
+    diff = centres[:, None, :] - centres[None, :, :]
+    r = np.sqrt(((diff[..., 0] ** 2 + diff[..., 1] ** 2) + diff[..., 2] ** 2))
+    weights = np.linalg.solve(r ** 3, sub.ravel()).reshape(n, n, n)
+    f = np.linspace(0, n - 1, (n - 1) * upscale + 1)
+    d2 = (f[:, None] - c[None, :]) ** 2                                # [fine, coarse]
+    # r2[i, j, k, a, b, c] = (x_j - b)^2 + (y_i - a)^2 + (z_k - c)^2, one i-slab at a time
+    m = len(f)
+    w = weights.ravel()
+    out = np.empty((m, m, m))
+    for i in range(m):
+        r2 = ((d2[None, :, None, None, :, None] + d2[i][None, None, None, :, None, None])
+              + d2[None, None, :, None, None, :])[0]                    # [j, k, a, b, c]
+        r2 = r2.reshape(m * m, n * n * n)
+        out[i] = ((r2 * np.sqrt(r2)) @ w).reshape(m, m)
+    return out
+
+
 def spline_from_window(window, peak, shape, upscale=10):
     """
     ``_splineloc`` on the 5x5x5 ``window`` of the normalised map centred on ``peak``: the
     sub-node maximum of a cubic RBF through the window, or the gridded maximum when the clipped
     window is not a cube or the interpolated maximum leaves it (scan.py:772-839).
     """
-    from scipy.interpolate import Rbf
-
     win = window.shape[0]
     half = (win - 1) // 2
     peak = np.asarray(peak)
@@ -101,11 +130,7 @@ def spline_from_window(window, peak, shape, upscale=10):
         return peak.astype(np.float64)
     a0, a1 = lo - (peak - half), hi - (peak - half)
     sub = window[a0[0]:a1[0], a0[1]:a1[1], a0[2]:a1[2]]
-    # default ("xy") meshgrid, as the reference: build and evaluation share the pairing
-    cx, cy, cz = np.meshgrid(*[np.linspace(0, n - 1, n) for n in sub.shape])
-    rbf = Rbf(cx.ravel(), cy.ravel(), cz.ravel(), sub.ravel(), function="cubic")
-    fx, fy, fz = np.meshgrid(*[np.linspace(0, n - 1, (n - 1) * upscale + 1) for n in sub.shape])
-    dense = rbf(fx.ravel(), fy.ravel(), fz.ravel()).reshape(fx.shape)
+    dense = _cubic_rbf_on_grid(sub, upscale)
     best = np.array(np.unravel_index(np.nanargmax(dense), dense.shape)) / upscale + lo
     if np.any(np.abs(peak - best) > half):
         return peak.astype(np.float64)
