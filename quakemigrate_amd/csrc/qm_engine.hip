@@ -1100,11 +1100,10 @@ int qm_engine_detect_partial(qm_engine *e, const double *log_onsets, int onsets_
     if (!e || !log_onsets || !d_part_max || !d_part_idx || !d_part_sum)
         return fail("qm_engine_detect_partial: NULL argument");
     DeviceGuard guard(e->device);
-    int ns = 0, sets = 0;
+    int ns = 0;
     if (check_step(e, T, fsmp, lsmp, available, &ns)) return 1;
     const double *d_on = nullptr;
     if (stage_onsets(e, log_onsets, onsets_on_device, T, &d_on)) return 1;
-    (void)sets;
     return detect_core(e, d_on, T, fsmp, ns, available, 0, 0, d_part_max, d_part_sum, d_part_idx);
 }
 
@@ -1132,13 +1131,12 @@ int qm_engine_detect(qm_engine *e, const double *log_onsets, int onsets_on_devic
     if (!e || !log_onsets || !max_coa || !max_norm_coa || !max_coa_idx)
         return fail("qm_engine_detect: NULL argument");
     DeviceGuard guard(e->device);
-    int ns = 0, sets = 0;
+    int ns = 0;
     if (check_step(e, T, fsmp, lsmp, available, &ns)) return 1;
     const double *d_on = nullptr;
     if (stage_onsets(e, log_onsets, onsets_on_device, T, &d_on)) return 1;
     OutStage st;
     if (stage_out(e, ns, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st)) return 1;
-    (void)sets;
     if (detect_core(e, d_on, T, fsmp, ns, available, 1, n_nodes_total, st.a, st.b, st.i)) return 1;
     return fetch_out(e, ns, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
 }
