@@ -678,7 +678,8 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
     hipLaunchKernelGGL(qm::screen_collect_kernel, dim3((ns + 63) / 64), dim3(256), 0, s,
                        (const int32_t *)e->d_counts.p, (const double *)e->d_cand_z.p,
                        (const int64_t *)e->d_cand_idx.p, (const double *)e->d_ssum.p, groups, ns,
-                       n_fit, e->d_flags.p, e->d_pmax.p + (size_t)groups_direct * ns,
+                       n_fit, (const double *)e->d_rowmax.p, S, available, e->d_flags.p,
+                       e->d_pmax.p + (size_t)groups_direct * ns,
                        e->d_pidx.p + (size_t)groups_direct * ns,
                        e->d_psum.p + (size_t)groups_direct * ns);
     QM_HIP(hipGetLastError());

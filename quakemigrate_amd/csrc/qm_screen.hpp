@@ -459,8 +459,9 @@ __global__ __launch_bounds__(256) void screen_refine_kernel(RefineArgs a) {
 __global__ __launch_bounds__(256) void screen_collect_kernel(
     const int32_t *__restrict__ counts, const double *__restrict__ cand_z,
     const int64_t *__restrict__ cand_idx, const double *__restrict__ part_sum, int ngroups,
-    int n_samples, int n_cells, int32_t *__restrict__ flags, double *__restrict__ out_max,
-    int64_t *__restrict__ out_idx, double *__restrict__ out_sum) {
+    int n_samples, int n_cells, const double *__restrict__ row_absmax, int n_rows, int available,
+    int32_t *__restrict__ flags, double *__restrict__ out_max, int64_t *__restrict__ out_idx,
+    double *__restrict__ out_sum) {
     __shared__ double ssum[4][kWave];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * kWave + lane;
@@ -485,6 +486,19 @@ __global__ __launch_bounds__(256) void screen_collect_kernel(
             bi = i;
         }
     }
+    // Accuracy of the sum: a float32 term is off by about E relative -- the add roundings of its
+    // stack (a random walk: ~sqrt(S)/sqrt(3) half-ulps of a partial sum <= A, taken twice over),
+    // the rounding of its operands and of z (<= 2 u A / available), v_exp_f32 -- independently from
+    // term to term, so the sum is off by about E * sqrt(sum of squared shares) <= E * sqrt(largest
+    // share).  With ~N comparable terms that is E / sqrt(N); if one node dominates the sum
+    // (extreme dynamic range on a small grid) it approaches E itself: then the step is redone in
+    // float64 (budget 3e-7 of the contract's 1e-6).
+    double A = 0.0;
+    for (int r = 0; r < n_rows; ++r) A += row_absmax[r];
+    const double E = (2.0 * __builtin_sqrt((double)n_rows / 3.0) + 2.0) * 5.9604644775390625e-08 * A /
+                         (double)available + 2e-7;
+    const double share = bi == kNoIndex ? 0.0 : qm_exp2_peak(best) / total;
+    if (!(E * __builtin_sqrt(share) <= 3e-7)) atomicOr(flags, 1);
     out_max[t] = best;
     out_idx[t] = bi;
     out_sum[t] = total;
