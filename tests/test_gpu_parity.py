@@ -540,9 +540,12 @@ def test_randomised_differential_with_many_exact_ties(lib, oracle):
     in exact arithmetic but differ in the last bits are a different matter: the reference then
     compares libmvec exp values, which merge such neighbours unpredictably -- DESIGN.md section 1.)
     """
-    rng = np.random.default_rng(20260927)
+    import os
+
+    rng = np.random.default_rng(int(os.environ.get("QM_TIES_SEED", "20260927")))
     n_ties = 0
-    for trial in range(40):
+    n_trials = int(os.environ.get("QM_TIES_TRIALS", "40"))
+    for trial in range(n_trials):
         grid = tuple(int(v) for v in rng.integers(1, 12, size=3))
         S = int(rng.integers(1, 40))
         ns = int(rng.integers(1, 400))
@@ -581,7 +584,7 @@ def test_randomised_differential_with_many_exact_ties(lib, oracle):
         np.testing.assert_allclose(vol, ref, rtol=1e-13, err_msg=str((trial, cfg)))
         assert np.array_equal(series[2], want[2]), (trial, cfg)
         eng.close()
-    assert n_ties > 1000                                   # the test does exercise ties
+    assert n_ties > 25 * n_trials                          # the test does exercise ties
 
 
 def test_end_to_end_synthetic_detect_example(lib, tmp_path):
