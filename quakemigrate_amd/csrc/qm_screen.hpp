@@ -6,16 +6,20 @@
 // with one ds_read_b64 and adds both with one v_pk_add_f32: half the LDS bytes and half the VALU
 // issue per node-sample.  The detect outputs do not need every node-sample in float64:
 //   * the sum over nodes behind max_norm_coa is an average of ~N values: float32 terms
-//     (relative error ~1e-7 each, unbiased) leave it accurate to ~1e-8, contract 1e-6;
+//     (relative error ~1e-7 each, independent) leave it accurate to ~1e-8, contract 1e-6 --
+//     unless the terms' errors are all alike (a numerically flat sample) or one term carries the
+//     sum; both are detected per sample (screen_collect_kernel) and such a step is redone;
 //   * the maximum and its node index must be exact.  With A = sum_r max_t |L_r(t)| the float32
 //     stack of any node differs from its float64 stack by at most D = 1.001 * S * 2^-24 * A
-//     (one rounding per stored operand, one per add, ascending row order).  So the node(s)
+//     (one rounding per stored operand, one per add, any order).  So the node(s)
 //     holding the true maximum have a float32 stack >= (float32 maximum) - 2 D.  The sweep keeps
 //     the float32 maximum of every (brick, sample) cell; every cell within 2 D of the sample's
 //     maximum is re-evaluated node by node in float64, in the reference's operation order, and the
 //     exact maximum / lowest node index is taken over those cells.  Typically that is one cell
-//     (512 nodes) per sample.  If a sample has more candidate cells than slots (flat, all-ties
-//     data) the caller falls back to the float64 kernel for the whole step.
+//     (512 nodes) per sample.  If a sample has more candidate cells than slots, or the onsets
+//     are not finite, the step is redone too.  "Redone" = the float64 kernel, enqueued behind
+//     every screened step, runs instead of returning at once: a device-side flag decides, the
+//     host never waits.
 // max_coa and max_coa_idx are therefore identical to the float64 path's; max_norm_coa agrees to
 // ~1e-8 relative.
 //
