@@ -204,7 +204,7 @@ def main():
     n_local = int(np.prod(case.traveltimes.shape[:-1]))
     t_samples = case.onsets.shape[1]
 
-    tunables = dict(waves=8)       # brick shape and samples per lane: chosen per table
+    tunables = {}                  # brick shape, samples per lane, workgroup layout: per table
     tunables.update(json.loads(args.engine))
     eng = lib.Engine(local_rank, **tunables)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -305,7 +305,8 @@ def main():
                    else "none", "engine": dict(tunables, brick=[eng.get("brick_x"),
                                                                    eng.get("brick_y"),
                                                                    eng.get("brick_z")],
-                                               samples_per_lane=eng.get("samples_per_lane"))},
+                                               samples_per_lane=eng.get("samples_per_lane"),
+                                               waves=eng.get("waves"))},
         "kernel": {"name": (f"qm::screen_lds_kernel<{eng.get('screen_pairs')},{(S + 7) // 8}>" if screened
                             else f"qm::stack_lds_kernel<{eng.get('samples_per_lane')},false,"
                                  f"{(S + 7) // 8}>"), "avg_ms": kern_s * 1e3,

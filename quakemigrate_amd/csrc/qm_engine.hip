@@ -83,6 +83,7 @@ struct qm_engine {
     int cfg_j = 0;                  // samples per lane (time tile = 64*J); 0 = by table width
     int n_rows_hint = 0;            // row count the automatic choice is based on
     int cfg_waves = 8;
+    bool user_waves = false, user_lds = false;   // set explicitly: no automatic layout
     int cfg_groups = 0;
     int cfg_lds_bytes = 80 * 1024;
     int cfg_force_direct = 0;
@@ -399,7 +400,9 @@ struct ScreenPlan {
     int jp = 0;                     // 0 = this table is not screened
     bool big = false;
     int kt() const { return 128 * jp; }
-    int lds_bytes(const qm_engine *e) const { return big ? 160 * 1024 : e->cfg_lds_bytes; }
+    int lds_bytes(const qm_engine *e) const {
+        return big ? 160 * 1024 : (e->user_lds ? e->cfg_lds_bytes : 80 * 1024);
+    }
     int window_bytes(const qm_engine *e) const {       // minus the cell-maximum row
         return (lds_bytes(e) - kt() * 4) / 16 * 16;
     }
@@ -415,7 +418,7 @@ bool screen_plan_feasible(const qm_engine *e, int S, const ScreenPlan &p) {
 // the brick-shape decision at load time)
 ScreenPlan screen_plan(const qm_engine *e, int S, int n_samples) {
     ScreenPlan best;
-    if (!e->cfg_screen || e->cfg_force_direct || e->cfg_waves != 8) return best;
+    if (!e->cfg_screen || e->cfg_force_direct || (e->user_waves && e->cfg_waves != 8)) return best;
     double best_cost = 1e300;
     // relative cost per sample, measured on C3 / C4-sized tables (tools/ab_screen.py)
     const struct { int jp; bool big; double cost; } options[] = {
@@ -876,12 +879,14 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
     } else if (k == "waves") {
         if (v < 1 || v > 16) return fail("waves must be 1..16");
         e->cfg_waves = (int)v;
+        e->user_waves = true;
     } else if (k == "groups") {
         if (v < 0) return fail("groups must be >= 0");
         e->cfg_groups = (int)v;
     } else if (k == "lds_bytes") {
         if (v < 1024 || v > 160 * 1024) return fail("lds_bytes must be in 1 KiB..160 KiB");
         e->cfg_lds_bytes = (int)(v / 16 * 16);
+        e->user_lds = true;
     } else if (k == "force_direct") {
         e->cfg_force_direct = v ? 1 : 0;
     } else if (k == "generic") {
@@ -971,6 +976,14 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
                                      {2, 4, 4}, {2, 2, 4}, {2, 2, 2}, {1, 1, 2}, {1, 1, 1}};
     const int n_shapes = e->cfg_bx > 0 ? 1 : (int)(sizeof(kShapes) / sizeof(kShapes[0]));
     e->n_rows_hint = n_rows;
+    // float64 kernel layout, unless set explicitly: two 8-wave workgroups per CU with 80 KB each;
+    // beyond 40 rows (two samples per lane) one 16-wave workgroup with all 160 KB, which keeps
+    // 8x8x8 bricks (C4 slab: 286 -> 239 ms)
+    if (!e->user_waves && !e->user_lds) {
+        const bool big = n_rows > 40 && n_rows <= 64;
+        e->cfg_waves = big ? 16 : 8;
+        e->cfg_lds_bytes = big ? 160 * 1024 : 80 * 1024;
+    }
     const int KT = qm::kWave * eff_j(e);
     qm::GridDesc g{};
     for (int s = 0; s < n_shapes; ++s) {
