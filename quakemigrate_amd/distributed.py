@@ -69,6 +69,27 @@ def exchange_partials(pmax, pidx, psum, n_nodes_total, group=None):
     return peak, peak * float(n_nodes_total) / gsum, gidx
 
 
+def gather_planes(local, nx_total, group=None):
+    """
+    All-gather of x-plane slabs: ``local`` is this rank's ``(x1 - x0, ny, nz)`` piece of a map
+    sharded with :func:`shard_planes`; returns the whole ``(nx_total, ny, nz)`` map on every rank.
+    Used for the marginalised coalescence map of a locate window ("the
+    marginal 3-D map is gathered (N doubles)").  Slabs differ by at most one plane, so every rank
+    pads to the largest slab and the padding is cut away after the exchange.
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    sizes = [shard_planes(nx_total, world, r) for r in range(world)]
+    biggest = max(x1 - x0 for x0, x1 in sizes)
+    padded = torch.zeros((biggest,) + tuple(local.shape[1:]), dtype=local.dtype,
+                         device=local.device)
+    padded[: local.shape[0]] = local
+    pieces = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(pieces, padded, group=group)
+    return torch.cat([p[: x1 - x0] for p, (x0, x1) in zip(pieces, sizes)], dim=0)
+
+
 class ShardedDetector:
     """
     One rank's share of a grid-sharded detect sweep.
@@ -90,3 +111,14 @@ class ShardedDetector:
                                    (self.pmax, self.pidx, self.psum))
         return exchange_partials(self.pmax, self.pidx, self.psum,
                                  self.n_nodes_total, self.group)
+
+    def marginal_map(self, log_onsets, fsmp, lsmp, available, first_sample, end_sample, nx_total):
+        """
+        Locate without the volume on a sharded grid: every rank marginalises its slab
+        (``Engine.marginal_map``), the slabs are gathered.  Returns the whole map on every rank.
+        """
+        nx, ny, nz = self.engine.grid
+        local = torch.zeros((nx, ny, nz), dtype=torch.float64, device=self.pmax.device)
+        self.engine.marginal_map(log_onsets, fsmp, lsmp, available, first_sample, end_sample,
+                                 out=local, n_nodes_total=self.n_nodes_total)
+        return gather_planes(local, nx_total, self.group)

@@ -162,7 +162,11 @@ def _worker(rank, world, port, tmp):
     pidx = torch.from_numpy(local_idx.astype(np.int64) + x0 * grid[1] * grid[2])
     psum = torch.from_numpy(vol.sum(axis=0))
     a, b, c = qd.exchange_partials(pmax, pidx, psum, int(np.prod(grid)))
-    np.savez(pathlib.Path(tmp) / f"rank{rank}.npz", a=a.numpy(), b=b.numpy(), c=c.numpy())
+    # the marginalised map of a locate window, slab by slab, gathered on every rank
+    marg = torch.from_numpy(vol[:, 40:150].sum(axis=1).reshape(x1 - x0, grid[1], grid[2]))
+    whole = qd.gather_planes(marg, grid[0])
+    np.savez(pathlib.Path(tmp) / f"rank{rank}.npz", a=a.numpy(), b=b.numpy(), c=c.numpy(),
+             marg=whole.numpy())
     dist.destroy_process_group()
 
 
@@ -177,11 +181,14 @@ def test_exchange_partials_world_size_2_gloo(oracle, tmp_path):
     case = synth.make_case("C2", step=5, grid=grid, rows=6, n_samples=211)
     want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
                          case.available, threads=2)
+    vol = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
+                           threads=2)
     for rank in range(2):
         got = np.load(tmp_path / f"rank{rank}.npz")
         assert np.array_equal(got["c"], want[2])
         np.testing.assert_allclose(got["a"], want[0], rtol=1e-12)
         np.testing.assert_allclose(got["b"], want[1], rtol=1e-12)
+        np.testing.assert_allclose(got["marg"], vol[..., 40:150].sum(axis=-1), rtol=1e-13)
 
 
 def _cube(a, centre, width):
