@@ -45,6 +45,15 @@ void find_max_coa(double *map4d, double *max_coa, double *max_norm_coa,
                   int64_t *max_coa_idx, int32_t n_samples, int64_t n_nodes,
                   int64_t threads);
 
+/* The two symbols above return void, like the reference's.  If one of them fails (no HIP device,
+ * a travel time beyond the post-pad, ...) it prints the reason to stderr, fills its outputs with
+ * NaN (indices with 0) and leaves a non-zero status here until the next call (text:
+ * qm_last_error()); QM_HIP_COMPAT_ON_ERROR=abort in the environment aborts the process instead.
+ * The travel-time table is kept resident between calls and re-uploaded only when its content
+ * (64-bit hash of every word) or shape changes; QM_HIP_ASSUME_ZERO_MAP=1 skips the scan of
+ * map4d for non-zero content (the reference's binding always passes zeros, lib.py:101). */
+int qm_compat_status(void);
+
 typedef struct {
     int n;
     int nsta;
@@ -147,6 +156,14 @@ int qm_engine_finalize(qm_engine *e, const double *d_part_max,
                        double *max_coa, double *max_norm_coa,
                        int64_t *max_coa_idx, int out_on_device);
 
+/* The same for the packed layout of the cross-GPU exchange: d_packed is f64 [n_sets][3][n_samples]
+ * on the device, per set the rows (maxima, indices as int64 bit patterns, sums) -- what one
+ * all-gather of every rank's [3][n_samples] partial produces ("one
+ * ncclAllGather of a packed [3][ns] buffer + local combine"). */
+int qm_engine_finalize_packed(qm_engine *e, const double *d_packed, int32_t n_sets,
+                              int32_t n_samples, int64_t n_nodes_total, double *max_coa,
+                              double *max_norm_coa, int64_t *max_coa_idx, int out_on_device);
+
 /* Materialising step (locate): volume f64 [n_nodes_local][n_samples] is written
  * (accumulate != 0: added on top of its current content first, the reference's
  * `+=`), and, if max_coa != NULL, the scan outputs too (same meaning as
@@ -201,8 +218,14 @@ int qm_engine_locate_fits(qm_engine *e, const double *coa_map, int map_on_device
  * log(clip(., 0.01)) (core/lib.py:93-94).
  *   signals    f64 [n_traces][t_samples], pre-processed (filtered / resampled) waveforms
  *   trace_row  [n_traces] onset row each trace feeds (the components of one station/phase)
- *   nsta/nlta  [n_rows] window lengths in samples;  transform 0 = energy (x*x), 1 = abs
- *   position   0 = classic / overlapping, 1 = centred;  taper_pad < 0 = no taper windows
+ *   nsta/nlta  [n_rows] window lengths in samples;  transform 0 = energy (x*x), 1 = abs.
+ *              The reference's "env" / "env_squared" (stalta.py:518-521) are abs / energy of the
+ *              envelope |hilbert(x)|: the Hilbert transform is an upstream signal transform like
+ *              the band-pass filters and stays with the caller (the Python binding applies
+ *              scipy.signal.hilbert, the reference's own call, to host signals).
+ *   position   0 = classic / overlapping (onsetlib.c:35-59), 1 = centred (:79-108),
+ *              2 = recursive (:126-148; exported by the reference's lib, not used by
+ *              STALTAOnset);  taper_pad < 0 = no taper windows
  *   raw_onsets (optional) and log_onsets: f64 [n_rows][t_samples]; log_onsets is what
  *   qm_engine_detect takes (pass it with onsets_on_device = 1 to keep everything on the GPU). */
 int qm_engine_onsets(qm_engine *e, const double *signals, int signals_on_device,

@@ -110,6 +110,58 @@ def load_reference_scan_module():
     return scan
 
 
+def load_reference_front_end(lib):
+    """
+    The reference's own front end around the hot path, imported as plain modules:
+    ``quakemigrate/util.py``, ``signal/onsets/base.py``, ``signal/onsets/stalta.py`` and
+    ``signal/scan.py``.  ``quakemigrate.core`` is a module holding the REAL reference binding
+    ``lib`` (core/lib.py against oracle/_ref/qmlib.so), so ``STALTAOnset._onset`` calls the
+    reference's C STA/LTA and ``QuakeScan._compute`` the reference's C migrate / find_max_coa.
+    Permissive empty modules stand in only for imports those methods never execute (obspy, the
+    io / plot / picker / magnitude packages).  Returns ``(util, stalta, scan)``.
+    """
+    class Blank(types.ModuleType):
+        __path__ = []
+
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return type(name, (), {})
+
+    def from_file(name, rel):
+        spec = importlib.util.spec_from_file_location(name, REF / "quakemigrate" / rel)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    saved = dict(sys.modules)
+    try:
+        for name in ("obspy", "quakemigrate", "quakemigrate.io", "quakemigrate.plot",
+                     "quakemigrate.plot.event", "quakemigrate.signal",
+                     "quakemigrate.signal.onsets", "quakemigrate.signal.pickers",
+                     "quakemigrate.signal.local_mag"):
+            sys.modules[name] = Blank(name)
+        core = types.ModuleType("quakemigrate.core")
+        for fn in ("migrate", "find_max_coa", "overlapping_sta_lta", "centred_sta_lta",
+                   "recursive_sta_lta"):
+            setattr(core, fn, getattr(lib, fn))
+        sys.modules["quakemigrate.core"] = core
+        util = from_file("quakemigrate.util", "util.py")
+        sys.modules["quakemigrate"].util = util
+        base = from_file("quakemigrate.signal.onsets.base", "signal/onsets/base.py")
+        sys.modules["quakemigrate.signal.onsets"].Onset = base.Onset
+        stalta = from_file("quakemigrate.signal.onsets.stalta", "signal/onsets/stalta.py")
+        scan = from_file("quakemigrate.signal.scan", "signal/scan.py")
+    finally:
+        for name in list(sys.modules):
+            if name not in saved and (name == "obspy" or name.startswith("quakemigrate")):
+                del sys.modules[name]
+        sys.modules.update({k: v for k, v in saved.items()
+                            if k == "obspy" or k.startswith("quakemigrate")})
+    return util, stalta, scan
+
+
 def reference_location(scan_mod, map4d, node_spacing):
     """
     Run the reference's QuakeScan._calculate_location on ``map4d`` with a stand-in ``self``
@@ -321,31 +373,124 @@ def main():
          served_50=served, decimate=np.array([2, 3, 4]), served_dec_250=served_dec,
          dec_node_count=np.array(dec.node_count))
 
-    # 10. onset stage: reference C STA/LTA (through lib.py) inside the NumPy glue of
-    #     STALTAOnset._onset (stalta.py:515-546, :579-581) and lib.migrate (lib.py:93-94)
-    from oracle import qm_oracle as oq
+    # 10. onset stage: the reference's OWN STALTAOnset._onset / _trim_taper_pad
+    #     (signal/onsets/stalta.py:491-583, calling the reference C STA/LTA through the
+    #     reference binding) on lists of trace-like objects, then lib.migrate's clip + log
+    #     (core/lib.py:93-94).  All four signal transforms, both window positions.
+    from scipy.signal import hilbert
 
+    util_mod, stalta_mod, scan_mod_fe = load_reference_front_end(lib)
     rng10 = np.random.default_rng(1010)
-    n_traces, T10 = 9, 1400
+    n_traces, T10, rate10 = 9, 1400, 50
     trace_row = np.array([0, 0, 0, 1, 2, 2, 3, 3, 3], dtype=np.int32)    # 3-, 1-, 2-, 3-component rows
-    nsta10 = np.array([11, 11, 21, 21], dtype=np.int32)
-    nlta10 = np.array([51, 51, 101, 101], dtype=np.int32)
+    row_phase = ["P", "P", "S", "S"]
+    windows10 = {"P": [0.2, 1.0], "S": [0.4, 2.0]}
     sig10 = rng10.standard_normal((n_traces, T10)) * np.exp(rng10.normal(0, 1, (n_traces, 1)))
     sig10[:, 700:720] *= 12.0                         # an arrival
     sig10[4, 200:260] = 0.0                           # a dead stretch (lta -> 0 guard)
-    arrays = dict(signals=sig10, trace_row=trace_row, nsta=nsta10, nlta=nlta10,
-                  taper_pad=37, min_onset_value=0.4)
+    timespan10 = 12.0                                 # seconds: sets the tapered margins
+    arrays = dict(signals=sig10, trace_row=trace_row, min_onset_value=0.4,
+                  sampling_rate=rate10, timespan=timespan10,
+                  envelopes=np.abs(hilbert(sig10, axis=-1)))
     for pos in ("classic", "centred"):
-        for tf in ("energy", "abs"):
-            raw, logged = oq.np_onset_stage(
-                sig10, trace_row, nsta10, nlta10, tf, pos, 37, 0.4,
-                stalta=(lib.overlapping_sta_lta, lib.centred_sta_lta))
+        for tf in ("energy", "abs", "env", "env_squared"):
+            onset = stalta_mod.STALTAOnset(sampling_rate=rate10, position=pos,
+                                           signal_transform=tf, sta_lta_windows=windows10,
+                                           min_onset_value=0.4)
+            onset.post_pad = 3.7                      # what QuakeScan sets from the LUT's ttmax
+            pre_total, _ = onset.pad(timespan10)
+            taper_pad = util_mod.time2sample(pre_total - onset.pre_pad, rate10)
+            rows_raw, nsta10, nlta10 = [], [], []
+            for row, phase in enumerate(row_phase):
+                stw = util_mod.time2sample(windows10[phase][0], rate10) + 1     # stalta.py:395-397
+                ltw = util_mod.time2sample(windows10[phase][1], rate10) + 1
+                stream = [types.SimpleNamespace(data=sig10[tr].copy())
+                          for tr in np.flatnonzero(trace_row == row)]
+                rows_raw.append(onset._onset(stream, stw, ltw, timespan10))
+                nsta10.append(stw)
+                nlta10.append(ltw)
+            raw = np.stack(rows_raw, axis=0)
             arrays[f"raw_{pos}_{tf}"] = raw
-            arrays[f"log_{pos}_{tf}"] = logged
-    raw, logged = oq.np_onset_stage(sig10, trace_row, nsta10, nlta10, "energy", "classic", -1,
-                                    0.01, stalta=(lib.overlapping_sta_lta, lib.centred_sta_lta))
-    arrays["raw_classic_energy_notaper"] = raw
+            arrays[f"log_{pos}_{tf}"] = np.log(np.clip(raw, 0.01, np.inf))      # lib.py:93-94
+    arrays.update(nsta=np.array(nsta10, dtype=np.int32), nlta=np.array(nlta10, dtype=np.int32),
+                  taper_pad=taper_pad)
+    onset = stalta_mod.STALTAOnset(sampling_rate=rate10, position="classic",
+                                   signal_transform="energy", sta_lta_windows=windows10,
+                                   min_onset_value=0.01)
+    arrays["raw_classic_energy_notaper"] = np.stack([
+        onset._onset([types.SimpleNamespace(data=sig10[tr].copy())
+                      for tr in np.flatnonzero(trace_row == row)],
+                     int(arrays["nsta"][row]), int(arrays["nlta"][row]), None)
+        for row in range(len(row_phase))], axis=0)
     save("onset_stage", **arrays)
+
+    # 12. QuakeScan._compute (signal/scan.py:593-647) run from the reference's own scan.py, both
+    #     stages: duck-typed onset object, the reference's own LUT class for serve_traveltimes /
+    #     index2coord (grid space: pyproj is absent, so coord2grid is the identity), run.stage.
+    lutmod12 = load_reference_lut_module()
+
+    class GridSpaceLUT(lutmod12.LUT):
+        def coord2grid(self, value, inverse=False):
+            return np.asarray(value, dtype=np.float64)
+
+    rng12 = np.random.default_rng(1212)
+    shape12, rate12 = (12, 10, 9), 50
+    stations12 = ["STA", "STB", "STC", "STD"]
+    lut12 = GridSpaceLUT.__new__(GridSpaceLUT)
+    lut12.node_count = np.array(shape12)
+    lut12.node_spacing = np.array([0.5, 0.5, 0.25])
+    lut12.ll_corner = np.array([10.0, -3.0, -1.0])
+    lut12.phases = ["P", "S"]
+    lut12.traveltimes = {}
+    pos12 = synth.station_positions(rng12, shape12, 0.5, len(stations12))
+    gx, gy, gz = np.meshgrid(*[np.arange(n) * sp for n, sp in zip(shape12, lut12.node_spacing)],
+                             indexing="ij")
+    grids12 = {}
+    for st, xyz in zip(stations12, pos12):
+        dist = np.sqrt((gx - xyz[0]) ** 2 + (gy - xyz[1]) ** 2 + (gz - xyz[2]) ** 2)
+        for ph, v in (("P", 5.0), ("S", 2.9)):
+            lut12.traveltimes.setdefault(st, {})[ph] = dist / v
+            grids12[f"{st}_{ph}"] = dist / v
+    availability12 = {f"{st}_{ph}": 1 for ph in ("P", "S") for st in stations12}
+    availability12["STB_S"] = 0
+    n_avail = sum(availability12.values())
+    pre12, post12, ns12 = 1.3, 3.0, 180
+    ttmax = max(g.max() for g in grids12.values())
+    assert ttmax < post12
+    T12 = util_mod.time2sample(pre12, rate12) + ns12 + util_mod.time2sample(post12, rate12)
+    onsets12 = np.clip(rng12.lognormal(0, 0.5, size=(n_avail, T12)), 0.4, None)
+    onsets12[:, 150:156] += 6.0
+
+    class OnsetData12:
+        sampling_rate = rate12
+        availability = availability12
+        phases = ["P", "S"]
+
+    class Onset12:
+        def calculate_onsets(self, data):
+            return onsets12, OnsetData12()
+
+    out12 = {}
+    for stage in ("detect", "locate"):
+        me = types.SimpleNamespace(onset=Onset12(), lut=lut12, pre_pad=pre12, post_pad=post12,
+                                   threads=2, run=types.SimpleNamespace(stage=stage),
+                                   scan_rate=rate12)
+        data = types.SimpleNamespace(starttime=1000.0)
+        event = types.SimpleNamespace(mw_times=lambda rate: np.arange(ns12) / rate)
+        out12[stage] = scan_mod_fe.QuakeScan._compute(me, data, event)
+    t_det, a_det, b_det, coord_det, _ = out12["detect"]
+    times_loc, a_loc, b_loc, coord_loc, map4d_loc, _ = out12["locate"]
+    assert np.array_equal(a_det, a_loc) and np.array_equal(coord_det, coord_loc)
+    rows12, vals12 = sample_rows(map4d_loc, k=160)
+    save("compute_glue",
+         grid_keys=np.array(list(grids12.keys())), grids=np.stack(list(grids12.values())),
+         availability_keys=np.array(list(availability12.keys())),
+         availability_values=np.array(list(availability12.values())),
+         node_spacing=lut12.node_spacing, ll_corner=lut12.ll_corner, sampling_rate=rate12,
+         pre_pad=pre12, post_pad=post12, onsets=onsets12, starttime=1000.0,
+         detect_time=t_det, max_coa=a_det, max_coa_n=b_det, coord=coord_det,
+         locate_times=times_loc, map4d_shape=np.array(map4d_loc.shape), map4d_rows=rows12,
+         map4d_vals=vals12)
 
     # 11. locate post-reductions: QuakeScan._calculate_location (scan.py:696-733) and the fits it
     #     calls, run from the reference's own scan.py on synthetic 4-D maps --------------------

@@ -56,6 +56,7 @@ for _f in (qmlib.overlapping_sta_lta, qmlib.centred_sta_lta,
 _vp = ctypes.c_void_p
 qmlib.qm_last_error.restype = ctypes.c_char_p
 qmlib.qm_device_count.restype = ctypes.c_int
+qmlib.qm_compat_status.restype = ctypes.c_int
 qmlib.qm_engine_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
 qmlib.qm_engine_destroy.argtypes = [_vp]
 qmlib.qm_engine_destroy.restype = None
@@ -79,6 +80,8 @@ qmlib.qm_engine_detect_partial.argtypes = [_vp, _vp, ctypes.c_int, c_int32,
                                            _vp]
 qmlib.qm_engine_finalize.argtypes = [_vp, _vp, _vp, _vp, c_int32, c_int32,
                                      c_int64, _vp, _vp, _vp, ctypes.c_int]
+qmlib.qm_engine_finalize_packed.argtypes = [_vp, _vp, c_int32, c_int32, c_int64, _vp, _vp,
+                                            _vp, ctypes.c_int]
 qmlib.qm_engine_migrate.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32,
                                     c_int32, c_int32, c_int64, _vp, ctypes.c_int,
                                     ctypes.c_int, _vp, _vp, _vp, ctypes.c_int]
@@ -172,20 +175,46 @@ class Engine:
         _check(qmlib.qm_engine_kernel_log(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return float(ms.value), int(n.value)
 
-    @staticmethod
-    def _ptr(x, dtype=None):
-        """(void*, on_device) for a NumPy array, a torch tensor or a raw int."""
+    _TORCH_NAMES = {np.dtype(np.float64): "torch.float64", np.dtype(np.int64): "torch.int64",
+                    np.dtype(np.int32): "torch.int32"}
+
+    def _ptr(self, x, dtype=None, count=None):
+        """
+        (void*, on_device) for a NumPy array, a torch tensor or a raw int.  Arrays and tensors
+        are checked: element type ``dtype``, contiguity, at least ``count`` elements, and -- for
+        a device tensor -- that it lives on this engine's GPU (a wrong type or device would be
+        reinterpreted silently by the C side).  A raw int is taken as a device address as is.
+        """
         if isinstance(x, np.ndarray):
             if dtype is not None and x.dtype != dtype:
-                raise TypeError(f"expected {dtype}, got {x.dtype}")
+                raise TypeError(f"expected {np.dtype(dtype)}, got {x.dtype}")
             if not x.flags["C_CONTIGUOUS"]:
                 raise ValueError("array must be C-contiguous")
+            if count is not None and x.size < count:
+                raise ValueError(f"array holds {x.size} elements, {count} needed")
             return _host(x), 0
-        if hasattr(x, "data_ptr"):                  # torch tensor on this GPU
+        if hasattr(x, "data_ptr"):                  # torch tensor
             if not x.is_contiguous():
                 raise ValueError("tensor must be contiguous")
+            if dtype is not None and str(x.dtype) != self._TORCH_NAMES[np.dtype(dtype)]:
+                raise TypeError(f"expected {self._TORCH_NAMES[np.dtype(dtype)]}, got {x.dtype}")
+            if count is not None and x.numel() < count:
+                raise ValueError(f"tensor holds {x.numel()} elements, {count} needed")
+            if x.is_cuda and x.device.index != self.device:
+                raise ValueError(f"tensor lives on cuda:{x.device.index}, this engine runs on "
+                                 f"cuda:{self.device}")
             return _vp(x.data_ptr()), (1 if x.is_cuda else 0)
         return _vp(int(x)), 1
+
+    def _series(self, out, n):
+        """Pointers of a (float64, float64, int64) output triple of >= n elements each; the
+        three must be all host or all device."""
+        (pa, da), (pb, db), (pc, dc) = (self._ptr(out[0], np.float64, n),
+                                        self._ptr(out[1], np.float64, n),
+                                        self._ptr(out[2], np.int64, n))
+        if not da == db == dc:
+            raise ValueError("the three output series must be all host or all device")
+        return pa, pb, pc, da
 
     # -- table --------------------------------------------------------------
     def load_lut(self, traveltimes, node_offset=0, shape=None):
@@ -261,9 +290,7 @@ class Engine:
             out = (np.zeros(max(n, 0)), np.zeros(max(n, 0)),
                    np.zeros(max(n, 0), dtype=np.int64))
         po, dev_on = self._ptr(log_onsets, np.float64)
-        (pa, da), (pb, _), (pc, _) = (self._ptr(out[0], np.float64),
-                                      self._ptr(out[1], np.float64),
-                                      self._ptr(out[2], np.int64))
+        pa, pb, pc, da = self._series(out, max(n, 0))
         total = self.n_nodes if n_nodes_total is None else int(n_nodes_total)
         _check(qmlib.qm_engine_detect(self._h, po, dev_on, t_samples, int(fsmp),
                                       int(lsmp), int(available), total, pa, pb,
@@ -275,21 +302,40 @@ class Engine:
         rows, t_samples = (int(v) for v in log_onsets.shape)
         self._check_rows(rows)
         po, dev_on = self._ptr(log_onsets, np.float64)
+        n = max(t_samples - int(fsmp) - int(lsmp), 0)
+        (pm, dm), (pi, di), (ps, ds) = (self._ptr(part[0], np.float64, n),
+                                        self._ptr(part[1], np.int64, n),
+                                        self._ptr(part[2], np.float64, n))
+        if not (dm and di and ds):
+            raise ValueError("detect_partial writes device buffers: pass tensors on this GPU")
         _check(qmlib.qm_engine_detect_partial(
-            self._h, po, dev_on, t_samples, int(fsmp), int(lsmp), int(available),
-            self._ptr(part[0])[0], self._ptr(part[1])[0], self._ptr(part[2])[0]))
+            self._h, po, dev_on, t_samples, int(fsmp), int(lsmp), int(available), pm, pi, ps))
 
     def finalize(self, part_max, part_idx, part_sum, n_sets, n_samples,
                  n_nodes_total, out=None):
         if out is None:
             out = (np.zeros(n_samples), np.zeros(n_samples),
                    np.zeros(n_samples, dtype=np.int64))
-        (pa, da), (pb, _), (pc, _) = (self._ptr(out[0]), self._ptr(out[1]),
-                                      self._ptr(out[2]))
+        pa, pb, pc, da = self._series(out, int(n_samples))
+        need = int(n_sets) * int(n_samples)
         _check(qmlib.qm_engine_finalize(
-            self._h, self._ptr(part_max)[0], self._ptr(part_idx)[0],
-            self._ptr(part_sum)[0], int(n_sets), int(n_samples),
-            int(n_nodes_total), pa, pb, pc, da))
+            self._h, self._ptr(part_max, np.float64, need)[0],
+            self._ptr(part_idx, np.int64, need)[0], self._ptr(part_sum, np.float64, need)[0],
+            int(n_sets), int(n_samples), int(n_nodes_total), pa, pb, pc, da))
+        return out
+
+    def finalize_packed(self, packed, n_sets, n_samples, n_nodes_total, out=None):
+        """``packed``: device float64 [n_sets][3][n_samples] (maxima, int64 index bits, sums) --
+        the all-gathered partials of a sharded detect; returns the final series."""
+        if out is None:
+            out = (np.zeros(n_samples), np.zeros(n_samples),
+                   np.zeros(n_samples, dtype=np.int64))
+        pa, pb, pc, da = self._series(out, int(n_samples))
+        pp, dev = self._ptr(packed, np.float64, 3 * int(n_sets) * int(n_samples))
+        if not dev:
+            raise ValueError("finalize_packed reads a device buffer")
+        _check(qmlib.qm_engine_finalize_packed(self._h, pp, int(n_sets), int(n_samples),
+                                               int(n_nodes_total), pa, pb, pc, da))
         return out
 
     def migrate(self, log_onsets, fsmp, lsmp, available, map4d, scan_out=None,
@@ -297,14 +343,13 @@ class Engine:
         rows, t_samples = (int(v) for v in log_onsets.shape)
         self._check_rows(rows)
         po, dev_on = self._ptr(log_onsets, np.float64)
-        pm, dev_map = self._ptr(map4d, np.float64)
+        n = max(t_samples - int(fsmp) - int(lsmp), 0)
+        pm, dev_map = self._ptr(map4d, np.float64, self.n_nodes * n)
         if scan_out is None:
             pa = pb = pc = _vp(None)
             da = 0
         else:
-            (pa, da), (pb, _), (pc, _) = (self._ptr(scan_out[0]),
-                                          self._ptr(scan_out[1]),
-                                          self._ptr(scan_out[2]))
+            pa, pb, pc, da = self._series(scan_out, n)
         total = self.n_nodes if n_nodes_total is None else int(n_nodes_total)
         _check(qmlib.qm_engine_migrate(
             self._h, po, dev_on, t_samples, int(fsmp), int(lsmp), int(available),
@@ -322,13 +367,12 @@ class Engine:
         if out is None:
             out = np.zeros(self.grid, dtype=np.float64)
         po, dev_on = self._ptr(log_onsets, np.float64)
-        pm, dev_map = self._ptr(out, np.float64)
+        pm, dev_map = self._ptr(out, np.float64, self.n_nodes)
         if scan_out is None:
             pa = pb = pc = _vp(None)
             da = 0
         else:
-            (pa, da), (pb, _), (pc, _) = (self._ptr(scan_out[0]), self._ptr(scan_out[1]),
-                                          self._ptr(scan_out[2]))
+            pa, pb, pc, da = self._series(scan_out, max(t_samples - int(fsmp) - int(lsmp), 0))
         total = self.n_nodes if n_nodes_total is None else int(n_nodes_total)
         _check(qmlib.qm_engine_marginal(
             self._h, po, dev_on, t_samples, int(fsmp), int(lsmp), int(available), total,
@@ -380,7 +424,22 @@ class Engine:
         Onset stage on the GPU (``STALTAOnset._onset`` + the clip/log of ``lib.migrate``): from
         pre-processed component waveforms ``signals`` (n_traces, T) to the raw onset rows and
         ``log(clip(onset, 0.01))`` rows, shape (n_rows, T).  Returns ``(raw, logged)``.
+
+        ``transform``: the reference's four ``signal_transform`` values (stalta.py:515-521).
+        ``"env"`` / ``"env_squared"`` take the envelope ``|hilbert(x)|`` first -- an upstream
+        transform like the filters, done here with the reference's own ``scipy.signal.hilbert``
+        call on host signals (pass the envelope yourself with ``"abs"`` / ``"energy"`` for
+        device-resident signals) -- the STA/LTA and everything after it run on the GPU.
+        ``position``: ``"classic"``, ``"centred"`` or ``"recursive"`` (onsetlib.c:126-148).
         """
+        if transform in ("env", "env_squared"):
+            if not isinstance(signals, np.ndarray):
+                raise ValueError("env transforms of device-resident signals: pass the envelope "
+                                 "|hilbert(x)| with transform='abs' / 'energy'")
+            from scipy.signal import hilbert
+
+            signals = np.ascontiguousarray(np.abs(hilbert(signals, axis=-1)))
+            transform = "abs" if transform == "env" else "energy"
         n_traces, t_samples = (int(v) for v in signals.shape)
         trace_row = np.ascontiguousarray(trace_row, dtype=np.int32)
         nsta = np.ascontiguousarray(nsta, dtype=np.int32)
@@ -391,11 +450,13 @@ class Engine:
             log_out = np.zeros((n_rows, t_samples))
         if raw_out is None and isinstance(log_out, np.ndarray):
             raw_out = np.zeros((n_rows, t_samples))
-        pl, dev_o = self._ptr(log_out, np.float64)
-        pr = self._ptr(raw_out, np.float64)[0] if raw_out is not None else _vp(None)
+        pl, dev_o = self._ptr(log_out, np.float64, n_rows * t_samples)
+        pr = (self._ptr(raw_out, np.float64, n_rows * t_samples)[0] if raw_out is not None
+              else _vp(None))
         _check(qmlib.qm_engine_onsets(
             self._h, ps, dev_s, n_traces, t_samples, trace_row, n_rows, nsta, nlta,
-            {"energy": 0, "abs": 1}[transform], {"classic": 0, "centred": 1}[position],
+            {"energy": 0, "abs": 1}[transform],
+            {"classic": 0, "centred": 1, "recursive": 2}[position],
             int(taper_pad), float(min_onset_value), pr, pl, dev_o))
         return raw_out, log_out
 
@@ -403,9 +464,8 @@ class Engine:
         if out is None:
             out = (np.zeros(n_samples), np.zeros(n_samples),
                    np.zeros(n_samples, dtype=np.int64))
-        pm, dev_map = self._ptr(map4d, np.float64)
-        (pa, da), (pb, _), (pc, _) = (self._ptr(out[0]), self._ptr(out[1]),
-                                      self._ptr(out[2]))
+        pm, dev_map = self._ptr(map4d, np.float64, int(n_samples) * int(n_nodes))
+        pa, pb, pc, da = self._series(out, int(n_samples))
         _check(qmlib.qm_engine_find_max_coa(self._h, pm, dev_map, int(n_samples),
                                             int(n_nodes), pa, pb, pc, da))
         return out

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -16,6 +17,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "qm_kernels.hpp"
@@ -89,7 +91,8 @@ struct qm_engine {
     int cfg_force_direct = 0;
     int cfg_generic = 0;            // 1 = always the generic (any row count) LDS kernel
     int64_t cfg_chunk_bytes = (int64_t)4 << 30;
-    int cfg_screen = 1;             // detect: float32 screening sweep + exact float64 refinement
+    int cfg_screen = 0;             // 1 (opt-in): detect = float32 screening sweep + exact float64
+                                    // refinement (qm_screen.hpp); 0: every node-sample in float64
     int cfg_screen_pairs = 0;       // pairs of samples per lane in the sweep (0 = automatic)
     int cfg_screen_brick16 = 0;     // also try 16x8x8 bricks for the sweep
     int cfg_screen_big = -1;        // 1: one 16-wave workgroup per CU with 160 KB of LDS; -1 = automatic
@@ -700,10 +703,11 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
 
 int combine(qm_engine *e, const double *pmax, const int64_t *pidx, const double *psum, int sets,
             int n, int mode, int64_t node_offset, int64_t n_nodes_total, double *o_max,
-            double *o_second, int64_t *o_idx, const int32_t *run_if = nullptr) {
+            double *o_second, int64_t *o_idx, const int32_t *run_if = nullptr,
+            int64_t set_stride = 0) {
     hipLaunchKernelGGL(qm::combine_kernel, dim3((n + qm::kWave - 1) / qm::kWave), dim3(256), 0,
-                       e->stream, pmax, pidx, psum, sets, n, mode, node_offset,
-                       (double)n_nodes_total, o_max, o_second, o_idx, run_if);
+                       e->stream, pmax, pidx, psum, sets, n, set_stride > 0 ? set_stride : (int64_t)n,
+                       mode, node_offset, (double)n_nodes_total, o_max, o_second, o_idx, run_if);
     QM_HIP(hipGetLastError());
     return 0;
 }
@@ -1138,6 +1142,23 @@ int qm_engine_finalize(qm_engine *e, const double *d_part_max, const int64_t *d_
     return fetch_out(e, n_samples, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
 }
 
+int qm_engine_finalize_packed(qm_engine *e, const double *d_packed, int32_t n_sets,
+                              int32_t n_samples, int64_t n_nodes_total, double *max_coa,
+                              double *max_norm_coa, int64_t *max_coa_idx, int out_on_device) {
+    if (!e || !d_packed || !max_coa || !max_norm_coa || !max_coa_idx)
+        return fail("qm_engine_finalize_packed: NULL argument");
+    if (n_sets < 1 || n_samples < 1) return fail("qm_engine_finalize_packed: empty input");
+    DeviceGuard guard(e->device);
+    OutStage st;
+    if (stage_out(e, n_samples, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st)) return 1;
+    // set s = rows [s][0] (maxima), [s][1] (indices, int64 bits), [s][2] (sums) of [n_sets][3][n]
+    if (combine(e, d_packed, reinterpret_cast<const int64_t *>(d_packed + n_samples),
+                d_packed + 2 * (int64_t)n_samples, n_sets, n_samples, 1, 0, n_nodes_total, st.a,
+                st.b, st.i, nullptr, 3 * (int64_t)n_samples))
+        return 1;
+    return fetch_out(e, n_samples, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
+}
+
 int qm_engine_detect(qm_engine *e, const double *log_onsets, int onsets_on_device, int32_t T,
                      int32_t fsmp, int32_t lsmp, int32_t available, int64_t n_nodes_total,
                      double *max_coa, double *max_norm_coa, int64_t *max_coa_idx,
@@ -1266,7 +1287,8 @@ int qm_engine_onsets(qm_engine *e, const double *signals, int signals_on_device,
         return fail("qm_engine_onsets: NULL argument");
     if (n_traces < 1 || n_rows < 1 || t_samples < 1) return fail("qm_engine_onsets: empty input");
     if (transform != 0 && transform != 1) return fail("transform must be 0 (energy) or 1 (abs)");
-    if (position != 0 && position != 1) return fail("position must be 0 (classic) or 1 (centred)");
+    if (position < 0 || position > 2)
+        return fail("position must be 0 (classic), 1 (centred) or 2 (recursive)");
     std::vector<int> per_row(n_rows, 0);
     for (int i = 0; i < n_traces; ++i) {
         if (trace_row[i] < 0 || trace_row[i] >= n_rows) return fail("trace %d: row out of range", i);
@@ -1588,64 +1610,160 @@ int qm_engine_last_kernel_ms(qm_engine *e, double *ms) {
 // ---------------------------------------------------------------- reference-compatible part
 // A process-wide engine on device $QM_HIP_DEVICE (default 0).  These two entry points receive
 // host arrays and no grid shape (qmlib.h:28-32), so the node axis is bricked along the flat
-// index.  They cannot report errors through their signature (void, like the reference): a
-// failure is printed and the process aborted rather than returning wrong numbers.
+// index.  They cannot report errors through their signature (void, like the reference).  On a
+// failure (no device, a travel time beyond the post-pad -- undefined behaviour in the reference --
+// ...) the message goes to stderr, the outputs are filled with NaN (indices 0) so that nothing
+// downstream can mistake them for results, and qm_compat_status() returns non-zero with the text
+// in qm_last_error(); with QM_HIP_COMPAT_ON_ERROR=abort the process is aborted instead.
 static std::mutex g_compat_mutex;
 static qm_engine *g_compat = nullptr;
+static int g_compat_status = 0;
+
+// what the resident table of the compat engine was built from: the reference's caller passes the
+// served table on every call (scan.py:629-634 -> lib.py:53-60), usually with unchanged content
+struct CompatTable {
+    uint64_t hash = 0;
+    int64_t n_nodes = -1;
+    int32_t n_rows = -1;
+    bool valid = false;
+};
+static CompatTable g_compat_table;
+
+extern "C++" {
+// run fn(lo, hi, thread) over [0, n) on a few host threads
+template <typename F>
+static void parallel_ranges(size_t n, size_t grain, F fn) {
+    size_t want = (n + grain - 1) / grain;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = std::max<size_t>(1, std::min<size_t>({want, hw ? hw : 4u, (size_t)32}));
+    if (nt == 1) {
+        fn(0, n, 0);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (n + nt - 1) / nt;
+    for (size_t t = 0; t < nt; ++t) {
+        const size_t lo = t * per, hi = std::min(n, lo + per);
+        if (lo >= hi) break;
+        pool.emplace_back(fn, lo, hi, t);
+    }
+    for (auto &th : pool) th.join();
+}
+
+// 64-bit content hash of the whole table (every word, order-sensitive), threads combined in order
+static uint64_t table_hash(const int32_t *p, size_t n) {
+    std::vector<uint64_t> part(32, 0);
+    parallel_ranges(n, (size_t)1 << 22, [&](size_t lo, size_t hi, size_t t) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)lo;
+        for (size_t i = lo; i < hi; ++i) {
+            h ^= (uint32_t)p[i];
+            h *= 0xFF51AFD7ED558CCDull;
+            h ^= h >> 29;
+        }
+        part[t] = h;
+    });
+    uint64_t h = n;
+    for (uint64_t v : part) h = (h ^ v) * 0xC4CEB9FE1A85EC53ull + 0x632BE59BD9B4E019ull;
+    return h;
+}
+
+static bool any_nonzero(const double *p, size_t n) {
+    std::atomic<bool> found{false};
+    parallel_ranges(n, (size_t)1 << 22, [&](size_t lo, size_t hi, size_t) {
+        // 8-byte words compared as integers: -0.0 counts as non-zero, which only costs an upload
+        const uint64_t *w = reinterpret_cast<const uint64_t *>(p);
+        for (size_t i = lo; i < hi && !found.load(std::memory_order_relaxed);) {
+            const size_t stop = std::min(hi, i + 4096);
+            uint64_t acc = 0;
+            for (; i < stop; ++i) acc |= w[i];
+            if (acc) found.store(true, std::memory_order_relaxed);
+        }
+    });
+    return found.load();
+}
+}  // extern "C++"
 
 static qm_engine *compat_engine() {
     if (!g_compat) {
         const char *dev = getenv("QM_HIP_DEVICE");
-        if (qm_engine_create(dev ? atoi(dev) : 0, &g_compat)) {
-            fprintf(stderr, "qmlib (HIP): %s\n", qm_last_error());
-            abort();
-        }
+        if (qm_engine_create(dev ? atoi(dev) : 0, &g_compat)) g_compat = nullptr;
     }
     return g_compat;
 }
 
-static void compat_check(int rc, const char *what) {
-    if (rc) {
-        fprintf(stderr, "qmlib (HIP) %s: %s\n", what, qm_last_error());
-        abort();
-    }
+static bool compat_failed(int rc, const char *what) {
+    if (!rc) return false;
+    g_compat_status = rc;
+    fprintf(stderr, "qmlib (HIP) %s: %s\n", what, qm_last_error());
+    const char *mode = getenv("QM_HIP_COMPAT_ON_ERROR");
+    if (mode && strcmp(mode, "abort") == 0) abort();
+    return true;
 }
+
+int qm_compat_status(void) { return g_compat_status; }
 
 void migrate(double *onsets, int32_t *lookup_tables, double *map4d, int32_t fsmp, int32_t lsmp,
              int32_t n_samples, int32_t n_stations, int32_t available, int64_t n_nodes,
              int64_t threads) {
     (void)threads;
     std::lock_guard<std::mutex> lock(g_compat_mutex);
+    g_compat_status = 0;
+    const size_t total = (size_t)(n_nodes > 0 ? n_nodes : 0) * (size_t)(n_samples > 0 ? n_samples : 0);
+    auto poison = [&]() {
+        for (size_t i = 0; i < total; ++i) map4d[i] = std::nan("");
+    };
     qm_engine *e = compat_engine();
-    e->have_lut = false;
-    e->cfg_bx = 1;
-    e->cfg_by = 1;
-    e->cfg_bz = 32;
-    if (n_nodes >= INT32_MAX) compat_check(fail("n_nodes too large"), "migrate");
-    compat_check(qm_engine_load_lut(e, lookup_tables, 0, 1, 1, (int32_t)n_nodes, n_stations, 0),
-                 "migrate/load");
+    if (!e) {
+        compat_failed(1, "migrate/create");
+        return poison();
+    }
+    if (n_nodes < 1 || n_nodes >= INT32_MAX || n_stations < 1) {
+        compat_failed(fail("migrate: bad sizes (n_nodes=%lld, n_stations=%d)", (long long)n_nodes,
+                           n_stations), "migrate");
+        return poison();
+    }
+    // table: re-uploaded (and its brick tables rebuilt) only when its content changed
+    const uint64_t h = table_hash(lookup_tables, (size_t)n_nodes * n_stations);
+    if (!(g_compat_table.valid && e->have_lut && g_compat_table.hash == h &&
+          g_compat_table.n_nodes == n_nodes && g_compat_table.n_rows == n_stations)) {
+        g_compat_table.valid = false;
+        e->cfg_bx = 1;
+        e->cfg_by = 1;
+        e->cfg_bz = 32;
+        if (compat_failed(qm_engine_load_lut(e, lookup_tables, 0, 1, 1, (int32_t)n_nodes,
+                                             n_stations, 0), "migrate/load"))
+            return poison();
+        g_compat_table.hash = h;
+        g_compat_table.n_nodes = n_nodes;
+        g_compat_table.n_rows = n_stations;
+        g_compat_table.valid = true;
+    }
     // the reference adds on top of map4d; the Python binding always passes zeros (lib.py:101),
-    // so only pay for the upload when something is there
-    const size_t total = (size_t)n_nodes * n_samples;
-    int accumulate = 0;
-    for (size_t i = 0; i < total; ++i)
-        if (map4d[i] != 0.0) {
-            accumulate = 1;
-            break;
-        }
-    compat_check(qm_engine_migrate(e, onsets, 0, fsmp + lsmp + n_samples, fsmp, lsmp, available,
-                                   n_nodes, map4d, 0, accumulate, nullptr, nullptr, nullptr, 0),
-                 "migrate");
+    // so only pay for the upload when something is there (QM_HIP_ASSUME_ZERO_MAP=1 skips the
+    // check: the caller vouches for a zeroed map, as the reference's own binding passes)
+    const char *zero = getenv("QM_HIP_ASSUME_ZERO_MAP");
+    const int accumulate = (zero && atoi(zero) != 0) ? 0 : (any_nonzero(map4d, total) ? 1 : 0);
+    if (compat_failed(qm_engine_migrate(e, onsets, 0, fsmp + lsmp + n_samples, fsmp, lsmp,
+                                        available, n_nodes, map4d, 0, accumulate, nullptr, nullptr,
+                                        nullptr, 0), "migrate"))
+        poison();
 }
 
 void find_max_coa(double *map4d, double *max_coa, double *max_norm_coa, int64_t *max_coa_idx,
                   int32_t n_samples, int64_t n_nodes, int64_t threads) {
     (void)threads;
     std::lock_guard<std::mutex> lock(g_compat_mutex);
+    g_compat_status = 0;
     qm_engine *e = compat_engine();
-    compat_check(qm_engine_find_max_coa(e, map4d, 0, n_samples, n_nodes, max_coa, max_norm_coa,
-                                        max_coa_idx, 0),
-                 "find_max_coa");
+    if (!e || compat_failed(qm_engine_find_max_coa(e, map4d, 0, n_samples, n_nodes, max_coa,
+                                                   max_norm_coa, max_coa_idx, 0),
+                            "find_max_coa")) {
+        if (!e) compat_failed(1, "find_max_coa/create");
+        for (int32_t i = 0; i < n_samples; ++i) {
+            max_coa[i] = max_norm_coa[i] = std::nan("");
+            max_coa_idx[i] = 0;
+        }
+    }
 }
 
 }  // extern "C"

@@ -165,7 +165,9 @@ __global__ void brick_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
 // trim/taper :550-583) followed by lib.migrate's clip + log (core/lib.py:93-94).
 //   pass 1  one thread per trace, sequential: the running short / long sums of the transformed
 //           signal in exactly the operation order of onsetlib.c:35-59 / :79-108 (the order fixes
-//           their rounding), stored per sample;
+//           their rounding), stored per sample; position 2: the exponentially weighted averages
+//           of recursive_sta_lta (onsetlib.c:126-148; not used by STALTAOnset itself, offered
+//           because the reference exports it), multiplications and additions kept unfused;
 //   pass 2  parallel: ratio * nlta/nsta, the 1.0 fill outside the valid range, the taper
 //           windows, then per onset row the root-mean-square over its component traces,
 //           clip at min_onset_value (raw onset) and log(clip(., 0.01)) (what the stack reads).
@@ -180,7 +182,7 @@ struct OnsetArgs {
     double *logged;            // [n_rows][T]
     int n_traces, n_rows, T;
     int transform;             // 0: energy x*x, 1: abs
-    int position;              // 0: classic (overlapping windows), 1: centred
+    int position;              // 0: classic (overlapping windows), 1: centred, 2: recursive
     int taper_pad;             // samples; < 0: no taper windows
     double min_onset_value;
 };
@@ -240,6 +242,18 @@ __device__ __forceinline__ void stalta_recurrence(const OnsetArgs &a, const doub
             S[i] = s_short;
             L[i] = s_long;
         }
+    } else if (a.position == 2) {                       // onsetlib.c:126-148
+#pragma clang fp contract(off)
+        const double cs = 1.0 / (double)ns, cl = 1.0 / (double)nl;
+        S[0] = 0.0;
+        L[0] = 0.0;
+        for (int i = 1; i < n; ++i) {
+            const double in = onset_sample<IN_LDS>(f, x, i, tf);
+            s_short = cs * in + (1 - cs) * s_short;
+            s_long = cl * in + (1 - cl) * s_long;
+            S[i] = s_short;
+            L[i] = s_long;
+        }
     } else {                                            // onsetlib.c:79-108
         if (nl + ns > n) return;
         for (int i = 0; i < nl; ++i) s_long += onset_sample<IN_LDS>(f, x, i, tf);
@@ -279,7 +293,8 @@ __global__ __launch_bounds__(256) void stalta_sums_kernel(OnsetArgs a, int in_ld
     const int ns = a.nsta[row], nl = a.nlta[row], n = a.T;
     const double *x = a.signals + (int64_t)tr * n;
     double *S = a.sta + (int64_t)tr * n, *L = a.lta + (int64_t)tr * n;
-    if (nl > n || ns > nl || ns < 1) return;            // pass 2 leaves such a trace at 1.0
+    if (a.position != 2 && (nl > n || ns > nl || ns < 1)) return;   // pass 2 leaves such a trace at 1.0
+    if (a.position == 2 && (ns < 1 || nl < 1)) return;
     if (in_lds) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) fx[i] = onset_transform(x[i], a.transform);
         __syncthreads();
@@ -291,6 +306,7 @@ __global__ __launch_bounds__(256) void stalta_sums_kernel(OnsetArgs a, int in_ld
 
 // thread <-> (row, sample); the components of a row are consecutive traces
 __global__ void onset_rows_kernel(OnsetArgs a) {
+#pragma clang fp contract(off)                           // numpy squares, then adds (stalta.py:544)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)a.n_rows * a.T) return;
     const int row = (int)(i / a.T), t = (int)(i % a.T);
@@ -301,11 +317,21 @@ __global__ void onset_rows_kernel(OnsetArgs a) {
     for (int tr = 0; tr < a.n_traces; ++tr) {
         if (a.trace_row[tr] != row) continue;
         double v = 1.0;                                  // lib.py pre-fills with ones
-        const bool sane = !(nl > n || ns > nl || ns < 1) && (a.position == 0 || nl + ns <= n);
-        const int last = a.position == 0 ? n - 1 : n - ns - 1;
-        if (sane && t >= nl - 1 && t <= last) {
-            const double s = a.sta[(int64_t)tr * n + t], l = a.lta[(int64_t)tr * n + t];
-            if (a.position == 0 || t == nl - 1 || l > 0.0) v = s / l * frac;
+        if (a.position == 2) {
+            // recursive: the binding pre-fills with zeros (lib.py:279), sample 0 is never written,
+            // the first nlta samples are nulled to 1 when the trace is longer than that
+            v = 0.0;
+            if (ns >= 1 && nl >= 1) {
+                if (t >= 1) v = a.sta[(int64_t)tr * n + t] / a.lta[(int64_t)tr * n + t];
+                if (nl < n && t < nl) v = 1.0;
+            }
+        } else {
+            const bool sane = !(nl > n || ns > nl || ns < 1) && (a.position == 0 || nl + ns <= n);
+            const int last = a.position == 0 ? n - 1 : n - ns - 1;
+            if (sane && t >= nl - 1 && t <= last) {
+                const double s = a.sta[(int64_t)tr * n + t], l = a.lta[(int64_t)tr * n + t];
+                if (a.position == 0 || t == nl - 1 || l > 0.0) v = s / l * frac;
+            }
         }
         if (a.taper_pad >= 0 && (t < a.taper_pad + nl - 1 || t >= n - (ns + a.taper_pad)))
             v = 1.0;                                     // stalta.py:579-581
@@ -1064,11 +1090,14 @@ __global__ void marginal_reduce_kernel(const double *__restrict__ part, int ntil
 // the sets, LDS combine.  mode 0: emit one combined partial (index + node_offset, still in the
 // log2 domain); mode 1: final series from log2-domain partials; mode 2: final series from
 // partials that already hold coalescence values (volume scan).  Ties -> lowest node index.
+// Set s of each array starts at element s * set_stride (n for [n_sets][n] arrays; 3 n for the
+// packed [n_sets][3][n] layout of the cross-GPU all-gather).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void combine_kernel(const double *__restrict__ part_max,
                                                       const int64_t *__restrict__ part_idx,
                                                       const double *__restrict__ part_sum,
-                                                      int n_sets, int n, int mode,
+                                                      int n_sets, int n, int64_t set_stride,
+                                                      int mode,
                                                       int64_t node_offset, double n_nodes_total,
                                                       double *__restrict__ out_max,
                                                       double *__restrict__ out_norm_or_sum,
@@ -1083,7 +1112,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const double *__restrict__
     double best = -__builtin_inf(), total = 0.0;
     int64_t bi = kNoIndex;
     for (int s = wave; s < n_sets; s += 4) {
-        const int64_t o = (int64_t)s * n + tc;
+        const int64_t o = (int64_t)s * set_stride + tc;
         const double v = part_max[o];
         const int64_t i = part_idx[o];
         total += part_sum[o];

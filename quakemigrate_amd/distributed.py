@@ -8,19 +8,28 @@ ranges of flat node indices, flat = (ix*ny+iy)*nz+iz, quakemigrate/lut/lut.py:16
 one process per GPU, each with its slab of the travel-time table resident, the
 (small) onset array replicated.  Per timestep every rank produces its partial
 ``(log2-domain max, global argmax, sum of coalescence)`` per sample with
-``Engine.detect_partial`` and the only exchange is three tiny all-reduces over
-``n_samples`` elements (48 KB each at 6000 samples) -- RCCL over xGMI on the GPU
-box, gloo in the CPU tests:
+``Engine.detect_partial``; the path's only exchange is over ``n_samples`` elements
+(48 KB per series at 6000 samples) -- RCCL over xGMI on the GPU box, gloo in the
+CPU tests.  Two equivalent forms:
 
-    gmax = all_reduce(pmax, MAX)
-    gidx = all_reduce(where(pmax == gmax, pidx, INT64_MAX), MIN)   # lowest index wins
-    gsum = all_reduce(psum, SUM)
-    max_coa = 2**gmax;  max_norm_coa = max_coa * n_nodes_total / gsum
+* **packed** (what :class:`ShardedDetector` runs): the three series live in ONE
+  ``[3][n_samples]`` float64 buffer (the int64 indices as bit patterns), ONE
+  all-gather moves every rank's buffer to every rank (``[world][3][n_samples]``),
+  and the engine's ``combine_kernel`` (``Engine.finalize_packed``) folds the
+  ``world`` sets on the device -- one collective launch and one kernel per step,
+  no temporaries;
+* **three all-reduces** (:func:`exchange_partials`, the plainly readable statement
+  kept as the tested reference of the packed form):
 
-which reproduces the reference's tie-break (strict '>' in ascending node order,
+      gmax = all_reduce(pmax, MAX)
+      gidx = all_reduce(where(pmax == gmax, pidx, INT64_MAX), MIN)   # lowest index wins
+      gsum = all_reduce(psum, SUM)
+      max_coa = 2**gmax;  max_norm_coa = max_coa * n_nodes_total / gsum
+
+Both reproduce the reference's tie-break (strict '>' in ascending node order,
 migratelib.c:102) exactly, because equal maxima on two ranks resolve to the lower
-global index.  The functions are plain torch ops on whatever device the tensors
-live on -- plumbing, not the hot path.
+global index.  torch supplies the process group and the device buffers -- plumbing,
+not the hot path.
 """
 
 from __future__ import annotations
@@ -55,7 +64,8 @@ def combine_partials_local(pmax, pidx, psum, n_nodes_total):
 def exchange_partials(pmax, pidx, psum, n_nodes_total, group=None):
     """
     Cross-rank combination of this rank's partial (three 1-D tensors of length
-    n_samples).  Returns ``(max_coa, max_norm_coa, max_coa_idx)`` on every rank.
+    n_samples) with three all-reduces.  Returns ``(max_coa, max_norm_coa,
+    max_coa_idx)`` on every rank.
     """
     import torch.distributed as dist
 
@@ -67,6 +77,37 @@ def exchange_partials(pmax, pidx, psum, n_nodes_total, group=None):
     dist.all_reduce(gsum, op=dist.ReduceOp.SUM, group=group)
     peak = torch.exp2(gmax)
     return peak, peak * float(n_nodes_total) / gsum, gidx
+
+
+def _backend(group=None):
+    import torch.distributed as dist
+
+    return str(dist.get_backend(group)).lower()
+
+
+def all_gather_packed(packed, gathered, group=None):
+    """
+    ONE all-gather of this rank's packed partial ``[3][n_samples]`` into ``gathered``
+    ``[world][3][n_samples]`` (rank order).  RCCL moves device buffers directly; gloo (the CPU
+    tests, and the one-GPU plumbing runs) has no device all-gather, so device tensors are staged
+    through the host there.
+    """
+    import torch.distributed as dist
+
+    # flat views: the collective concatenates the ranks' buffers in rank order
+    if packed.is_cuda and _backend(group) == "gloo":
+        host = torch.empty(gathered.numel(), dtype=gathered.dtype)
+        dist.all_gather_into_tensor(host, packed.reshape(-1).cpu(), group=group)
+        gathered.view(-1).copy_(host)
+    else:
+        dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=group)
+    return gathered
+
+
+def combine_packed_torch(gathered, n_nodes_total):
+    """The fold of ``Engine.finalize_packed`` stated with torch ops (CPU tests; any device)."""
+    return combine_partials_local(gathered[:, 0, :], gathered[:, 1, :].view(torch.int64),
+                                  gathered[:, 2, :], n_nodes_total)
 
 
 def gather_planes(local, nx_total, group=None):
@@ -85,9 +126,14 @@ def gather_planes(local, nx_total, group=None):
     padded = torch.zeros((biggest,) + tuple(local.shape[1:]), dtype=local.dtype,
                          device=local.device)
     padded[: local.shape[0]] = local
-    pieces = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(pieces, padded, group=group)
-    return torch.cat([p[: x1 - x0] for p, (x0, x1) in zip(pieces, sizes)], dim=0)
+    whole = torch.empty((world,) + tuple(padded.shape), dtype=local.dtype, device=local.device)
+    if local.is_cuda and _backend(group) == "gloo":      # no device all-gather in gloo
+        host = torch.empty(whole.numel(), dtype=whole.dtype)
+        dist.all_gather_into_tensor(host, padded.reshape(-1).cpu(), group=group)
+        whole.view(-1).copy_(host)
+    else:
+        dist.all_gather_into_tensor(whole.view(-1), padded.view(-1), group=group)
+    return torch.cat([whole[r, : x1 - x0] for r, (x0, x1) in enumerate(sizes)], dim=0)
 
 
 class ShardedDetector:
@@ -95,30 +141,70 @@ class ShardedDetector:
     One rank's share of a grid-sharded detect sweep.
 
     ``engine`` has this rank's slab resident (``load_lut(slab, node_offset=...)``);
-    ``detect(log_onsets_dev, fsmp, lsmp, available)`` returns the global series.
+    ``detect(log_onsets_dev, fsmp, lsmp, available)`` returns the global series (device
+    tensors, valid on torch's current stream).
+
+    Stream discipline: the engine's kernels and the collective must be ordered on ONE stream.
+    The detector therefore binds the engine to torch's current stream on ``device`` before every
+    step (an engine left on its private stream would let the collective read the partials before
+    the kernels have written them).
+
+    ``exchange``: ``"packed"`` (default: one all-gather + the engine's device-side fold) or
+    ``"allreduce"`` (three all-reduces, :func:`exchange_partials`).
     """
 
-    def __init__(self, engine, n_nodes_total, n_samples, device, group=None):
+    def __init__(self, engine, n_nodes_total, n_samples, device, group=None, exchange="packed"):
+        import torch.distributed as dist
+
+        if exchange not in ("packed", "allreduce"):
+            raise ValueError("exchange must be 'packed' or 'allreduce'")
         self.engine = engine
         self.n_nodes_total = int(n_nodes_total)
+        self.n_samples = int(n_samples)
         self.group = group
-        self.pmax = torch.empty(n_samples, dtype=torch.float64, device=device)
-        self.psum = torch.empty(n_samples, dtype=torch.float64, device=device)
-        self.pidx = torch.empty(n_samples, dtype=torch.int64, device=device)
+        self.exchange = exchange
+        self.device = torch.device(device)
+        self.world = dist.get_world_size(group)
+        ns = self.n_samples
+        # this rank's partial: rows (max, idx bits, sum) of one buffer, so that the three series
+        # travel in one message
+        self.packed = torch.empty((3, ns), dtype=torch.float64, device=self.device)
+        self.pmax = self.packed[0]
+        self.pidx = self.packed[1].view(torch.int64)
+        self.psum = self.packed[2]
+        self.gathered = torch.empty((self.world, 3, ns), dtype=torch.float64, device=self.device)
+        self.out = (torch.empty(ns, dtype=torch.float64, device=self.device),
+                    torch.empty(ns, dtype=torch.float64, device=self.device),
+                    torch.empty(ns, dtype=torch.int64, device=self.device))
+        self._bound = None
+
+    def _bind_stream(self):
+        if self.device.type != "cuda":
+            return
+        ptr = torch.cuda.current_stream(self.device).cuda_stream
+        if self._bound != ptr:
+            self.engine.set_stream(ptr)
+            self._bound = ptr
 
     def detect(self, log_onsets, fsmp, lsmp, available):
+        self._bind_stream()
         self.engine.detect_partial(log_onsets, fsmp, lsmp, available,
                                    (self.pmax, self.pidx, self.psum))
-        return exchange_partials(self.pmax, self.pidx, self.psum,
-                                 self.n_nodes_total, self.group)
+        if self.exchange == "allreduce":
+            return exchange_partials(self.pmax, self.pidx, self.psum, self.n_nodes_total,
+                                     self.group)
+        all_gather_packed(self.packed, self.gathered, self.group)
+        return self.engine.finalize_packed(self.gathered, self.world, self.n_samples,
+                                           self.n_nodes_total, out=self.out)
 
     def marginal_map(self, log_onsets, fsmp, lsmp, available, first_sample, end_sample, nx_total):
         """
         Locate without the volume on a sharded grid: every rank marginalises its slab
         (``Engine.marginal_map``), the slabs are gathered.  Returns the whole map on every rank.
         """
+        self._bind_stream()
         nx, ny, nz = self.engine.grid
-        local = torch.zeros((nx, ny, nz), dtype=torch.float64, device=self.pmax.device)
+        local = torch.zeros((nx, ny, nz), dtype=torch.float64, device=self.device)
         self.engine.marginal_map(log_onsets, fsmp, lsmp, available, first_sample, end_sample,
                                  out=local, n_nodes_total=self.n_nodes_total)
         return gather_planes(local, nx_total, self.group)

@@ -107,12 +107,14 @@ class Case:
 
 
 def make_case(name, step=0, x_range=None, n_samples=None, grid=None, rows=None,
-              n_events=3, quiet=False) -> Case:
+              n_events=3, quiet=False, table=True) -> Case:
     """
     Build configuration ``name`` (C1..C4, C3L) for timestep ``step``.  The table
     depends only on the configuration; the onsets also on ``step``.
     ``grid`` / ``rows`` / ``n_samples`` override the named sizes (tests use
-    shrunken variants of the same recipe).
+    shrunken variants of the same recipe).  ``table=False`` skips building the
+    travel-time table (``traveltimes`` is None): further timesteps of a configuration
+    whose table the caller already holds.
     """
     cfg = dict(CONFIGS[name])
     if grid is not None:
@@ -136,7 +138,7 @@ def make_case(name, step=0, x_range=None, n_samples=None, grid=None, rows=None,
     tt_max = int(np.rint(far / vel * cfg["rate"]).max())
     fsmp, lsmp = int(cfg["fsmp"]), tt_max + 100
     t_samples = fsmp + ns + lsmp
-    tt = homogeneous_lut(g, cfg["spacing"], st, vel, cfg["rate"], x_range)
+    tt = homogeneous_lut(g, cfg["spacing"], st, vel, cfg["rate"], x_range) if table else None
 
     rng_on = np.random.default_rng([BASE_SEED + CONFIG_IDS[name], 1 + step])
     nodes, arrivals = [], []

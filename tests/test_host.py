@@ -162,6 +162,15 @@ def _worker(rank, world, port, tmp):
     pidx = torch.from_numpy(local_idx.astype(np.int64) + x0 * grid[1] * grid[2])
     psum = torch.from_numpy(vol.sum(axis=0))
     a, b, c = qd.exchange_partials(pmax, pidx, psum, int(np.prod(grid)))
+    # the packed form ShardedDetector runs: one all-gather of [3][ns], then the fold
+    packed = torch.empty((3, vol.shape[1]), dtype=torch.float64)
+    packed[0], packed[2] = pmax, psum
+    packed[1].view(torch.int64).copy_(pidx)
+    gathered = torch.empty((world, 3, vol.shape[1]), dtype=torch.float64)
+    qd.all_gather_packed(packed, gathered)
+    pa, pb, pc = qd.combine_packed_torch(gathered, int(np.prod(grid)))
+    assert torch.equal(pc, c) and torch.equal(pa, a)
+    assert torch.allclose(pb, b, rtol=1e-14, atol=0)
     # the marginalised map of a locate window, slab by slab, gathered on every rank
     marg = torch.from_numpy(vol[:, 40:150].sum(axis=1).reshape(x1 - x0, grid[1], grid[2]))
     whole = qd.gather_planes(marg, grid[0])

@@ -147,16 +147,65 @@ def test_table_serving_restatement_matches_reference_lut_class(oracle):
     assert np.array_equal(oracle.np_serve_traveltimes(dec, 250), g["served_dec_250"])
 
 
-def test_onset_stage_restatement_with_the_c_port(oracle):
-    """np_onset_stage on the oracle's C STA/LTA port == the fixture made with the reference's."""
+def _onset_stage_inputs(g, tf):
+    """Signals and device-stage transform for the reference's four ``signal_transform`` values:
+    the envelope transforms take |hilbert(x)| (computed upstream, like the filters) as the signal
+    and then are ``abs`` / ``energy`` of it (stalta.py:518-521)."""
+    if tf in ("env", "env_squared"):
+        return g["envelopes"], ("abs" if tf == "env" else "energy")
+    return g["signals"], tf
+
+
+def test_onset_stage_restatement_matches_reference_stalta_onset(oracle):
+    """np_onset_stage (on the oracle's C STA/LTA port) == the reference's own
+    STALTAOnset._onset / _trim_taper_pad (fixture made by running signal/onsets/stalta.py:491-583,
+    oracle/make_golden.py section 10), all four transforms and both window positions."""
+    from scipy.signal import hilbert
+
     g = load_golden("onset_stage")
+    np.testing.assert_allclose(np.abs(hilbert(g["signals"], axis=-1)), g["envelopes"], rtol=1e-12)
     for pos in ("classic", "centred"):
-        for tf in ("energy", "abs"):
-            raw, logged = oracle.np_onset_stage(g["signals"], g["trace_row"], g["nsta"], g["nlta"],
-                                                tf, pos, int(g["taper_pad"]),
+        for tf in ("energy", "abs", "env", "env_squared"):
+            sig, stage_tf = _onset_stage_inputs(g, tf)
+            raw, logged = oracle.np_onset_stage(sig, g["trace_row"], g["nsta"], g["nlta"],
+                                                stage_tf, pos, int(g["taper_pad"]),
                                                 float(g["min_onset_value"]))
             np.testing.assert_allclose(raw, g[f"raw_{pos}_{tf}"], rtol=1e-12)
             np.testing.assert_allclose(logged, g[f"log_{pos}_{tf}"], rtol=1e-12, atol=1e-14)
+    raw, _ = oracle.np_onset_stage(g["signals"], g["trace_row"], g["nsta"], g["nlta"], "energy",
+                                   "classic", -1, 0.01)
+    np.testing.assert_allclose(raw, g["raw_classic_energy_notaper"], rtol=1e-12)
+
+
+def compute_glue_inputs(g, oracle):
+    """Served table, pads and available count of the compute_glue fixture, restated."""
+    index = {str(k): i for i, k in enumerate(g["grid_keys"])}
+    availability = {str(k): int(v) for k, v in zip(g["availability_keys"],
+                                                    g["availability_values"])}
+    picked = [g["grids"][index[k]] for k, v in availability.items() if v == 1]
+    rate = int(g["sampling_rate"])
+    tt = oracle.np_serve_traveltimes(picked, rate)
+    fsmp = int(round(float(g["pre_pad"]) * rate))               # util.time2sample
+    lsmp = int(round(float(g["post_pad"]) * rate))
+    return tt, fsmp, lsmp, availability
+
+
+def test_oracle_reproduces_reference_compute(oracle):
+    """The oracle chain (served table -> migrate -> find_max_coa -> index2grid) == outputs of
+    QuakeScan._compute run from the reference's own scan.py:593-647 (fixture compute_glue)."""
+    g = load_golden("compute_glue")
+    tt, fsmp, lsmp, availability = compute_glue_inputs(g, oracle)
+    avail = sum(availability.values())
+    a, b, c = oracle.detect(g["onsets"], tt, fsmp, lsmp, avail, threads=2)
+    np.testing.assert_allclose(a, g["max_coa"], rtol=1e-14)
+    np.testing.assert_allclose(b, g["max_coa_n"], rtol=1e-14)
+    ijk = np.column_stack(np.unravel_index(c, tt.shape[:3]))
+    assert np.array_equal(g["ll_corner"] + ijk * g["node_spacing"], g["coord"])
+    vol = oracle.c_migrate(g["onsets"], tt, fsmp, lsmp, avail, threads=2)
+    assert vol.shape == tuple(g["map4d_shape"])
+    np.testing.assert_allclose(vol.reshape(-1, vol.shape[-1])[g["map4d_rows"]], g["map4d_vals"],
+                               rtol=1e-14)
+    assert float(g["detect_time"]) == float(g["starttime"]) + float(g["pre_pad"])
 
 
 LOCATE_CASES = ["corner", "interior_even", "interior_odd", "near_face", "thin"]
