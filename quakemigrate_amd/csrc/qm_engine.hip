@@ -23,6 +23,7 @@
 #include "qm_kernels.hpp"
 #include "qm_locate.hpp"
 #include "qm_screen.hpp"
+#include "qm_pair.hpp"
 
 namespace {
 
@@ -90,7 +91,10 @@ struct qm_engine {
     int cfg_lds_bytes = 80 * 1024;
     int cfg_force_direct = 0;
     int cfg_generic = 0;            // 1 = always the generic (any row count) LDS kernel
+    int cfg_exact = 1;              // 1 = the exact-row-count kernel where one is built (see
+                                    //     QM_EXACT_ROWS), 0 = the chunked kernels only
     int64_t cfg_chunk_bytes = (int64_t)4 << 30;
+    int cfg_pair = 1;               // 1 = the 16-byte-operand kernel (qm_pair.hpp) where it applies
     int cfg_screen = 0;             // 1 (opt-in): detect = float32 screening sweep + exact float64
                                     // refinement (qm_screen.hpp); 0: every node-sample in float64
     int cfg_screen_pairs = 0;       // pairs of samples per lane in the sweep (0 = automatic)
@@ -122,6 +126,15 @@ struct qm_engine {
     int last_plan_jp = 0, last_plan_big = 0;
     int32_t *h_flags = nullptr;             // pinned ring of per-step (flags, candidates) pairs
     int flags_pending = 0, flags_head = 0;  // not yet folded into the counters
+
+    // paired (16-byte operand) layout of the float64 kernel (qm_pair.hpp): own brick grid
+    qm::GridDesc pg{};
+    DevBuf<int32_t> d_pmeta, d_pmeta_raw, d_ptotal, d_pwide;
+    DevBuf<uint16_t> d_prel;
+    DevBuf<double> d_sink;
+    int n_pwide = 0;
+    int pair_kt = 0;                        // tile length the paired tables were built for
+    bool pair_ok = false;                   // ... and whether (almost) every brick fits
 
     // float64 travel-time grids in seconds (optional; on-device table serving)
     DevBuf<double> d_grids;
@@ -218,6 +231,48 @@ int launch_lds(qm_engine *e, qm::StackArgs &a, int groups_lds, int threads, size
     return 0;
 }
 
+// Row counts the exact-row-count kernel (qm::stack_exact_kernel) is built for, each with the
+// samples-per-lane eff_j() picks for it (4 up to 40 rows, 2 up to 64).  Other row counts, other
+// tile lengths (short scans), accumulate requests and the marginal map use the chunked kernels.
+#ifndef QM_EXACT_ROWS
+#define QM_EXACT_ROWS(X)                                                                        \
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)      \
+    X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)   \
+    X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46)   \
+    X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61)   \
+    X(62) X(63) X(64)
+#endif
+constexpr int exact_j(int S) { return S <= 40 ? 4 : 2; }
+
+template <int J, bool VOLUME, int S>
+int launch_exact(qm_engine *e, qm::StackArgs &a, int groups_lds, int threads, size_t lds) {
+    QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_exact_kernel<J, VOLUME, S>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((qm::stack_exact_kernel<J, VOLUME, S>),
+                       dim3((unsigned)(a.ntiles * ((groups_lds + 7) / 8 * 8))), dim3(threads), lds,
+                       e->stream, a);
+    QM_HIP(hipGetLastError());
+    return 0;
+}
+
+// *done = false: no exact kernel for this (row count, samples per lane)
+template <int J, bool VOLUME>
+int launch_exact_if_built(qm_engine *e, qm::StackArgs &a, int groups_lds, int threads, size_t lds,
+                          bool *done) {
+    *done = true;
+    switch (e->g.n_rows) {
+#define QM_EXACT_CASE(SS)                                                                      \
+    case SS:                                                                                   \
+        if constexpr (exact_j(SS) == J) return launch_exact<J, VOLUME, SS>(e, a, groups_lds, threads, lds); \
+        else break;
+        QM_EXACT_ROWS(QM_EXACT_CASE)
+#undef QM_EXACT_CASE
+        default: break;
+    }
+    *done = false;
+    return 0;
+}
+
 template <int J, bool VOLUME>
 int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_direct,
                    bool use_lds, bool use_direct) {
@@ -229,11 +284,19 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
         a.ngroups = groups_lds;
         a.brick_list = nullptr;
         a.n_list = 0;
-        int rc;
+        int rc = 0;
+        bool exact = false;
+        // (detect only: the volume-writing variant of the b64 pipeline would need the branch-free
+        // store of qm_pair.hpp to stay in registers; the paired kernel covers that case)
+        if constexpr (!VOLUME) {
+            if (e->cfg_exact && !e->cfg_generic && !a.accumulate && a.marginal == nullptr)
+                rc = launch_exact_if_built<J, VOLUME>(e, a, groups_lds, threads, lds, &exact);
+        }
+        if (rc) return rc;
         // Variants specialised on the number of 8-row offset chunks (whole-node offset prefetch;
         // detect: software-pipelined node loop) for up to 64 table rows; otherwise, and for the
         // reference's accumulate-into-volume semantics, the generic kernel.
-        switch ((e->cfg_generic || a.accumulate) ? 0 : e->g.row_pad / 8) {
+        if (!exact) switch ((e->cfg_generic || a.accumulate) ? 0 : e->g.row_pad / 8) {
             case 1: rc = launch_lds<J, VOLUME, 1>(e, a, groups_lds, threads, lds); break;
             case 2: rc = launch_lds<J, VOLUME, 2>(e, a, groups_lds, threads, lds); break;
             case 3: rc = launch_lds<J, VOLUME, 3>(e, a, groups_lds, threads, lds); break;
@@ -266,6 +329,161 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
         a.set0 += groups_direct;
     }
     return 0;
+}
+
+// ---- paired (16-byte operand) layout (qm_pair.hpp) -------------------------------------------
+// Row counts the paired kernel is built for: JP = 2 pairs per lane (time tile 256) up to 32 rows,
+// JP = 1 (tile 128) up to 64 -- both copies of S row windows plus the delay spans in 160 KB.
+#ifndef QM_PAIR_ROWS
+#define QM_PAIR_ROWS(X) QM_EXACT_ROWS(X)
+#endif
+constexpr int pair_jp_of(int S) { return S <= 32 ? 2 : (S <= 64 ? 1 : 0); }
+constexpr int kPairLdsBytes = 160 * 1024;
+
+// pairs per lane for a launch over n_chunk samples; 0 = the chunked kernels run
+int pair_jp(const qm_engine *e, int n_chunk) {
+    if (!e->cfg_pair || e->cfg_generic || e->cfg_force_direct || e->user_waves || e->user_lds ||
+        e->cfg_j > 0)
+        return 0;
+    const int jp = pair_jp_of(e->g.n_rows);
+    if (e->cfg_pair == 2) return jp;                   // forced (tests): any scan length
+    // short scans run on shorter tiles (run_j): leave those to the chunked kernels
+    return (jp > 0 && run_j(e, n_chunk) == eff_j(e) && qm::kWave * eff_j(e) >= 128 * jp) ? jp : 0;
+}
+
+// Own brick grid (e->pg): the largest brick shape whose two staggered window copies fit 160 KB
+// for (almost) every brick; per-brick (min, span2, prefix) records and the 16-bit offset table.
+int ensure_pair_tables(qm_engine *e, int jp) {
+    const int KT = 128 * jp;
+    if (e->pair_kt == KT) return 0;
+    static const int kShapes[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4},
+                                     {2, 4, 4}, {2, 2, 4}, {2, 2, 2}, {1, 1, 2}, {1, 1, 1}};
+    const bool fixed = e->cfg_bx > 0;
+    const int n_shapes = fixed ? 1 : (int)(sizeof(kShapes) / sizeof(kShapes[0]));
+    qm::GridDesc g = e->g;
+    std::vector<int32_t> total, wide;
+    for (int s = 0; s < n_shapes; ++s) {
+        g = e->g;
+        if (!fixed) {
+            g.bx = std::min(kShapes[s][0], g.nx);
+            g.by = std::min(kShapes[s][1], g.ny);
+            g.bz = std::min(kShapes[s][2], g.nz);
+            g.nbx = (g.nx + g.bx - 1) / g.bx;
+            g.nby = (g.ny + g.by - 1) / g.by;
+            g.nbz = (g.nz + g.bz - 1) / g.bz;
+            g.nbricks = g.nbx * g.nby * g.nbz;
+            g.brick_nodes = g.bx * g.by * g.bz;
+        }
+        const size_t br = (size_t)g.nbricks * g.n_rows;
+        if (e->d_pmeta_raw.ensure(4 * br) || e->d_pmeta.ensure(4 * br) ||
+            e->d_ptotal.ensure(g.nbricks) || e->d_scalar.ensure(4))
+            return 1;
+        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
+        hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
+                           e->d_lut.p, reinterpret_cast<int4 *>(e->d_pmeta_raw.p), e->d_scalar.p);
+        hipLaunchKernelGGL(qm::screen_prefix_kernel, dim3((g.nbricks + 255) / 256), dim3(256), 0,
+                           e->stream, g, reinterpret_cast<const int4 *>(e->d_pmeta_raw.p),
+                           reinterpret_cast<int4 *>(e->d_pmeta.p), e->d_ptotal.p);
+        QM_HIP(hipGetLastError());
+        total.resize(g.nbricks);
+        QM_HIP(hipMemcpyAsync(total.data(), e->d_ptotal.p, (size_t)g.nbricks * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, e->stream));
+        QM_HIP(hipStreamSynchronize(e->stream));
+        wide.clear();
+        for (int b = 0; b < g.nbricks; ++b)
+            if (!qm::pair_fits(total[b], g.n_rows, KT, kPairLdsBytes)) wide.push_back(b);
+        if ((int64_t)wide.size() * 200 <= g.nbricks) break;    // <= 0.5 % on the slow path
+    }
+    e->n_pwide = (int)wide.size();
+    // an incoherent table (every shape leaves bricks that do not fit): the chunked kernels, whose
+    // single-copy windows are half the size, take it
+    // (with an explicit brick shape: whatever fits is paired, the rest goes to the direct kernel)
+    e->pair_ok = fixed ? (int)wide.size() < g.nbricks : (int64_t)wide.size() * 200 <= g.nbricks;
+    if (e->n_pwide) {
+        if (e->d_pwide.ensure(wide.size())) return 1;
+        QM_HIP(hipMemcpyAsync(e->d_pwide.p, wide.data(), wide.size() * sizeof(int32_t),
+                              hipMemcpyHostToDevice, e->stream));
+    }
+    if (e->pair_ok) {
+        if (e->d_prel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;
+        hipLaunchKernelGGL(qm::pair_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
+                           e->d_lut.p, reinterpret_cast<const int4 *>(e->d_pmeta.p), e->d_ptotal.p,
+                           KT, kPairLdsBytes, e->d_prel.p);
+        QM_HIP(hipGetLastError());
+    }
+    QM_HIP(hipStreamSynchronize(e->stream));           // `wide` is a stack-lifetime buffer
+    e->pg = g;
+    e->pair_kt = KT;
+    return 0;
+}
+
+template <int JP, bool VOLUME, int S>
+int launch_pair(qm_engine *e, qm::StackArgs &a) {
+    QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_pair_kernel<JP, VOLUME, S>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kPairLdsBytes));
+    hipLaunchKernelGGL((qm::stack_pair_kernel<JP, VOLUME, S>),
+                       dim3((unsigned)(a.ntiles * ((a.ngroups + 7) / 8 * 8))), dim3(1024),
+                       kPairLdsBytes, e->stream, a);
+    QM_HIP(hipGetLastError());
+    return 0;
+}
+
+// *done = false: no paired kernel for this (row count, pairs per lane)
+template <int JP, bool VOLUME>
+int launch_pair_if_built(qm_engine *e, qm::StackArgs &a, bool *done) {
+    *done = true;
+    switch (e->g.n_rows) {
+#define QM_PAIR_CASE(SS)                                                                       \
+    case SS:                                                                                   \
+        if constexpr (pair_jp_of(SS) == JP) return launch_pair<JP, VOLUME, SS>(e, a);           \
+        else break;
+        QM_PAIR_ROWS(QM_PAIR_CASE)
+#undef QM_PAIR_CASE
+        default: break;
+    }
+    *done = false;
+    return 0;
+}
+
+// LDS launch over the bricks that fit the paired layout + direct launch over those that do not
+template <int JP, bool VOLUME>
+int launch_pair_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_direct,
+                     bool use_lds, bool use_direct) {
+    if (use_lds) {
+        a.ngroups = groups_lds;
+        a.brick_list = nullptr;
+        a.n_list = 0;
+        bool done = false;
+        if (launch_pair_if_built<JP, VOLUME>(e, a, &done)) return 1;
+        if (!done) return fail("no paired kernel built for %d rows", e->g.n_rows);
+        a.set0 += groups_lds;
+    }
+    if (use_direct) {
+        constexpr int J = 2 * JP;                      // same tile length: 64 * J = 128 * JP
+        const int threads = 1024;
+        const size_t publish_bytes = (size_t)3 * (threads / qm::kWave) * qm::kWave * J * sizeof(double);
+        QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_direct_kernel<J, VOLUME>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)publish_bytes));
+        a.ngroups = groups_direct;
+        a.brick_list = e->d_pwide.p;
+        a.n_list = e->n_pwide;
+        hipLaunchKernelGGL((qm::stack_direct_kernel<J, VOLUME>),
+                           dim3((unsigned)(a.ntiles * ((groups_direct + 7) / 8 * 8))), dim3(threads),
+                           publish_bytes, e->stream, a);
+        QM_HIP(hipGetLastError());
+        a.set0 += groups_direct;
+    }
+    return 0;
+}
+
+bool pair_built(int S) {
+    switch (S) {
+#define QM_PAIR_CASE(SS) case SS: return true;
+        QM_PAIR_ROWS(QM_PAIR_CASE)
+#undef QM_PAIR_CASE
+        default: return false;
+    }
 }
 
 int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu) {
@@ -317,17 +535,37 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     a.n_nodes = e->n_nodes;
     a.run_if = run_if;
 
-    const bool use_direct = e->cfg_force_direct || e->n_wide > 0;
-    const bool use_lds = !e->cfg_force_direct && e->n_wide < e->g.nbricks;
-    const int threads = e->cfg_waves * qm::kWave;
+    // ---- the paired (16-byte operand) kernel where it applies: own brick grid and tables
+    int jp = (accumulate || marginal) ? 0 : pair_jp(e, n_chunk);
+    if (jp > 0 && (!pair_built(e->g.n_rows) || ensure_pair_tables(e, jp) != 0 || !e->pair_ok)) {
+        if (g_error.size() && !e->pair_kt) return 1;   // a HIP failure while building the tables
+        jp = 0;
+    }
+    if (jp > 0) {
+        const int PKT = 128 * jp;
+        a.g = e->pg;
+        a.rel = e->d_prel.p;
+        a.brick_meta = e->d_pmeta.p;
+        a.brick_total = e->d_ptotal.p;
+        a.ntiles = (n_chunk + PKT - 1) / PKT;
+        a.cap_doubles = kPairLdsBytes / 8;
+        if (e->d_sink.ensure(64)) return 1;
+        a.sink = e->d_sink.p;
+    }
+    const int n_wide_now = jp > 0 ? e->n_pwide : e->n_wide;
+    const int nbricks_now = jp > 0 ? e->pg.nbricks : e->g.nbricks;
+    const bool use_direct = e->cfg_force_direct || n_wide_now > 0;
+    const bool use_lds = !e->cfg_force_direct && n_wide_now < nbricks_now;
+    const int threads = jp > 0 ? 1024 : e->cfg_waves * qm::kWave;
     const int lds_blocks_per_cu =
-        std::max(1, std::min(160 * 1024 / std::max(1, e->cfg_lds_bytes), 2048 / threads));
+        jp > 0 ? 1
+               : std::max(1, std::min(160 * 1024 / std::max(1, e->cfg_lds_bytes), 2048 / threads));
     int groups_lds = 0, groups_direct = 0;
     if (use_lds)
-        groups_lds = e->cfg_groups > 0 ? std::min(e->cfg_groups, e->g.nbricks)
-                                       : auto_groups(e, a.ntiles, e->g.nbricks, lds_blocks_per_cu);
+        groups_lds = e->cfg_groups > 0 ? std::min(e->cfg_groups, nbricks_now)
+                                       : auto_groups(e, a.ntiles, nbricks_now, lds_blocks_per_cu);
     if (use_direct) {
-        const int units = e->cfg_force_direct ? e->g.nbricks : e->n_wide;
+        const int units = e->cfg_force_direct ? nbricks_now : n_wide_now;
         groups_direct = e->cfg_groups > 0 ? std::min(e->cfg_groups, units)
                                           : auto_groups(e, a.ntiles, units, 2048 / threads);
     }
@@ -363,7 +601,13 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     rc = (volume || marginal)                                                                 \
              ? launch_stack_j<JJ, true>(e, a, groups_lds, groups_direct, use_lds, use_direct)  \
                 : launch_stack_j<JJ, false>(e, a, groups_lds, groups_direct, use_lds, use_direct)
-    switch (J) {
+    if (jp == 2)
+        rc = volume ? launch_pair_path<2, true>(e, a, groups_lds, groups_direct, use_lds, use_direct)
+                    : launch_pair_path<2, false>(e, a, groups_lds, groups_direct, use_lds, use_direct);
+    else if (jp == 1)
+        rc = volume ? launch_pair_path<1, true>(e, a, groups_lds, groups_direct, use_lds, use_direct)
+                    : launch_pair_path<1, false>(e, a, groups_lds, groups_direct, use_lds, use_direct);
+    else switch (J) {
         case 1: QM_LAUNCH(1); break;
         case 2: QM_LAUNCH(2); break;
         case 4: QM_LAUNCH(4); break;
@@ -839,6 +1083,8 @@ void qm_engine_destroy(qm_engine *e) {
     e->d_cells.release(); e->d_work.release(); e->d_flags.release(); e->d_srel.release(); e->d_on32.release();
     e->d_cell.release(); e->d_gmax.release(); e->d_pm.release(); e->d_rowmax.release(); e->d_ssum.release();
     e->d_cand_z.release(); e->d_cand_idx.release();
+    e->d_pmeta.release(); e->d_pmeta_raw.release(); e->d_ptotal.release(); e->d_pwide.release();
+    e->d_prel.release(); e->d_sink.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
     for (hipEvent_t ev : e->ev_log) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -895,6 +1141,11 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
         e->cfg_force_direct = v ? 1 : 0;
     } else if (k == "generic") {
         e->cfg_generic = v ? 1 : 0;
+    } else if (k == "exact") {
+        e->cfg_exact = v ? 1 : 0;
+    } else if (k == "pair") {
+        if (v < 0 || v > 2) return fail("pair must be 0 (off), 1 (automatic) or 2 (any scan length)");
+        e->cfg_pair = (int)v;
     } else if (k == "screen") {
         e->cfg_screen = v ? 1 : 0;
     } else if (k == "screen_pairs") {
@@ -942,6 +1193,9 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "screen_pairs") *v = e->last_plan_jp;
     else if (k == "screen_big") *v = e->last_plan_big;
     else if (k == "screen_brick_nodes") *v = e->sg.brick_nodes;
+    else if (k == "pair_brick_nodes") *v = e->pair_kt ? e->pg.brick_nodes : 0;
+    else if (k == "pair_wide_bricks") *v = e->pair_kt ? e->n_pwide : 0;
+    else if (k == "pair_tile") *v = e->pair_ok ? e->pair_kt : 0;
     else if (k == "n_bricks") *v = e->g.nbricks;
     else if (k == "n_wide_bricks") {
         if (e->have_lut) {
@@ -1036,6 +1290,7 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     e->node_offset = node_offset;
     e->plan_j = -1;
     e->screen_kt = 0;
+    e->pair_kt = 0;
     e->have_lut = true;
     return plan_wide(e, eff_j(e));
 }

@@ -62,6 +62,8 @@ struct StackArgs {
     int64_t n_nodes;
     const int32_t *run_if;         // if set: do nothing unless *run_if != 0 (device-side fallback
                                    // of a screened step, qm_screen.hpp)
+    double *sink;                  // >= 64 doubles nobody reads: where the lanes past the end of a
+                                   // ragged last tile put their volume values (qm_pair.hpp)
 };
 
 // max of two non-NaN-producing operands without the canonicalising copy clang adds to fmax()
@@ -397,32 +399,80 @@ __global__ __launch_bounds__(256) void serve_table_kernel(ServeArgs a) {
 // argument is a mean of log-onsets (|x| < ~50 for any finite input), far from overflow.
 //   z = stack * (log2(e)/available) = k + f, |f| <= 1/2;   coa = 2^z = 2^k * 2^f
 //   2^f = sum_i (f ln2)^i / i!  as a Horner polynomial, scaled with v_ldexp_f64.
-// Per node-sample (kExp2Degree = 10): truncation 0.3466^11/11! = 2.2e-13 relative -- this feeds
-// the volume and the sum behind max_norm_coa (contract: 1e-6).  The running maximum is tracked
-// on z itself (monotone in the stack), and the final peak 2^z_best is evaluated once per sample
-// with the degree-13 form (~1 ulp + the 1-ulp rounding of z).  The reference's own exp is glibc
-// libmvec (<= 4 ulp).
+// Per node-sample: a minimax polynomial (below) -- this feeds the volume and the sum behind
+// max_norm_coa (contract: 1e-6).  The running maximum is tracked on z itself (monotone in the
+// stack), and the final peak 2^z_best is evaluated once per sample with the degree-13 Taylor
+// form (~1 ulp + the 1-ulp rounding of z).  The reference's own exp is glibc libmvec (<= 4 ulp,
+// SURVEY 8c).
 // ---------------------------------------------------------------------------------------
 #define QM_LOG2E 1.4426950408889634074
-// polynomial degree of the per-node-sample 2^f: 10 when the value only feeds the sum behind
-// max_norm_coa (truncation 2.2e-13), 12 when it is stored in the volume (1.7e-16)
-template <bool VOLUME> struct Exp2Degree { static constexpr int value = VOLUME ? 12 : 10; };
+// Polynomial of the per-node-sample 2^f, |f| <= 1/2.  Coefficients: Remez minimax in relative
+// error (tools/exp2_minimax.py, 60-digit arithmetic, then rounded to float64; the bound is that
+// of the ROUNDED polynomial evaluated exactly; the D Horner roundings add <= D * 1.2e-16):
+//   degree  6: 1.86e-09     degree  7: 4.03e-11     degree  8: 7.75e-13
+//   degree  9: 1.36e-14     degree 10: 2.8e-16
+// Detect (the value only feeds the sum behind max_norm_coa; every term is positive, so the sum
+// inherits at most the terms' relative error): QM_EXP2_DEGREE_SUM, default 8 -- the accuracy of
+// the degree-10 Taylor form used before (2.2e-13 .. 7.8e-13), two multiply-adds cheaper.  Stored
+// in the volume: QM_EXP2_DEGREE_VOLUME, default 10 (the accuracy of a degree-12 Taylor form).
+#ifndef QM_EXP2_DEGREE_SUM
+#define QM_EXP2_DEGREE_SUM 8
+#endif
+#ifndef QM_EXP2_DEGREE_VOLUME
+#define QM_EXP2_DEGREE_VOLUME 10
+#endif
+template <bool VOLUME> struct Exp2Degree {
+    static constexpr int value = VOLUME ? QM_EXP2_DEGREE_VOLUME : QM_EXP2_DEGREE_SUM;
+};
 
-// coefficient of f^i in 2^f: ln2^i / i!
+// coefficient of f^i in the degree-D polynomial
+template <int D>
 __device__ __forceinline__ constexpr double exp2_coeff(int i) {
-    constexpr double c[14] = {1.0,
-                              0.6931471805599453,    0.24022650695910072,   0.05550410866482158,
-                              0.009618129107628477,  0.0013333558146428443, 0.0001540353039338161,
-                              1.5252733804059841e-05, 1.321548679014431e-06, 1.01780860092397e-07,
-                              7.054911620801123e-09, 4.4455382718708116e-10, 2.5678435993488206e-11,
-                              1.3691488853904128e-12};
-    return c[i];
+    static_assert((D >= 6 && D <= 10) || D == 13, "no coefficient set for this degree");
+    if constexpr (D == 6) {
+        constexpr double c[7] = {1.0000000005541665, 0.6931472057372681, 0.2402264689063409,
+                                 0.055503287769647254, 0.009618488957115071, 0.001339993121934089,
+                                 0.00015345812002903349};
+        return c[i];
+    } else if constexpr (D == 7) {
+        constexpr double c[8] = {0.999999999961682, 0.6931471807284456, 0.24022651198157205,
+                                 0.05550410353453057, 0.009618027253714257, 0.0013333922559115655,
+                                 0.00015469291129672317, 1.5201922643927036e-05};
+        return c[i];
+    } else if constexpr (D == 8) {
+        constexpr double c[9] = {0.9999999999997623, 0.6931471805465141, 0.24022650698880368,
+                                 0.05550410939341707, 0.00961812854286291, 0.0013333452062251631,
+                                 0.00015403851748367633, 1.5309737421285583e-05,
+                                 1.3175858190329987e-06};
+        return c[i];
+    } else if constexpr (D == 9) {
+        constexpr double c[10] = {1.0000000000000127, 0.693147180559871, 0.24022650695649653,
+                                  0.05550410866868561, 0.009618129192067245, 0.0013333557617604443,
+                                  0.0001540343494807179, 1.5252984838653427e-05,
+                                  1.3259405609345135e-06, 1.0150336705309649e-07};
+        return c[i];
+    } else if constexpr (D == 10) {
+        constexpr double c[11] = {1.0, 0.6931471805599497, 0.24022650695908768,
+                                  0.05550410866445883, 0.009618129108034596, 0.0013333558228561797,
+                                  0.0001540352996112841, 1.5252658116392011e-05,
+                                  1.3215662835262992e-06, 1.020853793302931e-07,
+                                  7.0372789704963916e-09};
+        return c[i];
+    } else {                                            // 13: Taylor, ln2^i / i! (the final peak)
+        constexpr double c[14] = {1.0,
+                                  0.6931471805599453,    0.24022650695910072,   0.05550410866482158,
+                                  0.009618129107628477,  0.0013333558146428443, 0.0001540353039338161,
+                                  1.5252733804059841e-05, 1.321548679014431e-06, 1.01780860092397e-07,
+                                  7.054911620801123e-09, 4.4455382718708116e-10, 2.5678435993488206e-11,
+                                  1.3691488853904128e-12};
+        return c[i];
+    }
 }
 
 // Horner step I of a degree-D polynomial: I = 0 starts with the two highest coefficients
 template <int D, int I>
 __device__ __forceinline__ double exp2_horner(double p, double f) {
-    return __builtin_fma(I == 0 ? exp2_coeff(D) : p, f, exp2_coeff(D - 1 - I));
+    return __builtin_fma(I == 0 ? exp2_coeff<D>(D) : p, f, exp2_coeff<D>(D - 1 - I));
 }
 
 template <int D, int I = 0>
@@ -662,6 +712,7 @@ struct Epilogue {              // node whose sums are complete but not yet expon
     double x[J], f[J], p[J];
     int k[J];
     int node;
+    double *row;               // volume row of the node + first sample of the tile (wave-uniform)
 };
 
 // steps: 0 z | 1 k | 2 f | 3..3+D-1 Horner | then ldexp | sum(+store) | track
@@ -943,6 +994,203 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
                 finish_node<J, VOLUME>(a, run, acc, node, t_first, lane);
             }
         }
+        run.merge_brick();
+    }
+    if (a.want_scan) publish<J>(a, run, win, wave, nwaves, lane, t_first, a.set0 + group);
+}
+
+// ---------------------------------------------------------------------------------------
+// Exact-row-count variant of the LDS-tiled kernel (the table's row count S is a template
+// parameter): the software pipeline of stack_full_chunks covers ALL rows of a node -- no
+// hand-off to the asm ring for the last partial chunk, hence no LDS queue drain in the middle of
+// a node and no register copies around an asm statement; the first row lands in the accumulators
+// directly (0.0 + x == x, so the reference's `+=` from a zeroed volume is reproduced bit for bit
+// without the add); the previous node's epilogue -- including, when VOLUME, its stores -- is
+// spread over the rows of the current node.  Same operands, same ascending row order per sample,
+// same partial sets as stack_lds_kernel: the two are interchangeable (tests run both).
+// ---------------------------------------------------------------------------------------
+__host__ __device__ constexpr int exact_nch(int S) { return (S + 7) / 8; }   // offset chunks per node
+template <int J, int S> struct ExactPlan {
+    static constexpr int RB = BatchRows<J>::value;          // table rows per batch
+    static constexpr int NB = (S + RB - 1) / RB;            // batches per node
+    static constexpr int NCH = exact_nch(S);
+};
+
+// steps of the pipelined epilogue: 0 k | 1 f | 2..D+1 Horner | ldexp | sum | track | (store)
+template <bool VOLUME> struct XEpiSteps {
+    static constexpr int value = 2 + Exp2Degree<VOLUME>::value + 3 + (VOLUME ? 1 : 0);
+};
+
+template <int J, bool VOLUME, int STEP>
+__device__ __forceinline__ void xepi_step(Epilogue<J> &s, Running<J> &run, const StackArgs &a,
+                                          int t_first, int lane) {
+    constexpr int D = Exp2Degree<VOLUME>::value;
+    constexpr int H0 = 2, H1 = 2 + D;                  // Horner steps [H0, H1)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        if constexpr (STEP == 0) s.p[j] = __builtin_rint(s.x[j]);      // k (as double)
+        else if constexpr (STEP == 1) {
+            s.f[j] = s.x[j] - s.p[j];                                  // f = z - k
+            s.k[j] = (int)s.p[j];
+        } else if constexpr (STEP >= H0 && STEP < H1)
+            s.p[j] = exp2_horner<D, STEP - H0>(s.p[j], s.f[j]);
+        else if constexpr (STEP == H1) s.p[j] = __builtin_amdgcn_ldexp(s.p[j], s.k[j]);
+        else if constexpr (STEP == H1 + 1) run.vsum[j] += s.p[j];
+        else if constexpr (STEP == H1 + 2) {
+            const bool gt = s.x[j] > run.bmax[j];                      // strict: first node wins
+            run.bidx[j] = gt ? s.node : run.bidx[j];
+            run.bmax[j] = max_keep(run.bmax[j], s.x[j]);
+        } else if constexpr (VOLUME && STEP == H1 + 3) {
+            // the stores come last: every offset load of the node being stacked has been issued
+            // by now, so no later wait on such a load has to sit out these stores as well (loads
+            // and stores share one in-order counter on gfx9)
+            // (s.row is wave-uniform: scalar base + 32-bit lane offset, no 64-bit VGPR math)
+            const int u = lane + kWave * j;
+            if (t_first + u < a.n_chunk) __builtin_nontemporal_store(s.p[j], s.row + u);
+        }
+    }
+}
+
+template <int J, bool VOLUME, int FIRST, int LAST>
+__device__ __forceinline__ void xepi_steps(Epilogue<J> &s, Running<J> &run, const StackArgs &a,
+                                           int t_first, int lane) {
+    if constexpr (FIRST < LAST) {
+        xepi_step<J, VOLUME, FIRST>(s, run, a, t_first, lane);
+        xepi_steps<J, VOLUME, FIRST + 1, LAST>(s, run, a, t_first, lane);
+    }
+}
+
+// issue the LDS reads of batch I (rows I*RB ..) of the node whose offsets are in q; a chunk of
+// q is refilled with the NEXT node's offsets as soon as its last row has been issued
+template <int J, int S, int I>
+__device__ __forceinline__ void xissue(double (&buf)[BatchRows<J>::value * J],
+                                       uint4 (&q)[exact_nch(S)], const uint16_t *next,
+                                       unsigned lane_addr) {
+    constexpr int KT = kWave * J;
+    constexpr int RB = ExactPlan<J, S>::RB;
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int r = I * RB + k;                      // compile-time after unrolling
+        if (r < S) {
+            const int ci = r >> 3, e = r & 7;
+            const volatile lds_f64 *p = (const volatile lds_f64 *)(uintptr_t)(
+                lane_addr + (unsigned)(ci * 8 * KT * 8) + chunk_entry(q[ci], e));
+#pragma unroll
+            for (int j = 0; j < J; ++j) buf[k * J + j] = p[e * KT + kWave * j];
+            if (e == 7 || r == S - 1) q[ci] = load_offsets(next, ci * 8);
+        }
+    }
+}
+
+template <int J, int S, int I>
+__device__ __forceinline__ void xretire(double (&acc)[J],
+                                        const double (&buf)[BatchRows<J>::value * J]) {
+    constexpr int RB = ExactPlan<J, S>::RB;
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {                     // ascending row order per sample
+        const int r = I * RB + k;
+        if (r < S) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                if (r == 0) acc[j] = buf[k * J + j];   // 0.0 + x, without the add
+                else acc[j] += buf[k * J + j];
+            }
+        }
+    }
+}
+
+template <int J, bool VOLUME, int S, bool WITH_EPI, int I>
+__device__ __forceinline__ void xbatch(double (&acc)[J],
+                                       double (&even)[BatchRows<J>::value * J],
+                                       double (&odd)[BatchRows<J>::value * J],
+                                       uint4 (&q)[exact_nch(S)], const uint16_t *next,
+                                       unsigned lane_addr, Epilogue<J> &epi, Running<J> &run,
+                                       const StackArgs &a, int t_first, int lane) {
+    constexpr int NB = ExactPlan<J, S>::NB;
+    if constexpr (I < NB) {
+        if constexpr (I + 1 < NB) xissue<J, S, I + 1>((I & 1) ? even : odd, q, next, lane_addr);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WITH_EPI) {
+            constexpr int E = XEpiSteps<VOLUME>::value;
+            xepi_steps<J, VOLUME, I * E / NB, (I + 1) * E / NB>(epi, run, a, t_first, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        xretire<J, S, I>(acc, (I & 1) ? odd : even);
+        __builtin_amdgcn_sched_barrier(0);
+        xbatch<J, VOLUME, S, WITH_EPI, I + 1>(acc, even, odd, q, next, lane_addr, epi, run, a,
+                                              t_first, lane);
+    }
+}
+
+template <int J, bool VOLUME, int S>
+__global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    constexpr int KT = kWave * J;
+    constexpr int NCH = ExactPlan<J, S>::NCH;
+    constexpr int RB = ExactPlan<J, S>::RB;
+    const GridDesc &g = a.g;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    // XCD-aware workgroup -> (time tile, brick group) map, as stack_lds_kernel
+    const int slot = blockIdx.x >> 3;
+    const int tile = slot % a.ntiles;
+    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    if (group >= a.ngroups) return;
+    if (a.run_if != nullptr && *a.run_if == 0) return;
+    const int t_first = tile * KT;
+    const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 8u;
+
+    Running<J> run;
+    run.reset();
+
+    for (int b = group; b < g.nbricks; b += a.ngroups) {
+        if (!brick_fits(a.brick_total[b], S, KT, a.cap_doubles)) continue;   // direct kernel's job
+        __syncthreads();                              // previous brick fully consumed
+        stage_windows<J>(a, win, b, wave, nwaves, lane, t_first);
+        __syncthreads();
+
+        int x0, y0, z0, vx, vy, vz;
+        brick_extents(g, b, x0, y0, z0, vx, vy, vz);
+        const int nvalid = vx * vy * vz;
+        int lz = wave % vz, ly = (wave / vz) % vy, lx = wave / (vz * vy);
+        const uint16_t *brick_rel = a.rel + (int64_t)b * g.brick_nodes * g.row_pad;
+
+        uint4 q[NCH];                                  // offsets of the node about to be stacked
+        {
+            const uint16_t *p = brick_rel + (int64_t)(wave < nvalid ? wave : 0) * g.row_pad;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) q[c] = load_offsets(p, c * 8);
+        }
+        Epilogue<J> epi;
+        bool pending = false;                          // wave-uniform: epi holds a node
+        for (int m = wave; m < nvalid; m += nwaves) {
+            const int node = ((x0 + lx) * g.ny + (y0 + ly)) * g.nz + (z0 + lz);
+            lz += nwaves;
+            while (lz >= vz) { lz -= vz; ++ly; }
+            while (ly >= vy) { ly -= vy; ++lx; }
+            // the node after this one (or a harmless reload of this one at the end)
+            const uint16_t *next =
+                brick_rel + (int64_t)(m + nwaves < nvalid ? m + nwaves : m) * g.row_pad;
+
+            double acc[J], even[RB * J], odd[RB * J];
+            xissue<J, S, 0>(even, q, next, lane_addr);
+            if (pending)
+                xbatch<J, VOLUME, S, true, 0>(acc, even, odd, q, next, lane_addr, epi, run, a,
+                                              t_first, lane);
+            else
+                xbatch<J, VOLUME, S, false, 0>(acc, even, odd, q, next, lane_addr, epi, run, a,
+                                               t_first, lane);
+#pragma unroll
+            for (int j = 0; j < J; ++j) epi.x[j] = acc[j] * a.z_scale;   // z: log2 of the coalescence
+            epi.node = node;
+            if (VOLUME) epi.row = a.volume + ((int64_t)node * a.vol_stride + t_first);
+            pending = true;
+        }
+        if (pending)                                   // the brick's last node: not overlapped
+            xepi_steps<J, VOLUME, 0, XEpiSteps<VOLUME>::value>(epi, run, a, t_first, lane);
         run.merge_brick();
     }
     if (a.want_scan) publish<J>(a, run, win, wave, nwaves, lane, t_first, a.set0 + group);
