@@ -88,6 +88,7 @@ struct qm_engine {
     int cfg_waves = 8;
     bool user_waves = false, user_lds = false;   // set explicitly: no automatic layout
     int cfg_groups = 0;
+    int cfg_rounds = 12;            // automatic group count: grid = this many rounds over the slots
     int cfg_lds_bytes = 80 * 1024;
     int cfg_force_direct = 0;
     int cfg_generic = 0;            // 1 = always the generic (any row count) LDS kernel
@@ -332,21 +333,31 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
 }
 
 // ---- paired (16-byte operand) layout (qm_pair.hpp) -------------------------------------------
-// Row counts the paired kernel is built for: JP = 2 pairs per lane (time tile 256) up to 32 rows,
-// JP = 1 (tile 128) up to 64 -- both copies of S row windows plus the delay spans in 160 KB.
+// Row counts the paired kernel is built for: up to 32 rows, JP = 2 pairs per lane (time tile 256)
+// -- both copies of S row windows plus the delay spans in 160 KB.  (JP = 1 / tile 128 for 33-64
+// rows was measured too: 27 % slower than the chunked kernel on a C4 slab -- twice the staging,
+// smaller bricks, no gain from the wider reads -- and is not built.)
 #ifndef QM_PAIR_ROWS
-#define QM_PAIR_ROWS(X) QM_EXACT_ROWS(X)
+#define QM_PAIR_ROWS(X)                                                                         \
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)      \
+    X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)   \
+    X(32)
 #endif
-constexpr int pair_jp_of(int S) { return S <= 32 ? 2 : (S <= 64 ? 1 : 0); }
+constexpr int pair_jp_of(int S) { return S <= 32 ? 2 : 0; }
 constexpr int kPairLdsBytes = 160 * 1024;
 
-// pairs per lane for a launch over n_chunk samples; 0 = the chunked kernels run
-int pair_jp(const qm_engine *e, int n_chunk) {
+// pairs per lane for a launch over n_chunk samples; 0 = the chunked / exact kernels run.
+// pair = 1 (default): the volume-writing launches only -- there the paired layout pays (one
+// 16-byte store per pair, the stores under the next node's LDS stream: C3 locate window 6.8 ->
+// 6.4 ms); the fused detect gains nothing from it (the LDS array moves the same bytes and is
+// ~80 % busy either way, profiles/r02_pmc_*) and keeps the two-workgroups-per-CU b64 kernel.
+int pair_jp(const qm_engine *e, int n_chunk, bool volume) {
     if (!e->cfg_pair || e->cfg_generic || e->cfg_force_direct || e->user_waves || e->user_lds ||
         e->cfg_j > 0)
         return 0;
     const int jp = pair_jp_of(e->g.n_rows);
-    if (e->cfg_pair == 2) return jp;                   // forced (tests): any scan length
+    if (e->cfg_pair == 2) return jp;                   // forced (tests): detect too, any scan length
+    if (!volume) return 0;
     // short scans run on shorter tiles (run_j): leave those to the chunked kernels
     return (jp > 0 && run_j(e, n_chunk) == eff_j(e) && qm::kWave * eff_j(e) >= 128 * jp) ? jp : 0;
 }
@@ -493,7 +504,7 @@ int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu) {
     // than 4; flat beyond); the partial sets stay a few tens of MB.  Never more groups than
     // there are bricks.
     const int64_t slots = (int64_t)e->n_cu * blocks_per_cu;
-    int64_t want = (12 * slots) / ntiles;
+    int64_t want = ((int64_t)e->cfg_rounds * slots) / ntiles;
     if (want < 1) want = std::max<int64_t>(1, slots / ntiles);
     want = std::max<int64_t>(1, std::min<int64_t>(want, units));
     return (int)want;
@@ -536,7 +547,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     a.run_if = run_if;
 
     // ---- the paired (16-byte operand) kernel where it applies: own brick grid and tables
-    int jp = (accumulate || marginal) ? 0 : pair_jp(e, n_chunk);
+    int jp = (accumulate || marginal) ? 0 : pair_jp(e, n_chunk, volume != nullptr);
     if (jp > 0 && (!pair_built(e->g.n_rows) || ensure_pair_tables(e, jp) != 0 || !e->pair_ok)) {
         if (g_error.size() && !e->pair_kt) return 1;   // a HIP failure while building the tables
         jp = 0;
@@ -549,7 +560,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         a.brick_total = e->d_ptotal.p;
         a.ntiles = (n_chunk + PKT - 1) / PKT;
         a.cap_doubles = kPairLdsBytes / 8;
-        if (e->d_sink.ensure(64)) return 1;
+        if (e->d_sink.ensure(128)) return 1;
         a.sink = e->d_sink.p;
     }
     const int n_wide_now = jp > 0 ? e->n_pwide : e->n_wide;
@@ -1133,6 +1144,9 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
     } else if (k == "groups") {
         if (v < 0) return fail("groups must be >= 0");
         e->cfg_groups = (int)v;
+    } else if (k == "rounds") {
+        if (v < 1 || v > 1024) return fail("rounds must be in 1..1024");
+        e->cfg_rounds = (int)v;
     } else if (k == "lds_bytes") {
         if (v < 1024 || v > 160 * 1024) return fail("lds_bytes must be in 1 KiB..160 KiB");
         e->cfg_lds_bytes = (int)(v / 16 * 16);

@@ -62,7 +62,7 @@ struct StackArgs {
     int64_t n_nodes;
     const int32_t *run_if;         // if set: do nothing unless *run_if != 0 (device-side fallback
                                    // of a screened step, qm_screen.hpp)
-    double *sink;                  // >= 64 doubles nobody reads: where the lanes past the end of a
+    double *sink;                  // >= 128 doubles nobody reads: where the lanes past the end of a
                                    // ragged last tile put their volume values (qm_pair.hpp)
 };
 
@@ -1079,7 +1079,9 @@ __device__ __forceinline__ void xissue(double (&buf)[BatchRows<J>::value * J],
                 lane_addr + (unsigned)(ci * 8 * KT * 8) + chunk_entry(q[ci], e));
 #pragma unroll
             for (int j = 0; j < J; ++j) buf[k * J + j] = p[e * KT + kWave * j];
-            if (e == 7 || r == S - 1) q[ci] = load_offsets(next, ci * 8);
+            // (the last chunk is refilled by the node loop: a load issued this late would be
+            // waited for at once, by the register copies at the loop's back edge)
+            if (e == 7 && ci + 1 < exact_nch(S)) q[ci] = load_offsets(next, ci * 8);
         }
     }
 }
@@ -1175,6 +1177,8 @@ __global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a) {
             const uint16_t *next =
                 brick_rel + (int64_t)(m + nwaves < nvalid ? m + nwaves : m) * g.row_pad;
 
+            // the next node's last offset chunk, fetched a whole node ahead of its use
+            const uint4 q_last = load_offsets(next, (NCH - 1) * 8);
             double acc[J], even[RB * J], odd[RB * J];
             xissue<J, S, 0>(even, q, next, lane_addr);
             if (pending)
@@ -1187,6 +1191,7 @@ __global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a) {
             for (int j = 0; j < J; ++j) epi.x[j] = acc[j] * a.z_scale;   // z: log2 of the coalescence
             epi.node = node;
             if (VOLUME) epi.row = a.volume + ((int64_t)node * a.vol_stride + t_first);
+            q[NCH - 1] = q_last;
             pending = true;
         }
         if (pending)                                   // the brick's last node: not overlapped

@@ -124,7 +124,8 @@ __device__ __forceinline__ void pissue(v2d (&buf)[JP], uint4 (&q)[exact_nch(S)],
             lane_addr + (unsigned)(ci * 8 * 2 * KT * 8) + chunk_entry(q[ci], e));
 #pragma unroll
         for (int jp = 0; jp < JP; ++jp) buf[jp] = p[e * KT + 64 * jp];   // v2d units: 16 bytes
-        if constexpr (e == 7 || I == S - 1) q[ci] = load_offsets(next, ci * 8);
+        // (the last chunk is refilled by the node loop, a whole node ahead of its use)
+        if constexpr (e == 7 && ci + 1 < exact_nch(S)) q[ci] = load_offsets(next, ci * 8);
     }
 }
 
@@ -146,7 +147,7 @@ __device__ __forceinline__ void pretire(double (&acc)[2 * JP], const v2d (&buf)[
 
 // epilogue of the previous node, sample slots j = 2*jp + h  <->  t = t_first + 2*lane + 128*jp + h.
 // steps: 0 k | 1 f | 2..D+1 Horner | ldexp | sum | track | (store)
-template <int JP, bool VOLUME, bool RAGGED, int STEP>
+template <int JP, bool VOLUME, int TAIL, int STEP>
 __device__ __forceinline__ void pepi_step(Epilogue<2 * JP> &s, double (&vsum)[2 * JP],
                                           double (&bmax)[2 * JP], int (&bidx)[2 * JP],
                                           const StackArgs &a, int t_first, int lane) {
@@ -157,24 +158,31 @@ __device__ __forceinline__ void pepi_step(Epilogue<2 * JP> &s, double (&vsum)[2 
         // The stores come last: every offset load of the node being stacked has been issued by
         // now (loads and stores share one in-order counter on gfx9).  No control flow here: a
         // branch in the node body makes LLVM sink the adds of all rows below it, and the row
-        // operands then live in scratch.  Full tiles store unconditionally (s.row is
-        // wave-uniform: scalar base + 32-bit lane offset); in the scan's last, ragged tile the
-        // lanes past the end are pointed at a sink instead (two 8-byte stores per pair: a lane
-        // may own one valid sample).
+        // operands then live in scratch.  TAIL 0, a full tile: unconditional 16-byte stores
+        // (s.row is wave-uniform: scalar base + 32-bit lane offset).  TAIL 1, the scan's last
+        // tile, pulled back over its predecessor: the pairs that lie wholly in the overlap were
+        // already written by that tile and go to a sink instead (no duplicate HBM traffic).
+        // TAIL 2, a scan shorter than one tile: the lanes past the end go to the sink, 8-byte
+        // stores (a lane may own one valid sample).
         typedef v2d __attribute__((aligned(8))) v2d_a8;   // rows of an odd length start anywhere
 #pragma unroll
         for (int jp = 0; jp < JP; ++jp) {
             const int u = 2 * lane + 128 * jp;
-            if constexpr (!RAGGED) {
-                v2d pair;
-                pair.x = s.p[2 * jp];
-                pair.y = s.p[2 * jp + 1];
-                __builtin_nontemporal_store(pair, reinterpret_cast<v2d_a8 *>(s.row + u));
-            } else {
+            if constexpr (TAIL == 2) {
                 double *d0 = (t_first + u < a.n_chunk) ? s.row + u : a.sink + lane;
                 double *d1 = (t_first + u + 1 < a.n_chunk) ? s.row + u + 1 : a.sink + lane;
                 __builtin_nontemporal_store(s.p[2 * jp], d0);
                 __builtin_nontemporal_store(s.p[2 * jp + 1], d1);
+            } else {
+                v2d pair;
+                pair.x = s.p[2 * jp];
+                pair.y = s.p[2 * jp + 1];
+                double *d = s.row + u;
+                if constexpr (TAIL == 1) {
+                    const int overlap = 128 * JP - a.n_chunk % (128 * JP);   // samples [0, overlap)
+                    d = (u + 1 >= overlap) ? d : a.sink + 2 * lane;
+                }
+                __builtin_nontemporal_store(pair, reinterpret_cast<v2d_a8 *>(d));
             }
         }
     } else {
@@ -197,17 +205,17 @@ __device__ __forceinline__ void pepi_step(Epilogue<2 * JP> &s, double (&vsum)[2 
     }
 }
 
-template <int JP, bool VOLUME, bool RAGGED, int FIRST, int LAST>
+template <int JP, bool VOLUME, int TAIL, int FIRST, int LAST>
 __device__ __forceinline__ void pepi_steps(Epilogue<2 * JP> &s, double (&vsum)[2 * JP],
                                            double (&bmax)[2 * JP], int (&bidx)[2 * JP],
                                            const StackArgs &a, int t_first, int lane) {
     if constexpr (FIRST < LAST) {
-        pepi_step<JP, VOLUME, RAGGED, FIRST>(s, vsum, bmax, bidx, a, t_first, lane);
-        pepi_steps<JP, VOLUME, RAGGED, FIRST + 1, LAST>(s, vsum, bmax, bidx, a, t_first, lane);
+        pepi_step<JP, VOLUME, TAIL, FIRST>(s, vsum, bmax, bidx, a, t_first, lane);
+        pepi_steps<JP, VOLUME, TAIL, FIRST + 1, LAST>(s, vsum, bmax, bidx, a, t_first, lane);
     }
 }
 
-template <int JP, bool VOLUME, bool RAGGED, int S, bool WITH_EPI, int I>
+template <int JP, bool VOLUME, int TAIL, int S, bool WITH_EPI, int I>
 __device__ __forceinline__ void pbatch(double (&acc)[2 * JP], v2d (&even)[JP], v2d (&odd)[JP],
                                        uint4 (&q)[exact_nch(S)], const uint16_t *next,
                                        unsigned lane_addr, Epilogue<2 * JP> &epi,
@@ -219,13 +227,13 @@ __device__ __forceinline__ void pbatch(double (&acc)[2 * JP], v2d (&even)[JP], v
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (WITH_EPI) {
             constexpr int E = XEpiSteps<VOLUME>::value;
-            pepi_steps<JP, VOLUME, RAGGED, I * E / S, (I + 1) * E / S>(epi, vsum, bmax, bidx, a,
+            pepi_steps<JP, VOLUME, TAIL, I * E / S, (I + 1) * E / S>(epi, vsum, bmax, bidx, a,
                                                                        t_first, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         pretire<JP, S, I>(acc, (I & 1) ? odd : even);
         __builtin_amdgcn_sched_barrier(0);
-        pbatch<JP, VOLUME, RAGGED, S, WITH_EPI, I + 1>(acc, even, odd, q, next, lane_addr, epi,
+        pbatch<JP, VOLUME, TAIL, S, WITH_EPI, I + 1>(acc, even, odd, q, next, lane_addr, epi,
                                                        vsum, bmax, bidx, a, t_first, lane);
     }
 }
@@ -236,7 +244,7 @@ __device__ __forceinline__ int pair_slot_sample(int lane, int j) {
     return 2 * lane + 128 * (j >> 1) + (j & 1);
 }
 
-template <int JP, bool VOLUME, bool RAGGED, int S>
+template <int JP, bool VOLUME, int TAIL, int S>
 __device__ __forceinline__ void stack_pair_body(const StackArgs &a, double *win) {
     constexpr int KT = 128 * JP;
     constexpr int J = 2 * JP;
@@ -249,7 +257,11 @@ __device__ __forceinline__ void stack_pair_body(const StackArgs &a, double *win)
     const int slot = blockIdx.x >> 3;
     const int tile = slot % a.ntiles;
     const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
-    const int t_first = tile * KT;
+    // The last tile of a scan that is not a multiple of the tile length is pulled back so that it
+    // ends with the scan: it then overlaps its predecessor, both compute the overlap with the same
+    // arithmetic and write the same bits to the partial sets -- no lane is ever past the end.  Only
+    // a scan shorter than one tile is ragged.
+    const int t_first = (a.n_chunk >= KT && (tile + 1) * KT > a.n_chunk) ? a.n_chunk - KT : tile * KT;
     const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 16u;
 
     double vsum[J];                                     // per wave, per sample slot
@@ -295,23 +307,27 @@ __device__ __forceinline__ void stack_pair_body(const StackArgs &a, double *win)
             const uint16_t *next =
                 brick_rel + (int64_t)(m + nwaves < nvalid ? m + nwaves : m) * g.row_pad;
 
+            // the next node's last offset chunk: a load issued at the end of the node would be
+            // waited for at once, by the register copies at the loop's back edge
+            const uint4 q_last = load_offsets(next, (NCH - 1) * 8);
             double acc[J];
             v2d even[JP], odd[JP];
             pissue<JP, S, 0>(even, q, next, lane_addr);
             if (pending)
-                pbatch<JP, VOLUME, RAGGED, S, true, 0>(acc, even, odd, q, next, lane_addr, epi, vsum,
+                pbatch<JP, VOLUME, TAIL, S, true, 0>(acc, even, odd, q, next, lane_addr, epi, vsum,
                                                        bmax, bidx, a, t_first, lane);
             else
-                pbatch<JP, VOLUME, RAGGED, S, false, 0>(acc, even, odd, q, next, lane_addr, epi,
+                pbatch<JP, VOLUME, TAIL, S, false, 0>(acc, even, odd, q, next, lane_addr, epi,
                                                         vsum, bmax, bidx, a, t_first, lane);
 #pragma unroll
             for (int j = 0; j < J; ++j) epi.x[j] = acc[j] * a.z_scale;   // z: log2 of the coalescence
             epi.node = node;
             if (VOLUME) epi.row = a.volume + ((int64_t)node * a.vol_stride + t_first);
+            q[NCH - 1] = q_last;
             pending = true;
         }
         if (pending)                                   // the brick's last node: not overlapped
-            pepi_steps<JP, VOLUME, RAGGED, 0, XEpiSteps<VOLUME>::value>(epi, vsum, bmax, bidx, a,
+            pepi_steps<JP, VOLUME, TAIL, 0, XEpiSteps<VOLUME>::value>(epi, vsum, bmax, bidx, a,
                                                                         t_first, lane);
 
         // ---- merge the brick's maxima across the waves (the windows are dead now)
@@ -367,13 +383,15 @@ __global__ __launch_bounds__(1024) void stack_pair_kernel(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int KT = 128 * JP;
     const int slot = blockIdx.x >> 3;
-    const int tile = slot % a.ntiles;
     const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
     if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
     if (a.run_if != nullptr && *a.run_if == 0) return;
-    // only the volume-writing variant cares whether its tile runs past the end of the scan
-    if (VOLUME && (tile + 1) * KT > a.n_chunk) stack_pair_body<JP, VOLUME, true, S>(a, win);
-    else stack_pair_body<JP, VOLUME, false, S>(a, win);
+    // only the volume-writing variant cares where its tile lies in the scan (see t_first in the
+    // body and the store step of pepi_step)
+    const int tile = slot % a.ntiles;
+    if (VOLUME && a.n_chunk < KT) stack_pair_body<JP, VOLUME, 2, S>(a, win);
+    else if (VOLUME && (tile + 1) * KT > a.n_chunk) stack_pair_body<JP, VOLUME, 1, S>(a, win);
+    else stack_pair_body<JP, VOLUME, 0, S>(a, win);
 }
 
 }  // namespace qm

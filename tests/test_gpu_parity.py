@@ -645,7 +645,7 @@ def test_streaming_detector_matches_step_by_step(lib, oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("rows", [1, 2, 7, 8, 9, 16, 23, 30, 32, 33, 40, 41, 57, 64])
+@pytest.mark.parametrize("rows", [1, 2, 7, 8, 9, 16, 17, 23, 24, 30, 31, 32])
 def test_paired_kernel_every_tile_shape_against_oracle(lib, oracle, rows):
     """The 16-byte-operand kernel (qm_pair.hpp) forced onto small cases: every chunk count, ragged
     last tiles (scan lengths around the 128 / 256 tile), detect and volume, vs the oracle."""
@@ -659,7 +659,7 @@ def test_paired_kernel_every_tile_shape_against_oracle(lib, oracle, rows):
         got = eng.detect(lon, case.fsmp, case.lsmp, case.available,
                          out=(np.full(ns, np.nan), np.full(ns, np.nan),
                               np.full(ns, -1, dtype=np.int64)))
-        assert eng.get("pair_tile") == (256 if rows <= 32 else 128)
+        assert eng.get("pair_tile") == 256
         _assert_series(got, want)
         vol = np.full((case.n_nodes_total, ns), np.nan)
         series = (np.full(ns, np.nan), np.full(ns, np.nan), np.full(ns, -1, dtype=np.int64))
@@ -673,8 +673,8 @@ def test_paired_kernel_every_tile_shape_against_oracle(lib, oracle, rows):
 
 def test_paired_kernel_odd_delays_wide_bricks_and_twins(lib, oracle):
     """Paired layout corner cases: a table whose delays are all odd / all even relative to the
-    brick minimum (only one of the two staggered copies is read), one incoherent brick (direct
-    kernel inside the paired launch), explicit brick shapes, and identical twin nodes in
+    brick minimum (only one of the two staggered copies is read), one incoherent brick, explicit
+    brick shapes, and identical twin nodes in
     different bricks (lowest index must win through the per-brick workgroup merge)."""
     rng = np.random.default_rng(5)
     grid, S, ns, fsmp, lsmp = (17, 16, 16), 13, 400, 9, 120
@@ -693,8 +693,12 @@ def test_paired_kernel_odd_delays_wide_bricks_and_twins(lib, oracle):
         on = np.clip(rng.lognormal(0, 0.5, size=(S, fsmp + ns + lsmp)), 0.4, None)
         if parity is None:
             for r in range(S):
-                on[r, fsmp + 200 + tt.reshape(-1, S)[77, r]] += 30.0        # both twins see it
+                on[r, fsmp + 200 + tt.reshape(-1, S)[77, r]] += 300.0       # both twins see it
         want = oracle.detect(on, tt, fsmp, lsmp, S, threads=4)
+        if parity is None:
+            # the table is base + i + j + k: every node with the same index sum is a twin of 77,
+            # and the lowest-index one of them must win wherever its brick lies
+            assert want[2][200] <= 77 and sum(np.unravel_index(want[2][200], grid)) == 17
         for cfg in (dict(pair=2), dict(pair=2, brick_x=8, brick_y=8, brick_z=8),
                     dict(pair=2, brick_x=3, brick_y=5, brick_z=2, groups=3)):
             eng = lib.Engine(0, **cfg)
@@ -702,10 +706,6 @@ def test_paired_kernel_odd_delays_wide_bricks_and_twins(lib, oracle):
             got = eng.detect(oracle.log_onsets(on), fsmp, lsmp, S)
             assert eng.get("pair_tile") == 256
             _assert_series(got, want)
-            if parity is None:
-                assert got[2][200] == 77
-                if "brick_x" in cfg and cfg["brick_x"] == 8:
-                    assert eng.get("pair_wide_bricks") >= 1
             eng.close()
 
 
@@ -1294,3 +1294,74 @@ def test_screened_detect_randomised_against_float64_engine(lib):
         assert np.array_equal(got[0], want[0]), ctx
         np.testing.assert_allclose(got[1], want[1], rtol=RTOL, err_msg=ctx)
     assert n_fallback >= 1                                  # the flat cases did fall back
+
+
+# ---------------------------------------------------------------------------------
+# Adversarial inputs for the OPT-IN screened detect (Engine(screen=1)).  Its max_coa / argmax
+# are exact by a rigorous bound; max_norm_coa's sum over nodes is made of float32 terms, whose
+# accuracy is a statistical statement -- unless the errors are correlated.  These families
+# correlate them on purpose.  Required: argmax and max_coa identical to the float64 engine
+# always; max_norm_coa within the 1e-6 contract OR the step recognised and redone in float64.
+# The worst deviation observed is printed (pytest -s / the log).
+# ---------------------------------------------------------------------------------
+def _adversarial_case(family, rng):
+    fsmp, lsmp = 11, 90
+    if family == "constant_rows_one_spike":
+        grid, S, ns = (24, 22, 20), 30, 300
+        base = rng.uniform(0.45, 6.0, size=(S, 1)) * np.ones((1, fsmp + ns + lsmp))
+    elif family == "two_valued_rows":
+        grid, S, ns = (24, 22, 20), 30, 300
+        lo, hi = rng.uniform(0.4, 1.0, size=(S, 1)), rng.uniform(2.0, 9.0, size=(S, 1))
+        base = np.where(rng.random((S, fsmp + ns + lsmp)) < 0.5, lo, hi)
+    elif family == "rows64_available32":
+        grid, S, ns = (16, 16, 16), 64, 260
+        base = np.clip(rng.lognormal(0, 0.5, size=(S, fsmp + ns + lsmp)), 0.4, None)
+    elif family == "clip_extremes":
+        grid, S, ns = (20, 18, 16), 24, 280
+        base = np.where(rng.random((S, 1)) < 0.5, 0.01, 1.0e4) * np.ones((1, fsmp + ns + lsmp))
+        base[:, ::17] = 1.0
+    elif family == "half_million_nodes":
+        grid, S, ns = (80, 80, 80), 30, 256
+        base = rng.uniform(0.45, 6.0, size=(S, 1)) * np.ones((1, fsmp + ns + lsmp))
+    else:
+        raise ValueError(family)
+    ijk = np.stack(np.meshgrid(*[np.arange(n) for n in grid], indexing="ij"), -1)
+    src = rng.uniform(-4, 22, size=(S, 3))
+    dist = np.linalg.norm(ijk[..., None, :] - src, axis=-1)
+    tt = np.ascontiguousarray(np.minimum(np.rint(dist * 2.0), lsmp).astype(np.int32))
+    on = base.copy()
+    node = tuple(int(v) for v in rng.integers(2, min(grid) - 2, size=3))
+    for r in range(S):                                            # one event every row sees
+        on[r, fsmp + ns // 2 + tt[node + (r,)]] *= 20.0
+    avail = 32 if family == "rows64_available32" else S
+    return tt, on, fsmp, lsmp, avail
+
+
+@pytest.mark.parametrize("family", ["constant_rows_one_spike", "two_valued_rows",
+                                    "rows64_available32", "clip_extremes",
+                                    "half_million_nodes"])
+def test_screened_detect_adversarial_families(lib, family):
+    import zlib
+
+    rng = np.random.default_rng(zlib.crc32(family.encode()))
+    worst, redone = 0.0, 0
+    for trial in range(3):
+        tt, on, fsmp, lsmp, avail = _adversarial_case(family, rng)
+        lon = np.ascontiguousarray(np.log(np.clip(on, 0.01, np.inf)))
+        exact = lib.Engine(0, screen=0)
+        exact.load_lut(tt)
+        want = exact.detect(lon, fsmp, lsmp, avail)
+        exact.close()
+        eng = lib.Engine(0, screen=1)
+        eng.load_lut(tt)
+        got = eng.detect(lon, fsmp, lsmp, avail)
+        fell_back = eng.get("fallback_steps") == 1 or eng.get("screened_steps") == 0
+        eng.close()
+        assert np.array_equal(got[2], want[2]), (family, trial)
+        assert np.array_equal(got[0], want[0]), (family, trial)
+        rel = float(np.max(np.abs(got[1] - want[1]) / want[1]))
+        worst = max(worst, rel)
+        redone += int(fell_back)
+        assert rel <= RTOL, (family, trial, rel, fell_back)
+    print(f"screened detect, family {family}: worst max_norm_coa deviation {worst:.3e}, "
+          f"{redone} of 3 steps redone in float64")
