@@ -132,7 +132,6 @@ struct qm_engine {
     qm::GridDesc pg{};
     DevBuf<int32_t> d_pmeta, d_pmeta_raw, d_ptotal, d_pwide;
     DevBuf<uint16_t> d_prel;
-    DevBuf<double> d_sink;
     int n_pwide = 0;
     int pair_kt = 0;                        // tile length the paired tables were built for
     bool pair_ok = false;                   // ... and whether (almost) every brick fits
@@ -560,8 +559,6 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         a.brick_total = e->d_ptotal.p;
         a.ntiles = (n_chunk + PKT - 1) / PKT;
         a.cap_doubles = kPairLdsBytes / 8;
-        if (e->d_sink.ensure(128)) return 1;
-        a.sink = e->d_sink.p;
     }
     const int n_wide_now = jp > 0 ? e->n_pwide : e->n_wide;
     const int nbricks_now = jp > 0 ? e->pg.nbricks : e->g.nbricks;
@@ -1095,7 +1092,7 @@ void qm_engine_destroy(qm_engine *e) {
     e->d_cell.release(); e->d_gmax.release(); e->d_pm.release(); e->d_rowmax.release(); e->d_ssum.release();
     e->d_cand_z.release(); e->d_cand_idx.release();
     e->d_pmeta.release(); e->d_pmeta_raw.release(); e->d_ptotal.release(); e->d_pwide.release();
-    e->d_prel.release(); e->d_sink.release();
+    e->d_prel.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
     for (hipEvent_t ev : e->ev_log) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);

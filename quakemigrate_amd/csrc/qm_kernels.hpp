@@ -62,8 +62,6 @@ struct StackArgs {
     int64_t n_nodes;
     const int32_t *run_if;         // if set: do nothing unless *run_if != 0 (device-side fallback
                                    // of a screened step, qm_screen.hpp)
-    double *sink;                  // >= 128 doubles nobody reads: where the lanes past the end of a
-                                   // ragged last tile put their volume values (qm_pair.hpp)
 };
 
 // max of two non-NaN-producing operands without the canonicalising copy clang adds to fmax()

@@ -145,6 +145,32 @@ __device__ __forceinline__ void pretire(double (&acc)[2 * JP], const v2d (&buf)[
     }
 }
 
+// Stores of the lanes with `on` set, without a branch: EXEC is narrowed and restored inside one
+// asm statement.  `row` is wave-uniform (scalar base), `u` the lane's offset in doubles.  The
+// compiler's s_waitcnt bookkeeping does not see these stores; its waits can only come out
+// stricter than needed for that (the counter is in-order), never too weak.
+__device__ __forceinline__ void store_pair_masked(double *row, int u, v2d val, bool on) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(on);
+    const unsigned off = (unsigned)u * 8u;
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\t"
+                 "global_store_dwordx4 %2, %3, %4 nt\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save)
+                 : "s"(mask), "v"(off), "v"(val), "s"(row)
+                 : "memory");
+}
+
+__device__ __forceinline__ void store_one_masked(double *row, int u, double val, bool on) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(on);
+    const unsigned off = (unsigned)u * 8u;
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\t"
+                 "global_store_dwordx2 %2, %3, %4 nt\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save)
+                 : "s"(mask), "v"(off), "v"(val), "s"(row)
+                 : "memory");
+}
+
 // epilogue of the previous node, sample slots j = 2*jp + h  <->  t = t_first + 2*lane + 128*jp + h.
 // steps: 0 k | 1 f | 2..D+1 Horner | ldexp | sum | track | (store)
 template <int JP, bool VOLUME, int TAIL, int STEP>
@@ -161,28 +187,25 @@ __device__ __forceinline__ void pepi_step(Epilogue<2 * JP> &s, double (&vsum)[2 
         // operands then live in scratch.  TAIL 0, a full tile: unconditional 16-byte stores
         // (s.row is wave-uniform: scalar base + 32-bit lane offset).  TAIL 1, the scan's last
         // tile, pulled back over its predecessor: the pairs that lie wholly in the overlap were
-        // already written by that tile and go to a sink instead (no duplicate HBM traffic).
-        // TAIL 2, a scan shorter than one tile: the lanes past the end go to the sink, 8-byte
-        // stores (a lane may own one valid sample).
+        // already written by that tile, their lanes are masked out of the store (EXEC narrowed
+        // inside one asm statement: no branch, no duplicate HBM traffic).  TAIL 2, a scan shorter
+        // than one tile: the lanes past the end are masked out; the lane that owns the last
+        // sample of an odd-length scan stores 8 bytes.
         typedef v2d __attribute__((aligned(8))) v2d_a8;   // rows of an odd length start anywhere
 #pragma unroll
         for (int jp = 0; jp < JP; ++jp) {
             const int u = 2 * lane + 128 * jp;
-            if constexpr (TAIL == 2) {
-                double *d0 = (t_first + u < a.n_chunk) ? s.row + u : a.sink + lane;
-                double *d1 = (t_first + u + 1 < a.n_chunk) ? s.row + u + 1 : a.sink + lane;
-                __builtin_nontemporal_store(s.p[2 * jp], d0);
-                __builtin_nontemporal_store(s.p[2 * jp + 1], d1);
+            v2d pair;
+            pair.x = s.p[2 * jp];
+            pair.y = s.p[2 * jp + 1];
+            if constexpr (TAIL == 0) {
+                __builtin_nontemporal_store(pair, reinterpret_cast<v2d_a8 *>(s.row + u));
+            } else if constexpr (TAIL == 1) {
+                const int overlap = 128 * JP - a.n_chunk % (128 * JP);   // tile samples [0, overlap)
+                store_pair_masked(s.row, u, pair, u + 1 >= overlap);
             } else {
-                v2d pair;
-                pair.x = s.p[2 * jp];
-                pair.y = s.p[2 * jp + 1];
-                double *d = s.row + u;
-                if constexpr (TAIL == 1) {
-                    const int overlap = 128 * JP - a.n_chunk % (128 * JP);   // samples [0, overlap)
-                    d = (u + 1 >= overlap) ? d : a.sink + 2 * lane;
-                }
-                __builtin_nontemporal_store(pair, reinterpret_cast<v2d_a8 *>(d));
+                store_pair_masked(s.row, u, pair, t_first + u + 1 < a.n_chunk);
+                store_one_masked(s.row, u, pair.x, t_first + u + 1 == a.n_chunk);
             }
         }
     } else {
