@@ -148,13 +148,15 @@ __device__ __forceinline__ void pretire(double (&acc)[2 * JP], const v2d (&buf)[
 // Stores of the lanes with `on` set, without a branch: EXEC is narrowed and restored inside one
 // asm statement.  `row` is wave-uniform (scalar base), `u` the lane's offset in doubles.  The
 // compiler's s_waitcnt bookkeeping does not see these stores; its waits can only come out
-// stricter than needed for that (the counter is in-order), never too weak.
+// stricter than needed for that (the counter is in-order), never too weak.  Its hazard
+// recogniser does not see them either: gfx940+ needs 2 wait states between a VMEM store of more
+// than 8 bytes and a VALU write to its data registers -- the s_nop supplies them.
 __device__ __forceinline__ void store_pair_masked(double *row, int u, v2d val, bool on) {
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(on);
     const unsigned off = (unsigned)u * 8u;
     unsigned long long save;
     asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\t"
-                 "global_store_dwordx4 %2, %3, %4 nt\n\ts_mov_b64 exec, %0"
+                 "global_store_dwordx4 %2, %3, %4 nt\n\ts_mov_b64 exec, %0\n\ts_nop 1"
                  : "=&s"(save)
                  : "s"(mask), "v"(off), "v"(val), "s"(row)
                  : "memory");
@@ -165,7 +167,7 @@ __device__ __forceinline__ void store_one_masked(double *row, int u, double val,
     const unsigned off = (unsigned)u * 8u;
     unsigned long long save;
     asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\t"
-                 "global_store_dwordx2 %2, %3, %4 nt\n\ts_mov_b64 exec, %0"
+                 "global_store_dwordx2 %2, %3, %4 nt\n\ts_mov_b64 exec, %0\n\ts_nop 0"
                  : "=&s"(save)
                  : "s"(mask), "v"(off), "v"(val), "s"(row)
                  : "memory");
