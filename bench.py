@@ -56,7 +56,7 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12           # B/s  (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 LDS_PEAK = 150.0e12         # B/s  aggregate ds_read_b64/b128
 FP64_PEAK = 39.3e12         # vector FP64 instructions-lanes / s (78.6 TFLOP/s FMA)
-EXP_F32_OPS = 8             # float32 ops per node-sample besides the S adds in the screening sweep
+EXP_F32_OPS = 8             # 32-bit ops per node-sample besides the S adds in the screening sweep
 EXP_FP64_OPS = 18           # FP64-rate VALU ops per node-sample besides the S adds (2^z, sum, max)
 
 
@@ -147,11 +147,11 @@ def cpu_baseline(case, budget_s):
 def onchip(screened, local_ns, S, kern_s):
     """The ceilings that bind the stacking kernel: LDS operand bytes and VALU issue."""
     if screened:
-        # 4 operand bytes per add; packed float32: two adds per lane-instruction
+        # 4 operand bytes per add; v_add3_u32: two adds per lane-instruction
         ops = S + EXP_F32_OPS
         return {"lds": {"achieved": 4.0 * local_ns * S / kern_s / 1e12, "peak": LDS_PEAK / 1e12,
                         "unit": "TB/s", "frac": 4.0 * local_ns * S / kern_s / LDS_PEAK},
-                "fp32_packed_valu": {"achieved": local_ns * ops / kern_s / 1e12,
+                "int32_valu": {"achieved": local_ns * ops / kern_s / 1e12,
                                      "peak": 2 * FP64_PEAK / 1e12, "unit": "Tops/s",
                                      "frac": local_ns * ops / kern_s / (2 * FP64_PEAK),
                                      "ops_per_node_sample": ops}}
@@ -325,7 +325,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
         "vs_baseline": None,
-        "dtype": "f32 sweep + f64 refinement (opt-in screen=1)" if screened else "f64",
+        "dtype": "i32 fixed-point sweep + f64 refinement (opt-in screen=1)" if screened else "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.config} detect sweep: grid {grid[0]}x{ny}x{nz}, {S} onset "
                                f"rows, {ns} samples per step, fused migrate+find_max_coa in "
@@ -354,7 +354,7 @@ def main():
                      "traffic": None,       # PMC passes are separate runs (profiles/, README there)
                      "algorithmic_bytes_per_launch": b_fused,
                      "lds_frac": chip["lds"]["frac"],
-                     "valu_frac": chip["fp32_packed_valu" if screened else "fp64_valu"]["frac"],
+                     "valu_frac": chip["int32_valu" if screened else "fp64_valu"]["frac"],
                      "binding": "lds",
                      "note": "fused detect never writes the volume: compulsory HBM bytes "
                              "are the table, the onsets and the outputs only; the kernel is "
@@ -409,13 +409,14 @@ def main():
         xk_ms, xk_calls = sx.kernel_log()
         xk_s = xk_ms / 1e3 / max(xk_calls, 1)
         result["screened_optin"] = {
-            "what": "Engine(screen=1), NOT the default: every node-sample stacked in float32 "
-                    "(pairs of samples: ds_read_b64 + v_pk_add_f32), every (brick, sample) cell "
-                    "within the rigorous float32 error bound of the sample's maximum re-evaluated "
-                    "in float64 -- max_coa / max_coa_idx are the float64 engine's bits, "
-                    "max_norm_coa's sum over nodes has float32 terms (statistical accuracy "
-                    "argument, DESIGN.md section 3.2)",
-            "dtype": "f32 sweep + f64 refinement",
+            "what": "Engine(screen=1), NOT the default: every node-sample stacked as exact int32 "
+                    "fixed point (pairs of samples: ds_read_b64 + v_add3_u32), every (brick, "
+                    "sample) cell that can hold the maximum re-evaluated in float64 -- max_coa / "
+                    "max_coa_idx are the float64 engine's bits; max_norm_coa within 7.3e-7 of it "
+                    "by a deterministic bound whose preconditions are checked per step on the "
+                    "device (DESIGN.md section 3.2, qm_screen.hpp)",
+            "dtype": "i32 fixed-point sweep + f64 refinement",
+            "max_norm_coa_bound": 7.3e-7,
             "ms_per_step": dt * 1e3, "value": work_step / dt, "unit": "node-samples/s",
             "steps": n_x,
             "kernel": {"name": f"qm::screen_lds_kernel<{sx.get('screen_pairs')},{(S + 7) // 8}>",

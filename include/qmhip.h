@@ -93,14 +93,19 @@ int qm_engine_synchronize(qm_engine *e);
  * "waves" (wavefronts per workgroup), "groups" (brick groups per time tile,
  * 0 = auto), "lds_bytes" (window budget per workgroup), "force_direct"
  * (1 = bypass the LDS-tiled kernel; debugging / cross-check),
- * "screen" (default 1: detect / detect_partial run a float32 sweep over every node-sample and
+ * "screen" (default 0 = every node-sample in float64; 1 = opt-in screened detect, qm_screen.hpp:
+ * detect / detect_partial run an exact-integer (fixed-point) sweep over every node-sample and
  * re-evaluate in float64, in the reference's operation order, every (brick, sample) cell that
- * a rigorous float32 error bound cannot exclude from holding the maximum -- max_coa and
- * max_coa_idx are bit-identical to screen = 0, max_norm_coa's sum over nodes has float32 terms,
- * ~1e-7 relative at worst; 0 = every node-sample in float64), "screen_pairs" / "screen_big"
- * (sweep launch shape, 0 / -1 = automatic).
+ * can hold the maximum -- max_coa and max_coa_idx are bit-identical to screen = 0, max_norm_coa
+ * is within 7.3e-7 relative of it by a deterministic bound whose preconditions are checked per
+ * step on the device; a step that fails one is redone in float64), "screen_pairs" /
+ * "screen_big" (sweep launch shape, 0 / -1 = automatic), "exact" (default 1: the
+ * exact-row-count float64 kernel), "pair" (default 1: the 16-byte-operand kernel for
+ * volume-writing launches; 2 = for every launch, 0 = off), "rounds" (grid size of the automatic
+ * group count).
  * qm_engine_get additionally reports "screened_steps", "fallback_steps" (steps redone in
- * float64 on the device: flat all-ties data, non-finite onsets), "last_candidates". */
+ * float64 on the device: too many candidate cells -- flat all-ties data --, non-finite onsets,
+ * a dynamic range outside the bound's preconditions), "last_candidates". */
 int qm_engine_config(qm_engine *e, const char *key, int64_t value);
 int qm_engine_get(qm_engine *e, const char *key, int64_t *value);
 
@@ -233,6 +238,11 @@ int qm_engine_onsets(qm_engine *e, const double *signals, int signals_on_device,
                      int32_t n_rows, const int32_t *nsta, const int32_t *nlta, int transform,
                      int position, int32_t taper_pad, double min_onset_value,
                      double *raw_onsets, double *log_onsets, int out_on_device);
+
+/* Self-check behind the screened detect's error bound (qm_screen.hpp): the largest relative
+ * deviation of the device's v_exp_f32 from the float64 exp2 over EVERY float32 in [lo, hi]
+ * (lo <= hi, same sign).  The bound quotes <= 2^-23 for it. */
+int qm_exp2f_max_error(qm_engine *e, float lo, float hi, double *max_rel_error);
 
 /* Scan of an existing volume (find_max_coa semantics, no table needed). */
 int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,

@@ -99,6 +99,8 @@ qmlib.qm_engine_onsets.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32, c_i
                                    ctypes.c_double, _vp, _vp, ctypes.c_int]
 qmlib.qm_engine_find_max_coa.argtypes = [_vp, _vp, ctypes.c_int, c_int32,
                                          c_int64, _vp, _vp, _vp, ctypes.c_int]
+qmlib.qm_exp2f_max_error.argtypes = [_vp, ctypes.c_float, ctypes.c_float,
+                                     ctypes.POINTER(ctypes.c_double)]
 qmlib.qm_engine_last_kernel_ms.argtypes = [_vp, ctypes.POINTER(ctypes.c_double)]
 qmlib.qm_engine_kernel_log.argtypes = [_vp, ctypes.POINTER(ctypes.c_double),
                                        ctypes.POINTER(c_int32)]
@@ -168,6 +170,13 @@ class Engine:
         ms = ctypes.c_double()
         _check(qmlib.qm_engine_last_kernel_ms(self._h, ctypes.byref(ms)))
         return float(ms.value)
+
+    def exp2f_max_error(self, lo, hi):
+        """Largest relative deviation of the GPU's ``v_exp_f32`` from the float64 ``exp2`` over
+        every float32 in ``[lo, hi]`` (self-check behind the screened detect's error bound)."""
+        out = ctypes.c_double()
+        _check(qmlib.qm_exp2f_max_error(self._h, float(lo), float(hi), ctypes.byref(out)))
+        return float(out.value)
 
     def kernel_log(self):
         """(total ms, launches) of the stacking kernels since the last call."""

@@ -118,7 +118,7 @@ struct qm_engine {
     DevBuf<int32_t> d_smeta, d_smeta_raw, d_stotal, d_swide, d_counts, d_cells, d_work, d_flags;
     qm::GridDesc sg{};                      // the sweep's own brick grid
     DevBuf<uint16_t> d_srel;
-    DevBuf<float> d_on32, d_cell, d_gmax, d_pm;
+    DevBuf<int32_t> d_onq, d_cell, d_gmax, d_pm, d_sparams;
     DevBuf<double> d_rowmax, d_ssum, d_cand_z;
     DevBuf<int64_t> d_cand_idx;
     int n_swide = 0;
@@ -793,9 +793,6 @@ int launch_screen_jp(qm_engine *e, qm::ScreenArgs &a, size_t lds, int threads) {
 int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, int available,
                int *n_sets, bool *screened) {
     *screened = false;
-    // `available` far below the row count (never the case for the reference's caller, where it IS
-    // the row count) would amplify the float32 stack error in exp(stack / available)
-    if (2 * (int64_t)available < e->g.n_rows) return 0;
     const ScreenPlan plan = screen_plan(e, e->g.n_rows, ns);
     const int JP = plan.jp;
     if (JP == 0) return 0;
@@ -821,7 +818,7 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
                        : 0;
     const int sets = groups_direct + 1;
     constexpr int kGroupsPerBlock = 32;
-    if (e->d_on32.ensure((size_t)S * T) || e->d_rowmax.ensure(S) ||
+    if (e->d_onq.ensure((size_t)S * T) || e->d_rowmax.ensure(S) || e->d_sparams.ensure(4) ||
         e->d_cell.ensure((size_t)g.nbricks * ns_pad) ||
         e->d_gmax.ensure((size_t)std::max(1, groups) * ns_pad) || e->d_pm.ensure(ns) || e->d_ssum.ensure((size_t)std::max(1, groups) * ns) ||
         e->d_counts.ensure(ns) || e->d_cells.ensure((size_t)ns * qm::kScreenSlots) ||
@@ -848,13 +845,17 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
     hipStream_t s = e->stream;
     QM_HIP(hipMemsetAsync(e->d_counts.p, 0, (size_t)ns * sizeof(int32_t), s));
     QM_HIP(hipMemsetAsync(e->d_flags.p, 0, 4 * sizeof(int32_t), s));
-    hipLaunchKernelGGL(qm::screen_prepare_kernel, dim3(S), dim3(256), 0, s, d_onsets, T,
-                       e->d_on32.p, e->d_rowmax.p);
+    // this step's fixed-point scale (device-side: max |L| -> k) and the quantised log-onsets
+    hipLaunchKernelGGL(qm::screen_rowmax_kernel, dim3(S), dim3(256), 0, s, d_onsets, T,
+                       e->d_rowmax.p);
+    hipLaunchKernelGGL(qm::screen_quantise_kernel, dim3(S), dim3(256), 0, s, d_onsets, T, S,
+                       available, (const double *)e->d_rowmax.p, e->d_onq.p,
+                       reinterpret_cast<qm::ScreenParams *>(e->d_sparams.p), e->d_flags.p);
     QM_HIP(hipGetLastError());
 
     qm::ScreenArgs a{};
     a.g = g;
-    a.onsets32 = e->d_on32.p;
+    a.onsets_q = e->d_onq.p;
     a.rel = e->d_srel.p;
     a.brick_meta = e->d_smeta.p;
     a.brick_total = e->d_stotal.p;
@@ -864,7 +865,7 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
     a.ntiles = ntiles;
     a.ngroups = groups;
     a.window_bytes = plan.window_bytes(e);
-    a.z_scale = (float)(1.4426950408889634074 / (double)available);
+    a.params = reinterpret_cast<const qm::ScreenParams *>(e->d_sparams.p);
     a.cell_max = e->d_cell.p;
     a.group_max = e->d_gmax.p;
     a.ns_pad = ns_pad;
@@ -911,13 +912,13 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
     }
     const unsigned tcols = (unsigned)((ns + 63) / 64);
     hipLaunchKernelGGL(qm::screen_peak_kernel, dim3(tcols), dim3(256), 0, s,
-                       (const float *)e->d_gmax.p, ns_pad, ns, groups, e->d_pm.p);
+                       (const int32_t *)e->d_gmax.p, ns_pad, ns, groups, e->d_pm.p);
     hipLaunchKernelGGL(qm::screen_candidates_kernel,
                        dim3(tcols, (unsigned)std::max(1, (groups + kGroupsPerBlock - 1) / kGroupsPerBlock)),
-                       dim3(256), 0, s, (const float *)e->d_cell.p, (const float *)e->d_gmax.p,
-                       ns_pad, ns, g.nbricks, groups, kGroupsPerBlock, (const float *)e->d_pm.p,
-                       (const double *)e->d_rowmax.p, S, e->d_counts.p, e->d_cells.p, e->d_work.p,
-                       e->d_flags.p);
+                       dim3(256), 0, s, (const int32_t *)e->d_cell.p, (const int32_t *)e->d_gmax.p,
+                       ns_pad, ns, g.nbricks, groups, kGroupsPerBlock, (const int32_t *)e->d_pm.p,
+                       reinterpret_cast<const qm::ScreenParams *>(e->d_sparams.p), e->d_counts.p,
+                       e->d_cells.p, e->d_work.p, e->d_flags.p);
     QM_HIP(hipGetLastError());
     qm::RefineArgs r{};
     r.g = g;
@@ -936,7 +937,6 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
     hipLaunchKernelGGL(qm::screen_collect_kernel, dim3((ns + 63) / 64), dim3(256), 0, s,
                        (const int32_t *)e->d_counts.p, (const double *)e->d_cand_z.p,
                        (const int64_t *)e->d_cand_idx.p, (const double *)e->d_ssum.p, groups, ns,
-                       n_fit, (const double *)e->d_rowmax.p, S, available, e->d_flags.p,
                        e->d_pmax.p + (size_t)groups_direct * ns,
                        e->d_pidx.p + (size_t)groups_direct * ns,
                        e->d_psum.p + (size_t)groups_direct * ns);
@@ -1088,7 +1088,7 @@ void qm_engine_destroy(qm_engine *e) {
     e->d_fit_a.release(); e->d_fit_b.release(); e->d_fit_c.release(); e->d_fit_part.release();
     e->d_fit_val.release(); e->d_fit_win.release(); e->d_fit_pidx.release();
     e->d_smeta.release(); e->d_smeta_raw.release(); e->d_stotal.release(); e->d_swide.release(); e->d_counts.release();
-    e->d_cells.release(); e->d_work.release(); e->d_flags.release(); e->d_srel.release(); e->d_on32.release();
+    e->d_cells.release(); e->d_work.release(); e->d_flags.release(); e->d_srel.release(); e->d_onq.release(); e->d_sparams.release();
     e->d_cell.release(); e->d_gmax.release(); e->d_pm.release(); e->d_rowmax.release(); e->d_ssum.release();
     e->d_cand_z.release(); e->d_cand_idx.release();
     e->d_pmeta.release(); e->d_pmeta_raw.release(); e->d_ptotal.release(); e->d_pwide.release();
@@ -1842,6 +1842,24 @@ int qm_engine_locate_fits(qm_engine *e, const double *coa_map, int map_on_device
     summary[15] = h[4];
     std::memcpy(gau_window, w, 343 * sizeof(double));
     std::memcpy(spline_window, w + 343, 125 * sizeof(double));
+    return 0;
+}
+
+int qm_exp2f_max_error(qm_engine *e, float lo, float hi, double *max_rel_error) {
+    if (!e || !max_rel_error) return fail("qm_exp2f_max_error: NULL argument");
+    if (!(lo <= hi) || (lo < 0.f) != (hi < 0.f))
+        return fail("qm_exp2f_max_error: need lo <= hi of one sign");
+    DeviceGuard guard(e->device);
+    constexpr int kBlocks = 4096;
+    if (e->d_fit_part.ensure(kBlocks)) return 1;
+    hipLaunchKernelGGL(qm::exp2f_error_kernel, dim3(kBlocks), dim3(256), 0, e->stream, lo, hi,
+                       e->d_fit_part.p);
+    QM_HIP(hipGetLastError());
+    std::vector<double> h(kBlocks);
+    QM_HIP(hipMemcpyAsync(h.data(), e->d_fit_part.p, kBlocks * sizeof(double),
+                          hipMemcpyDeviceToHost, e->stream));
+    QM_HIP(hipStreamSynchronize(e->stream));
+    *max_rel_error = *std::max_element(h.begin(), h.end());
     return 0;
 }
 

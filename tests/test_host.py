@@ -232,28 +232,58 @@ def test_location_window_algebra_matches_reference(name):
     assert np.array_equal(got, g[f"{name}_spline"])
 
 
-def test_float32_screening_error_bound_holds_on_cpu():
-    """The bound the screened detect relies on (qm_screen.hpp): with A = sum_r max_t |L_r|, a
-    float32 stack (operands rounded to float32, float32 adds in any order) differs from the
-    float64 stack by at most D = 1.001 * S * 2^-24 * A; so the float64 arg-max node always has a
-    float32 stack within 2 D of the float32 maximum.  NumPy restatement, adversarial scales."""
+def _screen_scale(L, S, available):
+    """k and the quantised onsets exactly as screen_quantise_kernel computes them."""
+    c = 1.4426950408889634 / available
+    rmax = float(np.abs(L).max())
+    k = 30
+    while k > 0 and S * (rmax * c * 2.0 ** k + 1.0) >= 2147483647.0:
+        k -= 1
+    q = np.rint(L * (c * 2.0 ** k)).astype(np.int64)
+    return k, c, q
+
+
+def test_fixed_point_screening_bounds_hold_on_cpu():
+    """The two claims the screened detect rests on (qm_screen.hpp), restated in NumPy on
+    adversarial scales: (1) with q = rint(L c 2^k), integer stacks Q are within S/2 units of the
+    float64 z 2^k, so the float64 arg-max node has Q >= Qmax - (S + 2): it is always among the
+    candidates; (2) a term exp2f(float32(Q) 2^-k), four of them added in float32, is within 7.3e-7
+    relative of the float64 term whenever the preconditions hold -- also for CORRELATED inputs
+    (constant rows: every node stacks the same values)."""
     rng = np.random.default_rng(31)
-    for trial in range(40):
+    worst = 0.0
+    for trial in range(60):
         S = int(rng.integers(2, 65))
-        n_nodes, T = 700, 96
-        scale = 10.0 ** rng.uniform(-3, 3)
-        L = np.log(np.clip(rng.lognormal(0, 1.0, size=(S, T)) * scale, 0.01, np.inf))
+        available = S if trial % 3 else max(1, S // 2)
+        n_nodes, T = 800, 96
+        if trial % 4 == 0:                                           # constant rows: correlated
+            L = np.log(rng.uniform(0.4, 9.0, size=(S, 1))) * np.ones((1, T))
+        else:
+            scale = 10.0 ** rng.uniform(-1.5, 1.5)
+            L = np.log(np.clip(rng.lognormal(0, 1.0, size=(S, T)) * scale, 0.01, np.inf))
+        k, c, q = _screen_scale(L, S, available)
+        dz = S * 2.0 ** -(k + 1)
+        if not (np.log(2) * dz <= 1.0e-7 and np.abs(L).max(axis=1).sum() * c <= 8.0):
+            continue                                                  # the device redoes such a step
+        assert np.abs(q).max() * S < 2 ** 31
         tt = rng.integers(0, T, size=(n_nodes, S))
-        picked = L[np.arange(S)[None, :], tt]                      # (n_nodes, S) operands
-        s64 = np.zeros(n_nodes)
-        s32 = np.zeros(n_nodes, dtype=np.float32)
-        order = rng.permutation(S) if trial % 2 else np.arange(S)  # the bound is order-free
+        rows = np.arange(S)[None, :]
+        z64 = np.zeros(n_nodes)
         for r in range(S):
-            s64 += picked[:, r]
-        for r in order:
-            s32 = (s32 + picked[:, r].astype(np.float32)).astype(np.float32)
-        A = np.abs(L).max(axis=1).sum()
-        D = 1.001 * S * 2.0 ** -24 * A
-        assert np.abs(s32.astype(np.float64) - s64).max() <= D
-        winner = int(np.argmax(s64))
-        assert float(s32[winner]) >= float(s32.max()) - 2 * D
+            z64 += L[r, tt[:, r]]                                     # ascending rows, float64
+        z64 *= c
+        Q = q[rows, tt].sum(axis=1)
+        assert np.abs(Q * 2.0 ** -k - z64).max() <= dz * (1 + 1e-9)   # (1) the stack bound
+        assert Q[int(np.argmax(z64))] >= Q.max() - (S + 2)            #     the candidate rule
+        z32 = Q.astype(np.float32) * np.float32(2.0 ** -k)            # (2) one rounding
+        term = np.exp2(z32).astype(np.float32)                        #     <= 1 ulp
+        n4 = n_nodes // 4 * 4
+        part = term[:n4].reshape(-1, 4)
+        s32 = ((part[:, 0] + part[:, 1]) + part[:, 2]) + part[:, 3]   #     three float32 adds
+        want = np.exp2(z64[:n4]).reshape(-1, 4).sum(axis=1)
+        rel = np.abs(s32.astype(np.float64) - want) / want
+        worst = max(worst, float(rel.max()))
+        assert rel.max() <= 7.3e-7
+    assert worst > 0.0
+
+
