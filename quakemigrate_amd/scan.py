@@ -61,10 +61,14 @@ class MigrationScan:
         Defaults to the process-wide engine on ``$QM_HIP_DEVICE``.
     threads : int
         Accepted for signature compatibility; the GPU engine ignores it.
+    device_serving : bool
+        Build the int32 table on the GPU from ``lut.traveltimes`` (see ``_ensure_table``).
+    screen : bool, optional
+        Detect precision, see ``INTEGRATION.md`` section 4b.
     """
 
     def __init__(self, lut, onset, pre_pad, post_pad, stage="detect", scan_rate=None,
-                 engine=None, threads=1, device_serving=False):
+                 engine=None, threads=1, device_serving=False, screen=None):
         self.lut = lut
         self.onset = onset
         self.pre_pad = pre_pad
@@ -73,6 +77,11 @@ class MigrationScan:
         self.scan_rate = scan_rate
         self.threads = threads
         self.engine = engine if engine is not None else lib.default_engine()
+        # screen: None leaves the engine as configured (float64 throughout unless it was created
+        # with screen=1); True / False switch the opt-in screened detect (exact argmax and
+        # max_coa, max_coa_n within 7.3e-7 by a deterministic bound) on / off for this engine
+        if screen is not None:
+            self.engine.config("screen", 1 if screen else 0)
         self._resident_key = None
         # device_serving: the float64 grids of ``lut.traveltimes`` ({station: {phase: grid}},
         # quakemigrate/lut/lut.py) are uploaded once and the int32 table of the available
