@@ -97,7 +97,7 @@ int qm_engine_synchronize(qm_engine *e);
  * detect / detect_partial run an exact-integer (fixed-point) sweep over every node-sample and
  * re-evaluate in float64, in the reference's operation order, every (brick, sample) cell that
  * can hold the maximum -- max_coa and max_coa_idx are bit-identical to screen = 0, max_norm_coa
- * is within 7.3e-7 relative of it by a deterministic bound whose preconditions are checked per
+ * is within 6.7e-7 relative of it by a deterministic bound whose preconditions are checked per
  * step on the device; a step that fails one is redone in float64), "screen_pairs" /
  * "screen_big" (sweep launch shape, 0 / -1 = automatic), "exact" (default 1: the
  * exact-row-count float64 kernel), "pair" (default 1: the 16-byte-operand kernel for

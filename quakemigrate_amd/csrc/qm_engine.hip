@@ -125,6 +125,7 @@ struct qm_engine {
     int screen_kt = 0, screen_wb = 0;       // what the screening table was built for
     int64_t screened_steps = 0, fallback_steps = 0, last_candidates = 0;
     int last_plan_jp = 0, last_plan_big = 0;
+    int last_kernel = 0, last_j = 0;        // stacking kernel of the last launch: 0 chunked, 1 exact-row-count, 2 paired
     int32_t *h_flags = nullptr;             // pinned ring of per-step (flags, candidates) pairs
     int flags_pending = 0, flags_head = 0;  // not yet folded into the counters
 
@@ -293,6 +294,8 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
                 rc = launch_exact_if_built<J, VOLUME>(e, a, groups_lds, threads, lds, &exact);
         }
         if (rc) return rc;
+        e->last_kernel = exact ? 1 : 0;
+        e->last_j = J;
         // Variants specialised on the number of 8-row offset chunks (whole-node offset prefetch;
         // detect: software-pipelined node loop) for up to 64 table rows; otherwise, and for the
         // reference's accumulate-into-volume semantics, the generic kernel.
@@ -466,6 +469,8 @@ int launch_pair_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_
         bool done = false;
         if (launch_pair_if_built<JP, VOLUME>(e, a, &done)) return 1;
         if (!done) return fail("no paired kernel built for %d rows", e->g.n_rows);
+        e->last_kernel = 2;
+        e->last_j = 2 * JP;
         a.set0 += groups_lds;
     }
     if (use_direct) {
@@ -1204,6 +1209,8 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "screen_pairs") *v = e->last_plan_jp;
     else if (k == "screen_big") *v = e->last_plan_big;
     else if (k == "screen_brick_nodes") *v = e->sg.brick_nodes;
+    else if (k == "last_kernel") *v = e->last_kernel;
+    else if (k == "last_kernel_j") *v = e->last_j;
     else if (k == "pair_brick_nodes") *v = e->pair_kt ? e->pg.brick_nodes : 0;
     else if (k == "pair_wide_bricks") *v = e->pair_kt ? e->n_pwide : 0;
     else if (k == "pair_tile") *v = e->pair_ok ? e->pair_kt : 0;

@@ -23,14 +23,15 @@
 //     float64, in the reference's operation order, and the maximum / lowest index is taken over
 //     those cells.  Typically that is one cell per sample.
 //   * max_norm_coa = max * N / sum_n 2^z: the sweep's term for node n is exp2f(float(Q) * 2^-k),
-//     accumulated in float32 over 4 nodes, then in float64.  Relative error of a term, worst case:
+//     summed in float32 with compensation over a wave's nodes of a brick, then in float64.
+//     Relative error, worst case:
 //         ln2 * dz                      quantisation           (required <= 1.0e-7 per step)
 //       + ln2 * |z| * 2^-24             int32 -> float32       (3.3e-7 at |z| <= 8, required)
 //       + 2^-23                         v_exp_f32, <= 1 ulp    (1.2e-7; checked exhaustively on
 //                                                               the device, qm_exp2f_max_error)
-//       + 3 * 2^-24                     three float32 adds     (1.8e-7)
+//       + 2 * 2^-24                     compensated float32 sum (1.2e-7, any number of terms)
 //       (the scaling by 2^-k is exact; the float64 adds contribute ~1e-15)
-//     <= 7.3e-7.  Every term is positive, so the sum -- and with it max_norm_coa, whose numerator
+//     <= 6.7e-7.  Every term is positive, so the sum -- and with it max_norm_coa, whose numerator
 //     is the exact float64 maximum -- inherits at most that relative error: inside the 1e-6
 //     contract BY CONSTRUCTION, whatever the data (correlated errors included).
 //   The per-step preconditions (finite onsets, ln2 * dz <= 1e-7, sum_r max_t |L_r| c <= 8, at most
@@ -56,7 +57,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int qm_v2i __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) qm_v2i lds_v2i;
 constexpr int kScreenSlots = 16;        // candidate cells kept per sample
-constexpr int kScreenFlush = 4;         // nodes per float32 partial sum (3 adds: 3 * 2^-24)
 constexpr double kScreenMaxZ = 8.0;     // bound on |z| the int32 -> float32 budget is stated for
 constexpr double kScreenMaxQuant = 1.0e-7;   // budget of ln2 * dz
 
@@ -307,50 +307,56 @@ __device__ __forceinline__ void sweep_brick(const ScreenArgs &a, const uint16_t 
     constexpr int KT = 128 * JP;
     constexpr unsigned ROWB = 8 * KT - 8;               // bytes between consecutive rows
     const GridDesc &g = a.g;
-    v2f fsum[JP];
+    // float32 sum of this wave's terms over the brick, COMPENSATED (Kahan): the computed sum is
+    // within 2 * 2^-24 (+ O(n 2^-48)) of the exact sum of the float32 terms whatever their number
+    // -- tighter than flushing short plain sums into float64, and without float64 registers in
+    // the node loop.  (Plain HIP -O3 does not reassociate floating point, so the compensation
+    // survives; every term is positive.)
+    v2f fsum[JP], comp[JP];
 #pragma unroll
-    for (int j = 0; j < JP; ++j) fsum[j] = v2f{0.f, 0.f};
+    for (int j = 0; j < JP; ++j) {
+        fsum[j] = v2f{0.f, 0.f};
+        comp[j] = v2f{0.f, 0.f};
+    }
     uint4 qn[NCH];
     {
         const uint16_t *p = brick_rel + (int64_t)(wave < nvalid ? wave : 0) * g.row_pad;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) qn[c] = load_offsets(p, c * 8);
     }
-    // Two loop levels instead of an `if (count % 4 == 0)` in the node body: a branch there is
-    // control flow inside the loop, and LLVM then sinks the adds below it (operands in scratch).
-    for (int m = wave; m < nvalid;) {
-        for (int i = 0; i < kScreenFlush && m < nvalid; ++i, m += nwaves) {
-            // the node after this one (or a harmless reload of this one at the end): a chunk of
-            // qn is refilled with its offsets as soon as this node's copy has been unpacked
-            const uint16_t *next =
-                brick_rel + (int64_t)(m + nwaves < nvalid ? m + nwaves : m) * g.row_pad;
-            qm_v2i acc[JP];
+    for (int m = wave; m < nvalid; m += nwaves) {
+        // the node after this one (or a harmless reload of this one at the end): a chunk of
+        // qn is refilled with its offsets as soon as this node's copy has been unpacked
+        const uint16_t *next =
+            brick_rel + (int64_t)(m + nwaves < nvalid ? m + nwaves : m) * g.row_pad;
+        qm_v2i acc[JP];
 #pragma unroll
-            for (int j = 0; j < JP; ++j) acc[j] = qm_v2i{0, 0};
-            unsigned addr[8];
+        for (int j = 0; j < JP; ++j) acc[j] = qm_v2i{0, 0};
+        unsigned addr[8];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                unpack8(qn[c], lane_addr + (unsigned)c * 8u * ROWB, addr);
-                qn[c] = load_offsets(next, c * 8);
-                if (c + 1 < NCH) sweep_chunk<JP, 8>(acc, addr);
-                else sweep_chunk<JP, LAST>(acc, addr);
-            }
-#pragma unroll
-            for (int j = 0; j < JP; ++j) {
-                best[j].x = acc[j].x > best[j].x ? acc[j].x : best[j].x;
-                best[j].y = acc[j].y > best[j].y ? acc[j].y : best[j].y;
-                // z = float(Q) * 2^-k: one rounding (the conversion); the scaling is exact
-                const v2f z = v2f{(float)acc[j].x, (float)acc[j].y} * v2f{unit, unit};
-                fsum[j] += v2f{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)};
-            }
+        for (int c = 0; c < NCH; ++c) {
+            unpack8(qn[c], lane_addr + (unsigned)c * 8u * ROWB, addr);
+            qn[c] = load_offsets(next, c * 8);
+            if (c + 1 < NCH) sweep_chunk<JP, 8>(acc, addr);
+            else sweep_chunk<JP, LAST>(acc, addr);
         }
-        // float32 partial sums of at most 4 terms (3 adds), then float64
 #pragma unroll
         for (int j = 0; j < JP; ++j) {
-            vsum[2 * j] += (double)fsum[j].x;
-            vsum[2 * j + 1] += (double)fsum[j].y;
-            fsum[j] = v2f{0.f, 0.f};
+            best[j].x = acc[j].x > best[j].x ? acc[j].x : best[j].x;
+            best[j].y = acc[j].y > best[j].y ? acc[j].y : best[j].y;
+            // z = float(Q) * 2^-k: one rounding (the conversion); the scaling is exact
+            const v2f z = v2f{(float)acc[j].x, (float)acc[j].y} * v2f{unit, unit};
+            const v2f term = v2f{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)};
+            const v2f y = term - comp[j];
+            const v2f t = fsum[j] + y;
+            comp[j] = (t - fsum[j]) - y;
+            fsum[j] = t;
         }
+    }
+#pragma unroll
+    for (int j = 0; j < JP; ++j) {
+        vsum[2 * j] += (double)fsum[j].x;
+        vsum[2 * j + 1] += (double)fsum[j].y;
     }
 }
 

@@ -79,7 +79,7 @@ class MigrationScan:
         self.engine = engine if engine is not None else lib.default_engine()
         # screen: None leaves the engine as configured (float64 throughout unless it was created
         # with screen=1); True / False switch the opt-in screened detect (exact argmax and
-        # max_coa, max_coa_n within 7.3e-7 by a deterministic bound) on / off for this engine
+        # max_coa, max_coa_n within 6.7e-7 by a deterministic bound) on / off for this engine
         if screen is not None:
             self.engine.config("screen", 1 if screen else 0)
         self._resident_key = None

@@ -47,6 +47,11 @@ class StreamingDetector:
         ns = self.n_samples
         self.h_on = [torch.empty(shape, dtype=torch.float64).pin_memory()
                      for _ in range(self.depth)]
+        # NumPy views of the pinned input buffers: the host-side copy into them is a plain
+        # single-threaded memcpy.  (torch's CPU copy_ fans a 1-2 MB copy out over its OpenMP
+        # pool; after a blocking wait the pool has to be woken up, which on a 256-core host costs
+        # tens of milliseconds every few steps -- 4x the whole step at C2 size.)
+        self.h_on_np = [t.numpy() for t in self.h_on]
         self.d_on = [torch.empty(shape, dtype=torch.float64, device=self.device)
                      for _ in range(self.depth)]
         self.d_out = [(torch.empty(ns, dtype=torch.float64, device=self.device),
@@ -77,7 +82,7 @@ class StreamingDetector:
             # the slot's previous contents must have been consumed by its kernel
             if step >= self.depth:
                 self.consumed[slot].synchronize()
-            self.h_on[slot].copy_(torch.from_numpy(np.ascontiguousarray(array)))
+            np.copyto(self.h_on_np[slot], array)
             with torch.cuda.stream(self.copy_stream):
                 self.d_on[slot].copy_(self.h_on[slot], non_blocking=True)
                 self.copied[slot].record(self.copy_stream)

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 TIGHT = 1e-13
 # max_norm_coa: the engine is float64 throughout by default (the sum over nodes uses a degree-10
 # polynomial 2^f, truncation <= 7.8e-13) -> held to 1e-12.  The opt-in screened detect
-# (Engine(screen=1)) builds that sum from an exact-integer sweep; its terms are within 7.3e-7 of
+# (Engine(screen=1)) builds that sum from an exact-integer sweep; its terms are within 6.7e-7 of
 # the float64 ones by a deterministic bound (qm_screen.hpp; observed ~1e-8, contract RTOL = 1e-6)
 # -> held to SCREEN_NORM.
 NORM = 1e-12
@@ -1311,7 +1311,7 @@ def test_device_exp2f_is_within_one_ulp_everywhere(lib):
 # Adversarial inputs for the OPT-IN screened detect (Engine(screen=1)): families whose per-node
 # errors are correlated (constant rows: every node stacks the same values), extreme dynamic
 # range, available = rows / 2, half a million nodes.  Its max_coa / argmax are exact and its
-# max_norm_coa within 7.3e-7 by a deterministic bound, or the step is redone in float64 (the
+# max_norm_coa within 6.7e-7 by a deterministic bound, or the step is redone in float64 (the
 # preconditions are checked on the device).  The worst deviation observed is printed.
 # ---------------------------------------------------------------------------------
 def _adversarial_case(family, rng):
