@@ -680,9 +680,11 @@ ScreenPlan screen_plan(const qm_engine *e, int S, int n_samples) {
     ScreenPlan best;
     if (!e->cfg_screen || e->cfg_force_direct || (e->user_waves && e->cfg_waves != 8)) return best;
     double best_cost = 1e300;
-    // relative cost per sample, measured on C3 / C4-sized tables (tools/ab_screen.py)
+    // relative cost per sample, measured on C3 / C4-sized tables (tools/ab.py): with the integer
+    // sweep two pairs per lane in two 8-wave workgroups per CU run as fast as four pairs in one
+    // 16-wave workgroup, need no scratch and pad short scans less
     const struct { int jp; bool big; double cost; } options[] = {
-        {4, true, 1.00}, {2, false, 1.045}, {2, true, 1.045}, {1, false, 1.35}, {1, true, 1.35}};
+        {2, false, 1.00}, {4, true, 1.005}, {2, true, 1.05}, {1, false, 1.35}, {1, true, 1.35}};
     for (const auto &o : options) {
         ScreenPlan p;
         p.jp = o.jp;

@@ -23,7 +23,7 @@
 //     float64, in the reference's operation order, and the maximum / lowest index is taken over
 //     those cells.  Typically that is one cell per sample.
 //   * max_norm_coa = max * N / sum_n 2^z: the sweep's term for node n is exp2f(float(Q) * 2^-k),
-//     summed in float32 with compensation over a wave's nodes of a brick, then in float64.
+//     summed in float32 with compensation over all the nodes a wave visits, then in float64.
 //     Relative error, worst case:
 //         ln2 * dz                      quantisation           (required <= 1.0e-7 per step)
 //       + ln2 * |z| * 2^-24             int32 -> float32       (3.3e-7 at |z| <= 8, required)
@@ -303,21 +303,16 @@ __device__ __forceinline__ void sweep_chunk(qm_v2i (&acc)[JP], const unsigned (&
 template <int JP, int NCH, int LAST>
 __device__ __forceinline__ void sweep_brick(const ScreenArgs &a, const uint16_t *brick_rel,
                                             int nvalid, int wave, int nwaves, unsigned lane_addr,
-                                            float unit, qm_v2i (&best)[JP], double (&vsum)[2 * JP]) {
+                                            float unit, qm_v2i (&best)[JP], v2f (&fsum)[JP],
+                                            v2f (&comp)[JP]) {
     constexpr int KT = 128 * JP;
     constexpr unsigned ROWB = 8 * KT - 8;               // bytes between consecutive rows
     const GridDesc &g = a.g;
-    // float32 sum of this wave's terms over the brick, COMPENSATED (Kahan): the computed sum is
-    // within 2 * 2^-24 (+ O(n 2^-48)) of the exact sum of the float32 terms whatever their number
-    // -- tighter than flushing short plain sums into float64, and without float64 registers in
-    // the node loop.  (Plain HIP -O3 does not reassociate floating point, so the compensation
-    // survives; every term is positive.)
-    v2f fsum[JP], comp[JP];
-#pragma unroll
-    for (int j = 0; j < JP; ++j) {
-        fsum[j] = v2f{0.f, 0.f};
-        comp[j] = v2f{0.f, 0.f};
-    }
+    // fsum / comp: float32 sum of this wave's terms over ALL its bricks, COMPENSATED (Kahan): the
+    // computed sum is within 2 * 2^-24 (+ O(n 2^-48)) of the exact sum of the float32 terms
+    // whatever their number -- no float64 registers in the node loop, nothing to flush.  (Plain
+    // HIP -O3 does not reassociate floating point, so the compensation survives; every term is
+    // positive.)
     uint4 qn[NCH];
     {
         const uint16_t *p = brick_rel + (int64_t)(wave < nvalid ? wave : 0) * g.row_pad;
@@ -353,11 +348,6 @@ __device__ __forceinline__ void sweep_brick(const ScreenArgs &a, const uint16_t 
             fsum[j] = t;
         }
     }
-#pragma unroll
-    for (int j = 0; j < JP; ++j) {
-        vsum[2 * j] += (double)fsum[j].x;
-        vsum[2 * j + 1] += (double)fsum[j].y;
-    }
 }
 
 template <int JP, int NCH>
@@ -384,9 +374,12 @@ __global__ __launch_bounds__(1024) void screen_lds_kernel(ScreenArgs a) {
     int32_t *cellbuf = swin + a.window_bytes / 4;
     for (int k = threadIdx.x; k < KT; k += blockDim.x) cellbuf[k] = INT32_MIN;
 
-    double vsum[2 * JP];
+    v2f fsum[JP], comp[JP];                             // this wave's compensated float32 sums
 #pragma unroll
-    for (int i = 0; i < 2 * JP; ++i) vsum[i] = 0.0;
+    for (int j = 0; j < JP; ++j) {
+        fsum[j] = v2f{0.f, 0.f};
+        comp[j] = v2f{0.f, 0.f};
+    }
     int prev_b = -1;
     int32_t group_best = INT32_MIN;                     // threads k < KT: maximum of sample k
 
@@ -420,7 +413,8 @@ __global__ __launch_bounds__(1024) void screen_lds_kernel(ScreenArgs a) {
         switch (last_rows) {                            // once per brick, outside the node loop
 #define QM_SWEEP_CASE(L)                                                                       \
     case L:                                                                                    \
-        sweep_brick<JP, NCH, L>(a, brick_rel, nvalid, wave, nwaves, lane_addr, unit, best, vsum); \
+        sweep_brick<JP, NCH, L>(a, brick_rel, nvalid, wave, nwaves, lane_addr, unit, best, fsum,  \
+                                comp);                                                         \
         break;
             QM_SWEEP_CASE(1) QM_SWEEP_CASE(2) QM_SWEEP_CASE(3) QM_SWEEP_CASE(4)
             QM_SWEEP_CASE(5) QM_SWEEP_CASE(6) QM_SWEEP_CASE(7) QM_SWEEP_CASE(8)
@@ -454,8 +448,8 @@ __global__ __launch_bounds__(1024) void screen_lds_kernel(ScreenArgs a) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < JP; ++j) {
-        red[wave * KT + 128 * j + 2 * lane] = vsum[2 * j];
-        red[wave * KT + 128 * j + 2 * lane + 1] = vsum[2 * j + 1];
+        red[wave * KT + 128 * j + 2 * lane] = (double)fsum[j].x - (double)comp[j].x;
+        red[wave * KT + 128 * j + 2 * lane + 1] = (double)fsum[j].y - (double)comp[j].y;
     }
     __syncthreads();
     for (int k = threadIdx.x; k < KT; k += blockDim.x) {
