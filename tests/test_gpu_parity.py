@@ -669,6 +669,13 @@ def test_paired_kernel_every_tile_shape_against_oracle(lib, oracle, rows):
         ref = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
                                case.available, threads=4).reshape(vol.shape)
         np.testing.assert_allclose(vol, ref, rtol=TIGHT)
+        if ns == 300:
+            # the host volume streamed through the device in time chunks of one 256-sample tile
+            # (full tile + a ragged 44-sample chunk), and without the scan outputs
+            eng.config("chunk_bytes", 1 << 20)
+            vol2 = np.full_like(vol, np.nan)
+            eng.migrate(lon, case.fsmp, case.lsmp, case.available, vol2)
+            assert np.array_equal(vol2, vol)
         eng.close()
 
 
@@ -999,6 +1006,9 @@ def test_randomised_differential_with_many_exact_ties(lib, oracle):
         cfg = dict(samples_per_lane=int(rng.choice([0, 1, 2, 4])),
                    waves=int(rng.choice([1, 2, 4, 8, 16])),
                    groups=int(rng.choice([0, 1, 3, 7])))
+        if trial % 3 == 1:                                 # the automatic layout: exact-row-count
+            cfg = dict(groups=int(rng.choice([0, 1, 3, 7])),          # kernel, paired volume kernel
+                       pair=int(rng.choice([1, 2])), exact=int(rng.choice([0, 1])))
         if rng.random() < 0.4:
             cfg.update(brick_x=int(rng.integers(1, 9)), brick_y=int(rng.integers(1, 9)),
                        brick_z=int(rng.integers(1, 9)))
