@@ -1007,6 +1007,22 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
 // spread over the rows of the current node.  Same operands, same ascending row order per sample,
 // same partial sets as stack_lds_kernel: the two are interchangeable (tests run both).
 // ---------------------------------------------------------------------------------------
+// Store of the lanes with `on` set, without a branch: EXEC is narrowed and restored inside one asm
+// statement.  `row` is wave-uniform (scalar base), `u` the lane's offset in doubles.  (A branch in
+// the node body makes LLVM sink the adds of all rows below it: the operands then live in scratch.)
+// The compiler's s_waitcnt bookkeeping does not see these stores; its waits can only come out
+// stricter than needed for that (the counter is in-order), never too weak.
+__device__ __forceinline__ void store_one_masked(double *row, int u, double val, bool on) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(on);
+    const unsigned off = (unsigned)u * 8u;
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\t"
+                 "global_store_dwordx2 %2, %3, %4 nt\n\ts_mov_b64 exec, %0\n\ts_nop 0"
+                 : "=&s"(save)
+                 : "s"(mask), "v"(off), "v"(val), "s"(row)
+                 : "memory");
+}
+
 __host__ __device__ constexpr int exact_nch(int S) { return (S + 7) / 8; }   // offset chunks per node
 template <int J, int S> struct ExactPlan {
     static constexpr int RB = BatchRows<J>::value;          // table rows per batch
@@ -1014,12 +1030,30 @@ template <int J, int S> struct ExactPlan {
     static constexpr int NCH = exact_nch(S);
 };
 
+// Second operand path (VM > 0, J = 4 kernels): every VM-th row of a node is read straight from the
+// log-onset array through the vector memory path (L1 hits: a brick re-reads a few KB per row)
+// instead of from its LDS window, so that the LDS array -- the unit that bounds this kernel -- has
+// 1/VM fewer operands to deliver.  Same operands, same order of adds: the results are the same bits.
+// The 16-bit offset of a (node, row) is relative to the row's LDS window; the same number added to
+// a per-(brick, row) scalar base addresses the row in global memory.  The table's last row is
+// never read this way (lanes past the end of the scan read up to a tile past the row's end: that
+// is the next row, for every row but the last).  One row is in flight at a time, issued VM - 1
+// rows ahead of its adds.
+template <int S, int VM> __host__ __device__ constexpr bool vmem_row(int r) {
+    return VM > 0 && r >= 0 && r % (VM > 0 ? VM : 1) == VM - 1 && r < S - 1;
+}
+template <int S, int VM> __host__ __device__ constexpr int vmem_rows() {
+    int n = 0;
+    for (int r = 0; r < S; ++r) n += vmem_row<S, VM>(r) ? 1 : 0;
+    return n > 0 ? n : 1;
+}
+
 // steps of the pipelined epilogue: 0 k | 1 f | 2..D+1 Horner | ldexp | sum | track | (store)
 template <bool VOLUME> struct XEpiSteps {
     static constexpr int value = 2 + Exp2Degree<VOLUME>::value + 3 + (VOLUME ? 1 : 0);
 };
 
-template <int J, bool VOLUME, int STEP>
+template <int J, bool VOLUME, int TAIL, int STEP>
 __device__ __forceinline__ void xepi_step(Epilogue<J> &s, Running<J> &run, const StackArgs &a,
                                           int t_first, int lane) {
     constexpr int D = Exp2Degree<VOLUME>::value;
@@ -1039,28 +1073,34 @@ __device__ __forceinline__ void xepi_step(Epilogue<J> &s, Running<J> &run, const
             run.bidx[j] = gt ? s.node : run.bidx[j];
             run.bmax[j] = max_keep(run.bmax[j], s.x[j]);
         } else if constexpr (VOLUME && STEP == H1 + 3) {
-            // the stores come last: every offset load of the node being stacked has been issued
+            // The stores come last: every offset load of the node being stacked has been issued
             // by now, so no later wait on such a load has to sit out these stores as well (loads
-            // and stores share one in-order counter on gfx9)
-            // (s.row is wave-uniform: scalar base + 32-bit lane offset, no 64-bit VGPR math)
+            // and stores share one in-order counter on gfx9).  s.row is wave-uniform: scalar base
+            // + 32-bit lane offset.  TAIL 0, a full tile: unconditional.  TAIL 1, the scan's last
+            // tile, pulled back over its predecessor: the samples of the overlap were written by
+            // that tile already and are masked out.  TAIL 2, a scan shorter than one tile: the
+            // lanes past the end are masked out.
             const int u = lane + kWave * j;
-            if (t_first + u < a.n_chunk) __builtin_nontemporal_store(s.p[j], s.row + u);
+            if constexpr (TAIL == 0) __builtin_nontemporal_store(s.p[j], s.row + u);
+            else if constexpr (TAIL == 1)
+                store_one_masked(s.row, u, s.p[j], u >= kWave * J - a.n_chunk % (kWave * J));
+            else store_one_masked(s.row, u, s.p[j], t_first + u < a.n_chunk);
         }
     }
 }
 
-template <int J, bool VOLUME, int FIRST, int LAST>
+template <int J, bool VOLUME, int TAIL, int FIRST, int LAST>
 __device__ __forceinline__ void xepi_steps(Epilogue<J> &s, Running<J> &run, const StackArgs &a,
                                            int t_first, int lane) {
     if constexpr (FIRST < LAST) {
-        xepi_step<J, VOLUME, FIRST>(s, run, a, t_first, lane);
-        xepi_steps<J, VOLUME, FIRST + 1, LAST>(s, run, a, t_first, lane);
+        xepi_step<J, VOLUME, TAIL, FIRST>(s, run, a, t_first, lane);
+        xepi_steps<J, VOLUME, TAIL, FIRST + 1, LAST>(s, run, a, t_first, lane);
     }
 }
 
 // issue the LDS reads of batch I (rows I*RB ..) of the node whose offsets are in q; a chunk of
 // q is refilled with the NEXT node's offsets as soon as its last row has been issued
-template <int J, int S, int I>
+template <int J, int S, int VM, int I>
 __device__ __forceinline__ void xissue(double (&buf)[BatchRows<J>::value * J],
                                        uint4 (&q)[exact_nch(S)], const uint16_t *next,
                                        unsigned lane_addr) {
@@ -1068,15 +1108,15 @@ __device__ __forceinline__ void xissue(double (&buf)[BatchRows<J>::value * J],
     constexpr int RB = ExactPlan<J, S>::RB;
 #pragma unroll
     for (int k = 0; k < RB; ++k) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int r = I * RB + k;                      // compile-time after unrolling
         if (r < S) {
             const int ci = r >> 3, e = r & 7;
-            const volatile lds_f64 *p = (const volatile lds_f64 *)(uintptr_t)(
-                lane_addr + (unsigned)(ci * 8 * KT * 8) + chunk_entry(q[ci], e));
+            if (!vmem_row<S, VM>(r)) {
+                const volatile lds_f64 *p = (const volatile lds_f64 *)(uintptr_t)(
+                    lane_addr + (unsigned)(ci * 8 * KT * 8) + chunk_entry(q[ci], e));
 #pragma unroll
-            for (int j = 0; j < J; ++j) buf[k * J + j] = p[e * KT + kWave * j];
+                for (int j = 0; j < J; ++j) buf[k * J + j] = p[e * KT + kWave * j];
+            }
             // (the last chunk is refilled by the node loop: a load issued this late would be
             // waited for at once, by the register copies at the loop's back edge)
             if (e == 7 && ci + 1 < exact_nch(S)) q[ci] = load_offsets(next, ci * 8);
@@ -1084,9 +1124,23 @@ __device__ __forceinline__ void xissue(double (&buf)[BatchRows<J>::value * J],
     }
 }
 
-template <int J, int S, int I>
+// issue the global loads of row R (a vmem_row) of the node whose offsets are in q
+template <int J, int S, int VM, int R>
+__device__ __forceinline__ void xissue_vmem(double (&vbuf)[J], const uint4 (&q)[exact_nch(S)],
+                                            const char *const (&gbase)[vmem_rows<S, VM>()],
+                                            unsigned lane8) {
+    if constexpr (vmem_row<S, VM>(R)) {
+        const unsigned voff = lane8 + chunk_entry(q[R >> 3], R & 7);
+        const double *p = reinterpret_cast<const double *>(gbase[R / VM] + voff);
+#pragma unroll
+        for (int j = 0; j < J; ++j) vbuf[j] = p[kWave * j];
+    }
+}
+
+template <int J, int S, int VM, int I>
 __device__ __forceinline__ void xretire(double (&acc)[J],
-                                        const double (&buf)[BatchRows<J>::value * J]) {
+                                        const double (&buf)[BatchRows<J>::value * J],
+                                        const double (&vbuf)[J]) {
     constexpr int RB = ExactPlan<J, S>::RB;
 #pragma unroll
     for (int k = 0; k < RB; ++k) {                     // ascending row order per sample
@@ -1094,39 +1148,47 @@ __device__ __forceinline__ void xretire(double (&acc)[J],
         if (r < S) {
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                if (r == 0) acc[j] = buf[k * J + j];   // 0.0 + x, without the add
-                else acc[j] += buf[k * J + j];
+                const double x = vmem_row<S, VM>(r) ? vbuf[j] : buf[k * J + j];
+                if (r == 0) acc[j] = x;                // 0.0 + x, without the add
+                else acc[j] += x;
             }
         }
     }
 }
 
-template <int J, bool VOLUME, int S, bool WITH_EPI, int I>
+template <int J, bool VOLUME, int TAIL, int S, int VM, bool WITH_EPI, int I>
 __device__ __forceinline__ void xbatch(double (&acc)[J],
                                        double (&even)[BatchRows<J>::value * J],
-                                       double (&odd)[BatchRows<J>::value * J],
+                                       double (&odd)[BatchRows<J>::value * J], double (&vbuf)[J],
                                        uint4 (&q)[exact_nch(S)], const uint16_t *next,
-                                       unsigned lane_addr, Epilogue<J> &epi, Running<J> &run,
+                                       unsigned lane_addr,
+                                       const char *const (&gbase)[vmem_rows<S, VM>()],
+                                       Epilogue<J> &epi, Running<J> &run,
                                        const StackArgs &a, int t_first, int lane) {
     constexpr int NB = ExactPlan<J, S>::NB;
     if constexpr (I < NB) {
-        if constexpr (I + 1 < NB) xissue<J, S, I + 1>((I & 1) ? even : odd, q, next, lane_addr);
+        // (VM > 0 implies one row per batch) the global row retired VM - 1 batches from now;
+        // its predecessor was retired by the previous batch, so vbuf is free
+        if constexpr (VM > 0) xissue_vmem<J, S, VM, I + VM - 1>(vbuf, q, gbase, (unsigned)lane * 8u);
+        if constexpr (I + 1 < NB)
+            xissue<J, S, VM, I + 1>((I & 1) ? even : odd, q, next, lane_addr);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (WITH_EPI) {
             constexpr int E = XEpiSteps<VOLUME>::value;
-            xepi_steps<J, VOLUME, I * E / NB, (I + 1) * E / NB>(epi, run, a, t_first, lane);
+            xepi_steps<J, VOLUME, TAIL, I * E / NB, (I + 1) * E / NB>(epi, run, a, t_first, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
-        xretire<J, S, I>(acc, (I & 1) ? odd : even);
+        xretire<J, S, VM, I>(acc, (I & 1) ? odd : even, vbuf);
         __builtin_amdgcn_sched_barrier(0);
-        xbatch<J, VOLUME, S, WITH_EPI, I + 1>(acc, even, odd, q, next, lane_addr, epi, run, a,
-                                              t_first, lane);
+        xbatch<J, VOLUME, TAIL, S, VM, WITH_EPI, I + 1>(acc, even, odd, vbuf, q, next, lane_addr,
+                                                        gbase, epi, run, a, t_first, lane);
     }
 }
 
-template <int J, bool VOLUME, int S>
-__global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double win[];
+template <int J, bool VOLUME, int TAIL, int S, int VM>
+__device__ __forceinline__ void stack_exact_body(const StackArgs &a, double *win) {
+    static_assert(VM == 0 || (BatchRows<J>::value == 1 && VM >= 3 && S <= kWave),
+                  "global-path rows: one row per batch, table records in one wave");
     constexpr int KT = kWave * J;
     constexpr int NCH = ExactPlan<J, S>::NCH;
     constexpr int RB = ExactPlan<J, S>::RB;
@@ -1138,9 +1200,10 @@ __global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a) {
     const int slot = blockIdx.x >> 3;
     const int tile = slot % a.ntiles;
     const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
-    if (group >= a.ngroups) return;
-    if (a.run_if != nullptr && *a.run_if == 0) return;
-    const int t_first = tile * KT;
+    // TAIL 1: the last tile of a scan that is not a multiple of the tile length is pulled back so
+    // that it ends with the scan (it overlaps its predecessor; both compute the overlap with the
+    // same arithmetic and write the same bits to the partial sets): no lane is past the end
+    const int t_first = TAIL == 1 ? a.n_chunk - KT : tile * KT;
     const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 8u;
 
     Running<J> run;
@@ -1164,6 +1227,22 @@ __global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) q[c] = load_offsets(p, c * 8);
         }
+        // scalar bases of the rows read through the global path: LDS offset of (node, row) =
+        // 8 * (prefix_r + delay - min_r), so row r's sample `delay + fsmp + t` lies at
+        // base_r + offset + 8 * (t - t_first)
+        const char *gbase[vmem_rows<S, VM>()];
+        if constexpr (VM > 0) {
+            int4 rec = make_int4(0, 0, 0, 0);
+            if (lane < S) rec = reinterpret_cast<const int4 *>(a.brick_meta)[(int64_t)b * S + lane];
+#pragma unroll
+            for (int r = 0; r < S; ++r)
+                if (vmem_row<S, VM>(r)) {
+                    const int lo = __builtin_amdgcn_readlane(rec.x, r);
+                    const int pre = __builtin_amdgcn_readlane(rec.z, r);
+                    gbase[r / VM] = reinterpret_cast<const char *>(
+                        a.onsets + ((int64_t)r * a.T + lo + a.fsmp + a.sample0 + t_first - pre));
+                }
+        } else gbase[0] = nullptr;
         Epilogue<J> epi;
         bool pending = false;                          // wave-uniform: epi holds a node
         for (int m = wave; m < nvalid; m += nwaves) {
@@ -1177,14 +1256,14 @@ __global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a) {
 
             // the next node's last offset chunk, fetched a whole node ahead of its use
             const uint4 q_last = load_offsets(next, (NCH - 1) * 8);
-            double acc[J], even[RB * J], odd[RB * J];
-            xissue<J, S, 0>(even, q, next, lane_addr);
+            double acc[J], even[RB * J], odd[RB * J], vbuf[J];
+            xissue<J, S, VM, 0>(even, q, next, lane_addr);
             if (pending)
-                xbatch<J, VOLUME, S, true, 0>(acc, even, odd, q, next, lane_addr, epi, run, a,
-                                              t_first, lane);
+                xbatch<J, VOLUME, TAIL, S, VM, true, 0>(acc, even, odd, vbuf, q, next, lane_addr,
+                                                        gbase, epi, run, a, t_first, lane);
             else
-                xbatch<J, VOLUME, S, false, 0>(acc, even, odd, q, next, lane_addr, epi, run, a,
-                                               t_first, lane);
+                xbatch<J, VOLUME, TAIL, S, VM, false, 0>(acc, even, odd, vbuf, q, next, lane_addr,
+                                                         gbase, epi, run, a, t_first, lane);
 #pragma unroll
             for (int j = 0; j < J; ++j) epi.x[j] = acc[j] * a.z_scale;   // z: log2 of the coalescence
             epi.node = node;
@@ -1193,10 +1272,25 @@ __global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a) {
             pending = true;
         }
         if (pending)                                   // the brick's last node: not overlapped
-            xepi_steps<J, VOLUME, 0, XEpiSteps<VOLUME>::value>(epi, run, a, t_first, lane);
+            xepi_steps<J, VOLUME, TAIL, 0, XEpiSteps<VOLUME>::value>(epi, run, a, t_first, lane);
         run.merge_brick();
     }
     if (a.want_scan) publish<J>(a, run, win, wave, nwaves, lane, t_first, a.set0 + group);
+}
+
+template <int J, bool VOLUME, int S, int VM = 0>
+__global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    constexpr int KT = kWave * J;
+    const int slot = blockIdx.x >> 3;
+    const int tile = slot % a.ntiles;
+    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
+    if (a.run_if != nullptr && *a.run_if == 0) return;
+    // only the volume-writing variant cares where its tile lies in the scan
+    if (VOLUME && a.n_chunk < KT) stack_exact_body<J, VOLUME, 2, S, VM>(a, win);
+    else if (VOLUME && (tile + 1) * KT > a.n_chunk) stack_exact_body<J, VOLUME, 1, S, VM>(a, win);
+    else stack_exact_body<J, VOLUME, 0, S, VM>(a, win);
 }
 
 // ---------------------------------------------------------------------------------------

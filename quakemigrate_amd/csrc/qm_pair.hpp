@@ -162,17 +162,6 @@ __device__ __forceinline__ void store_pair_masked(double *row, int u, v2d val, b
                  : "memory");
 }
 
-__device__ __forceinline__ void store_one_masked(double *row, int u, double val, bool on) {
-    const unsigned long long mask = __builtin_amdgcn_ballot_w64(on);
-    const unsigned off = (unsigned)u * 8u;
-    unsigned long long save;
-    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\t"
-                 "global_store_dwordx2 %2, %3, %4 nt\n\ts_mov_b64 exec, %0\n\ts_nop 0"
-                 : "=&s"(save)
-                 : "s"(mask), "v"(off), "v"(val), "s"(row)
-                 : "memory");
-}
-
 // epilogue of the previous node, sample slots j = 2*jp + h  <->  t = t_first + 2*lane + 128*jp + h.
 // steps: 0 k | 1 f | 2..D+1 Horner | ldexp | sum | track | (store)
 template <int JP, bool VOLUME, int TAIL, int STEP>
