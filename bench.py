@@ -343,7 +343,7 @@ def main():
                                f"float64, table resident in HBM, onsets "
                                + ("streamed from pinned host memory (copies inside the timed "
                                   "region)" if streaming else "resident in HBM")
-                               + (f"; {x_range[1] - x_range[0]} x-planes of it on rank 0"
+                               + (f"; {x_range[1] - x_range[0]} x-planes of it on rank {part_rank}"
                                   if part_world > 1 else ""),
                    "n_nodes_per_gpu": n_local, "n_rows": S, "n_samples": ns,
                    "sharding": "x-plane slabs" if world > 1 else "none",

@@ -92,8 +92,6 @@ struct qm_engine {
     int cfg_lds_bytes = 80 * 1024;
     int cfg_force_direct = 0;
     int cfg_generic = 0;            // 1 = always the generic (any row count) LDS kernel
-    int cfg_vmem = 0;               // detect, J = 4 exact kernels: read every cfg_vmem-th row through
-                                    //     the global path instead of LDS (0 = off; QM_VMEM_VARIANTS)
     int cfg_exact = 1;              // 1 = the exact-row-count kernel where one is built (see
                                     //     QM_EXACT_ROWS), 0 = the chunked kernels only
     int64_t cfg_chunk_bytes = (int64_t)4 << 30;
@@ -262,37 +260,6 @@ int launch_exact(qm_engine *e, qm::StackArgs &a, int groups_lds, int threads, si
     return 0;
 }
 
-// (row count, VM) pairs the global-path variants of the detect kernel are built for
-#ifndef QM_VMEM_VARIANTS
-#define QM_VMEM_VARIANTS(X) X(30, 4) X(30, 5) X(30, 6) X(30, 8) X(20, 5) X(24, 5)
-#endif
-
-// *done = false: no such variant, or the onset rows are too short for it (lanes past the end of a
-// scan read up to a tile past their row's end; that must stay inside the array)
-template <int J, bool VOLUME>
-int launch_vmem_if_built(qm_engine *e, qm::StackArgs &a, int groups_lds, int threads, size_t lds,
-                         bool *done) {
-    *done = false;
-    if constexpr (J == 4 && !VOLUME) {
-        if (a.T < 2 * qm::kWave * J) return 0;
-#define QM_VMEM_CASE(SS, VM)                                                                    \
-        if (e->g.n_rows == SS && e->cfg_vmem == VM) {                                           \
-            QM_HIP(hipFuncSetAttribute(                                                         \
-                reinterpret_cast<const void *>(&qm::stack_exact_kernel<4, false, SS, VM>),      \
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
-            hipLaunchKernelGGL((qm::stack_exact_kernel<4, false, SS, VM>),                      \
-                               dim3((unsigned)(a.ntiles * ((groups_lds + 7) / 8 * 8))),         \
-                               dim3(threads), lds, e->stream, a);                               \
-            QM_HIP(hipGetLastError());                                                          \
-            *done = true;                                                                       \
-            return 0;                                                                           \
-        }
-        QM_VMEM_VARIANTS(QM_VMEM_CASE)
-#undef QM_VMEM_CASE
-    }
-    return 0;
-}
-
 // *done = false: no exact kernel for this (row count, samples per lane)
 template <int J, bool VOLUME>
 int launch_exact_if_built(qm_engine *e, qm::StackArgs &a, int groups_lds, int threads, size_t lds,
@@ -325,11 +292,8 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
         a.n_list = 0;
         int rc = 0;
         bool exact = false;
-        if (e->cfg_exact && !e->cfg_generic && !a.accumulate && a.marginal == nullptr) {
-            if (e->cfg_vmem) rc = launch_vmem_if_built<J, VOLUME>(e, a, groups_lds, threads, lds, &exact);
-            if (!rc && !exact)
-                rc = launch_exact_if_built<J, VOLUME>(e, a, groups_lds, threads, lds, &exact);
-        }
+        if (e->cfg_exact && !e->cfg_generic && !a.accumulate && a.marginal == nullptr)
+            rc = launch_exact_if_built<J, VOLUME>(e, a, groups_lds, threads, lds, &exact);
         if (rc) return rc;
         e->last_kernel = exact ? 1 : 0;
         e->last_j = J;
@@ -1198,9 +1162,7 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
         e->cfg_generic = v ? 1 : 0;
     } else if (k == "exact") {
         e->cfg_exact = v ? 1 : 0;
-    } else if (k == "vmem") {
-        if (v < 0 || v == 1 || v == 2 || v > 64) return fail("vmem must be 0 (off) or 3..64");
-        e->cfg_vmem = (int)v;
+
     } else if (k == "pair") {
         if (v < 0 || v > 2) return fail("pair must be 0 (off), 1 (automatic) or 2 (any scan length)");
         e->cfg_pair = (int)v;

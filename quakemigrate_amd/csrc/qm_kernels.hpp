@@ -540,7 +540,13 @@ __device__ __forceinline__ void finish_node(const StackArgs &a, Running<J> &run,
     double e[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {                       // branch-free: the J chains interleave
-        const double x = acc[j] * a.z_scale;            // z: log2 of the coalescence
+        double x;                                       // z: log2 of the coalescence
+        {   // a rounded product, as in the pipelined epilogues (there z crosses a loop back edge):
+            // fused into f = fma(acc, scale, -k) the stored value would differ in its last bits
+            // from what the other stacking kernels write for the same node-sample
+#pragma clang fp contract(off)
+            x = acc[j] * a.z_scale;
+        }
         e[j] = qm_exp2<Exp2Degree<VOLUME>::value>(x);
         run.vsum[j] += e[j];
         run.bidx[j] = (x > run.bmax[j]) ? node : run.bidx[j];   // strict: first node wins
@@ -723,7 +729,10 @@ __device__ __forceinline__ void epi_step(Epilogue<J> &s, Running<J> &run, const 
     constexpr int H0 = 3, H1 = 3 + D;                  // Horner steps [H0, H1)
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        if constexpr (STEP == 0) s.x[j] *= a.z_scale;                  // z = stack * log2e/avail
+        if constexpr (STEP == 0) {                                     // z = stack * log2e/avail
+#pragma clang fp contract(off)                                         // rounded (see finish_node)
+            s.x[j] = s.x[j] * a.z_scale;
+        }
         else if constexpr (STEP == 1) s.p[j] = __builtin_rint(s.x[j]); // k (as double)
         else if constexpr (STEP == 2) {
             s.f[j] = s.x[j] - s.p[j];                                  // f = z - k
@@ -1030,24 +1039,6 @@ template <int J, int S> struct ExactPlan {
     static constexpr int NCH = exact_nch(S);
 };
 
-// Second operand path (VM > 0, J = 4 kernels): every VM-th row of a node is read straight from the
-// log-onset array through the vector memory path (L1 hits: a brick re-reads a few KB per row)
-// instead of from its LDS window, so that the LDS array -- the unit that bounds this kernel -- has
-// 1/VM fewer operands to deliver.  Same operands, same order of adds: the results are the same bits.
-// The 16-bit offset of a (node, row) is relative to the row's LDS window; the same number added to
-// a per-(brick, row) scalar base addresses the row in global memory.  The table's last row is
-// never read this way (lanes past the end of the scan read up to a tile past the row's end: that
-// is the next row, for every row but the last).  One row is in flight at a time, issued VM - 1
-// rows ahead of its adds.
-template <int S, int VM> __host__ __device__ constexpr bool vmem_row(int r) {
-    return VM > 0 && r >= 0 && r % (VM > 0 ? VM : 1) == VM - 1 && r < S - 1;
-}
-template <int S, int VM> __host__ __device__ constexpr int vmem_rows() {
-    int n = 0;
-    for (int r = 0; r < S; ++r) n += vmem_row<S, VM>(r) ? 1 : 0;
-    return n > 0 ? n : 1;
-}
-
 // steps of the pipelined epilogue: 0 k | 1 f | 2..D+1 Horner | ldexp | sum | track | (store)
 template <bool VOLUME> struct XEpiSteps {
     static constexpr int value = 2 + Exp2Degree<VOLUME>::value + 3 + (VOLUME ? 1 : 0);
@@ -1100,7 +1091,7 @@ __device__ __forceinline__ void xepi_steps(Epilogue<J> &s, Running<J> &run, cons
 
 // issue the LDS reads of batch I (rows I*RB ..) of the node whose offsets are in q; a chunk of
 // q is refilled with the NEXT node's offsets as soon as its last row has been issued
-template <int J, int S, int VM, int I>
+template <int J, int S, int I>
 __device__ __forceinline__ void xissue(double (&buf)[BatchRows<J>::value * J],
                                        uint4 (&q)[exact_nch(S)], const uint16_t *next,
                                        unsigned lane_addr) {
@@ -1111,12 +1102,10 @@ __device__ __forceinline__ void xissue(double (&buf)[BatchRows<J>::value * J],
         const int r = I * RB + k;                      // compile-time after unrolling
         if (r < S) {
             const int ci = r >> 3, e = r & 7;
-            if (!vmem_row<S, VM>(r)) {
-                const volatile lds_f64 *p = (const volatile lds_f64 *)(uintptr_t)(
-                    lane_addr + (unsigned)(ci * 8 * KT * 8) + chunk_entry(q[ci], e));
+            const volatile lds_f64 *p = (const volatile lds_f64 *)(uintptr_t)(
+                lane_addr + (unsigned)(ci * 8 * KT * 8) + chunk_entry(q[ci], e));
 #pragma unroll
-                for (int j = 0; j < J; ++j) buf[k * J + j] = p[e * KT + kWave * j];
-            }
+            for (int j = 0; j < J; ++j) buf[k * J + j] = p[e * KT + kWave * j];
             // (the last chunk is refilled by the node loop: a load issued this late would be
             // waited for at once, by the register copies at the loop's back edge)
             if (e == 7 && ci + 1 < exact_nch(S)) q[ci] = load_offsets(next, ci * 8);
@@ -1124,23 +1113,9 @@ __device__ __forceinline__ void xissue(double (&buf)[BatchRows<J>::value * J],
     }
 }
 
-// issue the global loads of row R (a vmem_row) of the node whose offsets are in q
-template <int J, int S, int VM, int R>
-__device__ __forceinline__ void xissue_vmem(double (&vbuf)[J], const uint4 (&q)[exact_nch(S)],
-                                            const char *const (&gbase)[vmem_rows<S, VM>()],
-                                            unsigned lane8) {
-    if constexpr (vmem_row<S, VM>(R)) {
-        const unsigned voff = lane8 + chunk_entry(q[R >> 3], R & 7);
-        const double *p = reinterpret_cast<const double *>(gbase[R / VM] + voff);
-#pragma unroll
-        for (int j = 0; j < J; ++j) vbuf[j] = p[kWave * j];
-    }
-}
-
-template <int J, int S, int VM, int I>
+template <int J, int S, int I>
 __device__ __forceinline__ void xretire(double (&acc)[J],
-                                        const double (&buf)[BatchRows<J>::value * J],
-                                        const double (&vbuf)[J]) {
+                                        const double (&buf)[BatchRows<J>::value * J]) {
     constexpr int RB = ExactPlan<J, S>::RB;
 #pragma unroll
     for (int k = 0; k < RB; ++k) {                     // ascending row order per sample
@@ -1148,47 +1123,38 @@ __device__ __forceinline__ void xretire(double (&acc)[J],
         if (r < S) {
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                const double x = vmem_row<S, VM>(r) ? vbuf[j] : buf[k * J + j];
-                if (r == 0) acc[j] = x;                // 0.0 + x, without the add
-                else acc[j] += x;
+                if (r == 0) acc[j] = buf[k * J + j];   // 0.0 + x, without the add
+                else acc[j] += buf[k * J + j];
             }
         }
     }
 }
 
-template <int J, bool VOLUME, int TAIL, int S, int VM, bool WITH_EPI, int I>
+template <int J, bool VOLUME, int TAIL, int S, bool WITH_EPI, int I>
 __device__ __forceinline__ void xbatch(double (&acc)[J],
                                        double (&even)[BatchRows<J>::value * J],
-                                       double (&odd)[BatchRows<J>::value * J], double (&vbuf)[J],
+                                       double (&odd)[BatchRows<J>::value * J],
                                        uint4 (&q)[exact_nch(S)], const uint16_t *next,
-                                       unsigned lane_addr,
-                                       const char *const (&gbase)[vmem_rows<S, VM>()],
-                                       Epilogue<J> &epi, Running<J> &run,
+                                       unsigned lane_addr, Epilogue<J> &epi, Running<J> &run,
                                        const StackArgs &a, int t_first, int lane) {
     constexpr int NB = ExactPlan<J, S>::NB;
     if constexpr (I < NB) {
-        // (VM > 0 implies one row per batch) the global row retired VM - 1 batches from now;
-        // its predecessor was retired by the previous batch, so vbuf is free
-        if constexpr (VM > 0) xissue_vmem<J, S, VM, I + VM - 1>(vbuf, q, gbase, (unsigned)lane * 8u);
-        if constexpr (I + 1 < NB)
-            xissue<J, S, VM, I + 1>((I & 1) ? even : odd, q, next, lane_addr);
+        if constexpr (I + 1 < NB) xissue<J, S, I + 1>((I & 1) ? even : odd, q, next, lane_addr);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (WITH_EPI) {
             constexpr int E = XEpiSteps<VOLUME>::value;
             xepi_steps<J, VOLUME, TAIL, I * E / NB, (I + 1) * E / NB>(epi, run, a, t_first, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
-        xretire<J, S, VM, I>(acc, (I & 1) ? odd : even, vbuf);
+        xretire<J, S, I>(acc, (I & 1) ? odd : even);
         __builtin_amdgcn_sched_barrier(0);
-        xbatch<J, VOLUME, TAIL, S, VM, WITH_EPI, I + 1>(acc, even, odd, vbuf, q, next, lane_addr,
-                                                        gbase, epi, run, a, t_first, lane);
+        xbatch<J, VOLUME, TAIL, S, WITH_EPI, I + 1>(acc, even, odd, q, next, lane_addr, epi, run,
+                                                    a, t_first, lane);
     }
 }
 
-template <int J, bool VOLUME, int TAIL, int S, int VM>
+template <int J, bool VOLUME, int TAIL, int S>
 __device__ __forceinline__ void stack_exact_body(const StackArgs &a, double *win) {
-    static_assert(VM == 0 || (BatchRows<J>::value == 1 && VM >= 3 && S <= kWave),
-                  "global-path rows: one row per batch, table records in one wave");
     constexpr int KT = kWave * J;
     constexpr int NCH = ExactPlan<J, S>::NCH;
     constexpr int RB = ExactPlan<J, S>::RB;
@@ -1227,22 +1193,6 @@ __device__ __forceinline__ void stack_exact_body(const StackArgs &a, double *win
 #pragma unroll
             for (int c = 0; c < NCH; ++c) q[c] = load_offsets(p, c * 8);
         }
-        // scalar bases of the rows read through the global path: LDS offset of (node, row) =
-        // 8 * (prefix_r + delay - min_r), so row r's sample `delay + fsmp + t` lies at
-        // base_r + offset + 8 * (t - t_first)
-        const char *gbase[vmem_rows<S, VM>()];
-        if constexpr (VM > 0) {
-            int4 rec = make_int4(0, 0, 0, 0);
-            if (lane < S) rec = reinterpret_cast<const int4 *>(a.brick_meta)[(int64_t)b * S + lane];
-#pragma unroll
-            for (int r = 0; r < S; ++r)
-                if (vmem_row<S, VM>(r)) {
-                    const int lo = __builtin_amdgcn_readlane(rec.x, r);
-                    const int pre = __builtin_amdgcn_readlane(rec.z, r);
-                    gbase[r / VM] = reinterpret_cast<const char *>(
-                        a.onsets + ((int64_t)r * a.T + lo + a.fsmp + a.sample0 + t_first - pre));
-                }
-        } else gbase[0] = nullptr;
         Epilogue<J> epi;
         bool pending = false;                          // wave-uniform: epi holds a node
         for (int m = wave; m < nvalid; m += nwaves) {
@@ -1256,16 +1206,19 @@ __device__ __forceinline__ void stack_exact_body(const StackArgs &a, double *win
 
             // the next node's last offset chunk, fetched a whole node ahead of its use
             const uint4 q_last = load_offsets(next, (NCH - 1) * 8);
-            double acc[J], even[RB * J], odd[RB * J], vbuf[J];
-            xissue<J, S, VM, 0>(even, q, next, lane_addr);
+            double acc[J], even[RB * J], odd[RB * J];
+            xissue<J, S, 0>(even, q, next, lane_addr);
             if (pending)
-                xbatch<J, VOLUME, TAIL, S, VM, true, 0>(acc, even, odd, vbuf, q, next, lane_addr,
-                                                        gbase, epi, run, a, t_first, lane);
+                xbatch<J, VOLUME, TAIL, S, true, 0>(acc, even, odd, q, next, lane_addr, epi, run,
+                                                    a, t_first, lane);
             else
-                xbatch<J, VOLUME, TAIL, S, VM, false, 0>(acc, even, odd, vbuf, q, next, lane_addr,
-                                                         gbase, epi, run, a, t_first, lane);
+                xbatch<J, VOLUME, TAIL, S, false, 0>(acc, even, odd, q, next, lane_addr, epi, run,
+                                                     a, t_first, lane);
 #pragma unroll
-            for (int j = 0; j < J; ++j) epi.x[j] = acc[j] * a.z_scale;   // z: log2 of the coalescence
+            for (int j = 0; j < J; ++j) {                  // z: log2 of the coalescence (rounded
+#pragma clang fp contract(off)                             // product: see finish_node)
+                epi.x[j] = acc[j] * a.z_scale;
+            }
             epi.node = node;
             if (VOLUME) epi.row = a.volume + ((int64_t)node * a.vol_stride + t_first);
             q[NCH - 1] = q_last;
@@ -1278,7 +1231,7 @@ __device__ __forceinline__ void stack_exact_body(const StackArgs &a, double *win
     if (a.want_scan) publish<J>(a, run, win, wave, nwaves, lane, t_first, a.set0 + group);
 }
 
-template <int J, bool VOLUME, int S, int VM = 0>
+template <int J, bool VOLUME, int S>
 __global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int KT = kWave * J;
@@ -1288,9 +1241,9 @@ __global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a) {
     if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
     if (a.run_if != nullptr && *a.run_if == 0) return;
     // only the volume-writing variant cares where its tile lies in the scan
-    if (VOLUME && a.n_chunk < KT) stack_exact_body<J, VOLUME, 2, S, VM>(a, win);
-    else if (VOLUME && (tile + 1) * KT > a.n_chunk) stack_exact_body<J, VOLUME, 1, S, VM>(a, win);
-    else stack_exact_body<J, VOLUME, 0, S, VM>(a, win);
+    if (VOLUME && a.n_chunk < KT) stack_exact_body<J, VOLUME, 2, S>(a, win);
+    else if (VOLUME && (tile + 1) * KT > a.n_chunk) stack_exact_body<J, VOLUME, 1, S>(a, win);
+    else stack_exact_body<J, VOLUME, 0, S>(a, win);
 }
 
 // ---------------------------------------------------------------------------------------

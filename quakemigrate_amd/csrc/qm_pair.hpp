@@ -334,7 +334,10 @@ __device__ __forceinline__ void stack_pair_body(const StackArgs &a, double *win)
                 pbatch<JP, VOLUME, TAIL, S, false, 0>(acc, even, odd, q, next, lane_addr, epi,
                                                         vsum, bmax, bidx, a, t_first, lane);
 #pragma unroll
-            for (int j = 0; j < J; ++j) epi.x[j] = acc[j] * a.z_scale;   // z: log2 of the coalescence
+            for (int j = 0; j < J; ++j) {                  // z: log2 of the coalescence (rounded
+#pragma clang fp contract(off)                             // product: see finish_node)
+                epi.x[j] = acc[j] * a.z_scale;
+            }
             epi.node = node;
             if (VOLUME) epi.row = a.volume + ((int64_t)node * a.vol_stride + t_first);
             q[NCH - 1] = q_last;

@@ -669,6 +669,16 @@ def test_paired_kernel_every_tile_shape_against_oracle(lib, oracle, rows):
         ref = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
                                case.available, threads=4).reshape(vol.shape)
         np.testing.assert_allclose(vol, ref, rtol=TIGHT)
+        if ns == 257:
+            # a stored value does not depend on the kernel that wrote it: same bits from the
+            # chunked 8-byte-operand kernel
+            eng8 = lib.Engine(0, pair=0, exact=0)
+            eng8.load_lut(case.traveltimes)
+            vol8 = np.full_like(vol, np.nan)
+            eng8.migrate(lon, case.fsmp, case.lsmp, case.available, vol8)
+            assert eng8.get("last_kernel") == 0
+            assert np.array_equal(vol8, vol)
+            eng8.close()
         if ns == 300:
             # the host volume streamed through the device in time chunks of one 256-sample tile
             # (full tile + a ragged 44-sample chunk), and without the scan outputs
@@ -677,6 +687,36 @@ def test_paired_kernel_every_tile_shape_against_oracle(lib, oracle, rows):
             eng.migrate(lon, case.fsmp, case.lsmp, case.available, vol2)
             assert np.array_equal(vol2, vol)
         eng.close()
+
+
+@pytest.mark.parametrize("rows", [33, 40, 41, 47, 56, 60, 64])
+def test_exact_volume_kernels_33_to_64_rows_every_tail(lib, oracle, rows):
+    """Volume-writing exact-row-count kernels (tables of 33-64 rows; up to 32 rows the paired
+    kernel writes the volume): a scan shorter than one tile (masked lanes), whole tiles, and a
+    ragged scan whose last tile is pulled back over its predecessor (masked overlap) -- every
+    element of the volume and the series vs the oracle, and the chunked kernel gives the same bits."""
+    for ns in (1, 100, 256, 301):
+        case = synth.make_case("C2", step=4, grid=(11, 9, 10), rows=rows, n_samples=ns)
+        lon = oracle.log_onsets(case.onsets)
+        want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
+                             threads=4)
+        ref = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
+                               case.available, threads=4)
+        vols = []
+        for exact in (1, 0):
+            # the table width's own samples-per-lane for every scan length (a short scan would
+            # otherwise run on a smaller tile, for which no exact kernel is built)
+            eng = lib.Engine(0, exact=exact, samples_per_lane=4 if rows <= 40 else 2)
+            eng.load_lut(case.traveltimes)
+            vol = np.full((case.n_nodes_total, ns), np.nan)
+            series = (np.full(ns, np.nan), np.full(ns, np.nan), np.full(ns, -1, dtype=np.int64))
+            eng.migrate(lon, case.fsmp, case.lsmp, case.available, vol, scan_out=series)
+            assert eng.get("last_kernel") == exact
+            _assert_series(series, want)
+            np.testing.assert_allclose(vol, ref.reshape(vol.shape), rtol=TIGHT)
+            vols.append(vol)
+            eng.close()
+        assert np.array_equal(vols[0], vols[1])
 
 
 def test_paired_kernel_odd_delays_wide_bricks_and_twins(lib, oracle):
