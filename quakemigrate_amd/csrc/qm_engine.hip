@@ -92,6 +92,7 @@ struct qm_engine {
     int cfg_lds_bytes = 80 * 1024;
     int cfg_force_direct = 0;
     int cfg_generic = 0;            // 1 = always the generic (any row count) LDS kernel
+    int cfg_scan_waves = 32;        // find_max_coa of a volume: wavefronts per CU over the whole grid
     int cfg_exact = 1;              // 1 = the exact-row-count kernel where one is built (see
                                     //     QM_EXACT_ROWS), 0 = the chunked kernels only
     int64_t cfg_chunk_bytes = (int64_t)4 << 30;
@@ -1162,6 +1163,9 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
         e->cfg_generic = v ? 1 : 0;
     } else if (k == "exact") {
         e->cfg_exact = v ? 1 : 0;
+    } else if (k == "scan_waves") {
+        if (v < 1 || v > 4096) return fail("scan_waves must be in 1..4096");
+        e->cfg_scan_waves = (int)v;
 
     } else if (k == "pair") {
         if (v < 0 || v > 2) return fail("pair must be 0 (off), 1 (automatic) or 2 (any scan length)");
@@ -1647,18 +1651,22 @@ int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
     OutStage st;
     if (stage_out(e, n_samples, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st)) return 1;
     auto scan = [&](const double *vol, int64_t stride, int nk, int k0) -> int {
-        // ~32 workgroups per CU in total; at least 256 nodes per chunk
+        // a workgroup = up to 16 adjacent tiles (one wavefront each); ~cfg_scan_waves wavefronts
+        // per CU in total; at least 256 nodes per chunk
         const int tiles = (nk + qm::kWave - 1) / qm::kWave;
-        int64_t sets = std::max<int64_t>(1, ((int64_t)32 * e->n_cu + tiles - 1) / tiles);
+        const int groups = (tiles + qm::kScanWaves - 1) / qm::kScanWaves;
+        const int waves = (tiles + groups - 1) / groups;          // per workgroup, balanced
+        const int xgroups = (tiles + waves - 1) / waves;
+        int64_t sets = std::max<int64_t>(1, ((int64_t)e->cfg_scan_waves * e->n_cu + tiles - 1) / tiles);
         sets = std::min<int64_t>(sets, std::max<int64_t>(1, n_nodes / 256));
         sets = std::min<int64_t>(sets, 65535);
         const int64_t per = (n_nodes + sets - 1) / sets;
         sets = (n_nodes + per - 1) / per;
         const size_t need = (size_t)sets * nk;
         if (e->d_pmax.ensure(need) || e->d_psum.ensure(need) || e->d_pidx.ensure(need)) return 1;
-        hipLaunchKernelGGL(qm::scan_volume_kernel, dim3(tiles, (unsigned)sets), dim3(256), 0,
-                           e->stream, vol, stride, nk, n_nodes, per, e->d_pmax.p, e->d_pidx.p,
-                           e->d_psum.p);
+        hipLaunchKernelGGL(qm::scan_volume_kernel, dim3(xgroups, (unsigned)sets),
+                           dim3(waves * qm::kWave), 0, e->stream, vol, stride, nk, n_nodes, per,
+                           e->d_pmax.p, e->d_pidx.p, e->d_psum.p);
         QM_HIP(hipGetLastError());
         return combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, (int)sets, nk, 2, 0, n_nodes,
                        st.a + k0, st.b + k0, st.i + k0);

@@ -1308,22 +1308,21 @@ __global__ __launch_bounds__(1024) void stack_direct_kernel(StackArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Scan of a materialised volume (find_max_coa).  Workgroup = (64-sample tile, node chunk);
-// lanes <-> samples (512-byte coalesced row segments), wavefront w walks nodes w, w+4, ... of the
+// Scan of a materialised volume (find_max_coa).  Workgroup = (up to 16 adjacent 64-sample tiles,
+// node chunk); wavefront w owns tile w of the group (lanes <-> samples) and walks EVERY node of the
 // chunk in ascending order (strict '>' keeps the first maximum, migratelib.c:102) with 8 loads in
-// flight; the 4 wavefronts are combined through LDS with the lowest-index tie-break.  Values are
-// compared as stored (already exponentiated).  HBM-read bound: 8 bytes per node-sample.
+// flight, so the wavefronts of a workgroup together read whole contiguous stretches of each volume
+// row, row after row -- one sequential stream per workgroup -- and need no cross-wave combine.
+// Values are compared as stored (already exponentiated).  HBM-read bound: 8 bytes per node-sample.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void scan_volume_kernel(const double *__restrict__ vol,
-                                                          int64_t vol_stride, int n_chunk,
-                                                          int64_t n_nodes, int64_t nodes_per_set,
-                                                          double *__restrict__ part_max,
-                                                          int64_t *__restrict__ part_idx,
-                                                          double *__restrict__ part_sum) {
-    __shared__ double smax[4][kWave], ssum[4][kWave];
-    __shared__ int64_t sidx[4][kWave];
+constexpr int kScanWaves = 16;                         // tiles per workgroup, at most
+__global__ __launch_bounds__(kScanWaves * kWave) void scan_volume_kernel(
+    const double *__restrict__ vol, int64_t vol_stride, int n_chunk, int64_t n_nodes,
+    int64_t nodes_per_set, double *__restrict__ part_max, int64_t *__restrict__ part_idx,
+    double *__restrict__ part_sum) {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int t = blockIdx.x * kWave + lane;
+    const int t = (blockIdx.x * (blockDim.x >> 6) + wave) * kWave + lane;
+    if (t - lane >= n_chunk) return;                    // whole wave past the end (no barriers here)
     const int tc = t < n_chunk ? t : n_chunk - 1;       // clamp: keep every lane's loads in range
     const int set = blockIdx.y;
     const int64_t n0 = (int64_t)set * nodes_per_set;
@@ -1332,40 +1331,29 @@ __global__ __launch_bounds__(256) void scan_volume_kernel(const double *__restri
     double best = -__builtin_inf(), total = 0.0;
     int64_t bi = kNoIndex;
     const double *col = vol + tc;
-    int64_t n = n0 + wave;
-    for (; n + 4 * 7 < n1; n += 4 * 8) {
+    int64_t n = n0;
+    for (; n + 7 < n1; n += 8) {
         double v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = col[(n + 4 * k) * vol_stride];
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(col + (n + k) * vol_stride);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             total += v[k];
             if (v[k] > best) {
                 best = v[k];
-                bi = n + 4 * k;
+                bi = n + k;
             }
         }
     }
-    for (; n < n1; n += 4) {
-        const double v = col[n * vol_stride];
+    for (; n < n1; ++n) {
+        const double v = __builtin_nontemporal_load(col + n * vol_stride);
         total += v;
         if (v > best) {
             best = v;
             bi = n;
         }
     }
-    smax[wave][lane] = best;
-    ssum[wave][lane] = total;
-    sidx[wave][lane] = bi;
-    __syncthreads();
-    if (wave == 0 && t < n_chunk) {
-        for (int w = 1; w < 4; ++w) {
-            total += ssum[w][lane];
-            if (better(smax[w][lane], sidx[w][lane], best, bi)) {
-                best = smax[w][lane];
-                bi = sidx[w][lane];
-            }
-        }
+    if (t < n_chunk) {
         const int64_t o = (int64_t)set * n_chunk + t;
         part_max[o] = best;
         part_idx[o] = bi;

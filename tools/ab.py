@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of engine builds and engine configurations on one workload (development aid).
 
-usage: ab.py [--config C3] [--mode detect|volume|marginal] [--steps 6]
+usage: ab.py [--config C3] [--mode detect|volume|marginal|scan] [--steps 6]
              [--engines '[{"exact": 0}, {"exact": 1}]'] lib1.so lib2.so ...   ('-' = in-tree build)
 
 Every (library, engine configuration) pair runs in its own process; the line printed carries the
@@ -30,13 +30,17 @@ ns = case.n_samples
 n = int(np.prod(case.traveltimes.shape[:3]))
 out = (torch.zeros(ns, dtype=torch.float64, device="cuda"), torch.zeros(ns, dtype=torch.float64, device="cuda"),
        torch.zeros(ns, dtype=torch.int64, device="cuda"))
-vol = torch.zeros((n, ns), dtype=torch.float64, device="cuda") if mode == "volume" else None
+vol = torch.zeros((n, ns), dtype=torch.float64, device="cuda") if mode in ("volume", "scan") else None
+if mode == "scan":            # find_max_coa of a resident volume, written once
+    eng.migrate(lon, case.fsmp, case.lsmp, case.available, vol)
 cmap = torch.zeros(n, dtype=torch.float64, device="cuda") if mode == "marginal" else None
 def step():
     if mode == "detect":
         eng.detect(lon, case.fsmp, case.lsmp, case.available, out=out)
     elif mode == "volume":
         eng.migrate(lon, case.fsmp, case.lsmp, case.available, vol, scan_out=out)
+    elif mode == "scan":
+        eng.find_max_coa(vol, ns, n, out)
     else:
         eng.marginal_map(lon, case.fsmp, case.lsmp, case.available, ns // 4, ns - ns // 4, out=cmap, scan_out=out)
 for _ in range(2):
@@ -64,7 +68,7 @@ print(json.dumps({"ms": round(ms, 3), "kernel_ms": round(kms / max(calls, 1), 3)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--mode", default="detect", choices=["detect", "volume", "marginal"])
+    ap.add_argument("--mode", default="detect", choices=["detect", "volume", "marginal", "scan"])
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--engines", default="[{}]", help="json list of engine configurations")
     ap.add_argument("--case", default="{}", help='make_case kwargs, e.g. {"x_range": [150, 200]}')
