@@ -1030,7 +1030,7 @@ def test_randomised_differential_with_many_exact_ties(lib, oracle):
     n_trials = int(os.environ.get("QM_TIES_TRIALS", "40"))
     for trial in range(n_trials):
         grid = tuple(int(v) for v in rng.integers(1, 12, size=3))
-        S = int(rng.integers(1, 40))
+        S = int(rng.integers(1, 65))
         ns = int(rng.integers(1, 400))
         fsmp = int(rng.integers(0, 20))
         lsmp = int(rng.integers(1, 60))
