@@ -151,6 +151,10 @@ class ShardedDetector:
 
     ``exchange``: ``"packed"`` (default: one all-gather + the engine's device-side fold) or
     ``"allreduce"`` (three all-reduces, :func:`exchange_partials`).
+
+    More ranks than x-planes: a rank whose slab is empty (``shard_planes`` gave ``x0 == x1``) passes
+    an engine WITHOUT a resident table; it contributes the neutral partial (maximum ``-inf``, no
+    index, sum 0) and takes part in every collective like the others.
     """
 
     def __init__(self, engine, n_nodes_total, n_samples, device, group=None, exchange="packed"):
@@ -188,8 +192,13 @@ class ShardedDetector:
 
     def detect(self, log_onsets, fsmp, lsmp, available):
         self._bind_stream()
-        self.engine.detect_partial(log_onsets, fsmp, lsmp, available,
-                                   (self.pmax, self.pidx, self.psum))
+        if self.engine.n_rows is None:                       # empty slab: the neutral partial
+            self.pmax.fill_(float("-inf"))
+            self.pidx.fill_(INT64_MAX)
+            self.psum.zero_()
+        else:
+            self.engine.detect_partial(log_onsets, fsmp, lsmp, available,
+                                       (self.pmax, self.pidx, self.psum))
         if self.exchange == "allreduce":
             return exchange_partials(self.pmax, self.pidx, self.psum, self.n_nodes_total,
                                      self.group)
@@ -197,12 +206,19 @@ class ShardedDetector:
         return self.engine.finalize_packed(self.gathered, self.world, self.n_samples,
                                            self.n_nodes_total, out=self.out)
 
-    def marginal_map(self, log_onsets, fsmp, lsmp, available, first_sample, end_sample, nx_total):
+    def marginal_map(self, log_onsets, fsmp, lsmp, available, first_sample, end_sample, nx_total,
+                     plane_shape=None):
         """
         Locate without the volume on a sharded grid: every rank marginalises its slab
         (``Engine.marginal_map``), the slabs are gathered.  Returns the whole map on every rank.
+        ``plane_shape`` = ``(ny, nz)`` is needed only on a rank with an empty slab.
         """
         self._bind_stream()
+        if self.engine.n_rows is None:                       # empty slab: nothing to add
+            if plane_shape is None:
+                raise ValueError("a rank without x-planes needs plane_shape=(ny, nz)")
+            local = torch.zeros((0,) + tuple(plane_shape), dtype=torch.float64, device=self.device)
+            return gather_planes(local, nx_total, self.group)
         nx, ny, nz = self.engine.grid
         local = torch.zeros((nx, ny, nz), dtype=torch.float64, device=self.device)
         self.engine.marginal_map(log_onsets, fsmp, lsmp, available, first_sample, end_sample,

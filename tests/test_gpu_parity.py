@@ -258,7 +258,7 @@ def test_sharded_partials_combine_to_single_gpu_result(lib, oracle):
     np.testing.assert_allclose(b.cpu().numpy(), want[1], rtol=NORM)
 
 
-def _sharded_rank(rank, world, port, tmp, exchange):
+def _sharded_rank(rank, world, port, tmp, exchange, grid=(37, 20, 18)):
     """One rank of a 2-rank sharded detect, both ranks on GPU 0, gloo rendezvous (RCCL refuses two
     ranks on one device).  The Engine is default-constructed: ShardedDetector itself has to order
     the engine's kernels with the collective (stream binding)."""
@@ -279,20 +279,23 @@ def _sharded_rank(rank, world, port, tmp, exchange):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    grid = (37, 20, 18)
     x0, x1 = qd.shard_planes(grid[0], world, rank)
-    case = synth.make_case("C2", step=3, grid=grid, rows=14, n_samples=777, x_range=(x0, x1))
+    # (a rank without planes builds the case of plane 0 for the onsets only and loads no table)
+    case = synth.make_case("C2", step=3, grid=grid, rows=14, n_samples=777,
+                           x_range=(x0, x1) if x1 > x0 else (0, 1))
     lon = torch.from_numpy(np.ascontiguousarray(
         np.log(np.clip(case.onsets, 0.01, np.inf)))).cuda()
     eng = _lib.Engine(0)                                     # private stream until bound
-    eng.load_lut(case.traveltimes, node_offset=x0 * grid[1] * grid[2])
+    if x1 > x0:
+        eng.load_lut(case.traveltimes, node_offset=x0 * grid[1] * grid[2])
     sd = qd.ShardedDetector(eng, case.n_nodes_total, case.n_samples, torch.device("cuda", 0),
                             exchange=exchange)
     series = []
     for _ in range(3):                                       # repeated steps reuse the buffers
         a, b, c = sd.detect(lon, case.fsmp, case.lsmp, case.available)
         series.append(tuple(t.clone() for t in (a, b, c)))
-    cmap = sd.marginal_map(lon, case.fsmp, case.lsmp, case.available, 100, 400, grid[0])
+    cmap = sd.marginal_map(lon, case.fsmp, case.lsmp, case.available, 100, 400, grid[0],
+                           plane_shape=grid[1:])
     torch.cuda.synchronize()
     for s in series[1:]:
         assert all(torch.equal(u, v) for u, v in zip(s, series[0]))
@@ -303,11 +306,15 @@ def _sharded_rank(rank, world, port, tmp, exchange):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["packed", "allreduce"])
-def test_sharded_detector_two_ranks_real_partials(lib, oracle, tmp_path, exchange):
+@pytest.mark.parametrize("exchange,grid", [("packed", (37, 20, 18)), ("allreduce", (37, 20, 18)),
+                                           ("packed", (1, 20, 18)), ("allreduce", (1, 20, 18))],
+                         ids=["packed", "allreduce", "packed-empty-slab", "allreduce-empty-slab"])
+def test_sharded_detector_two_ranks_real_partials(lib, oracle, tmp_path, exchange, grid):
     """Two processes, each with a slab resident on its own Engine, ShardedDetector.detect and
     .marginal_map with REAL Engine.detect_partial outputs exchanged across the ranks == the
-    unsharded engine (argmax and maximum bit for bit) == the oracle."""
+    unsharded engine (argmax and maximum bit for bit) == the oracle.  With a one-plane grid the
+    second rank holds no plane at all (more ranks than planes) and contributes the neutral
+    partial."""
     import socket
 
     import torch.multiprocessing as mp
@@ -315,8 +322,7 @@ def test_sharded_detector_two_ranks_real_partials(lib, oracle, tmp_path, exchang
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_sharded_rank, args=(2, port, str(tmp_path), exchange), nprocs=2, join=True)
-    grid = (37, 20, 18)
+    mp.spawn(_sharded_rank, args=(2, port, str(tmp_path), exchange, grid), nprocs=2, join=True)
     case = synth.make_case("C2", step=3, grid=grid, rows=14, n_samples=777)
     lon = oracle.log_onsets(case.onsets)
     eng = lib.Engine(0)

@@ -97,12 +97,35 @@ def test_engine_calls_fail_loudly_without_a_gpu(built):
 def test_shard_planes_partition():
     from quakemigrate_amd.distributed import shard_planes
 
-    for nx, world in [(201, 8), (7, 8), (401, 3), (5, 1)]:
+    for nx, world in [(201, 8), (7, 8), (401, 3), (5, 1), (1, 2)]:
         spans = [shard_planes(nx, world, r) for r in range(world)]
         assert spans[0][0] == 0 and spans[-1][1] == nx
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_neutral_partial_of_an_empty_slab_leaves_the_fold_unchanged():
+    """More ranks than x-planes: ShardedDetector lets such a rank contribute (-inf, no index, 0);
+    the fold over the ranks' sets must not see it."""
+    import torch
+
+    from quakemigrate_amd import distributed as qd
+
+    rng = np.random.default_rng(5)
+    ns, n_total = 64, 1000
+    g = torch.empty((3, 3, ns), dtype=torch.float64)
+    for r in range(2):
+        g[r, 0] = torch.from_numpy(rng.integers(-8, 9, size=ns) / 4.0)      # many ties
+        g[r, 1].view(torch.int64).copy_(torch.from_numpy(rng.integers(0, n_total, size=ns)))
+        g[r, 2] = torch.from_numpy(rng.uniform(1.0, 2.0, size=ns))
+    g[2, 0] = float("-inf")
+    g[2, 1].view(torch.int64).fill_(qd.INT64_MAX)
+    g[2, 2] = 0.0
+    with_empty = qd.combine_packed_torch(g, n_total)
+    without = qd.combine_packed_torch(g[:2].contiguous(), n_total)
+    assert all(torch.equal(u, v) for u, v in zip(with_empty, without))
+    assert int(with_empty[2].max()) < n_total
 
 
 def test_scan_glue_shapes_and_errors(built):
