@@ -20,7 +20,9 @@
 #include <thread>
 #include <vector>
 
+#define QM_ENGINE_TU 1
 #include "qm_kernels.hpp"
+#include "qm_launch.hpp"
 #include "qm_locate.hpp"
 #include "qm_screen.hpp"
 #include "qm_pair.hpp"
@@ -94,7 +96,7 @@ struct qm_engine {
     int cfg_generic = 0;            // 1 = always the generic (any row count) LDS kernel
     int cfg_scan_waves = 32;        // find_max_coa of a volume: wavefronts per CU over the whole grid
     int cfg_exact = 1;              // 1 = the exact-row-count kernel where one is built (see
-                                    //     QM_EXACT_ROWS), 0 = the chunked kernels only
+                                    //     qm_launch.hpp), 0 = the chunked kernels only
     int64_t cfg_chunk_bytes = (int64_t)4 << 30;
     int cfg_pair = 1;               // 1 = the 16-byte-operand kernel (qm_pair.hpp) where it applies
     int cfg_screen = 0;             // 1 (opt-in): detect = float32 screening sweep + exact float64
@@ -222,61 +224,28 @@ int plan_wide(qm_engine *e, int J) {
     return 0;
 }
 
-template <int J, bool VOLUME, int NCH>
-int launch_lds(qm_engine *e, qm::StackArgs &a, int groups_lds, int threads, size_t lds) {
-    QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_lds_kernel<J, VOLUME, NCH>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((qm::stack_lds_kernel<J, VOLUME, NCH>),
-                       dim3((unsigned)(a.ntiles * ((groups_lds + 7) / 8 * 8))), dim3(threads), lds,
-                       e->stream, a);
-    QM_HIP(hipGetLastError());
-    return 0;
+// HIP status of a launcher of qm_launch.hpp -> this file's error convention
+#define QM_TABLE(call)                                                                       \
+    do {                                                                                     \
+        hipError_t err__ = (call);                                                           \
+        if (err__ != hipSuccess)                                                             \
+            return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__,   \
+                        __LINE__);                                                           \
+    } while (0)
+
+qm::LaunchShape stack_shape(const qm_engine *e, const qm::StackArgs &a, int groups, int threads,
+                            size_t lds) {
+    // the grid is padded to a multiple of 8 groups (XCD-aware workgroup -> (tile, group) map)
+    return {(unsigned)(a.ntiles * ((groups + 7) / 8 * 8)), threads, lds, e->stream};
 }
 
-// Row counts the exact-row-count kernel (qm::stack_exact_kernel) is built for, each with the
-// samples-per-lane eff_j() picks for it (4 up to 40 rows, 2 up to 64).  Other row counts, other
-// tile lengths (short scans), accumulate requests and the marginal map use the chunked kernels.
-#ifndef QM_EXACT_ROWS
-#define QM_EXACT_ROWS(X)                                                                        \
-    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)      \
-    X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)   \
-    X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46)   \
-    X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61)   \
-    X(62) X(63) X(64)
-#endif
-constexpr int exact_j(int S) { return S <= 40 ? 4 : 2; }
-// Volume-writing launches of up to this many rows go through the paired kernel (QM_PAIR_ROWS),
-// which measures the same there (profiles/r02_ab_runs.txt); the exact-row-count volume variants
-// are built for the row counts above it, where the alternative is the chunked kernel.
-constexpr int kPairMaxRows = 32;
-
-template <int J, bool VOLUME, int S>
-int launch_exact(qm_engine *e, qm::StackArgs &a, int groups_lds, int threads, size_t lds) {
-    QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_exact_kernel<J, VOLUME, S>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((qm::stack_exact_kernel<J, VOLUME, S>),
-                       dim3((unsigned)(a.ntiles * ((groups_lds + 7) / 8 * 8))), dim3(threads), lds,
-                       e->stream, a);
-    QM_HIP(hipGetLastError());
-    return 0;
-}
-
-// *done = false: no exact kernel for this (row count, samples per lane)
-template <int J, bool VOLUME>
-int launch_exact_if_built(qm_engine *e, qm::StackArgs &a, int groups_lds, int threads, size_t lds,
-                          bool *done) {
-    *done = true;
-    switch (e->g.n_rows) {
-#define QM_EXACT_CASE(SS)                                                                      \
-    case SS:                                                                                   \
-        if constexpr (exact_j(SS) == J && (!VOLUME || SS > kPairMaxRows))                      \
-            return launch_exact<J, VOLUME, SS>(e, a, groups_lds, threads, lds);               \
-        else break;
-        QM_EXACT_ROWS(QM_EXACT_CASE)
-#undef QM_EXACT_CASE
-        default: break;
-    }
-    *done = false;
+int launch_direct(qm_engine *e, const qm::StackArgs &a, int J, bool volume, int groups,
+                  int threads, size_t publish_bytes) {
+    const qm::LaunchShape shape = stack_shape(e, a, groups, threads, publish_bytes);
+    bool built = false;
+    if (volume) QM_TABLE(qm::launch_direct_volume(J, a, shape, &built));
+    else QM_TABLE(qm::launch_direct_detect(J, a, shape, &built));
+    if (!built) return fail("no direct stacking kernel for %d samples per lane", J);
     return 0;
 }
 
@@ -291,34 +260,34 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
         a.ngroups = groups_lds;
         a.brick_list = nullptr;
         a.n_list = 0;
-        int rc = 0;
+        const qm::LaunchShape shape = stack_shape(e, a, groups_lds, threads, lds);
+        const int S = e->g.n_rows;
         bool exact = false;
-        if (e->cfg_exact && !e->cfg_generic && !a.accumulate && a.marginal == nullptr)
-            rc = launch_exact_if_built<J, VOLUME>(e, a, groups_lds, threads, lds, &exact);
-        if (rc) return rc;
+        // the exact-row-count kernels: fused detect for up to 64 rows, volume-writing for 33-64
+        // rows (up to 32 the paired kernel writes volumes), when the launch uses the table
+        // width's own samples per lane
+        if (e->cfg_exact && !e->cfg_generic && !a.accumulate && a.marginal == nullptr &&
+            S <= qm::kExactMaxRows && qm::exact_j(S) == J) {
+            if (!VOLUME && S <= 32) QM_TABLE(qm::launch_exact_detect_1_32(S, a, shape, &exact));
+            else if (!VOLUME) QM_TABLE(qm::launch_exact_detect_33_64(S, a, shape, &exact));
+            else if (S > qm::kPairMaxRows) QM_TABLE(qm::launch_exact_volume_33_64(S, a, shape, &exact));
+        }
         e->last_kernel = exact ? 1 : 0;
         e->last_j = J;
         // Variants specialised on the number of 8-row offset chunks (whole-node offset prefetch;
         // detect: software-pipelined node loop) for up to 64 table rows; otherwise, and for the
         // reference's accumulate-into-volume semantics, the generic kernel.
-        if (!exact) switch ((e->cfg_generic || a.accumulate) ? 0 : e->g.row_pad / 8) {
-            case 1: rc = launch_lds<J, VOLUME, 1>(e, a, groups_lds, threads, lds); break;
-            case 2: rc = launch_lds<J, VOLUME, 2>(e, a, groups_lds, threads, lds); break;
-            case 3: rc = launch_lds<J, VOLUME, 3>(e, a, groups_lds, threads, lds); break;
-            case 4: rc = launch_lds<J, VOLUME, 4>(e, a, groups_lds, threads, lds); break;
-            case 5: rc = launch_lds<J, VOLUME, 5>(e, a, groups_lds, threads, lds); break;
-            case 6: rc = launch_lds<J, VOLUME, 6>(e, a, groups_lds, threads, lds); break;
-            case 7: rc = launch_lds<J, VOLUME, 7>(e, a, groups_lds, threads, lds); break;
-            case 8: rc = launch_lds<J, VOLUME, 8>(e, a, groups_lds, threads, lds); break;
-            default: rc = launch_lds<J, VOLUME, 0>(e, a, groups_lds, threads, lds); break;
+        if (!exact) {
+            int nch = (e->cfg_generic || a.accumulate) ? 0 : e->g.row_pad / 8;
+            if (nch > 8) nch = 0;
+            bool built = false;
+            if (VOLUME) QM_TABLE(qm::launch_chunked_volume(J, nch, a, shape, &built));
+            else QM_TABLE(qm::launch_chunked_detect(J, nch, a, shape, &built));
+            if (!built) return fail("no chunked stacking kernel for %d samples per lane", J);
         }
-        if (rc) return rc;
         a.set0 += groups_lds;
     }
     if (use_direct) {
-        QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_direct_kernel<J, VOLUME>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)publish_bytes));
         a.ngroups = groups_direct;
         if (e->cfg_force_direct) {
             a.brick_list = nullptr;
@@ -327,28 +296,15 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
             a.brick_list = e->d_wide.p;
             a.n_list = e->n_wide;
         }
-        hipLaunchKernelGGL((qm::stack_direct_kernel<J, VOLUME>),
-                           dim3((unsigned)(a.ntiles * ((groups_direct + 7) / 8 * 8))), dim3(threads),
-                           publish_bytes, e->stream, a);
-        QM_HIP(hipGetLastError());
+        if (launch_direct(e, a, J, VOLUME, groups_direct, threads, publish_bytes)) return 1;
         a.set0 += groups_direct;
     }
     return 0;
 }
 
-// ---- paired (16-byte operand) layout (qm_pair.hpp) -------------------------------------------
-// Row counts the paired kernel is built for: up to 32 rows, JP = 2 pairs per lane (time tile 256)
-// -- both copies of S row windows plus the delay spans in 160 KB.  (JP = 1 / tile 128 for 33-64
-// rows was measured too: 27 % slower than the chunked kernel on a C4 slab -- twice the staging,
-// smaller bricks, no gain from the wider reads -- and is not built.)
-#ifndef QM_PAIR_ROWS
-#define QM_PAIR_ROWS(X)                                                                         \
-    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)      \
-    X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)   \
-    X(32)
-#endif
-constexpr int pair_jp_of(int S) { return S <= 32 ? 2 : 0; }
-constexpr int kPairLdsBytes = 160 * 1024;
+// ---- paired (16-byte operand) layout (qm_pair.hpp; row counts and constants: qm_launch.hpp) ----
+using qm::kPairLdsBytes;
+using qm::pair_jp_of;
 
 // pairs per lane for a launch over n_chunk samples; 0 = the chunked / exact kernels run.
 // pair = 1 (default): the volume-writing launches only -- there the paired layout pays (one
@@ -432,34 +388,6 @@ int ensure_pair_tables(qm_engine *e, int jp) {
     return 0;
 }
 
-template <int JP, bool VOLUME, int S>
-int launch_pair(qm_engine *e, qm::StackArgs &a) {
-    QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_pair_kernel<JP, VOLUME, S>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kPairLdsBytes));
-    hipLaunchKernelGGL((qm::stack_pair_kernel<JP, VOLUME, S>),
-                       dim3((unsigned)(a.ntiles * ((a.ngroups + 7) / 8 * 8))), dim3(1024),
-                       kPairLdsBytes, e->stream, a);
-    QM_HIP(hipGetLastError());
-    return 0;
-}
-
-// *done = false: no paired kernel for this (row count, pairs per lane)
-template <int JP, bool VOLUME>
-int launch_pair_if_built(qm_engine *e, qm::StackArgs &a, bool *done) {
-    *done = true;
-    switch (e->g.n_rows) {
-#define QM_PAIR_CASE(SS)                                                                       \
-    case SS:                                                                                   \
-        if constexpr (pair_jp_of(SS) == JP) return launch_pair<JP, VOLUME, SS>(e, a);           \
-        else break;
-        QM_PAIR_ROWS(QM_PAIR_CASE)
-#undef QM_PAIR_CASE
-        default: break;
-    }
-    *done = false;
-    return 0;
-}
-
 // LDS launch over the bricks that fit the paired layout + direct launch over those that do not
 template <int JP, bool VOLUME>
 int launch_pair_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_direct,
@@ -469,7 +397,11 @@ int launch_pair_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_
         a.brick_list = nullptr;
         a.n_list = 0;
         bool done = false;
-        if (launch_pair_if_built<JP, VOLUME>(e, a, &done)) return 1;
+        const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, 1024, kPairLdsBytes);
+        if (pair_jp_of(e->g.n_rows) == JP) {
+            if (VOLUME) QM_TABLE(qm::launch_pair_volume(e->g.n_rows, a, shape, &done));
+            else QM_TABLE(qm::launch_pair_detect(e->g.n_rows, a, shape, &done));
+        }
         if (!done) return fail("no paired kernel built for %d rows", e->g.n_rows);
         e->last_kernel = 2;
         e->last_j = 2 * JP;
@@ -479,29 +411,16 @@ int launch_pair_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_
         constexpr int J = 2 * JP;                      // same tile length: 64 * J = 128 * JP
         const int threads = 1024;
         const size_t publish_bytes = (size_t)3 * (threads / qm::kWave) * qm::kWave * J * sizeof(double);
-        QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_direct_kernel<J, VOLUME>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)publish_bytes));
         a.ngroups = groups_direct;
         a.brick_list = e->d_pwide.p;
         a.n_list = e->n_pwide;
-        hipLaunchKernelGGL((qm::stack_direct_kernel<J, VOLUME>),
-                           dim3((unsigned)(a.ntiles * ((groups_direct + 7) / 8 * 8))), dim3(threads),
-                           publish_bytes, e->stream, a);
-        QM_HIP(hipGetLastError());
+        if (launch_direct(e, a, J, VOLUME, groups_direct, threads, publish_bytes)) return 1;
         a.set0 += groups_direct;
     }
     return 0;
 }
 
-bool pair_built(int S) {
-    switch (S) {
-#define QM_PAIR_CASE(SS) case SS: return true;
-        QM_PAIR_ROWS(QM_PAIR_CASE)
-#undef QM_PAIR_CASE
-        default: return false;
-    }
-}
+bool pair_built(int S) { return S >= 1 && S <= qm::kPairMaxRows; }
 
 int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu) {
     // Workgroups all do the same amount of work, so the grid should be a whole number of
@@ -912,12 +831,11 @@ int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, in
         d.n_list = e->n_swide;
         d.n_nodes = e->n_nodes;
         const size_t publish_bytes = (size_t)3 * 8 * 64 * sizeof(double);
-        QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stack_direct_kernel<1, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)publish_bytes));
-        hipLaunchKernelGGL((qm::stack_direct_kernel<1, false>),
-                           dim3((unsigned)(d.ntiles * ((groups_direct + 7) / 8 * 8))), dim3(512),
-                           publish_bytes, s, d);
-        QM_HIP(hipGetLastError());
+        bool built = false;
+        QM_TABLE(qm::launch_direct_detect(
+            1, d, {(unsigned)(d.ntiles * ((groups_direct + 7) / 8 * 8)), 512, publish_bytes, s},
+            &built));
+        if (!built) return fail("no direct stacking kernel built");
     }
     const unsigned tcols = (unsigned)((ns + 63) / 64);
     hipLaunchKernelGGL(qm::screen_peak_kernel, dim3(tcols), dim3(256), 0, s,

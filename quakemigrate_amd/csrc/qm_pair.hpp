@@ -45,6 +45,7 @@ __host__ __device__ __forceinline__ bool pair_fits(int64_t p_total, int n_rows, 
 
 // offsets of the paired layout (one launch per (table, tile length)); smeta = (min, span2, P, 0)
 // per (brick, row) as screen_prefix_kernel builds it
+#ifdef QM_ENGINE_TU
 __global__ void pair_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
                                 const int4 *__restrict__ smeta,
                                 const int32_t *__restrict__ stotal, int kt, int lds_bytes,
@@ -69,6 +70,7 @@ __global__ void pair_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
         rel[(int64_t)b * per + i] = v;
     }
 }
+#endif  // QM_ENGINE_TU
 
 // Stage both copies of every row window of brick b (a.brick_meta = smeta).  One global load per
 // element, two LDS stores.
