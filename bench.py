@@ -194,6 +194,13 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    # stdout carries the result line and nothing else: RCCL writes a version banner to the C-level
+    # stdout of every process that creates a communicator (seen with RCCL 2.26.6: five lines,
+    # flushed at exit, i.e. AFTER the JSON line).  File descriptor 1 is pointed at stderr for the
+    # whole run -- on every rank -- and rank 0 writes its one line to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -209,11 +216,23 @@ def main():
     one_device = os.environ.get("QM_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
+    # development aid: QM_BENCH_FORCE_DIST=1 at N = 1 runs the step through the N>1 code path on a
+    # one-rank RCCL group (ShardedDetector, device all-gather, barrier / all-reduce of the timing)
+    force_dist = world == 1 and os.environ.get("QM_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
     backend = None
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        if one_device:
+        if force_dist:
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            dist.init_process_group("nccl", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", local_rank))
+        elif one_device:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -256,7 +275,7 @@ def main():
            torch.empty(ns, dtype=torch.float64, device=dev),
            torch.empty(ns, dtype=torch.int64, device=dev))
     sharded = (qd.ShardedDetector(eng, n_total, ns, dev, exchange=args.exchange)
-               if world > 1 else None)
+               if use_dist else None)
 
     def step(i):
         on = onsets_dev[i % n_pool]
@@ -267,7 +286,7 @@ def main():
         return sharded.detect(on, case.fsmp, case.lsmp, case.available)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -298,7 +317,7 @@ def main():
     kern_ms, kern_calls = eng.kernel_log()
     eng.config("log_timing", 0)
     screened = eng.get("screened_steps") > 0 and eng.get("fallback_steps") == 0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -317,7 +336,7 @@ def main():
             f"event at sample {t_ev}: node {found} is not at {ijk}"
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -349,7 +368,7 @@ def main():
                    "sharding": "x-plane slabs" if world > 1 else "none",
                    "exchange": ({"packed": "1 x all_gather([3][n_samples]) + device fold per step",
                                  "allreduce": "3 x all_reduce(n_samples) per step"}[args.exchange]
-                                if world > 1 else "none"),
+                                if use_dist else "none"),
                    "collective_backend": backend, "ranks": world,
                    "engine": dict(tunables, brick=[eng.get("brick_x"), eng.get("brick_y"),
                                                    eng.get("brick_z")],
@@ -526,9 +545,11 @@ def main():
         result["cpu_baseline"] = cpu_baseline(case, args.cpu_seconds)
     else:
         result["cpu_baseline"] = None
-    print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(result) + "\n").encode())
+    os.close(result_fd)
 
 
 if __name__ == "__main__":
