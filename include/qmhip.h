@@ -216,6 +216,17 @@ int qm_engine_locate_fits(qm_engine *e, const double *coa_map, int map_on_device
                           int out_on_device, double *summary, double *gau_window,
                           double *spline_window);
 
+/* _splineloc's refinement (quakemigrate/signal/scan.py:777-812): the cubic radial-basis
+ * interpolant through an n x n x n window -- scipy.interpolate.Rbf(x, y, z, values,
+ * function="cubic") with the reference's "xy" meshgrid pairing -- evaluated on the device on the
+ * `upscale`-times finer grid of ((n-1)*upscale + 1)^3 points, and its first maximum.
+ * weights: host f64 [n][n][n], the solution of  |c_i - c_j|^3 w = values  (a 125 x 125 solve for
+ * the reference's 5^3 window: left to the caller's LAPACK).  peak_index: flat C-order index
+ * (i*m + j)*m + k into the fine grid, m = (n-1)*upscale + 1 -- what
+ * np.unravel_index(np.nanargmax(dense), dense.shape) receives in scan.py:806-808. */
+int qm_engine_rbf_peak(qm_engine *e, const double *weights, int32_t n, int32_t upscale,
+                       double *peak_value, int64_t *peak_index);
+
 /* Onset stage on the device -- the step immediately upstream of the path:
  * STALTAOnset._onset (quakemigrate/signal/onsets/stalta.py:491-548: signal transform, STA/LTA
  * per component trace with the arithmetic of core/src/onsetlib.c, taper windows :550-583,

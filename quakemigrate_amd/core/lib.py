@@ -94,6 +94,8 @@ qmlib.qm_engine_locate_fits.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32
                                         ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_double)]
+qmlib.qm_engine_rbf_peak.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), c_int32, c_int32,
+                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]
 qmlib.qm_engine_onsets.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32, c_i32Pt, c_int32,
                                    c_i32Pt, c_i32Pt, ctypes.c_int, ctypes.c_int, c_int32,
                                    ctypes.c_double, _vp, _vp, ctypes.c_int]
@@ -426,6 +428,23 @@ class Engine:
                 "weight": sm[4], "expectation": sm[5:8].copy(), "covariance": cov,
                 "pass_maxima": sm[14:16].copy(), "gaussian_window": gau,
                 "spline_window": spl}
+
+    def rbf_peak(self, weights, upscale=10):
+        """
+        First maximum of the cubic radial-basis interpolant with the given ``weights`` (n, n, n)
+        on the ``upscale``-times finer grid (``_splineloc``'s refinement, scan.py:777-812),
+        evaluated on the GPU.  Returns ``(value, (i, j, k))`` -- indices into the fine grid of
+        ``(n - 1) * upscale + 1`` points per axis.
+        """
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        if w.ndim != 3 or not (w.shape[0] == w.shape[1] == w.shape[2]):
+            raise ValueError("weights must be a cube")
+        n = int(w.shape[0])
+        value, index = ctypes.c_double(), c_int64()
+        _check(qmlib.qm_engine_rbf_peak(self._h, w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                        n, int(upscale), ctypes.byref(value), ctypes.byref(index)))
+        m = (n - 1) * int(upscale) + 1
+        return float(value.value), tuple(int(v) for v in np.unravel_index(int(index.value), (m, m, m)))
 
     def onsets(self, signals, trace_row, nsta, nlta, transform="energy", position="classic",
                taper_pad=-1, min_onset_value=0.4, raw_out=None, log_out=None):

@@ -1782,6 +1782,39 @@ int qm_engine_locate_fits(qm_engine *e, const double *coa_map, int map_on_device
     return 0;
 }
 
+int qm_engine_rbf_peak(qm_engine *e, const double *weights, int32_t n, int32_t upscale,
+                       double *peak_value, int64_t *peak_index) {
+    if (!e || !weights || !peak_value || !peak_index)
+        return fail("qm_engine_rbf_peak: NULL argument");
+    if (n < 2 || n > 9 || upscale < 1 || upscale > 64)
+        return fail("qm_engine_rbf_peak: need 2 <= n <= 9 centres per axis and 1 <= upscale <= 64");
+    DeviceGuard guard(e->device);
+    const int m = (n - 1) * upscale + 1;
+    const int64_t fine = (int64_t)m * m * m;
+    constexpr int NB = qm::kFitBlocks, BS = qm::kFitBlock;
+    if (e->d_fit_a.ensure((size_t)fine) || e->d_fit_win.ensure(9 * 9 * 9) ||
+        e->d_fit_part.ensure((size_t)NB * 6) || e->d_fit_pidx.ensure(NB) || e->d_fit_val.ensure(32))
+        return 1;
+    hipStream_t s = e->stream;
+    QM_HIP(hipMemcpyAsync(e->d_fit_win.p, weights, (size_t)n * n * n * sizeof(double),
+                          hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(qm::rbf_dense_kernel, dim3((unsigned)((fine + BS - 1) / BS)), dim3(BS), 0, s,
+                       (const double *)e->d_fit_win.p, (int)n, m, (double)(n - 1) / (double)(m - 1),
+                       e->d_fit_a.p);
+    hipLaunchKernelGGL(qm::argmax_partial_kernel, dim3(NB), dim3(BS), 0, s,
+                       (const double *)e->d_fit_a.p, fine, e->d_fit_part.p, e->d_fit_pidx.p);
+    hipLaunchKernelGGL(qm::argmax_final_kernel, dim3(1), dim3(BS), 0, s, e->d_fit_part.p,
+                       e->d_fit_pidx.p, NB, e->d_fit_val.p, e->d_fit_val.p + 1);
+    QM_HIP(hipGetLastError());
+    double h[2];
+    QM_HIP(hipMemcpyAsync(h, e->d_fit_val.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    QM_HIP(hipStreamSynchronize(s));
+    if (h[1] < 0) return fail("qm_engine_rbf_peak: the interpolant holds no finite value");
+    *peak_value = h[0];
+    *peak_index = (int64_t)h[1];
+    return 0;
+}
+
 int qm_exp2f_max_error(qm_engine *e, float lo, float hi, double *max_rel_error) {
     if (!e || !max_rel_error) return fail("qm_exp2f_max_error: NULL argument");
     if (!(lo <= hi) || (lo < 0.f) != (hi < 0.f))

@@ -221,4 +221,33 @@ __global__ void window_kernel(const double *__restrict__ m, int nx, int ny, int 
     win[t] = v;
 }
 
+// ---- cubic radial-basis interpolant on the refined window (_splineloc, scan.py:777-804) -------
+// dense[(i*m + j)*m + k] = sum over the n^3 centres (a, b, c) of w[a][b][c] * r^3 with
+// r^2 = ((x_j - b)^2 + (y_i - a)^2) + (z_k - c)^2 and x_t = y_t = z_t = t * step (the last point is
+// exactly n - 1, as numpy.linspace makes it) -- scipy.interpolate.Rbf(function="cubic") through
+// the window, evaluated on the `upscale`-times finer grid with the reference's "xy" meshgrid
+// pairing.  One thread per fine point.
+__global__ __launch_bounds__(kFitBlock) void rbf_dense_kernel(const double *__restrict__ w, int n,
+                                                              int m, double step,
+                                                              double *__restrict__ dense) {
+    const int t = blockIdx.x * kFitBlock + threadIdx.x;
+    if (t >= m * m * m) return;
+    const int i = t / (m * m), j = (t / m) % m, k = t % m;
+    const double y = i == m - 1 ? (double)(n - 1) : i * step;
+    const double x = j == m - 1 ? (double)(n - 1) : j * step;
+    const double z = k == m - 1 ? (double)(n - 1) : k * step;
+    double acc = 0.0;
+    for (int a = 0; a < n; ++a) {
+        const double dy2 = (y - a) * (y - a);
+        for (int b = 0; b < n; ++b) {
+            const double dxy2 = (x - b) * (x - b) + dy2;
+            for (int c = 0; c < n; ++c) {
+                const double r2 = dxy2 + (z - c) * (z - c);
+                acc += w[(a * n + b) * n + c] * (r2 * sqrt(r2));
+            }
+        }
+    }
+    dense[t] = acc;
+}
+
 }  // namespace qm

@@ -7,9 +7,10 @@ The sweeps over the whole 3-D map run on the GPU (``Engine.locate_fits``): norma
 the maximum, the two-pass Gaussian smoothing of ``_gaufilt3d`` (scan.py:1008-1043), the
 thresholded moments of ``_covfit3d`` (scan.py:939-1005).  What is left on the host is the
 algebra on the two small windows the engine hands back: the 10-parameter log-quadratic least
-squares of ``_gaufit3d`` on (at most) 7x7x7 smoothed values (scan.py:844-936) and the cubic
-radial-basis interpolation of ``_splineloc`` on 5x5x5 values (scan.py:736-841), for which the
-reference's own libraries (numpy.linalg, scipy.interpolate.Rbf) are used.
+squares of ``_gaufit3d`` on (at most) 7x7x7 smoothed values (scan.py:844-936) and, of the cubic
+radial-basis interpolation of ``_splineloc`` on 5x5x5 values (scan.py:736-841), the 125 x 125
+solve for its weights; the interpolant's 41^3 values and their maximum go back to the GPU
+(``Engine.rbf_peak``).
 
 Everything is returned in grid-index / grid-xyz space.  Pass ``lut`` (anything with the
 reference's ``index2coord`` / ``coord2grid`` / ``ll_corner``, lut/lut.py:174-243) to get the
@@ -84,6 +85,22 @@ def gaussian_from_window(window, smoothed_mean, peak, shape, thresh=0.0):
     return loc + np.asarray(peak), sigma, float(np.exp(-k))
 
 
+def _cubic_rbf_weights(sub):
+    """
+    Weights of ``scipy.interpolate.Rbf(x, y, z, d, function="cubic")`` (smooth = 0, Euclidean
+    norm) through the cube ``sub``: ``solve(|ci - cj|^3, d)``, with the reference's (default,
+    "xy") meshgrid pairing -- the value ``sub[a, b, c]`` sits at ``(x, y, z) = (b, a, c)``
+    (scan.py:777-797).  Returned in the shape of ``sub``.
+    """
+    n = sub.shape[0]
+    c = np.arange(n, dtype=np.float64)
+    a, b, cc = np.meshgrid(c, c, c, indexing="ij")                     # value index (a, b, c)
+    centres = np.stack([b.ravel(), a.ravel(), cc.ravel()], axis=1)     # its (x, y, z)
+    diff = centres[:, None, :] - centres[None, :, :]
+    r = np.sqrt(((diff[..., 0] ** 2 + diff[..., 1] ** 2) + diff[..., 2] ** 2))
+    return np.linalg.solve(r ** 3, sub.ravel()).reshape(n, n, n)
+
+
 def _cubic_rbf_on_grid(sub, upscale):
     """
     ``scipy.interpolate.Rbf(x, y, z, d, function="cubic")`` (smooth = 0, Euclidean norm) through
@@ -96,11 +113,7 @@ def _cubic_rbf_on_grid(sub, upscale):
     """
     n = sub.shape[0]
     c = np.arange(n, dtype=np.float64)
-    a, b, cc = np.meshgrid(c, c, c, indexing="ij")                     # value index (a, b, c)
-    centres = np.stack([b.ravel(), a.ravel(), cc.ravel()], axis=1)     # its (x, y, z)
-    diff = centres[:, None, :] - centres[None, :, :]
-    r = np.sqrt(((diff[..., 0] ** 2 + diff[..., 1] ** 2) + diff[..., 2] ** 2))
-    weights = np.linalg.solve(r ** 3, sub.ravel()).reshape(n, n, n)
+    weights = _cubic_rbf_weights(sub)
     f = np.linspace(0, n - 1, (n - 1) * upscale + 1)
     d2 = (f[:, None] - c[None, :]) ** 2                                # [fine, coarse]
     # r2[i, j, k, a, b, c] = (x_j - b)^2 + (y_i - a)^2 + (z_k - c)^2, one i-slab at a time
@@ -115,11 +128,13 @@ def _cubic_rbf_on_grid(sub, upscale):
     return out
 
 
-def spline_from_window(window, peak, shape, upscale=10):
+def spline_from_window(window, peak, shape, upscale=10, engine=None):
     """
     ``_splineloc`` on the 5x5x5 ``window`` of the normalised map centred on ``peak``: the
     sub-node maximum of a cubic RBF through the window, or the gridded maximum when the clipped
-    window is not a cube or the interpolated maximum leaves it (scan.py:772-839).
+    window is not a cube or the interpolated maximum leaves it (scan.py:772-839).  With an
+    ``engine`` the interpolant's 41^3 values and their maximum are evaluated on the GPU
+    (``Engine.rbf_peak``; the 125 x 125 solve for the weights stays here), otherwise in NumPy.
     """
     win = window.shape[0]
     half = (win - 1) // 2
@@ -130,8 +145,12 @@ def spline_from_window(window, peak, shape, upscale=10):
         return peak.astype(np.float64)
     a0, a1 = lo - (peak - half), hi - (peak - half)
     sub = window[a0[0]:a1[0], a0[1]:a1[1], a0[2]:a1[2]]
-    dense = _cubic_rbf_on_grid(sub, upscale)
-    best = np.array(np.unravel_index(np.nanargmax(dense), dense.shape)) / upscale + lo
+    if engine is not None:
+        _, fine = engine.rbf_peak(_cubic_rbf_weights(sub), upscale)
+        best = np.array(fine) / upscale + lo
+    else:
+        dense = _cubic_rbf_on_grid(sub, upscale)
+        best = np.array(np.unravel_index(np.nanargmax(dense), dense.shape)) / upscale + lo
     if np.any(np.abs(peak - best) > half):
         return peak.astype(np.float64)
     return best
@@ -150,7 +169,7 @@ def calculate_location(engine, coa_map, node_spacing, sgm=0.8, cov_thresh=0.90,
                              norm_out=norm_out, smoothed_out=smoothed_out)
     gaussian, sigma, value = gaussian_from_window(dev["gaussian_window"], dev["smoothed_mean"],
                                                   dev["smoothed_peak"], shape)
-    spline = spline_from_window(dev["spline_window"], dev["peak"], shape)
+    spline = spline_from_window(dev["spline_window"], dev["peak"], shape, engine=engine)
     return LocationFits(map_max=dev["map_max"], peak=dev["peak"], spline=spline,
                         gaussian=gaussian, gaussian_sigma=sigma, gaussian_peak_value=value,
                         expectation=dev["expectation"], covariance=dev["covariance"],

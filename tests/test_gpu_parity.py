@@ -1174,6 +1174,31 @@ def test_locate_fits_match_reference_calculate_location(lib, oracle, name):
     eng.close()
 
 
+def test_rbf_peak_on_device_matches_the_host_interpolant(lib):
+    """Engine.rbf_peak (the 41^3 values of _splineloc's cubic RBF and their first maximum, on the
+    GPU) vs the NumPy evaluation of the same interpolant (locate._cubic_rbf_on_grid, which the CPU
+    suite pins to scipy.interpolate.Rbf's algebra): same fine-grid maximum, value to 1e-12, on
+    peaked windows with noise, for the reference's 5^3 window and other sizes / refinements."""
+    from quakemigrate_amd import locate
+
+    rng = np.random.default_rng(31)
+    eng = lib.Engine(0)
+    for n, upscale in [(5, 10), (5, 10), (5, 10), (5, 4), (3, 10), (7, 5)]:
+        g = np.indices((n, n, n)).astype(np.float64)
+        centre = rng.uniform(0.8, n - 1.8, size=3)
+        sub = np.exp(-((g[0] - centre[0]) ** 2 + (g[1] - centre[1]) ** 2
+                       + (g[2] - centre[2]) ** 2) / rng.uniform(1.0, 4.0))
+        sub += 0.02 * rng.random(sub.shape)
+        dense = locate._cubic_rbf_on_grid(sub, upscale)
+        want = np.unravel_index(np.nanargmax(dense), dense.shape)
+        value, got = eng.rbf_peak(locate._cubic_rbf_weights(sub), upscale)
+        assert got == tuple(int(v) for v in want), (n, upscale)
+        np.testing.assert_allclose(value, dense[want], rtol=1e-12)
+    with pytest.raises(ValueError):
+        eng.rbf_peak(np.zeros((5, 5, 4)))
+    eng.close()
+
+
 def test_locate_chain_marginal_map_to_location_stays_on_device(lib, oracle):
     """Locate without the volume: marginal map (device tensor) -> locate_fits (device in, device
     maps out) vs the oracle's migrate -> sum -> fits on the host."""
