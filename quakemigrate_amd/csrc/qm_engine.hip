@@ -263,10 +263,14 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
         const qm::LaunchShape shape = stack_shape(e, a, groups_lds, threads, lds);
         const int S = e->g.n_rows;
         bool exact = false;
-        // the exact-row-count kernels: fused detect for up to 64 rows, volume-writing for 33-64
-        // rows (up to 32 the paired kernel writes volumes), when the launch uses the table
-        // width's own samples per lane
-        if (e->cfg_exact && !e->cfg_generic && !a.accumulate && a.marginal == nullptr &&
+        // the exact-row-count kernels: fused detect and the marginalised map for up to 64 rows,
+        // volume-writing for 33-64 rows (up to 32 the paired kernel writes volumes), when the
+        // launch uses the table width's own samples per lane
+        if (e->cfg_exact && !e->cfg_generic && !a.accumulate && a.marginal != nullptr &&
+            S <= qm::kExactMaxRows && qm::exact_j(S) == J) {
+            if (S <= 32) QM_TABLE(qm::launch_exact_marginal_1_32(S, a, shape, &exact));
+            else QM_TABLE(qm::launch_exact_marginal_33_64(S, a, shape, &exact));
+        } else if (e->cfg_exact && !e->cfg_generic && !a.accumulate && a.marginal == nullptr &&
             S <= qm::kExactMaxRows && qm::exact_j(S) == J) {
             if (!VOLUME && S <= 32) QM_TABLE(qm::launch_exact_detect_1_32(S, a, shape, &exact));
             else if (!VOLUME) QM_TABLE(qm::launch_exact_detect_33_64(S, a, shape, &exact));

@@ -579,7 +579,8 @@ __device__ __forceinline__ void finish_node(const StackArgs &a, Running<J> &run,
                 m += (t >= a.m0 && t < a.m1) ? e[j] : 0.0;
             }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off, kWave);
+            for (int off = 1; off < kWave; off <<= 1)   // same order as wave_sum_to_last_lane
+                m += __shfl_xor(m, off, kWave);
             if (lane == 0) a.marginal[(int64_t)(t_first / (kWave * J)) * a.n_nodes + node] = m;
         } else {
             double *row = a.volume + (int64_t)node * a.vol_stride + (t_first + lane);
@@ -1047,6 +1048,28 @@ __device__ __forceinline__ void store_one_masked(double *row, int u, double val,
                  : "memory");
 }
 
+// Sum over the wavefront without LDS traffic: DPP moves + adds in the order of an xor butterfly
+// with strides 1, 2, 4, 8, 16, 32 (row_half_mirror / row_mirror deliver the partner group's sum
+// because the sums are uniform within a group by then; the two broadcasts add the row sums in the
+// butterfly's pairing, a + b == b + a) -- the total, bit-identical to that butterfly's, lands in
+// lane 63.  Other lanes hold partial sums.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_moved(double x) {     // rows outside ROW_MASK receive 0.0
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_to_last_lane(double m) {
+    m += dpp_moved<0xB1, 0xf>(m);                      // quad_perm [1,0,3,2]
+    m += dpp_moved<0x4E, 0xf>(m);                      // quad_perm [2,3,0,1]
+    m += dpp_moved<0x141, 0xf>(m);                     // row_half_mirror
+    m += dpp_moved<0x140, 0xf>(m);                     // row_mirror
+    m += dpp_moved<0x142, 0xa>(m);                     // row_bcast:15 into rows 1, 3
+    m += dpp_moved<0x143, 0xc>(m);                     // row_bcast:31 into rows 2, 3
+    return m;
+}
+
 __host__ __device__ constexpr int exact_nch(int S) { return (S + 7) / 8; }   // offset chunks per node
 template <int J, int S> struct ExactPlan {
     static constexpr int RB = BatchRows<J>::value;          // table rows per batch
@@ -1064,6 +1087,23 @@ __device__ __forceinline__ void xepi_step(Epilogue<J> &s, Running<J> &run, const
                                           int t_first, int lane) {
     constexpr int D = Exp2Degree<VOLUME>::value;
     constexpr int H0 = 2, H1 = 2 + D;                  // Horner steps [H0, H1)
+    if constexpr (VOLUME && TAIL == 3 && STEP == H1 + 3) {
+        // TAIL 3, the marginalised map instead of the volume: the node's coalescence summed over
+        // the samples of [m0, m1) that fall into this tile (event.trim2window + np.sum(axis=-1),
+        // quakemigrate/io/event.py:421-439, signal/scan.py:720) -- per lane over its J samples,
+        // then over the wavefront; lane 63 stores the tile's share of the node (s.row is the
+        // element's address; no branch: see store_one_masked).  Same order of additions as
+        // finish_node: the chunked kernels give the same bits.
+        double m = 0.0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int t = t_first + lane + kWave * j;
+            m += (t >= a.m0 && t < a.m1) ? s.p[j] : 0.0;
+        }
+        m = wave_sum_to_last_lane(m);
+        store_one_masked(s.row, 0, m, lane == kWave - 1);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         if constexpr (STEP == 0) s.p[j] = __builtin_rint(s.x[j]);      // k (as double)
@@ -1235,7 +1275,9 @@ __device__ __forceinline__ void stack_exact_body(const StackArgs &a, double *win
                 epi.x[j] = acc[j] * a.z_scale;
             }
             epi.node = node;
-            if (VOLUME) epi.row = a.volume + ((int64_t)node * a.vol_stride + t_first);
+            if (VOLUME && TAIL == 3)
+                epi.row = a.marginal + ((int64_t)tile * a.n_nodes + node);
+            else if (VOLUME) epi.row = a.volume + ((int64_t)node * a.vol_stride + t_first);
             q[NCH - 1] = q_last;
             pending = true;
         }
@@ -1244,6 +1286,16 @@ __device__ __forceinline__ void stack_exact_body(const StackArgs &a, double *win
         run.merge_brick();
     }
     if (a.want_scan) publish<J>(a, run, win, wave, nwaves, lane, t_first, a.set0 + group);
+}
+
+// the marginalised map of a locate window instead of its volume (a.marginal: [ntiles][n_nodes])
+template <int J, int S>
+__global__ __launch_bounds__(1024) void stack_exact_marginal_kernel(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    const int group = (int)(blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / a.ntiles);
+    if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
+    if (a.run_if != nullptr && *a.run_if == 0) return;
+    stack_exact_body<J, true, 3, S>(a, win);
 }
 
 template <int J, bool VOLUME, int S>

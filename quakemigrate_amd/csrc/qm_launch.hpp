@@ -58,6 +58,9 @@ inline hipError_t launch_with_lds(Kernel kernel, const Args &a, const LaunchShap
 hipError_t launch_exact_detect_1_32(int S, const StackArgs &a, const LaunchShape &s, bool *built);
 hipError_t launch_exact_detect_33_64(int S, const StackArgs &a, const LaunchShape &s, bool *built);
 hipError_t launch_exact_volume_33_64(int S, const StackArgs &a, const LaunchShape &s, bool *built);
+// stack_exact_marginal_kernel<exact_j(S), S>: the marginalised map instead of the volume
+hipError_t launch_exact_marginal_1_32(int S, const StackArgs &a, const LaunchShape &s, bool *built);
+hipError_t launch_exact_marginal_33_64(int S, const StackArgs &a, const LaunchShape &s, bool *built);
 // stack_pair_kernel<2, VOLUME, S>, S = 1..32
 hipError_t launch_pair_detect(int S, const StackArgs &a, const LaunchShape &s, bool *built);
 hipError_t launch_pair_volume(int S, const StackArgs &a, const LaunchShape &s, bool *built);

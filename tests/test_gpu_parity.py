@@ -889,6 +889,36 @@ def test_marginal_map_equals_time_sum_of_the_volume(lib, oracle, cfg):
     eng.close()
 
 
+@pytest.mark.parametrize("rows", [1, 7, 9, 24, 30, 32, 33, 40, 41, 60, 64])
+def test_exact_marginal_kernels_give_the_chunked_kernels_bits(lib, oracle, rows):
+    """The marginalised map from the exact-row-count kernels (epilogue slice: per-lane sum of the
+    window's samples, DPP wave sum, one masked store per node and tile) == the chunked kernels'
+    map bit for bit (same order of additions) == the time sum of the oracle volume; windows that
+    start / end inside tiles, cover one sample, or the whole ragged scan."""
+    ns = 401
+    case = synth.make_case("C2", step=11, grid=(12, 11, 9), rows=rows, n_samples=ns)
+    ref = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
+                           threads=4)
+    want_series = oracle.c_find_max_coa(ref, threads=2)
+    lon = oracle.log_onsets(case.onsets)
+    maps = {}
+    for exact in (1, 0):
+        eng = lib.Engine(0, exact=exact, samples_per_lane=4 if rows <= 40 else 2)
+        eng.load_lut(case.traveltimes)
+        for i0, i1 in [(100, 301), (0, ns), (255, 257), (400, 401), (0, 1)]:
+            series = (np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64))
+            got = eng.marginal_map(lon, case.fsmp, case.lsmp, case.available, i0, i1,
+                                   scan_out=series)
+            assert eng.get("last_kernel") == exact
+            np.testing.assert_allclose(got, ref[..., i0:i1].sum(axis=-1), rtol=1e-12)
+            _assert_series(series, want_series)
+            maps[(exact, i0, i1)] = got
+        eng.close()
+    for (exact, i0, i1), got in maps.items():
+        if exact:
+            assert np.array_equal(got, maps[(0, i0, i1)]), (i0, i1)
+
+
 def test_onset_stage_on_device_matches_reference_stalta_onset(lib, oracle):
     """qm_engine_onsets vs the reference's OWN STALTAOnset._onset / _trim_taper_pad (fixture made
     by running signal/onsets/stalta.py:491-583 on the reference C STA/LTA, make_golden.py
