@@ -1,11 +1,19 @@
 # -*- coding: utf-8 -*-
 """Shared pytest plumbing: markers, paths, golden-vector loading."""
 
+import os
 import pathlib
 import sys
 
-import numpy as np
-import pytest
+# The oracle's OpenMP loops run with one thread per logical CPU.  On a box whose CPU share is
+# smaller than its CPU count (a container quota, a busy neighbour) libgomp's default of spinning
+# at barriers turns that into minutes per call; blocked waits cost nothing measurable here.  Must
+# be in the environment before libgomp initialises, i.e. before numpy / torch / the oracle load.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
