@@ -102,7 +102,7 @@ int qm_engine_synchronize(qm_engine *e);
  * "screen_big" (sweep launch shape, 0 / -1 = automatic), "exact" (default 1: the
  * exact-row-count float64 kernel), "pair" (default 1: the 16-byte-operand kernel for
  * volume-writing launches; 2 = for every launch, 0 = off), "rounds" (grid size of the automatic
- * group count).
+ * group count), "scan_waves" (find_max_coa of a volume: wavefronts per CU over the whole grid).
  * qm_engine_get additionally reports "screened_steps", "fallback_steps" (steps redone in
  * float64 on the device: too many candidate cells -- flat all-ties data --, non-finite onsets,
  * a dynamic range outside the bound's preconditions), "last_candidates". */
