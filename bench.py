@@ -246,6 +246,13 @@ def main():
     # ---- workload: this rank's slab of the grid ---------------------------------------
     streaming = args.config == "C5"
     cfg_name = "C3" if streaming else args.config
+    # The continuous stream (configs[4]) shards over TIME, not over the grid: timesteps are
+    # independent given their onsets, so rank r scans timesteps r, r + N, ... of the WHOLE grid
+    # (every rank holds the whole table: 0.5 GB at C3) and there is no collective in the data
+    # path at all.  Per-GPU work is fixed as N grows: weak scaling.
+    time_sharded = streaming and world > 1
+    if time_sharded:
+        part_world, part_rank = 1, 0
     base = synth.CONFIGS[cfg_name]
     nx, ny, nz = base["grid"]
     if args.weak:                                       # a full slab per GPU
@@ -275,7 +282,7 @@ def main():
            torch.empty(ns, dtype=torch.float64, device=dev),
            torch.empty(ns, dtype=torch.int64, device=dev))
     sharded = (qd.ShardedDetector(eng, n_total, ns, dev, exchange=args.exchange)
-               if use_dist else None)
+               if use_dist and not time_sharded else None)
 
     def step(i):
         on = onsets_dev[i % n_pool]
@@ -306,7 +313,9 @@ def main():
     eng.config("log_timing", 1)
     t0 = time.perf_counter()
     if streaming:
-        got = sd.run(host_onsets[(args.warmup + i) % n_pool] for i in range(args.steps))
+        # (time-sharded: this rank's timesteps are rank, rank + world, ... of the stream)
+        got = sd.run(host_onsets[(args.warmup + rank + world * i) % n_pool]
+                     for i in range(args.steps))
         res = tuple(torch.from_numpy(a) for a in got[-1])
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
     else:
@@ -324,6 +333,8 @@ def main():
 
     # ---- in-bench sanity: injected events are found where they were put ------------
     last = (args.warmup + args.steps - 1) % n_pool
+    if time_sharded:
+        last = (args.warmup + rank + world * (args.steps - 1)) % n_pool
     idx = res[2].cpu().numpy()
     for (ijk, t_ev) in cases[last].event_nodes:
         if part_world != world and not (x_range[0] <= ijk[0] < x_range[1]):
@@ -344,6 +355,8 @@ def main():
     if part_world != world:
         n_total = n_local                               # emulated slab: count what was stacked
     work_step = n_total * ns                            # node-samples per step, whole job
+    if time_sharded:
+        work_step *= world                              # every rank scanned its own timesteps
     value = work_step * args.steps / elapsed
     kern_s = kern_ms / 1e3 / max(kern_calls, 1)         # avg stacking-kernel time, this rank
     local_ns = n_local * ns
@@ -353,7 +366,8 @@ def main():
         "metric": "grid-nodes x time-samples stacked /sec (detect sweep)",
         "value": value, "unit": "node-samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
+        "higher_is_better": True,
+        "scaling": "weak" if (args.weak or time_sharded) else "strong",
         "vs_baseline": None,
         "dtype": "i32 fixed-point sweep + f64 refinement (opt-in screen=1)" if screened else "f64",
         "data": "synthetic",
@@ -365,10 +379,11 @@ def main():
                                + (f"; {x_range[1] - x_range[0]} x-planes of it on rank {part_rank}"
                                   if part_world > 1 else ""),
                    "n_nodes_per_gpu": n_local, "n_rows": S, "n_samples": ns,
-                   "sharding": "x-plane slabs" if world > 1 else "none",
+                   "sharding": ("timesteps round-robin over the ranks, whole grid on every rank"
+                                if time_sharded else "x-plane slabs" if world > 1 else "none"),
                    "exchange": ({"packed": "1 x all_gather([3][n_samples]) + device fold per step",
                                  "allreduce": "3 x all_reduce(n_samples) per step"}[args.exchange]
-                                if use_dist else "none"),
+                                if use_dist and not time_sharded else "none"),
                    "collective_backend": backend, "ranks": world,
                    "engine": dict(tunables, brick=[eng.get("brick_x"), eng.get("brick_y"),
                                                    eng.get("brick_z")],

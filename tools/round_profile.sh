@@ -18,6 +18,7 @@ python bench.py --config C5 --steps 30 --warmup 3 > $OUT/bench_C5_stream.json 2>
 # N > 1 plumbing on one GPU (gloo rendezvous; RCCL refuses two ranks on one device): self-launch
 QM_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --steps 5 --warmup 1 > $OUT/bench_C3_2ranks_one_gpu.json 2> $OUT/bench_2ranks.err; tail -c 600 $OUT/bench_C3_2ranks_one_gpu.json; tail -3 $OUT/bench_2ranks.err
 QM_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --config C4 --steps 2 --warmup 1 > $OUT/bench_C4_2ranks_one_gpu.json 2>> $OUT/bench_2ranks.err; tail -c 400 $OUT/bench_C4_2ranks_one_gpu.json
+QM_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --config C5 --steps 6 --warmup 1 > $OUT/bench_C5_2ranks_one_gpu.json 2>> $OUT/bench_2ranks.err; tail -c 400 $OUT/bench_C5_2ranks_one_gpu.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- \
     python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_C3_under_rocprof.json 2> $OUT/prof.err
