@@ -1105,6 +1105,12 @@ def test_randomised_differential_with_many_exact_ties(lib, oracle):
         eng.migrate(lon, fsmp, lsmp, avail, vol, scan_out=series)
         np.testing.assert_allclose(vol, ref, rtol=1e-13, err_msg=str((trial, cfg)))
         assert np.array_equal(series[2], want[2]), (trial, cfg)
+        if trial % 4 == 0:                                 # the marginalised map of a random window
+            i0 = int(rng.integers(0, ns))
+            i1 = int(rng.integers(i0 + 1, ns + 1))
+            got_map = eng.marginal_map(lon, fsmp, lsmp, avail, i0, i1)
+            np.testing.assert_allclose(got_map, ref[..., i0:i1].sum(axis=-1), rtol=1e-12,
+                                       err_msg=str((trial, cfg, i0, i1)))
         eng.close()
     assert n_ties > 25 * n_trials                          # the test does exercise ties
 
