@@ -223,6 +223,32 @@ def test_exchange_partials_world_size_2_gloo(oracle, tmp_path):
         np.testing.assert_allclose(got["marg"], vol[..., 40:150].sum(axis=-1), rtol=1e-13)
 
 
+def test_cubic_rbf_algebra_is_scipys_rbf():
+    """locate._cubic_rbf_weights / _cubic_rbf_on_grid (what Engine.rbf_peak evaluates on the GPU)
+    against scipy.interpolate.Rbf(function="cubic") called the way _splineloc calls it
+    (scan.py:777-804: default "xy" meshgrids of the window and of the 10x finer grid)."""
+    from scipy.interpolate import Rbf
+
+    from quakemigrate_amd import locate
+
+    rng = np.random.default_rng(8)
+    n, upscale = 5, 10
+    g = np.indices((n, n, n)).astype(np.float64)
+    sub = np.exp(-((g[0] - 2.3) ** 2 + (g[1] - 1.6) ** 2 + (g[2] - 2.1) ** 2) / 2.5)
+    sub += 0.01 * rng.random(sub.shape)
+    c = np.arange(n, dtype=np.float64)
+    x, y, z = np.meshgrid(c, c, c)
+    rbf = Rbf(x.ravel(), y.ravel(), z.ravel(), sub.ravel(), function="cubic")
+    f = np.linspace(0, n - 1, (n - 1) * upscale + 1)
+    xf, yf, zf = np.meshgrid(f, f, f)
+    want = rbf(xf.ravel(), yf.ravel(), zf.ravel()).reshape(xf.shape)
+    got = locate._cubic_rbf_on_grid(sub, upscale)
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
+    assert np.unravel_index(np.argmax(got), got.shape) == np.unravel_index(np.argmax(want), want.shape)
+    np.testing.assert_allclose(locate._cubic_rbf_weights(sub).ravel(), rbf.nodes, rtol=1e-8,
+                               atol=1e-12)
+
+
 def _cube(a, centre, width):
     out = np.full((width,) * 3, np.nan)
     half = width // 2
