@@ -87,6 +87,7 @@ struct qm_engine {
     int cfg_bx = 0, cfg_by = 0, cfg_bz = 0;      // 0 = choose the brick shape per table
     int cfg_j = 0;                  // samples per lane (time tile = 64*J); 0 = by table width
     int n_rows_hint = 0;            // row count the automatic choice is based on
+    int auto_j = 0;                 // samples per lane picked by the table's layout search (> 64 rows)
     int cfg_waves = 8;
     bool user_waves = false, user_lds = false;   // set explicitly: no automatic layout
     int cfg_groups = 0;
@@ -178,6 +179,7 @@ int lds_cap_doubles(const qm_engine *e) { return e->cfg_lds_bytes / 8; }
 int eff_j(const qm_engine *e) {
     const int S = e->n_rows_hint > 0 ? e->n_rows_hint : 1;
     if (e->cfg_j > 0) return (e->cfg_j == 4 && S > 40) ? 2 : e->cfg_j;   // see below
+    if (e->auto_j > 0) return e->auto_j;
     for (int j : {4, 2, 1}) {
         if (j == 4 && S > 40) continue;
         if ((int64_t)S * qm::kWave * j * 8 * 5 <= (int64_t)e->cfg_lds_bytes * 4) return j;
@@ -1183,50 +1185,75 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     const int n_shapes = e->cfg_bx > 0 ? 1 : (int)(sizeof(kShapes) / sizeof(kShapes[0]));
     e->n_rows_hint = n_rows;
     // float64 kernel layout, unless set explicitly: two 8-wave workgroups per CU with 80 KB each;
-    // beyond 40 rows (two samples per lane) one 16-wave workgroup with all 160 KB, which keeps
-    // 8x8x8 bricks (C4 slab: 286 -> 239 ms)
+    // beyond 40 rows one 16-wave workgroup with all 160 KB, which keeps the bricks large (C4
+    // slab, 60 rows: 286 -> 239 ms; 128 rows on the C2 grid: 622 -> 75 ms together with the
+    // layout search below)
+    e->auto_j = 0;
     if (!e->user_waves && !e->user_lds) {
-        const bool big = n_rows > 40 && n_rows <= 64;
+        const bool big = n_rows > 40;
         e->cfg_waves = big ? 16 : 8;
         e->cfg_lds_bytes = big ? 160 * 1024 : 80 * 1024;
     }
-    const int KT = qm::kWave * eff_j(e);
     qm::GridDesc g{};
-    for (int s = 0; s < n_shapes; ++s) {
-        g = qm::GridDesc{};
-        g.nx = nx; g.ny = ny; g.nz = nz;
-        g.bx = std::min(e->cfg_bx > 0 ? e->cfg_bx : kShapes[s][0], (int)nx);
-        g.by = std::min(e->cfg_bx > 0 ? e->cfg_by : kShapes[s][1], (int)ny);
-        g.bz = std::min(e->cfg_bx > 0 ? e->cfg_bz : kShapes[s][2], (int)nz);
-        g.nbx = (nx + g.bx - 1) / g.bx;
-        g.nby = (ny + g.by - 1) / g.by;
-        g.nbz = (nz + g.bz - 1) / g.bz;
-        const int64_t nbricks = (int64_t)g.nbx * g.nby * g.nbz;
-        if (nbricks >= INT32_MAX) return fail("too many bricks");
-        g.nbricks = (int)nbricks;
-        g.brick_nodes = g.bx * g.by * g.bz;
-        g.n_rows = n_rows;
-        g.row_pad = (n_rows + 7) / 8 * 8;
-        const size_t br = (size_t)nbricks * n_rows;
-        if (e->d_bmeta.ensure(4 * br) || e->d_btotal.ensure(nbricks)) return 1;
-        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
-        hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
-                           e->d_lut.p, reinterpret_cast<int4 *>(e->d_bmeta.p), e->d_scalar.p);
-        QM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(qm::brick_prefix_kernel, dim3((g.nbricks + 255) / 256), dim3(256), 0,
-                           e->stream, g, reinterpret_cast<int4 *>(e->d_bmeta.p), e->d_btotal.p);
-        QM_HIP(hipGetLastError());
-        e->h_btotal.resize(nbricks);
-        QM_HIP(hipMemcpyAsync(e->h_btotal.data(), e->d_btotal.p, nbricks * sizeof(int32_t),
-                              hipMemcpyDeviceToHost, e->stream));
-        QM_HIP(hipMemcpyAsync(&e->lut_max, e->d_scalar.p, sizeof(int32_t), hipMemcpyDeviceToHost,
-                              e->stream));
-        QM_HIP(hipStreamSynchronize(e->stream));
-        int64_t wide = 0;
-        for (int64_t b = 0; b < nbricks; ++b)
-            if (!qm::brick_fits(e->h_btotal[b], n_rows, KT, lds_cap_doubles(e))) ++wide;
-        if (wide * 200 <= nbricks) break;              // <= 0.5 % of the bricks on the slow path
+    // largest candidate shape whose windows fit for tile length 64 * J (result in g, e->d_bmeta,
+    // e->d_btotal, e->h_btotal)
+    auto search = [&](int J) -> int {
+        const int KT = qm::kWave * J;
+        for (int s = 0; s < n_shapes; ++s) {
+            g = qm::GridDesc{};
+            g.nx = nx; g.ny = ny; g.nz = nz;
+            g.bx = std::min(e->cfg_bx > 0 ? e->cfg_bx : kShapes[s][0], (int)nx);
+            g.by = std::min(e->cfg_bx > 0 ? e->cfg_by : kShapes[s][1], (int)ny);
+            g.bz = std::min(e->cfg_bx > 0 ? e->cfg_bz : kShapes[s][2], (int)nz);
+            g.nbx = (nx + g.bx - 1) / g.bx;
+            g.nby = (ny + g.by - 1) / g.by;
+            g.nbz = (nz + g.bz - 1) / g.bz;
+            const int64_t nbricks = (int64_t)g.nbx * g.nby * g.nbz;
+            if (nbricks >= INT32_MAX) return fail("too many bricks");
+            g.nbricks = (int)nbricks;
+            g.brick_nodes = g.bx * g.by * g.bz;
+            g.n_rows = n_rows;
+            g.row_pad = (n_rows + 7) / 8 * 8;
+            const size_t br = (size_t)nbricks * n_rows;
+            if (e->d_bmeta.ensure(4 * br) || e->d_btotal.ensure(nbricks)) return 1;
+            QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
+            hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
+                               e->d_lut.p, reinterpret_cast<int4 *>(e->d_bmeta.p), e->d_scalar.p);
+            QM_HIP(hipGetLastError());
+            hipLaunchKernelGGL(qm::brick_prefix_kernel, dim3((g.nbricks + 255) / 256), dim3(256),
+                               0, e->stream, g, reinterpret_cast<int4 *>(e->d_bmeta.p),
+                               e->d_btotal.p);
+            QM_HIP(hipGetLastError());
+            e->h_btotal.resize(nbricks);
+            QM_HIP(hipMemcpyAsync(e->h_btotal.data(), e->d_btotal.p, nbricks * sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, e->stream));
+            QM_HIP(hipMemcpyAsync(&e->lut_max, e->d_scalar.p, sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, e->stream));
+            QM_HIP(hipStreamSynchronize(e->stream));
+            int64_t wide = 0;
+            for (int64_t b = 0; b < nbricks; ++b)
+                if (!qm::brick_fits(e->h_btotal[b], n_rows, KT, lds_cap_doubles(e))) ++wide;
+            if (wide * 200 <= nbricks) break;          // <= 0.5 % of the bricks on the slow path
+        }
+        return 0;
+    };
+    if (n_rows > 64 && e->cfg_j == 0 && e->cfg_bx == 0 && !e->user_waves && !e->user_lds) {
+        // Wide tables: all S windows of a brick must sit in LDS together, so the tile length
+        // trades against the brick size -- two samples per lane halve the per-sample overhead
+        // (measured 1.12x vs 1.4x the work of four), but leave less room for the delay spans and
+        // force smaller bricks, whose staging is amortised over fewer nodes (measured on 65-200
+        // rows: time ~ (1 + 30 / nodes per brick)).  Search both and keep the cheaper.
+        double best_cost = 1e300;
+        int best_j = 1;
+        for (int j : {2, 1}) {
+            if ((int64_t)n_rows * qm::kWave * j * 8 * 5 > (int64_t)e->cfg_lds_bytes * 4) continue;
+            if (search(j)) return 1;
+            const double cost = (j == 2 ? 1.12 : 1.4) * (1.0 + 30.0 / g.brick_nodes);
+            if (cost < best_cost) { best_cost = cost; best_j = j; }
+        }
+        e->auto_j = best_j;
     }
+    if (search(eff_j(e))) return 1;
     if (e->d_rel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;
     hipLaunchKernelGGL(qm::brick_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
                        e->d_lut.p, reinterpret_cast<const int4 *>(e->d_bmeta.p), e->d_btotal.p,
