@@ -1184,16 +1184,7 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
                                      {2, 4, 4}, {2, 2, 4}, {2, 2, 2}, {1, 1, 2}, {1, 1, 1}};
     const int n_shapes = e->cfg_bx > 0 ? 1 : (int)(sizeof(kShapes) / sizeof(kShapes[0]));
     e->n_rows_hint = n_rows;
-    // float64 kernel layout, unless set explicitly: two 8-wave workgroups per CU with 80 KB each;
-    // beyond 40 rows one 16-wave workgroup with all 160 KB, which keeps the bricks large (C4
-    // slab, 60 rows: 286 -> 239 ms; 128 rows on the C2 grid: 622 -> 75 ms together with the
-    // layout search below)
     e->auto_j = 0;
-    if (!e->user_waves && !e->user_lds) {
-        const bool big = n_rows > 40;
-        e->cfg_waves = big ? 16 : 8;
-        e->cfg_lds_bytes = big ? 160 * 1024 : 80 * 1024;
-    }
     qm::GridDesc g{};
     // largest candidate shape whose windows fit for tile length 64 * J (result in g, e->d_bmeta,
     // e->d_btotal, e->h_btotal)
@@ -1237,21 +1228,45 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
         }
         return 0;
     };
-    if (n_rows > 64 && e->cfg_j == 0 && e->cfg_bx == 0 && !e->user_waves && !e->user_lds) {
-        // Wide tables: all S windows of a brick must sit in LDS together, so the tile length
-        // trades against the brick size -- two samples per lane halve the per-sample overhead
-        // (measured 1.12x vs 1.4x the work of four), but leave less room for the delay spans and
-        // force smaller bricks, whose staging is amortised over fewer nodes (measured on 65-200
-        // rows: time ~ (1 + 30 / nodes per brick)).  Search both and keep the cheaper.
+    if (e->cfg_j == 0 && e->cfg_bx == 0 && !e->user_waves && !e->user_lds) {
+        // Automatic layout.  All S windows of a brick sit in LDS together, so workgroup shape
+        // (two 8-wave workgroups with 80 KB each, or one 16-wave workgroup with all 160 KB --
+        // measured 4 % slower at equal bricks: barriers), samples per lane and brick size trade
+        // against each other: more samples per lane cost less per sample (measured 1.0 / 1.12 /
+        // 1.4 for 4 / 2 / 1) but leave less room for the delay spans, and smaller bricks amortise
+        // their staging over fewer nodes (measured on 20-200 rows: time ~ 1 + 30 / nodes per
+        // brick).  Up to 64 rows the samples per lane follow from the budget (eff_j) and an
+        // exact-row-count kernel exists for one of them (3 % faster); beyond, both 2 and 1 are
+        // tried.  C3 (30 rows) keeps 2 x 80 KB; 33-64 rows and coarse grids get 160 KB.
         double best_cost = 1e300;
-        int best_j = 1;
-        for (int j : {2, 1}) {
-            if ((int64_t)n_rows * qm::kWave * j * 8 * 5 > (int64_t)e->cfg_lds_bytes * 4) continue;
-            if (search(j)) return 1;
-            const double cost = (j == 2 ? 1.12 : 1.4) * (1.0 + 30.0 / g.brick_nodes);
-            if (cost < best_cost) { best_cost = cost; best_j = j; }
+        int best_j = 0, best_waves = 8, best_lds = 80 * 1024;
+        for (int single = 0; single < 2; ++single) {
+            e->cfg_waves = single ? 16 : 8;
+            e->cfg_lds_bytes = single ? 160 * 1024 : 80 * 1024;
+            const int j_budget = eff_j(e);
+            for (int j : {4, 2, 1}) {
+                if (n_rows <= 64 ? j != j_budget : (j == 4 || j > j_budget)) continue;
+                if (search(j)) return 1;
+                double cost = (j == 4 ? 1.0 : j == 2 ? 1.12 : 1.4) * (1.0 + 30.0 / g.brick_nodes) *
+                              (single ? 1.04 : 1.0);
+                if (e->cfg_exact && n_rows <= qm::kExactMaxRows && j == qm::exact_j(n_rows))
+                    cost *= 0.97;
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_j = j;
+                    best_waves = e->cfg_waves;
+                    best_lds = e->cfg_lds_bytes;
+                }
+            }
         }
-        e->auto_j = best_j;
+        e->cfg_waves = best_waves;
+        e->cfg_lds_bytes = best_lds;
+        if (n_rows > 64) e->auto_j = best_j;           // (up to 64 rows eff_j gives it back)
+    } else if (!e->user_waves && !e->user_lds) {
+        // brick shape or samples per lane given: the workgroup shape by the row count alone
+        const bool big = n_rows > 40;
+        e->cfg_waves = big ? 16 : 8;
+        e->cfg_lds_bytes = big ? 160 * 1024 : 80 * 1024;
     }
     if (search(eff_j(e))) return 1;
     if (e->d_rel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;

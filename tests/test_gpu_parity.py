@@ -773,7 +773,7 @@ def test_any_row_count_picks_a_fitting_tile_and_matches_oracle(lib, oracle, rows
     eng.load_lut(case.traveltimes)
     j = eng.get("samples_per_lane")
     # (beyond 64 rows the table's layout search weighs tile length against brick size)
-    assert j == (4 if rows <= 32 else 2) if rows <= 64 else j in (1, 2)
+    assert j == (4 if rows <= 40 else 2) if rows <= 64 else j in (1, 2)
     got = eng.detect(oracle.log_onsets(case.onsets), case.fsmp, case.lsmp, case.available)
     _assert_series(got, want)
     assert eng.get("n_wide_bricks") == 0
