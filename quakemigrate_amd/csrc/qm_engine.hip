@@ -173,15 +173,16 @@ struct DeviceGuard {
 
 int lds_cap_doubles(const qm_engine *e) { return e->cfg_lds_bytes / 8; }
 
-// Samples per lane: explicit, or the largest J whose S row windows leave >= 20 % of the LDS
-// budget for the delay spans (J = 4 additionally needs S <= 40: beyond that its software-
-// pipelined kernel no longer fits 128 VGPRs).
+// Samples per lane: explicit, the table's layout search's choice (load_lut), or the largest J
+// whose S row windows leave >= 20 % of the LDS budget for the delay spans (J = 4 up to 64 rows:
+// beyond 40 its pipelined kernels spill a few offset chunks per node, and only the exact-row-count
+// kernels are built for that).
 int eff_j(const qm_engine *e) {
     const int S = e->n_rows_hint > 0 ? e->n_rows_hint : 1;
-    if (e->cfg_j > 0) return (e->cfg_j == 4 && S > 40) ? 2 : e->cfg_j;   // see below
+    if (e->cfg_j > 0) return (e->cfg_j == 4 && S > qm::kJ4MaxRows) ? 2 : e->cfg_j;   // see below
     if (e->auto_j > 0) return e->auto_j;
     for (int j : {4, 2, 1}) {
-        if (j == 4 && S > 40) continue;
+        if (j == 4 && S > qm::kJ4MaxRows) continue;
         if ((int64_t)S * qm::kWave * j * 8 * 5 <= (int64_t)e->cfg_lds_bytes * 4) return j;
     }
     return 1;
@@ -268,15 +269,20 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
         // the exact-row-count kernels: fused detect and the marginalised map for up to 64 rows,
         // volume-writing for 33-64 rows (up to 32 the paired kernel writes volumes), when the
         // launch uses the table width's own samples per lane
-        if (e->cfg_exact && !e->cfg_generic && !a.accumulate && a.marginal != nullptr &&
-            S <= qm::kExactMaxRows && qm::exact_j(S) == J) {
-            if (S <= 32) QM_TABLE(qm::launch_exact_marginal_1_32(S, a, shape, &exact));
-            else QM_TABLE(qm::launch_exact_marginal_33_64(S, a, shape, &exact));
-        } else if (e->cfg_exact && !e->cfg_generic && !a.accumulate && a.marginal == nullptr &&
-            S <= qm::kExactMaxRows && qm::exact_j(S) == J) {
-            if (!VOLUME && S <= 32) QM_TABLE(qm::launch_exact_detect_1_32(S, a, shape, &exact));
-            else if (!VOLUME) QM_TABLE(qm::launch_exact_detect_33_64(S, a, shape, &exact));
-            else if (S > qm::kPairMaxRows) QM_TABLE(qm::launch_exact_volume_33_64(S, a, shape, &exact));
+        if (e->cfg_exact && !e->cfg_generic && !a.accumulate && qm::exact_built(S, J)) {
+            const bool j4_wide = J == 4 && S > 40;     // the second variant of 41-64 rows
+            if (a.marginal != nullptr) {
+                if (S <= 32) QM_TABLE(qm::launch_exact_marginal_1_32(S, a, shape, &exact));
+                else if (!j4_wide) QM_TABLE(qm::launch_exact_marginal_33_64(S, a, shape, &exact));
+                else QM_TABLE(qm::launch_exact_marginal_j4_41_64(S, a, shape, &exact));
+            } else if (!VOLUME) {
+                if (S <= 32) QM_TABLE(qm::launch_exact_detect_1_32(S, a, shape, &exact));
+                else if (!j4_wide) QM_TABLE(qm::launch_exact_detect_33_64(S, a, shape, &exact));
+                else QM_TABLE(qm::launch_exact_detect_j4_41_64(S, a, shape, &exact));
+            } else if (S > qm::kPairMaxRows) {
+                if (!j4_wide) QM_TABLE(qm::launch_exact_volume_33_64(S, a, shape, &exact));
+                else QM_TABLE(qm::launch_exact_volume_j4_41_64(S, a, shape, &exact));
+            }
         }
         e->last_kernel = exact ? 1 : 0;
         e->last_j = J;
@@ -438,6 +444,11 @@ int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu) {
     int64_t want = ((int64_t)e->cfg_rounds * slots) / ntiles;
     if (want < 1) want = std::max<int64_t>(1, slots / ntiles);
     want = std::max<int64_t>(1, std::min<int64_t>(want, units));
+    // Group g runs on XCD g % 8 (the XCD-aware workgroup map of the stacking kernels), so a
+    // group count that is not a multiple of 8 leaves some XCDs one group short: 65 groups = 9 on
+    // one XCD, 8 on the others = 11 % of the step spent waiting for one XCD (C3 x 60 rows at
+    // 12000 samples: 255 -> see profiles/r02_ab_runs.txt).  Round down to a multiple of 8.
+    if (want > 8) want -= want % 8;
     return (int)want;
 }
 
@@ -1153,6 +1164,10 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
             if (plan_wide(e, eff_j(e))) return 1;
         }
         *v = e->n_wide;
+    } else if (k == "mean_span") {                     // mean delay span per (brick, row), samples
+        int64_t sum = 0;
+        for (int32_t t : e->h_btotal) sum += t;
+        *v = e->h_btotal.empty() ? 0 : sum / ((int64_t)e->h_btotal.size() * std::max(1, e->g.n_rows));
     } else if (k == "n_cu") *v = e->n_cu;
     else if (k == "n_nodes") *v = e->n_nodes;
     else if (k == "n_rows") *v = e->g.n_rows;
@@ -1245,12 +1260,14 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
             e->cfg_lds_bytes = single ? 160 * 1024 : 80 * 1024;
             const int j_budget = eff_j(e);
             for (int j : {4, 2, 1}) {
-                if (n_rows <= 64 ? j != j_budget : (j == 4 || j > j_budget)) continue;
+                if (j > j_budget || (j == 1 && j_budget > 1 && n_rows <= 64)) continue;
+                if (j == 4 && n_rows > 40 && !e->cfg_exact) continue;   // exact kernels only
                 if (search(j)) return 1;
-                double cost = (j == 4 ? 1.0 : j == 2 ? 1.12 : 1.4) * (1.0 + 30.0 / g.brick_nodes) *
-                              (single ? 1.04 : 1.0);
-                if (e->cfg_exact && n_rows <= qm::kExactMaxRows && j == qm::exact_j(n_rows))
-                    cost *= 0.97;
+                // (four samples per lane beyond 40 rows: the spilled offset chunks leave 1-3 %
+                // over two samples per lane at equal bricks, more where the delay spans are long)
+                double cost = (j == 4 ? (n_rows > 40 ? 1.08 : 1.0) : j == 2 ? 1.12 : 1.4) *
+                              (1.0 + 30.0 / g.brick_nodes) * (single ? 1.04 : 1.0);
+                if (e->cfg_exact && qm::exact_built(n_rows, j)) cost *= 0.97;
                 if (cost < best_cost) {
                     best_cost = cost;
                     best_j = j;
@@ -1261,7 +1278,7 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
         }
         e->cfg_waves = best_waves;
         e->cfg_lds_bytes = best_lds;
-        if (n_rows > 64) e->auto_j = best_j;           // (up to 64 rows eff_j gives it back)
+        e->auto_j = best_j;
     } else if (!e->user_waves && !e->user_lds) {
         // brick shape or samples per lane given: the workgroup shape by the row count alone
         const bool big = n_rows > 40;

@@ -25,7 +25,18 @@ namespace qm {
     X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62)   \
     X(63) X(64)
 constexpr int kExactMaxRows = 64;
+#define QM_ROWS_41_64(X)                                                                        \
+    X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55)   \
+    X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63) X(64)
+// Samples per lane of the exact-row-count kernels: 4 up to 40 rows; for 41-64 rows both 2 (the
+// whole node pipeline in registers) and 4 (a few offset chunks of the next node spill to scratch
+// inside the node loop, yet 6-20 % faster where the bricks stay large: the table's layout search
+// decides) are built.
+constexpr int kJ4MaxRows = 64;      // widest table that may run four samples per lane
 constexpr int exact_j(int S) { return S <= 40 ? 4 : 2; }
+constexpr bool exact_built(int S, int J) {
+    return S >= 1 && S <= kExactMaxRows && (J == exact_j(S) || (J == 4 && S > 40));
+}
 
 // Paired (16-byte operand) layout, qm_pair.hpp: up to 32 rows, JP = 2 pairs per lane (time tile
 // 256) -- both copies of S row windows plus the delay spans in 160 KB.  (JP = 1 / tile 128 for
@@ -54,13 +65,17 @@ inline hipError_t launch_with_lds(Kernel kernel, const Args &a, const LaunchShap
     return hipGetLastError();
 }
 
-// stack_exact_kernel<exact_j(S), false, S>: S = 1..32 / 33..64; <.., true, S>: S = 33..64
+// stack_exact_kernel<exact_j(S), false, S>: S = 1..32 / 33..64; <.., true, S>: S = 33..64;
+// the *_j4_41_64 tables hold the four-samples-per-lane variants of 41-64 rows
 hipError_t launch_exact_detect_1_32(int S, const StackArgs &a, const LaunchShape &s, bool *built);
 hipError_t launch_exact_detect_33_64(int S, const StackArgs &a, const LaunchShape &s, bool *built);
+hipError_t launch_exact_detect_j4_41_64(int S, const StackArgs &a, const LaunchShape &s, bool *built);
 hipError_t launch_exact_volume_33_64(int S, const StackArgs &a, const LaunchShape &s, bool *built);
-// stack_exact_marginal_kernel<exact_j(S), S>: the marginalised map instead of the volume
+hipError_t launch_exact_volume_j4_41_64(int S, const StackArgs &a, const LaunchShape &s, bool *built);
+// stack_exact_marginal_kernel<J, S>: the marginalised map instead of the volume
 hipError_t launch_exact_marginal_1_32(int S, const StackArgs &a, const LaunchShape &s, bool *built);
 hipError_t launch_exact_marginal_33_64(int S, const StackArgs &a, const LaunchShape &s, bool *built);
+hipError_t launch_exact_marginal_j4_41_64(int S, const StackArgs &a, const LaunchShape &s, bool *built);
 // stack_pair_kernel<2, VOLUME, S>, S = 1..32
 hipError_t launch_pair_detect(int S, const StackArgs &a, const LaunchShape &s, bool *built);
 hipError_t launch_pair_volume(int S, const StackArgs &a, const LaunchShape &s, bool *built);

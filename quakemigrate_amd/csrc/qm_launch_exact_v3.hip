@@ -1,0 +1,6 @@
+// stack_exact_kernel, volume-writing, 41-64 table rows, four samples per lane
+#define QM_LAUNCH_FN launch_exact_volume_j4_41_64
+#define QM_LAUNCH_VOLUME true
+#define QM_LAUNCH_ROWS QM_ROWS_41_64
+#define QM_LAUNCH_J(SS) 4
+#include "qm_launch_exact.inc"

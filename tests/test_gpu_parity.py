@@ -709,20 +709,21 @@ def test_exact_volume_kernels_33_to_64_rows_every_tail(lib, oracle, rows):
         ref = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
                                case.available, threads=4)
         vols = []
-        for exact in (1, 0):
-            # the table width's own samples-per-lane for every scan length (a short scan would
-            # otherwise run on a smaller tile, for which no exact kernel is built)
-            eng = lib.Engine(0, exact=exact, samples_per_lane=4 if rows <= 40 else 2)
+        # the table width's own samples-per-lane for every scan length (a short scan would
+        # otherwise run on a smaller tile, for which no exact kernel is built); 41-64 rows have
+        # exact kernels for two and for four samples per lane
+        for exact, spl in [(1, 4), (0, 4)] if rows <= 40 else [(1, 2), (1, 4), (0, 2)]:
+            eng = lib.Engine(0, exact=exact, samples_per_lane=spl)
             eng.load_lut(case.traveltimes)
             vol = np.full((case.n_nodes_total, ns), np.nan)
             series = (np.full(ns, np.nan), np.full(ns, np.nan), np.full(ns, -1, dtype=np.int64))
             eng.migrate(lon, case.fsmp, case.lsmp, case.available, vol, scan_out=series)
-            assert eng.get("last_kernel") == exact
+            assert (eng.get("last_kernel"), eng.get("last_kernel_j")) == (exact, spl)
             _assert_series(series, want)
             np.testing.assert_allclose(vol, ref.reshape(vol.shape), rtol=TIGHT)
             vols.append(vol)
             eng.close()
-        assert np.array_equal(vols[0], vols[1])
+        assert all(np.array_equal(vols[0], v) for v in vols[1:])
 
 
 def test_paired_kernel_odd_delays_wide_bricks_and_twins(lib, oracle):
@@ -773,11 +774,21 @@ def test_any_row_count_picks_a_fitting_tile_and_matches_oracle(lib, oracle, rows
     eng.load_lut(case.traveltimes)
     j = eng.get("samples_per_lane")
     # (beyond 64 rows the table's layout search weighs tile length against brick size)
-    assert j == (4 if rows <= 40 else 2) if rows <= 64 else j in (1, 2)
+    # (beyond 40 rows the table's layout search weighs tile length against brick size)
+    assert j == 4 if rows <= 40 else j in (2, 4) if rows <= 64 else j in (1, 2)
     got = eng.detect(oracle.log_onsets(case.onsets), case.fsmp, case.lsmp, case.available)
     _assert_series(got, want)
     assert eng.get("n_wide_bricks") == 0
     eng.close()
+    if 40 < rows <= 64:          # both exact-row-count variants of 41-64 rows
+        for spl in (2, 4):
+            eng = lib.Engine(0, samples_per_lane=spl)
+            eng.load_lut(case.traveltimes)
+            got = eng.detect(oracle.log_onsets(case.onsets), case.fsmp, case.lsmp,
+                             case.available)
+            assert (eng.get("last_kernel"), eng.get("last_kernel_j")) == (1, spl)
+            _assert_series(got, want)
+            eng.close()
 
 
 def test_incoherent_table_and_tiny_scans(lib, oracle):
@@ -903,21 +914,24 @@ def test_exact_marginal_kernels_give_the_chunked_kernels_bits(lib, oracle, rows)
     want_series = oracle.c_find_max_coa(ref, threads=2)
     lon = oracle.log_onsets(case.onsets)
     maps = {}
-    for exact in (1, 0):
-        eng = lib.Engine(0, exact=exact, samples_per_lane=4 if rows <= 40 else 2)
+    variants = [(1, 4), (0, 4)] if rows <= 40 else [(1, 2), (1, 4), (0, 2), (0, 4)]
+    for exact, spl in variants:
+        eng = lib.Engine(0, exact=exact, samples_per_lane=spl)
         eng.load_lut(case.traveltimes)
         for i0, i1 in [(100, 301), (0, ns), (255, 257), (400, 401), (0, 1)]:
             series = (np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64))
             got = eng.marginal_map(lon, case.fsmp, case.lsmp, case.available, i0, i1,
                                    scan_out=series)
-            assert eng.get("last_kernel") == exact
+            assert (eng.get("last_kernel"), eng.get("last_kernel_j")) == (exact, spl)
             np.testing.assert_allclose(got, ref[..., i0:i1].sum(axis=-1), rtol=1e-12)
             _assert_series(series, want_series)
-            maps[(exact, i0, i1)] = got
+            maps[(exact, spl, i0, i1)] = got
         eng.close()
-    for (exact, i0, i1), got in maps.items():
+    # same samples per lane (same time tiles, same order of additions): the same bits from the
+    # exact-row-count and the chunked kernels
+    for (exact, spl, i0, i1), got in maps.items():
         if exact:
-            assert np.array_equal(got, maps[(0, i0, i1)]), (i0, i1)
+            assert np.array_equal(got, maps[(0, spl, i0, i1)]), (spl, i0, i1)
 
 
 def test_onset_stage_on_device_matches_reference_stalta_onset(lib, oracle):

@@ -1,6 +1,7 @@
 """What layout the engine picks for a table (development aid): brick shape, samples per lane,
 bricks left to the direct kernel, and the detect step time."""
 import json
+import os
 import sys
 import time
 
@@ -14,7 +15,9 @@ from quakemigrate_amd.core import lib  # noqa: E402
 config = sys.argv[1] if len(sys.argv) > 1 else "C2"
 engine_cfg = json.loads(sys.argv[2]) if len(sys.argv) > 2 else {}
 for rows in [int(v) for v in sys.argv[3:]] or [64, 65, 96, 128]:
-    case = synth.make_case(config, step=0, rows=rows)
+    extra = {"x_range": (150, 200)} if config == "C4" else {}
+    extra.update(json.loads(os.environ.get("QM_DIAG_CASE", "{}")))
+    case = synth.make_case(config, step=0, rows=rows, **extra)
     eng = lib.Engine(0, **engine_cfg)
     eng.load_lut(case.traveltimes)
     lon = torch.from_numpy(np.log(np.clip(case.onsets, 0.01, np.inf))).cuda()
@@ -31,7 +34,8 @@ for rows in [int(v) for v in sys.argv[3:]] or [64, 65, 96, 128]:
     ms = (time.perf_counter() - t0) / 3 * 1e3
     n = int(np.prod(case.traveltimes.shape[:3]))
     info = {k: eng.get(k) for k in ("brick_x", "brick_y", "brick_z", "samples_per_lane",
-                                    "n_bricks", "n_wide_bricks", "last_kernel", "last_kernel_j")}
+                                    "n_bricks", "n_wide_bricks", "last_kernel", "last_kernel_j",
+                                    "mean_span", "waves")}
     info.update(cfg=engine_cfg, rows=rows, ms=round(ms, 2), Tadds_per_s=round(n * case.n_samples * rows / ms / 1e9, 2),
                 lut_max=eng.lut_max)
     print(json.dumps(info))
