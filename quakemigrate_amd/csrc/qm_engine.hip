@@ -901,7 +901,8 @@ int combine(qm_engine *e, const double *pmax, const int64_t *pidx, const double 
             int n, int mode, int64_t node_offset, int64_t n_nodes_total, double *o_max,
             double *o_second, int64_t *o_idx, const int32_t *run_if = nullptr,
             int64_t set_stride = 0) {
-    hipLaunchKernelGGL(qm::combine_kernel, dim3((n + qm::kWave - 1) / qm::kWave), dim3(256), 0,
+    hipLaunchKernelGGL(qm::combine_kernel, dim3((n + qm::kWave - 1) / qm::kWave),
+                       dim3(qm::kCombineWaves * qm::kWave), 0,
                        e->stream, pmax, pidx, psum, sets, n, set_stride > 0 ? set_stride : (int64_t)n,
                        mode, node_offset, (double)n_nodes_total, o_max, o_second, o_idx, run_if);
     QM_HIP(hipGetLastError());
