@@ -1264,9 +1264,10 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
                 if (j > j_budget || (j == 1 && j_budget > 1 && n_rows <= 64)) continue;
                 if (j == 4 && n_rows > 40 && !e->cfg_exact) continue;   // exact kernels only
                 if (search(j)) return 1;
-                // (four samples per lane beyond 40 rows: the spilled offset chunks leave 1-3 %
-                // over two samples per lane at equal bricks, more where the delay spans are long)
-                double cost = (j == 4 ? (n_rows > 40 ? 1.08 : 1.0) : j == 2 ? 1.12 : 1.4) *
+                // (four samples per lane beyond 40 rows keep a ring of four offset chunks in
+                // registers instead of the whole node's: 7 % ahead of two samples per lane at
+                // equal bricks on the C3 grid x 60 rows)
+                double cost = (j == 4 ? (n_rows > 40 ? 1.04 : 1.0) : j == 2 ? 1.12 : 1.4) *
                               (1.0 + 30.0 / g.brick_nodes) * (single ? 1.04 : 1.0);
                 if (e->cfg_exact && qm::exact_built(n_rows, j)) cost *= 0.97;
                 if (cost < best_cost) {

@@ -1071,10 +1071,23 @@ __device__ __forceinline__ double wave_sum_to_last_lane(double m) {
 }
 
 __host__ __device__ constexpr int exact_nch(int S) { return (S + 7) / 8; }   // offset chunks per node
+// Offset chunks held in registers.  Normally all of a node's chunks: a chunk is refilled with the
+// NEXT node's offsets as soon as its last row has been issued (a whole node of prefetch distance
+// at no extra registers).  Four samples per lane beyond 40 rows would need 6-8 chunks on top of
+// twice the accumulators and read buffers and spill them inside the node loop (measured: 38 GB of
+// scratch traffic per C3-sized step of 60 rows, 114.9 ms; with the ring 107.3 ms and none): there
+// a ring of 4 chunks is kept, chunk c in slot c % 4,
+// refilled four chunks ahead -- from the same node, or from the next one once past the end (the
+// chunk count is padded to a multiple of 4 for that; the padding's refills ride on the last row).
+__host__ __device__ constexpr int exact_ring(int J, int S) {
+    return (J == 4 && S > 40) ? 4 : exact_nch(S);
+}
 template <int J, int S> struct ExactPlan {
     static constexpr int RB = BatchRows<J>::value;          // table rows per batch
     static constexpr int NB = (S + RB - 1) / RB;            // batches per node
     static constexpr int NCH = exact_nch(S);
+    static constexpr int R = exact_ring(J, S);              // chunks in registers
+    static constexpr int NCHP = (NCH + R - 1) / R * R;      // chunk count padded to the ring
 };
 
 // steps of the pipelined epilogue: 0 k | 1 f | 2..D+1 Horner | ldexp | sum | track | (store)
@@ -1148,22 +1161,33 @@ __device__ __forceinline__ void xepi_steps(Epilogue<J> &s, Running<J> &run, cons
 // q is refilled with the NEXT node's offsets as soon as its last row has been issued
 template <int J, int S, int I>
 __device__ __forceinline__ void xissue(double (&buf)[BatchRows<J>::value * J],
-                                       uint4 (&q)[exact_nch(S)], const uint16_t *next,
-                                       unsigned lane_addr) {
+                                       uint4 (&q)[exact_ring(J, S)], const uint16_t *cur,
+                                       const uint16_t *next, unsigned lane_addr) {
     constexpr int KT = kWave * J;
     constexpr int RB = ExactPlan<J, S>::RB;
+    constexpr int NCH = ExactPlan<J, S>::NCH, R = ExactPlan<J, S>::R;
+    constexpr int NCHP = ExactPlan<J, S>::NCHP;
 #pragma unroll
     for (int k = 0; k < RB; ++k) {
         const int r = I * RB + k;                      // compile-time after unrolling
         if (r < S) {
             const int ci = r >> 3, e = r & 7;
             const volatile lds_f64 *p = (const volatile lds_f64 *)(uintptr_t)(
-                lane_addr + (unsigned)(ci * 8 * KT * 8) + chunk_entry(q[ci], e));
+                lane_addr + (unsigned)(ci * 8 * KT * 8) + chunk_entry(q[ci % R], e));
 #pragma unroll
             for (int j = 0; j < J; ++j) buf[k * J + j] = p[e * KT + kWave * j];
-            // (the last chunk is refilled by the node loop: a load issued this late would be
-            // waited for at once, by the register copies at the loop's back edge)
-            if (e == 7 && ci + 1 < exact_nch(S)) q[ci] = load_offsets(next, ci * 8);
+            if constexpr (R == NCH) {
+                // (the last chunk is refilled by the node loop: a load issued this late would be
+                // waited for at once, by the register copies at the loop's back edge)
+                if (e == 7 && ci + 1 < NCH) q[ci] = load_offsets(next, ci * 8);
+            } else if (e == 7 && r != S - 1) {         // the chunk's last row: its slot is free
+                if (ci + R < NCH) q[ci % R] = load_offsets(cur, (ci + R) * 8);
+                else if (ci + R >= NCHP) q[ci % R] = load_offsets(next, (ci + R - NCHP) * 8);
+                // (the refills that fall on the node's LAST row -- its last chunk's and the
+                // padding chunks' -- are issued by the node loop at the start of the next node: a
+                // load issued at the end of the loop body is waited for at once, by the register
+                // copies at the back edge)
+            }
         }
     }
 }
@@ -1189,12 +1213,14 @@ template <int J, bool VOLUME, int TAIL, int S, bool WITH_EPI, int I>
 __device__ __forceinline__ void xbatch(double (&acc)[J],
                                        double (&even)[BatchRows<J>::value * J],
                                        double (&odd)[BatchRows<J>::value * J],
-                                       uint4 (&q)[exact_nch(S)], const uint16_t *next,
+                                       uint4 (&q)[exact_ring(J, S)], const uint16_t *cur,
+                                       const uint16_t *next,
                                        unsigned lane_addr, Epilogue<J> &epi, Running<J> &run,
                                        const StackArgs &a, int t_first, int lane) {
     constexpr int NB = ExactPlan<J, S>::NB;
     if constexpr (I < NB) {
-        if constexpr (I + 1 < NB) xissue<J, S, I + 1>((I & 1) ? even : odd, q, next, lane_addr);
+        if constexpr (I + 1 < NB)
+            xissue<J, S, I + 1>((I & 1) ? even : odd, q, cur, next, lane_addr);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (WITH_EPI) {
             constexpr int E = XEpiSteps<VOLUME>::value;
@@ -1203,8 +1229,8 @@ __device__ __forceinline__ void xbatch(double (&acc)[J],
         __builtin_amdgcn_sched_barrier(0);
         xretire<J, S, I>(acc, (I & 1) ? odd : even);
         __builtin_amdgcn_sched_barrier(0);
-        xbatch<J, VOLUME, TAIL, S, WITH_EPI, I + 1>(acc, even, odd, q, next, lane_addr, epi, run,
-                                                    a, t_first, lane);
+        xbatch<J, VOLUME, TAIL, S, WITH_EPI, I + 1>(acc, even, odd, q, cur, next, lane_addr, epi,
+                                                    run, a, t_first, lane);
     }
 }
 
@@ -1242,11 +1268,12 @@ __device__ __forceinline__ void stack_exact_body(const StackArgs &a, double *win
         int lz = wave % vz, ly = (wave / vz) % vy, lx = wave / (vz * vy);
         const uint16_t *brick_rel = a.rel + (int64_t)b * g.brick_nodes * g.row_pad;
 
-        uint4 q[NCH];                                  // offsets of the node about to be stacked
-        {
+        constexpr int R = ExactPlan<J, S>::R;
+        uint4 q[R];                                    // offsets of the node about to be stacked
+        {                                              //   (all its chunks, or the first R)
             const uint16_t *p = brick_rel + (int64_t)(wave < nvalid ? wave : 0) * g.row_pad;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) q[c] = load_offsets(p, c * 8);
+            for (int c = 0; c < R; ++c) q[c] = load_offsets(p, c * 8);
         }
         Epilogue<J> epi;
         bool pending = false;                          // wave-uniform: epi holds a node
@@ -1256,19 +1283,29 @@ __device__ __forceinline__ void stack_exact_body(const StackArgs &a, double *win
             while (lz >= vz) { lz -= vz; ++ly; }
             while (ly >= vy) { ly -= vy; ++lx; }
             // the node after this one (or a harmless reload of this one at the end)
+            const uint16_t *cur = brick_rel + (int64_t)m * g.row_pad;
             const uint16_t *next =
                 brick_rel + (int64_t)(m + nwaves < nvalid ? m + nwaves : m) * g.row_pad;
 
-            // the next node's last offset chunk, fetched a whole node ahead of its use
-            const uint4 q_last = load_offsets(next, (NCH - 1) * 8);
+            // the next node's last offset chunk, fetched a whole node ahead of its use (when all
+            // chunks of a node are held)
+            uint4 q_last;
+            if constexpr (R == NCH) q_last = load_offsets(next, (NCH - 1) * 8);
+            else {
+                // ring: the refills the previous node's last row left to this one (for a brick's
+                // first node they reload what the initial fill put there)
+                constexpr int NCHP = ExactPlan<J, S>::NCHP;
+#pragma unroll
+                for (int d = NCH - 1; d < NCHP; ++d) q[d % R] = load_offsets(cur, (d + R - NCHP) * 8);
+            }
             double acc[J], even[RB * J], odd[RB * J];
-            xissue<J, S, 0>(even, q, next, lane_addr);
+            xissue<J, S, 0>(even, q, cur, next, lane_addr);
             if (pending)
-                xbatch<J, VOLUME, TAIL, S, true, 0>(acc, even, odd, q, next, lane_addr, epi, run,
-                                                    a, t_first, lane);
+                xbatch<J, VOLUME, TAIL, S, true, 0>(acc, even, odd, q, cur, next, lane_addr, epi,
+                                                    run, a, t_first, lane);
             else
-                xbatch<J, VOLUME, TAIL, S, false, 0>(acc, even, odd, q, next, lane_addr, epi, run,
-                                                     a, t_first, lane);
+                xbatch<J, VOLUME, TAIL, S, false, 0>(acc, even, odd, q, cur, next, lane_addr, epi,
+                                                     run, a, t_first, lane);
 #pragma unroll
             for (int j = 0; j < J; ++j) {                  // z: log2 of the coalescence (rounded
 #pragma clang fp contract(off)                             // product: see finish_node)
@@ -1278,7 +1315,7 @@ __device__ __forceinline__ void stack_exact_body(const StackArgs &a, double *win
             if (VOLUME && TAIL == 3)
                 epi.row = a.marginal + ((int64_t)tile * a.n_nodes + node);
             else if (VOLUME) epi.row = a.volume + ((int64_t)node * a.vol_stride + t_first);
-            q[NCH - 1] = q_last;
+            if constexpr (R == NCH) q[NCH - 1] = q_last;
             pending = true;
         }
         if (pending)                                   // the brick's last node: not overlapped

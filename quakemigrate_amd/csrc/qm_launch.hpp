@@ -28,10 +28,10 @@ constexpr int kExactMaxRows = 64;
 #define QM_ROWS_41_64(X)                                                                        \
     X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55)   \
     X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63) X(64)
-// Samples per lane of the exact-row-count kernels: 4 up to 40 rows; for 41-64 rows both 2 (the
-// whole node pipeline in registers) and 4 (a few offset chunks of the next node spill to scratch
-// inside the node loop, yet 6-20 % faster where the bricks stay large: the table's layout search
-// decides) are built.
+// Samples per lane of the exact-row-count kernels: 4 up to 40 rows; for 41-64 rows both 2 and 4
+// are built (4 holds a ring of four offset chunks instead of the whole node's, exact_ring() in
+// qm_kernels.hpp, and is 7-20 % faster where the bricks stay large: the table's layout search
+// decides).
 constexpr int kJ4MaxRows = 64;      // widest table that may run four samples per lane
 constexpr int exact_j(int S) { return S <= 40 ? 4 : 2; }
 constexpr bool exact_built(int S, int J) {
