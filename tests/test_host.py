@@ -341,3 +341,39 @@ def test_fixed_point_screening_bounds_hold_on_cpu():
     assert worst > 0.0
 
 
+
+
+def test_headline_kernels_stay_in_registers(tmp_path):
+    """Compile the kernels the BASELINE configs run (gfx950, no GPU needed) and read the
+    compiler's resource summary: no scratch (a spill inside the node loop costs 20-30x, as two
+    versions of this code found out), at most 128 VGPRs (4 wavefronts per SIMD, which the
+    workgroup layouts are sized for)."""
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not pathlib.Path(hipcc).exists():
+        pytest.skip("no hipcc")
+    src = tmp_path / "k.hip"
+    src.write_text(
+        '#include <hip/hip_runtime.h>\n#include "qm_kernels.hpp"\n#include "qm_pair.hpp"\n'
+        "template __global__ void qm::stack_exact_kernel<4, false, 30>(qm::StackArgs);\n"   # C3
+        "template __global__ void qm::stack_exact_kernel<4, false, 20>(qm::StackArgs);\n"   # C2
+        "template __global__ void qm::stack_exact_kernel<4, false, 60>(qm::StackArgs);\n"   # C4
+        "template __global__ void qm::stack_exact_kernel<2, false, 60>(qm::StackArgs);\n"
+        "template __global__ void qm::stack_pair_kernel<2, true, 30>(qm::StackArgs);\n"     # locate
+        "template __global__ void qm::stack_exact_marginal_kernel<4, 30>(qm::StackArgs);\n"
+        "template __global__ void qm::stack_lds_kernel<2, false, 3>(qm::StackArgs);\n")     # C1
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17",
+                           f"-I{ROOT / 'quakemigrate_amd' / 'csrc'}", "-c", str(src), "-o",
+                           str(tmp_path / "k.o"), "--save-temps"], cwd=tmp_path,
+                          stderr=subprocess.DEVNULL)
+    asm = next(tmp_path.glob("k-hip-amdgcn-*.s")).read_text()
+    seen = 0
+    for name, vgprs in re.findall(r"\.set (\S*(?:stack_\w+_kernel)\S*)\.num_vgpr, (\d+)", asm):
+        scratch = re.search(re.escape(name) + r"\.private_seg_size, (\d+)", asm)
+        assert int(vgprs) <= 128, (name, vgprs)
+        assert scratch is not None and int(scratch.group(1)) == 0, (name, scratch and scratch.group(1))
+        seen += 1
+    assert seen == 7
