@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""
+Generate qm_shift_asm.inc: the gfx950 inner loop of the shift-reuse stacking kernel.
+
+Idea.  The round-2 kernels fetch every operand of every add from LDS
+(8 bytes per add, the binding unit).  Here a lane owns FOUR CONSECUTIVE samples (t = 4*lane + k)
+and a wavefront stacks a 2x2x2 GROUP of nodes at a time: for one table row the eight nodes'
+delays differ by a few samples, so the operands of all eight nodes are a window of
+4 + (largest - smallest delay) consecutive samples per lane.  The window is read ONCE into
+registers and node g's four adds take their operands from window registers [idx_g, idx_g + 4)
+-- a wave-uniform, data-dependent register index: gfx9 VGPR-index mode (s_set_gpr_idx_on, SRC0
+relative).  Per (node, sample) the rows are still added one at a time in ascending order, so
+every sum has the reference's bits (migratelib.c:54-59); LDS operand reads drop to about half.
+
+LDS layout of a row window (u = sample index inside the window, staged by the kernel): two
+planes of 16-byte slots, plane A slot s = samples (4s, 4s+1), plane B slot s = (4s+2, 4s+3), B
+kShiftPlane bytes above A.  Lane l's window quad m (registers 4m .. 4m+3 = samples
+e0 + 4l + 4m ..) is then ONE aligned ds_read_b128 per plane at slot e0/4 + l + m: conflict-free,
+consecutive registers, half the LDS instructions of 8-byte reads.
+
+Stream format (built once per table, qm_shift.hpp): per (brick, wave) a contiguous run of 64-byte
+records: a lead-in record, one record per (group, row) with rows padded to an even count, one
+trailing pad.  Record of row r:
+    dwords 0..7   idx[g] = 2 * (delay_g - e0_r)     register offset of node g's first operand
+    dwords 8, 9   header of row r + 1 (the lead-in carries row 0's; the last row's is harmless):
+                  LDS byte offset of plane A's slot e0/4 of that row; its quad count (2 .. NQMAX)
+    dwords 10, 11 row 0 of a group only: flat index of the group's first node, valid-node mask
+One s_load_dwordx16 per row, issued one row ahead; the window is read one row ahead into the other
+of two register windows (rows unrolled by two).
+
+Usage: python gen_shift_asm.py > qm_shift_asm.inc   (committed; build() checks it is current).
+"""
+
+import os
+
+EXP = set(filter(None, os.environ.get("QM_SHIFT_EXP", "").split(",")))   # timing experiments only
+NQMAX = int(os.environ.get("QM_SHIFT_NQMAX", "6"))    # window = 4 * NQMAX doubles
+NQMIN = int(os.environ.get("QM_SHIFT_NQMIN", "3"))    # quads fetched unconditionally
+WMAX = 4 * NQMAX
+PLANE = 40896            # plane A -> plane B, bytes: 128 q + 64 keeps the staging stores conflict-free
+REC = 64                 # bytes per stream record
+VB = int(os.environ.get("QM_SHIFT_VB", "32"))         # first hard VGPR
+ACC = VB                 # acc[g][k] = v[ACC + 8 g + 2 k : +1]
+WIN = [ACC + 64, ACC + 64 + 2 * WMAX]
+VADDR = WIN[1] + 2 * WMAX
+VNODE = VADDR + 1
+VC = VNODE + 1           # leading polynomial coefficient (pair)
+VPF = VC + 2             # L2 prefetch of the stream: dummy destination, zero offset
+VZERO = VPF + 1
+VEND = VZERO + 1
+PF_AHEAD = int(os.environ.get("QM_SHIFT_PF", "0"))   # records ahead (0: no prefetch)
+# epilogue temporaries live in window 1 (free between a group's last row and the next group's row 1)
+F = WIN[1]
+P = WIN[1] + 8
+KI = WIN[1] + 16
+GMAX = WIN[1] + 20
+GIDX = WIN[1] + 28
+assert GIDX + 4 <= WIN[1] + 2 * WMAX
+
+SB = 48                  # first hard SGPR (s_load_dwordx16 destinations)
+BUF = [SB, SB + 16]
+ST = SB + 32             # [ST:ST+1], [ST+2:ST+3] compare masks
+SBASE = ST + 4
+SMASK = ST + 5
+SPAIRS = ST + 6
+SNODE = ST + 7
+STAB = ST + 8            # stream base (pair, even)
+SOFF = ST + 10           # byte offset of the record loaded last
+SPF = ST + 12            # prefetch address (pair)
+SEND = ST + 14
+assert STAB % 2 == 0 and SB % 4 == 0
+
+
+def v2(r):
+    return f"v[{r}:{r + 1}]"
+
+
+def s2(r):
+    return f"s[{r}:{r + 1}]"
+
+
+class Emitter:
+    def __init__(self):
+        self.lines = []
+        self.nlabel = 0
+
+    def __call__(self, text):
+        self.lines.append(text)
+
+    def label(self, stem):
+        self.nlabel += 1
+        return f"L{stem}{self.nlabel}_%="
+
+
+def quad_reads(win, m):
+    return [f"ds_read_b128 v[{win + 8 * m}:{win + 8 * m + 3}], v{VADDR} offset:{16 * m}",
+            f"ds_read_b128 v[{win + 8 * m + 4}:{win + 8 * m + 7}], v{VADDR} offset:{PLANE + 16 * m}"]
+
+
+def issue_window(e, q, hdr):
+    """block form (prologue only): reads of the row whose header is s[hdr], s[hdr+1] into WIN[q]"""
+    e(f"v_add_u32 v{VADDR}, s{hdr}, %[lane]")          # src0 scalar: untouched by SRC0-relative mode
+    for m in range(NQMIN):
+        for line in quad_reads(WIN[q], m):
+            e(line)
+    done = e.label("rd")
+    for m in range(NQMIN, NQMAX):
+        e(f"s_cmp_le_u32 s{hdr + 1}, {m}")
+        e(f"s_cbranch_scc1 {done}")
+        for line in quad_reads(WIN[q], m):
+            e(line)
+    e(f"{done}:")
+
+
+def node_adds(e, p, g, first):
+    if "noidx" in EXP:
+        e("s_nop 0")
+    else:
+        e(f"s_set_gpr_idx_on s{BUF[p] + g}, 1")               # SRC0 relative, index = idx[g]
+    for k in range(4):
+        a = v2(ACC + 8 * g + 2 * k)
+        w = v2(WIN[p] + 2 * k)
+        e(f"v_add_f64 {a}, {w}, {'0' if first else a}")
+
+
+def row_iter(e, p, first):
+    """row of parity p: its record is in BUF[p], its window in WIN[p].  The next row's window is
+    requested before this row's adds (a block of reads at the row's start: spread between the adds,
+    the late ones land after the next row's wait -- measured slower, tools/micro results r03a)."""
+    q = 1 - p
+    hdr = BUF[p] + 8
+    if "nowait" not in EXP:
+        e("s_waitcnt lgkmcnt(0)")                              # both have landed
+    if first:
+        e(f"s_mov_b32 s{SBASE}, s{BUF[p] + 10}")
+        e(f"s_mov_b32 s{SMASK}, s{BUF[p] + 11}")
+    if "nosmem" not in EXP:
+        e(f"s_add_u32 s{SOFF}, s{SOFF}, {REC}")
+        e(f"s_load_dwordx16 s[{BUF[q]}:{BUF[q] + 15}], {s2(STAB)}, s{SOFF}")
+    issue_window(e, q, hdr)
+    for g in range(8):
+        node_adds(e, p, g, first)
+        if g == 3 and PF_AHEAD:
+            # pull the record PF_AHEAD rows ahead into L2 with a vector load nobody waits for (its
+            # own counter, vmcnt): the scalar load then finds it there instead of in HBM
+            e(f"global_load_dword v{VPF}, v{VZERO}, {s2(SPF)}")
+            e(f"s_add_u32 s{SPF}, s{SPF}, {REC}")
+            e(f"s_addc_u32 s{SPF + 1}, s{SPF + 1}, 0")
+
+
+def epilogue(e, degree):
+    e("s_set_gpr_idx_off")
+    # group-level running maximum (nodes of a group are visited in ascending flat index: strict >)
+    for k in range(4):
+        e(f"v_mov_b32 v{GMAX + 2 * k}, 0")
+        e(f"v_mov_b32 v{GMAX + 2 * k + 1}, 0xfff00000")        # -inf
+        e(f"v_mov_b32 v{GIDX + k}, 0x7fffffff")
+    for g in range(8):
+        skip = e.label("nd")
+        e(f"s_bitcmp1_b32 s{SMASK}, {g}")
+        e(f"s_cbranch_scc0 {skip}")
+        # flat index of node g: base + dx*ny*nz + dy*nz + dz (g = 4 dx + 2 dy + dz)
+        e(f"s_mov_b32 s{SNODE}, s{SBASE}")
+        if g & 4:
+            e(f"s_add_u32 s{SNODE}, s{SNODE}, %[nynz]")
+        if g & 2:
+            e(f"s_add_u32 s{SNODE}, s{SNODE}, %[nz]")
+        if g & 1:
+            e(f"s_add_u32 s{SNODE}, s{SNODE}, 1")
+        e(f"v_mov_b32 v{VNODE}, s{SNODE}")
+        A = [ACC + 8 * g + 2 * k for k in range(4)]
+        for k in range(4):                                      # z = stack * log2(e)/available
+            e(f"v_mul_f64 {v2(A[k])}, {v2(A[k])}, %[scale]")
+        for k in range(4):
+            e(f"v_rndne_f64 {v2(F + 2 * k)}, {v2(A[k])}")
+        for k in range(4):
+            e(f"v_cvt_i32_f64 v{KI + k}, {v2(F + 2 * k)}")
+        for k in range(4):                                      # f = z - k
+            e(f"v_add_f64 {v2(F + 2 * k)}, {v2(A[k])}, -{v2(F + 2 * k)}")
+        for k in range(4):
+            e(f"v_fma_f64 {v2(P + 2 * k)}, {v2(VC)}, {v2(F + 2 * k)}, %[c{degree - 1}]")
+        for i in range(degree - 2, -1, -1):
+            for k in range(4):
+                e(f"v_fma_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, {v2(F + 2 * k)}, %[c{i}]")
+        for k in range(4):
+            e(f"v_ldexp_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, v{KI + k}")
+        for k in range(4):
+            e(f"v_add_f64 %[sum{k}], %[sum{k}], {v2(P + 2 * k)}")
+        for k in range(4):
+            e(f"v_cmp_gt_f64 vcc, {v2(A[k])}, {v2(GMAX + 2 * k)}")
+            e(f"v_cndmask_b32 v{GIDX + k}, v{GIDX + k}, v{VNODE}, vcc")
+            e(f"v_max_f64 {v2(GMAX + 2 * k)}, {v2(GMAX + 2 * k)}, {v2(A[k])}")
+        e(f"{skip}:")
+    # merge into the wave's running pair: larger z, ties -> lower flat index
+    for k in range(4):
+        g_ = v2(GMAX + 2 * k)
+        e(f"v_cmp_gt_f64 {s2(ST)}, {g_}, %[max{k}]")
+        e(f"v_cmp_eq_f64 {s2(ST + 2)}, {g_}, %[max{k}]")
+        e(f"v_cmp_lt_i32 vcc, v{GIDX + k}, %[idx{k}]")
+        e(f"s_and_b64 {s2(ST + 2)}, {s2(ST + 2)}, vcc")
+        e(f"s_or_b64 vcc, {s2(ST)}, {s2(ST + 2)}")
+        e(f"v_cndmask_b32 %[idx{k}], %[idx{k}], v{GIDX + k}, vcc")
+        e(f"v_max_f64 %[max{k}], %[max{k}], {g_}")
+
+
+def body(degree):
+    e = Emitter()
+    # leading coefficient into a VGPR pair (two different SGPR pairs cannot feed one VALU op)
+    e(f"v_mov_b32 v{VC}, %[clo]")
+    e(f"v_mov_b32 v{VC + 1}, %[chi]")
+    e(f"s_mov_b32 s{STAB}, %[tablo]")
+    e(f"s_mov_b32 s{STAB + 1}, %[tabhi]")
+    # prologue: lead-in record (header of row 0) and row 0's record; window of row 0
+    e(f"s_load_dwordx16 s[{BUF[1]}:{BUF[1] + 15}], {s2(STAB)}, 0")
+    e(f"s_load_dwordx16 s[{BUF[0]}:{BUF[0] + 15}], {s2(STAB)}, {REC}")
+    e(f"s_mov_b32 s{SOFF}, {REC}")
+    e(f"v_mov_b32 v{VZERO}, 0")
+    e(f"s_add_u32 s{SPF}, s{STAB}, {PF_AHEAD * REC}")
+    e(f"s_addc_u32 s{SPF + 1}, s{STAB + 1}, 0")
+    e("s_waitcnt lgkmcnt(0)")
+    issue_window(e, 0, BUF[1] + 8)
+    group = e.label("grp")
+    pair = e.label("pair")
+    nopair = e.label("np")
+    e(f"{group}:")
+    row_iter(e, 0, True)
+    row_iter(e, 1, False)
+    e(f"s_sub_u32 s{SPAIRS}, %[npairs], 2")                    # borrow <=> the group has one pair
+    e(f"s_cbranch_scc1 {nopair}")
+    e(f"{pair}:")
+    row_iter(e, 0, False)
+    row_iter(e, 1, False)
+    e(f"s_sub_u32 s{SPAIRS}, s{SPAIRS}, 1")
+    e(f"s_cbranch_scc0 {pair}")
+    e(f"{nopair}:")
+    epilogue(e, degree)
+    e("s_sub_u32 %[ng], %[ng], 1")
+    e("s_cmp_lg_u32 %[ng], 0")
+    e(f"s_cbranch_scc1 {group}")
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    return e.lines
+
+
+def main():
+    print("// GENERATED by gen_shift_asm.py -- do not edit.  See that file for the schedule and the")
+    print("// stream format.")
+    print(f"constexpr int kShiftNqMax = {NQMAX};")
+    print(f"constexpr int kShiftPlane = {PLANE};        // bytes from plane A to plane B")
+    print(f"constexpr int kShiftRec = {REC};            // bytes per stream record")
+    print(f"constexpr int kShiftVgprs = {VEND};         // hard VGPRs reach v{VEND - 1}")
+    for degree, name in ((8, "shift_groups_d8"), (10, "shift_groups_d10")):
+        lines = body(degree)
+        # the stream pointer lives in a hard SGPR pair (the halves of an s[lo:hi] operand cannot be
+        # named in inline asm): it is handed over as two 32-bit scalars
+        text = "\\n\\t".join(lines)
+        print()
+        print(f"// degree-{degree} 2^f; window of up to {WMAX} doubles; hard VGPRs v{VB}..v{VEND - 1}, "
+              f"SGPRs s{SB}..s{SEND - 1}")
+        print(f"__device__ __forceinline__ void {name}(double (&vmax)[4], double (&vsum)[4], "
+              "int (&vidx)[4],")
+        print("        const void *stream, int ngroups, int npairs, unsigned lane_addr, int nz, "
+              f"int nynz, double scale, const double (&c)[{degree + 1}]) {{")
+        print("    const unsigned long long sp = (unsigned long long)stream;")
+        print("    const unsigned tablo = (unsigned)sp, tabhi = (unsigned)(sp >> 32);")
+        print(f"    const unsigned long long cl = (unsigned long long)__double_as_longlong(c[{degree}]);")
+        print("    const unsigned clo = (unsigned)cl, chi = (unsigned)(cl >> 32);")
+        outs = [f'[max{k}] "+v"(vmax[{k}])' for k in range(4)]
+        outs += [f'[sum{k}] "+v"(vsum[{k}])' for k in range(4)]
+        outs += [f'[idx{k}] "+v"(vidx[{k}])' for k in range(4)]
+        outs += ['[ng] "+s"(ngroups)']
+        ins = ['[tablo] "s"(tablo)', '[tabhi] "s"(tabhi)', '[lane] "v"(lane_addr)',
+               '[npairs] "s"(npairs)', '[nz] "s"(nz)', '[nynz] "s"(nynz)', '[scale] "s"(scale)',
+               '[clo] "s"(clo)', '[chi] "s"(chi)']
+        ins += [f'[c{i}] "s"(c[{i}])' for i in range(degree)]
+        clob = [f'"v{r}"' for r in range(VB, VEND)] + [f'"s{r}"' for r in range(SB, SEND)]
+        clob += ['"vcc"', '"scc"', '"m0"', '"memory"']
+        print(f'    asm volatile("{text}"')
+        print(f'                 : {", ".join(outs)}')
+        print(f'                 : {", ".join(ins)}')
+        print(f'                 : {", ".join(clob)});')
+        print("}")
+
+
+if __name__ == "__main__":
+    main()
