@@ -48,7 +48,7 @@ VC = VNODE + 1           # leading polynomial coefficient (pair)
 VPF = VC + 2             # L2 prefetch of the stream: dummy destination, zero offset
 VZERO = VPF + 1
 VEND = VZERO + 1
-PF_AHEAD = int(os.environ.get("QM_SHIFT_PF", "0"))   # records ahead (0: no prefetch)
+PF_AHEAD = int(os.environ.get("QM_SHIFT_PF", "16"))   # records ahead (0: no prefetch)
 # epilogue temporaries live in window 1 (free between a group's last row and the next group's row 1)
 F = WIN[1]
 P = WIN[1] + 8
@@ -244,7 +244,8 @@ def body(degree):
 def main():
     print("// GENERATED by gen_shift_asm.py -- do not edit.  See that file for the schedule and the")
     print("// stream format.")
-    print(f"constexpr int kShiftNqMax = {NQMAX};")
+    print(f"constexpr int kShiftNqMax = {NQMAX};          // quads (4 samples) a register window holds")
+    print(f"constexpr int kShiftNqMin = {NQMIN};          // quads fetched unconditionally")
     print(f"constexpr int kShiftPlane = {PLANE};        // bytes from plane A to plane B")
     print(f"constexpr int kShiftRec = {REC};            // bytes per stream record")
     print(f"constexpr int kShiftVgprs = {VEND};         // hard VGPRs reach v{VEND - 1}")

@@ -26,6 +26,7 @@
 #include "qm_locate.hpp"
 #include "qm_screen.hpp"
 #include "qm_pair.hpp"
+#include "qm_shift.hpp"
 
 namespace {
 
@@ -140,6 +141,15 @@ struct qm_engine {
     int n_pwide = 0;
     int pair_kt = 0;                        // tile length the paired tables were built for
     bool pair_ok = false;                   // ... and whether (almost) every brick fits
+
+    // shift-reuse layout of the fused float64 detect (qm_shift.hpp): own brick grid, row-window
+    // slots, record stream
+    int cfg_shift = -1;                     // -1: where the table qualifies, 0: never, 1: as -1 (explicit)
+    qm::GridDesc shg{};
+    DevBuf<int32_t> d_shraw, d_shmeta, d_shtotal, d_shfit, d_shwide;
+    DevBuf<uint32_t> d_shstream;
+    int n_shwide = 0, shift_rows2 = 0;
+    bool shift_built = false, shift_ok = false;
 
     // float64 travel-time grids in seconds (optional; on-device table serving)
     DevBuf<double> d_grids;
@@ -434,6 +444,122 @@ int launch_pair_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_
 
 bool pair_built(int S) { return S >= 1 && S <= qm::kPairMaxRows; }
 
+// ---- shift-reuse layout (qm_shift.hpp) ----------------------------------------------------------
+// Own brick grid (e->shg, even brick dimensions: the kernel walks 2x2x2 node groups): the largest
+// shape whose de-interleaved row windows fit 80 KB and whose groups' delay spread fits the
+// register window for (almost) every brick; per-(brick, row) slot records and the record stream.
+int ensure_shift_tables(qm_engine *e) {
+    if (e->shift_built) return 0;
+    e->shift_built = true;
+    e->shift_ok = false;
+    const int S = e->g.n_rows;
+    if (S > qm::kShiftMaxRows) return 0;
+    static const int kShapes[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4}, {2, 4, 4}};
+    const bool fixed = e->cfg_bx > 0;
+    const int n_shapes = fixed ? 1 : (int)(sizeof(kShapes) / sizeof(kShapes[0]));
+    qm::GridDesc g = e->g;
+    std::vector<int32_t> fit, wide;
+    bool ok = false;
+    auto even_up = [](int v) { return v + (v & 1); };
+    for (int s = 0; s < n_shapes; ++s) {
+        g = e->g;
+        g.bx = std::min(even_up(fixed ? e->cfg_bx : kShapes[s][0]), even_up(g.nx));
+        g.by = std::min(even_up(fixed ? e->cfg_by : kShapes[s][1]), even_up(g.ny));
+        g.bz = std::min(even_up(fixed ? e->cfg_bz : kShapes[s][2]), even_up(g.nz));
+        g.nbx = (g.nx + g.bx - 1) / g.bx;
+        g.nby = (g.ny + g.by - 1) / g.by;
+        g.nbz = (g.nz + g.bz - 1) / g.bz;
+        g.nbricks = g.nbx * g.nby * g.nbz;
+        g.brick_nodes = g.bx * g.by * g.bz;
+        const size_t br = (size_t)g.nbricks * S;
+        if (e->d_shraw.ensure(4 * br) || e->d_shmeta.ensure(4 * br) ||
+            e->d_shtotal.ensure(g.nbricks) || e->d_shfit.ensure(g.nbricks) || e->d_scalar.ensure(4))
+            return 1;
+        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
+        hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
+                           e->d_lut.p, reinterpret_cast<int4 *>(e->d_shraw.p), e->d_scalar.p);
+        hipLaunchKernelGGL(qm::shift_need_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
+                           e->d_lut.p, reinterpret_cast<const int4 *>(e->d_shraw.p),
+                           reinterpret_cast<int4 *>(e->d_shmeta.p), e->d_shtotal.p, e->d_shfit.p);
+        QM_HIP(hipGetLastError());
+        fit.resize(g.nbricks);
+        QM_HIP(hipMemcpyAsync(fit.data(), e->d_shfit.p, (size_t)g.nbricks * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, e->stream));
+        QM_HIP(hipStreamSynchronize(e->stream));
+        wide.clear();
+        for (int b = 0; b < g.nbricks; ++b)
+            if (!fit[b]) wide.push_back(b);
+        ok = fixed ? (int)wide.size() < g.nbricks : (int64_t)wide.size() * 200 <= g.nbricks;
+        if (ok) break;
+    }
+    if (!ok) return 0;                                   // an incoherent table: the other kernels
+    const int rows2 = S + (S & 1);
+    const int64_t words = (int64_t)g.nbricks * qm::kShiftWaves * qm::shift_recs_per_wave(g, rows2) *
+                          (qm::kShiftRec / 4);
+    // (+ one record of slack: the loop's last prefetch of a wave's run reads one record past it)
+    if (e->d_shstream.ensure((size_t)words + 64)) return 1;
+    const size_t hdr_bytes = (size_t)qm::shift_groups_per_brick(g) * rows2 * sizeof(uint2);
+    QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(qm::shift_stream_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_bytes));
+    hipLaunchKernelGGL(qm::shift_stream_kernel, dim3(g.nbricks), dim3(256), hdr_bytes, e->stream, g,
+                       e->d_lut.p, reinterpret_cast<const int4 *>(e->d_shmeta.p), e->d_shtotal.p,
+                       e->d_shfit.p, rows2, e->d_shstream.p);
+    QM_HIP(hipGetLastError());
+    e->n_shwide = (int)wide.size();
+    if (e->n_shwide) {
+        if (e->d_shwide.ensure(wide.size())) return 1;
+        QM_HIP(hipMemcpyAsync(e->d_shwide.p, wide.data(), wide.size() * sizeof(int32_t),
+                              hipMemcpyHostToDevice, e->stream));
+    }
+    QM_HIP(hipStreamSynchronize(e->stream));           // `wide` is a stack-lifetime buffer
+    e->d_shraw.release();
+    e->shg = g;
+    e->shift_rows2 = rows2;
+    e->shift_ok = true;
+    return 0;
+}
+
+// does this launch take the shift-reuse kernel?  (fused detect over whole 256-sample tiles' worth of
+// scan; short scans run on shorter tiles, run_j)
+bool shift_wanted(const qm_engine *e, int n_chunk, bool plain_detect) {
+    if (!plain_detect || e->cfg_shift == 0 || e->cfg_generic || e->cfg_force_direct ||
+        e->user_waves || e->user_lds || e->cfg_j > 0 || e->cfg_pair == 2)
+        return false;
+    return n_chunk >= 192;
+}
+
+int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_direct,
+                      bool use_lds, bool use_direct) {
+    if (use_lds) {
+        a.ngroups = groups_lds;
+        a.brick_list = nullptr;
+        a.n_list = 0;
+        qm::ShiftArgs s{};
+        s.a = a;
+        s.smeta = reinterpret_cast<const int4 *>(e->d_shmeta.p);
+        s.stotal = e->d_shtotal.p;
+        s.sfit = e->d_shfit.p;
+        s.stream = reinterpret_cast<const char *>(e->d_shstream.p);
+        s.rows2 = e->shift_rows2;
+        const qm::LaunchShape shape =
+            stack_shape(e, a, a.ngroups, qm::kShiftWaves * qm::kWave, qm::kShiftLdsBytes);
+        QM_TABLE(qm::launch_shift_detect(s, shape));
+        e->last_kernel = 3;
+        e->last_j = 4;
+        a.set0 += groups_lds;
+    }
+    if (use_direct) {
+        const int threads = 512;
+        const size_t publish_bytes = (size_t)3 * (threads / qm::kWave) * qm::kShiftKT * sizeof(double);
+        a.ngroups = groups_direct;
+        a.brick_list = e->d_shwide.p;
+        a.n_list = e->n_shwide;
+        if (launch_direct(e, a, 4, false, groups_direct, threads, publish_bytes)) return 1;
+        a.set0 += groups_direct;
+    }
+    return 0;
+}
+
 int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu) {
     // Workgroups all do the same amount of work, so the grid should be a whole number of
     // "rounds" over the resident slots (n_cu * blocks_per_cu): ntiles * groups <= rounds * slots,
@@ -494,6 +620,21 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         if (g_error.size() && !e->pair_kt) return 1;   // a HIP failure while building the tables
         jp = 0;
     }
+    // ---- the shift-reuse kernel (qm_shift.hpp): the fused detect's default where the table fits
+    bool shift = shift_wanted(e, n_chunk, !volume && !marginal && !accumulate && want_scan);
+    if (shift) {
+        if (ensure_shift_tables(e)) return 1;
+        shift = e->shift_ok;
+    }
+    if (shift) {
+        jp = 0;
+        a.g = e->shg;
+        a.rel = nullptr;
+        a.brick_meta = nullptr;
+        a.brick_total = nullptr;
+        a.ntiles = (n_chunk + qm::kShiftKT - 1) / qm::kShiftKT;
+        a.cap_doubles = qm::kShiftLdsBytes / 8;
+    }
     if (jp > 0) {
         const int PKT = 128 * jp;
         a.g = e->pg;
@@ -503,13 +644,13 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         a.ntiles = (n_chunk + PKT - 1) / PKT;
         a.cap_doubles = kPairLdsBytes / 8;
     }
-    const int n_wide_now = jp > 0 ? e->n_pwide : e->n_wide;
-    const int nbricks_now = jp > 0 ? e->pg.nbricks : e->g.nbricks;
+    const int n_wide_now = shift ? e->n_shwide : jp > 0 ? e->n_pwide : e->n_wide;
+    const int nbricks_now = shift ? e->shg.nbricks : jp > 0 ? e->pg.nbricks : e->g.nbricks;
     const bool use_direct = e->cfg_force_direct || n_wide_now > 0;
     const bool use_lds = !e->cfg_force_direct && n_wide_now < nbricks_now;
-    const int threads = jp > 0 ? 1024 : e->cfg_waves * qm::kWave;
+    const int threads = shift ? 512 : jp > 0 ? 1024 : e->cfg_waves * qm::kWave;   // (direct launch)
     const int lds_blocks_per_cu =
-        jp > 0 ? 1
+        shift ? 2 : jp > 0 ? 1
                : std::max(1, std::min(160 * 1024 / std::max(1, e->cfg_lds_bytes), 2048 / threads));
     int groups_lds = 0, groups_direct = 0;
     if (use_lds)
@@ -552,7 +693,9 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     rc = (volume || marginal)                                                                 \
              ? launch_stack_j<JJ, true>(e, a, groups_lds, groups_direct, use_lds, use_direct)  \
                 : launch_stack_j<JJ, false>(e, a, groups_lds, groups_direct, use_lds, use_direct)
-    if (jp == 2)
+    if (shift)
+        rc = launch_shift_path(e, a, groups_lds, groups_direct, use_lds, use_direct);
+    else if (jp == 2)
         rc = volume ? launch_pair_path<2, true>(e, a, groups_lds, groups_direct, use_lds, use_direct)
                     : launch_pair_path<2, false>(e, a, groups_lds, groups_direct, use_lds, use_direct);
     else if (jp == 1)
@@ -1026,6 +1169,8 @@ void qm_engine_destroy(qm_engine *e) {
     e->d_grids.release(); e->d_rows.release(); e->d_served.release();
     e->d_sig.release(); e->d_sta.release(); e->d_lta.release(); e->d_raw.release();
     e->d_onset_meta.release();
+    e->d_shraw.release(); e->d_shmeta.release(); e->d_shtotal.release(); e->d_shfit.release();
+    e->d_shwide.release(); e->d_shstream.release();
     e->d_lut.release(); e->d_bmeta.release();
     e->d_btotal.release(); e->d_wide.release(); e->d_scalar.release(); e->d_rel.release();
     e->d_onsets.release(); e->d_pmax.release(); e->d_psum.release(); e->d_out_a.release();
@@ -1106,6 +1251,9 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
     } else if (k == "pair") {
         if (v < 0 || v > 2) return fail("pair must be 0 (off), 1 (automatic) or 2 (any scan length)");
         e->cfg_pair = (int)v;
+    } else if (k == "shift") {
+        if (v < -1 || v > 1) return fail("shift must be -1 (automatic), 0 (off) or 1");
+        e->cfg_shift = (int)v;
     } else if (k == "screen") {
         e->cfg_screen = v ? 1 : 0;
     } else if (k == "screen_pairs") {
@@ -1155,6 +1303,10 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "screen_brick_nodes") *v = e->sg.brick_nodes;
     else if (k == "last_kernel") *v = e->last_kernel;
     else if (k == "last_kernel_j") *v = e->last_j;
+    else if (k == "shift") *v = e->cfg_shift;
+    else if (k == "shift_ok") *v = e->shift_built && e->shift_ok ? 1 : 0;
+    else if (k == "shift_brick_nodes") *v = e->shift_ok ? e->shg.brick_nodes : 0;
+    else if (k == "shift_wide_bricks") *v = e->shift_ok ? e->n_shwide : 0;
     else if (k == "pair_brick_nodes") *v = e->pair_kt ? e->pg.brick_nodes : 0;
     else if (k == "pair_wide_bricks") *v = e->pair_kt ? e->n_pwide : 0;
     else if (k == "pair_tile") *v = e->pair_ok ? e->pair_kt : 0;
@@ -1300,6 +1452,8 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     e->plan_j = -1;
     e->screen_kt = 0;
     e->pair_kt = 0;
+    e->shift_built = false;
+    e->shift_ok = false;
     e->have_lut = true;
     return plan_wide(e, eff_j(e));
 }

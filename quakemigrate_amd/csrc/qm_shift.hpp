@@ -1,0 +1,323 @@
+// qm_shift.hpp -- the shift-reuse float64 stacking kernel (fused detect), round 3.
+//
+// Same arithmetic as the other stacking kernels (qm_kernels.hpp): float64 sums in ascending row
+// order per (node, sample) -- migratelib.c:54-59 --, 2^z, running maximum / first index / sum.
+// What changes is how many operands leave LDS.  The round-2 kernels read one 8-byte operand per
+// add; on gfx950 the data returning from LDS and the float64 adds share the SIMD's cycles
+// (2 cycles per 8-byte operand + 4 per add), so operands are the lever.
+//
+//   * a lane owns FOUR CONSECUTIVE samples, t = t_first + 4*lane + k (time tile = 256 samples);
+//   * a wavefront stacks a 2x2x2 GROUP of nodes at a time: for one table row their delays differ
+//     by a few samples, so all eight nodes' operands are one WINDOW of 4 + (max - min delay)
+//     consecutive samples per lane, read once into registers (2.2 operands per node-row at C3
+//     instead of 4);
+//   * node g's four adds take window registers [idx_g, idx_g + 4): a wave-uniform, data-dependent
+//     register index -- gfx9 VGPR-index mode (gen_shift_asm.py, where the schedule is described).
+//
+// LDS: per brick the S row windows, each de-interleaved into two planes of 16-byte slots (plane A
+// slot s = window samples 4s, 4s+1; plane B = 4s+2, 4s+3) so that a window quad of every lane is
+// one aligned, conflict-free ds_read_b128 per plane.  Two 4-wave workgroups per CU, 80 KB each.
+// The per-(group, row) schedule (register indices, window address, quad count) is a stream of
+// 64-byte records built once per table (shift_stream_kernel) and read with scalar loads.
+#pragma once
+
+#include "qm_kernels.hpp"
+
+namespace qm {
+
+#ifndef QM_SHIFT_ASM_INC                     // (development: tools/shift_variants.sh swaps the loop)
+#define QM_SHIFT_ASM_INC "qm_shift_asm.inc"
+#endif
+#include QM_SHIFT_ASM_INC
+
+constexpr int kShiftWaves = 4;                          // wavefronts per workgroup
+constexpr int kShiftKT = 256;                           // samples per time tile
+constexpr int kShiftLdsBytes = 2 * kShiftPlane;         // both planes
+constexpr int kShiftMaxRows = 64;                       // table rows the stream builder handles
+static_assert(QM_EXP2_DEGREE_SUM == 8, "the generated loop carries the degree-8 2^f of the detect path");
+
+// records per (brick, wave): lead-in + groups * rows2 + trailing pad; every (brick, wave) owns a
+// fixed-size run (a brick at the grid's edge uses a prefix of it)
+__host__ __device__ __forceinline__ int shift_groups_per_brick(const GridDesc &g) {
+    return (g.bx / 2) * (g.by / 2) * (g.bz / 2);
+}
+__host__ __device__ __forceinline__ int64_t shift_recs_per_wave(const GridDesc &g, int rows2) {
+    return (int64_t)((shift_groups_per_brick(g) + kShiftWaves - 1) / kShiftWaves) * rows2 + 2;
+}
+
+struct ShiftArgs {
+    StackArgs a;                 // grid (shift bricks), onsets, scan geometry, partial sets
+    const int4 *smeta;           // [nbricks][S] (min delay, span, first slot, slots) per row window
+    const int32_t *stotal;       // [nbricks] slots of all rows (the zero row of an odd S follows)
+    const int32_t *sfit;         // [nbricks] 1: the brick runs here, 0: direct kernel
+    const char *stream;          // records, [nbricks][kShiftWaves][shift_recs_per_wave]
+    int rows2;                   // stream rows per group: S rounded up to even
+};
+
+struct LaunchShape;
+hipError_t launch_shift_detect(const ShiftArgs &a, const LaunchShape &s);   // qm_launch_shift.hip
+
+// valid 2x2x2 groups of a brick form a box [0,cx) x [0,cy) x [0,cz) in group coordinates
+__device__ __forceinline__ void shift_group_box(const GridDesc &g, int b, int &x0, int &y0, int &z0,
+                                                int &vx, int &vy, int &vz, int &cx, int &cy,
+                                                int &cz) {
+    brick_extents(g, b, x0, y0, z0, vx, vy, vz);
+    cx = (vx + 1) / 2; cy = (vy + 1) / 2; cz = (vz + 1) / 2;
+}
+
+// delays of the (up to) eight nodes of group (gx, gy, gz) for row r, relative to the row's brick
+// minimum; invalid nodes (outside the grid) copy node 0.  Returns the valid-node mask.
+__device__ __forceinline__ unsigned shift_group_delays(const GridDesc &g, const int32_t *lut, int x0,
+                                                       int y0, int z0, int vx, int vy, int vz,
+                                                       int gx, int gy, int gz, int r, int lo,
+                                                       int (&d)[8]) {
+    unsigned mask = 0;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int lx = 2 * gx + (n >> 2), ly = 2 * gy + ((n >> 1) & 1), lz = 2 * gz + (n & 1);
+        if (lx < vx && ly < vy && lz < vz) {
+            const int64_t node = ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + (z0 + lz);
+            int t = lut[node * g.n_rows + r];
+            t = t < 0 ? 0 : t;                            // migratelib.c:55
+            d[n] = t - lo;
+            mask |= 1u << n;
+        } else {
+            d[n] = d[0];                                  // node 0 of a valid group is valid
+        }
+    }
+    return mask;
+}
+
+__device__ __forceinline__ void shift_window(const int (&d)[8], int &e0, int &nq) {
+    int dmin = d[0], dmax = d[0];
+#pragma unroll
+    for (int n = 1; n < 8; ++n) {
+        dmin = d[n] < dmin ? d[n] : dmin;
+        dmax = d[n] > dmax ? d[n] : dmax;
+    }
+    e0 = dmin & ~3;
+    nq = (dmax - e0 + 4 + 3) / 4;
+    nq = nq < 2 ? 2 : nq;
+}
+
+#ifdef QM_ENGINE_TU
+// Pass 1, one workgroup per brick: slots every row window needs (the furthest slot a lane may
+// touch: e0/4 + 63 + the quads fetched), their prefix, and whether the brick fits.
+// meta_raw = (min, span, ., .) per (brick, row) from brick_minmax_kernel.
+__global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32_t *__restrict__ lut,
+                                                         const int4 *__restrict__ meta_raw,
+                                                         int4 *__restrict__ smeta,
+                                                         int32_t *__restrict__ stotal,
+                                                         int32_t *__restrict__ sfit) {
+    __shared__ int need[kShiftMaxRows];
+    __shared__ int overflow;
+    const int b = blockIdx.x, S = g.n_rows;
+    int x0, y0, z0, vx, vy, vz, cx, cy, cz;
+    shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
+    for (int r = threadIdx.x; r < S; r += blockDim.x) need[r] = 0;
+    if (threadIdx.x == 0) overflow = 0;
+    __syncthreads();
+    const int nvg = cx * cy * cz;
+    for (int i = threadIdx.x; i < nvg * S; i += blockDim.x) {
+        const int j = i / S, r = i % S;
+        const int gz = j % cz, gy = (j / cz) % cy, gx = j / (cz * cy);
+        int d[8], e0, nq;
+        shift_group_delays(g, lut, x0, y0, z0, vx, vy, vz, gx, gy, gz, r,
+                           meta_raw[(int64_t)b * S + r].x, d);
+        shift_window(d, e0, nq);
+        if (nq > kShiftNqMax) atomicOr(&overflow, 1);
+        atomicMax(&need[r], e0 / 4 + 63 + (nq > kShiftNqMin ? nq : kShiftNqMin));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int r = 0; r < S; ++r) {
+            const int4 raw = meta_raw[(int64_t)b * S + r];
+            smeta[(int64_t)b * S + r] = make_int4(raw.x, raw.y, run, need[r]);
+            run += need[r];
+        }
+        stotal[b] = run;
+        const int zero_row = (S & 1) ? 64 + kShiftNqMin : 0;   // all-zero window of the padding row
+        sfit[b] = (!overflow && (int64_t)(run + zero_row) * 16 <= kShiftPlane) ? 1 : 0;
+    }
+}
+
+// Pass 2, one workgroup per brick: the record stream (format: gen_shift_asm.py).
+__global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int32_t *__restrict__ lut,
+                                                           const int4 *__restrict__ smeta,
+                                                           const int32_t *__restrict__ stotal,
+                                                           const int32_t *__restrict__ sfit, int rows2,
+                                                           uint32_t *__restrict__ stream) {
+    extern __shared__ uint2 hdr[];                      // [group j][row] (LDS address, quads)
+    const int b = blockIdx.x, S = g.n_rows;
+    if (!sfit[b]) return;
+    int x0, y0, z0, vx, vy, vz, cx, cy, cz;
+    shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
+    const int nvg = cx * cy * cz;
+    const int64_t rpw = shift_recs_per_wave(g, rows2);
+    uint32_t *base = stream + (int64_t)b * kShiftWaves * rpw * (kShiftRec / 4);
+    for (int i = threadIdx.x; i < nvg * rows2; i += blockDim.x) {
+        const int j = i / rows2, r = i % rows2;
+        const int w = j % kShiftWaves, pos = j / kShiftWaves;
+        uint32_t *rec = base + ((int64_t)w * rpw + 1 + (int64_t)pos * rows2 + r) * (kShiftRec / 4);
+        if (r >= S) {                                   // padding row of an odd S: adds 0.0
+            for (int n = 0; n < 8; ++n) rec[n] = 0;
+            hdr[j * rows2 + r] = make_uint2(16u * (unsigned)stotal[b], 2u);
+            continue;
+        }
+        const int gz = j % cz, gy = (j / cz) % cy, gx = j / (cz * cy);
+        const int4 m = smeta[(int64_t)b * S + r];
+        int d[8], e0, nq;
+        const unsigned mask = shift_group_delays(g, lut, x0, y0, z0, vx, vy, vz, gx, gy, gz, r, m.x, d);
+        shift_window(d, e0, nq);
+        for (int n = 0; n < 8; ++n) rec[n] = 2u * (unsigned)(d[n] - e0);
+        hdr[j * rows2 + r] = make_uint2(16u * (unsigned)(m.z + e0 / 4), (unsigned)nq);
+        if (r == 0) {
+            rec[10] = (uint32_t)(((int64_t)(x0 + 2 * gx) * g.ny + (y0 + 2 * gy)) * g.nz + (z0 + 2 * gz));
+            rec[11] = mask;
+        }
+    }
+    __syncthreads();
+    // headers travel one record ahead of their row
+    for (int i = threadIdx.x; i < nvg * rows2 + kShiftWaves; i += blockDim.x) {
+        if (i >= nvg * rows2) {                          // lead-in record of wave w
+            const int w = i - nvg * rows2;
+            if (w < nvg) {
+                const uint2 h = hdr[w * rows2];
+                uint32_t *rec = base + (int64_t)w * rpw * (kShiftRec / 4);
+                rec[8] = h.x;
+                rec[9] = h.y;
+            }
+            continue;
+        }
+        const int j = i / rows2, r = i % rows2;
+        const int w = j % kShiftWaves, pos = j / kShiftWaves;
+        uint32_t *rec = base + ((int64_t)w * rpw + 1 + (int64_t)pos * rows2 + r) * (kShiftRec / 4);
+        uint2 h = make_uint2(0u, 2u);                    // after the wave's last row: harmless
+        if (r + 1 < rows2) h = hdr[j * rows2 + r + 1];
+        else if (j + kShiftWaves < nvg) h = hdr[(j + kShiftWaves) * rows2];
+        rec[8] = h.x;
+        rec[9] = h.y;
+    }
+}
+#endif  // QM_ENGINE_TU
+
+#ifdef QM_SHIFT_TU
+// Stage the row windows of brick b for the tile starting at t_first: window sample u of row r goes
+// to plane (u & 2) / 2, slot first_r + u / 4, half u & 1.  Every slot of the row is written (zero
+// past the data the brick can touch and past the rows' end): a lane may fetch whole quads.
+__device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *win, int b, int wave,
+                                                    int lane, int t_first) {
+    const StackArgs &a = s.a;
+    const int S = a.g.n_rows;
+    constexpr int U = 5;
+    for (int r = wave; r < S; r += kShiftWaves) {
+        const int4 m = s.smeta[(int64_t)b * S + r];
+        const int len = m.y + kShiftKT;                            // samples the brick can touch
+        const int first = m.x + a.fsmp + a.sample0 + t_first;      // index inside the row
+        const int room = a.T - first;
+        const double *src = a.onsets + (int64_t)r * a.T + first;
+        const int total = 4 * m.w;
+        for (int u0 = 0; u0 < total; u0 += kWave * U) {
+            double v[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int u = u0 + kWave * i + lane;
+                v[i] = (u < len && u < room) ? src[u] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int u = u0 + kWave * i + lane;
+                if (u < total)
+                    win[((u & 2) ? kShiftPlane / 8 : 0) + 2 * (m.z + (u >> 2)) + (u & 1)] = v[i];
+            }
+        }
+    }
+    if ((S & 1) && wave == 0) {                                    // the padding row's zero window
+        const int z = s.stotal[b];
+        for (int u = lane; u < 4 * (64 + kShiftNqMin); u += kWave)
+            win[((u & 2) ? kShiftPlane / 8 : 0) + 2 * (z + (u >> 2)) + (u & 1)] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(kShiftWaves * kWave, 2) void stack_shift_kernel(ShiftArgs s) {
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    const StackArgs &a = s.a;
+    const GridDesc &g = a.g;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD-aware workgroup -> (time tile, brick group) map, as stack_lds_kernel
+    const int slot = blockIdx.x >> 3;
+    const int tile = slot % a.ntiles;
+    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
+    if (a.run_if != nullptr && *a.run_if == 0) return;
+    // the last tile of a scan that is not a multiple of the tile length is pulled back so that it
+    // ends with the scan (it overlaps its predecessor: same arithmetic, same bits)
+    const int t_first =
+        ((tile + 1) * kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT) ? a.n_chunk - kShiftKT : tile * kShiftKT;
+    const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 16u;
+
+    double vmax[4], vsum[4];
+    int vidx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        vmax[k] = -__builtin_inf();
+        vsum[k] = 0.0;
+        vidx[k] = INT32_MAX;
+    }
+    double c[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c[i] = exp2_coeff<8>(i);
+
+    const int64_t rpw = shift_recs_per_wave(g, s.rows2);
+    for (int b = group; b < g.nbricks; b += a.ngroups) {
+        if (!s.sfit[b]) continue;                     // direct kernel's job
+        __syncthreads();                              // previous brick fully consumed
+        stage_shift_windows(s, win, b, wave, lane, t_first);
+        __syncthreads();
+        int x0, y0, z0, vx, vy, vz, cx, cy, cz;
+        shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
+        const int nvg = cx * cy * cz;
+        const int mine = (nvg - wave + kShiftWaves - 1) / kShiftWaves;     // groups of this wave
+        if (mine > 0)
+            shift_groups_d8(vmax, vsum, vidx,
+                            s.stream + ((int64_t)b * kShiftWaves + wave) * rpw * kShiftRec, mine,
+                            s.rows2 / 2, lane_addr, g.nz, g.ny * g.nz, a.z_scale, c);
+    }
+    if (!a.want_scan) return;
+    // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
+    __syncthreads();
+    double *smax = win, *ssum = win + kShiftWaves * kShiftKT;
+    int *sidx = reinterpret_cast<int *>(win + 2 * kShiftWaves * kShiftKT);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int o = wave * kShiftKT + 4 * lane + k;
+        smax[o] = vmax[k];
+        ssum[o] = vsum[k];
+        sidx[o] = vidx[k];
+    }
+    __syncthreads();
+    const int k = threadIdx.x;
+    double best = smax[k], total = ssum[k];
+    int bi = sidx[k];
+    for (int w = 1; w < kShiftWaves; ++w) {
+        const double v = smax[w * kShiftKT + k];
+        const int i = sidx[w * kShiftKT + k];
+        total += ssum[w * kShiftKT + k];
+        if (better(v, i, best, bi)) {
+            best = v;
+            bi = i;
+        }
+    }
+    const int t = t_first + k;
+    if (t < a.n_chunk) {
+        const int64_t o = (int64_t)(a.set0 + group) * a.n_chunk + t;
+        a.part_max[o] = best;
+        a.part_idx[o] = bi == INT32_MAX ? kNoIndex : (int64_t)bi;
+        a.part_sum[o] = total;
+    }
+}
+#endif  // QM_SHIFT_TU
+
+}  // namespace qm
