@@ -35,7 +35,7 @@ import os
 
 EXP = set(filter(None, os.environ.get("QM_SHIFT_EXP", "").split(",")))   # timing experiments only
 NQMAX = int(os.environ.get("QM_SHIFT_NQMAX", "6"))    # window = 4 * NQMAX doubles
-NQMIN = int(os.environ.get("QM_SHIFT_NQMIN", "3"))    # quads fetched unconditionally
+NQMIN = int(os.environ.get("QM_SHIFT_NQMIN", "4"))    # quads fetched unconditionally
 WMAX = 4 * NQMAX
 PLANE = 40896            # plane A -> plane B, bytes: 128 q + 64 keeps the staging stores conflict-free
 REC = 64                 # bytes per stream record

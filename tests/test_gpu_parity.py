@@ -1507,3 +1507,126 @@ def test_screened_detect_adversarial_families(lib, family):
         assert rel <= SCREEN_NORM, (family, trial, rel, fell_back)
     print(f"screened detect, family {family}: worst max_norm_coa deviation {worst:.3e}, "
           f"{redone} of 3 steps redone in float64")
+
+
+# ---- round 3: the shift-reuse fused detect (qm_shift.hpp) --------------------------------------
+def _detect_both(lib, lon, tt, fsmp, lsmp, avail, **cfg):
+    """(result, last kernel id, shift diagnostics) of the automatic engine and of Engine(shift=0)"""
+    out = {}
+    for tag, extra in (("shift", {}), ("round2", {"shift": 0})):
+        eng = lib.Engine(0, **cfg, **extra)
+        eng.load_lut(tt)
+        out[tag] = eng.detect(lon, fsmp, lsmp, avail)
+        out[tag + "_kernel"] = eng.get("last_kernel")
+        if tag == "shift":
+            out["wide"] = eng.get("shift_wide_bricks")
+            out["brick_nodes"] = eng.get("shift_brick_nodes")
+        eng.close()
+    return out
+
+
+SHIFT_SHAPES = [  # recipe, grid, rows, scanned samples
+    ("C3", (40, 33, 21), 30, 1000),      # whole and partial bricks, partial 2x2x2 groups (odd dims)
+    ("C3", (17, 16, 9), 30, 256),        # exactly one tile
+    ("C3", (16, 18, 16), 29, 193),       # odd row count (padding row), scan shorter than a tile
+    ("C3", (9, 10, 33), 1, 300),         # one row
+    ("C3", (12, 13, 8), 2, 513),         # last tile pulled back by 255 samples
+    ("C1", (23, 20, 19), 24, 625),       # the Icequake geometry's spacing / rates
+    ("C3", (3, 2, 70), 31, 700),         # a grid thinner than a brick in two axes
+    ("C3", (25, 24, 10), 32, 450),       # 32 rows: about the widest table whose windows fit 80 KB
+]
+
+
+@pytest.mark.parametrize("recipe,grid,rows,ns", SHIFT_SHAPES)
+def test_shift_kernel_equals_round2_kernels_and_oracle(lib, oracle, recipe, grid, rows, ns):
+    """The shift-reuse kernel stacks the same operands in the same row order as every other
+    stacking kernel: maxima and indices are the round-2 kernels' bits, and the oracle's argmax."""
+    case = synth.make_case(recipe, step=1, grid=grid, rows=rows, n_samples=ns)
+    lon = oracle.log_onsets(case.onsets)
+    r = _detect_both(lib, lon, case.traveltimes, case.fsmp, case.lsmp, case.available)
+    assert r["shift_kernel"] == 3 and r["round2_kernel"] != 3, r
+    want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
+                         threads=4)
+    _assert_series(r["shift"], want)
+    assert np.array_equal(r["shift"][2], r["round2"][2])
+    assert np.array_equal(r["shift"][0], r["round2"][0])            # same bits
+    np.testing.assert_allclose(r["shift"][1], r["round2"][1], rtol=NORM)
+
+
+def test_shift_kernel_exact_ties_resolve_to_the_lowest_index(lib, oracle):
+    """Quantised log-onsets (every partial sum exact): many nodes reach exactly the same maximum;
+    the 2x2x2 groups of a wavefront are NOT visited in ascending flat index, so the lowest index
+    must come out of the explicit tie-breaks (group -> wave -> workgroup -> partial sets)."""
+    rng = np.random.default_rng(33)
+    n_ties = 0
+    for trial in range(6):
+        grid = tuple(int(v) for v in rng.integers(5, 30, size=3))
+        S = int(rng.integers(1, 40))
+        ns = int(rng.integers(192, 700))
+        fsmp, lsmp = int(rng.integers(0, 20)), int(rng.integers(20, 60))
+        base = rng.integers(0, lsmp // 2, size=S)
+        ijk = np.indices(grid).sum(axis=0)[..., None]
+        tt = np.minimum(base[None, None, None, :] + ijk // 3, lsmp).astype(np.int32)
+        if trial % 2:                                      # negative delays clamp to 0 (migratelib.c:55)
+            tt[(tt <= 1) & (rng.random(tt.shape) < 0.5)] = -2
+        lon = rng.choice([-48, -16, 0, 16, 80], size=(S, fsmp + ns + lsmp),
+                         p=[0.45, 0.25, 0.15, 0.1, 0.05]) / 64.0
+        avail = int(2 ** rng.integers(0, 5))
+        want = oracle.detect(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True)
+        ref = oracle.c_migrate(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True).reshape(-1, ns)
+        n_ties += int((np.sum(ref == ref.max(axis=0)[None, :], axis=0) > 1).sum())
+        r = _detect_both(lib, lon, tt, fsmp, lsmp, avail, groups=int(rng.choice([0, 1, 5])))
+        assert r["shift_kernel"] == 3, (trial, grid, S, ns)
+        assert np.array_equal(r["shift"][2], want[2]), (trial, grid, S, ns)
+        assert np.array_equal(r["shift"][0], r["round2"][0])
+        np.testing.assert_allclose(r["shift"][1], want[1], rtol=NORM)
+    assert n_ties > 500
+
+
+def test_shift_kernel_beside_the_direct_kernel_nan_and_shards(lib, oracle):
+    """(a) A table with an incoherent corner and a fixed brick shape: bricks whose delay spread
+    does not fit the register window go to the direct kernel, the partial sets of both launches
+    fold to the oracle's series.  (b) NaN onsets: that sample's sum is NaN, a NaN never wins the
+    maximum, every other sample is untouched (as the round-2 kernels).  (c) Two slabs through
+    detect_partial + finalize equal the single-engine result."""
+    case = synth.make_case("C3", step=2, grid=(24, 20, 18), rows=12, n_samples=400)
+    tt = case.traveltimes.copy()
+    rng = np.random.default_rng(5)
+    tt[:6, :5, :7] = rng.integers(0, case.lsmp, size=tt[:6, :5, :7].shape)
+    lon = oracle.log_onsets(case.onsets)
+    want = oracle.detect(case.onsets, tt, case.fsmp, case.lsmp, case.available, threads=4)
+    r = _detect_both(lib, lon, tt, case.fsmp, case.lsmp, case.available, brick_x=4, brick_y=4, brick_z=4)
+    assert r["shift_kernel"] == 3 and r["wide"] > 0 and r["brick_nodes"] == 64, r
+    _assert_series(r["shift"], want)
+    assert np.array_equal(r["shift"][0], r["round2"][0])
+    # (b)
+    bad = lon.copy()
+    t_nan = 123
+    bad[3, case.fsmp + int(case.traveltimes[..., 3].min()) + t_nan] = np.nan
+    rb = _detect_both(lib, bad, case.traveltimes, case.fsmp, case.lsmp, case.available)
+    assert rb["shift_kernel"] == 3
+    for k in range(3):
+        assert np.array_equal(rb["shift"][k], rb["round2"][k], equal_nan=True) or k == 1
+    np.testing.assert_allclose(rb["shift"][1], rb["round2"][1], rtol=NORM, equal_nan=True)
+    assert np.isnan(rb["shift"][1]).sum() >= 1 and np.isfinite(rb["shift"][0]).all()
+    # (c)
+    import torch
+
+    whole = lib.Engine(0)
+    whole.load_lut(case.traveltimes)
+    single = whole.detect(lon, case.fsmp, case.lsmp, case.available)
+    whole.close()
+    ns, n_plane = case.n_samples, case.grid[1] * case.grid[2]
+    pmax = torch.empty((2, ns), dtype=torch.float64, device="cuda")
+    psum = torch.empty((2, ns), dtype=torch.float64, device="cuda")
+    pidx = torch.empty((2, ns), dtype=torch.int64, device="cuda")
+    eng = lib.Engine(0)
+    for k, (x0, x1) in enumerate(((0, 11), (11, 24))):
+        eng.load_lut(np.ascontiguousarray(case.traveltimes[x0:x1]), node_offset=x0 * n_plane)
+        eng.detect_partial(lon, case.fsmp, case.lsmp, case.available, (pmax[k], pidx[k], psum[k]))
+        assert eng.get("last_kernel") == 3
+    eng.synchronize()
+    folded = eng.finalize(pmax, pidx, psum, 2, ns, case.n_nodes_total)
+    assert np.array_equal(folded[2], single[2]) and np.array_equal(folded[0], single[0])
+    np.testing.assert_allclose(folded[1], single[1], rtol=NORM)
+    eng.close()

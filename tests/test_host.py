@@ -343,6 +343,18 @@ def test_fixed_point_screening_bounds_hold_on_cpu():
 
 
 
+def test_generated_shift_loop_is_current():
+    """qm_shift_asm.inc is generated (gen_shift_asm.py) and committed: the two must agree."""
+    import subprocess
+    import sys
+
+    csrc = ROOT / "quakemigrate_amd" / "csrc"
+    gen = subprocess.check_output([sys.executable, str(csrc / "gen_shift_asm.py")], text=True,
+                                  env={k: v for k, v in __import__("os").environ.items()
+                                       if not k.startswith("QM_SHIFT_")})
+    assert gen == (csrc / "qm_shift_asm.inc").read_text()
+
+
 def test_headline_kernels_stay_in_registers(tmp_path):
     """Compile the kernels the BASELINE configs run (gfx950, no GPU needed) and read the
     compiler's resource summary: no scratch (a spill inside the node loop costs 20-30x, as two
@@ -365,6 +377,19 @@ def test_headline_kernels_stay_in_registers(tmp_path):
         "template __global__ void qm::stack_pair_kernel<2, true, 30>(qm::StackArgs);\n"     # locate
         "template __global__ void qm::stack_exact_marginal_kernel<4, 30>(qm::StackArgs);\n"
         "template __global__ void qm::stack_lds_kernel<2, false, 3>(qm::StackArgs);\n")     # C1
+    # the shift-reuse detect kernel (C3 / C5 since round 3): two wavefronts per SIMD by design (64
+    # accumulators + two register windows of 24 doubles), i.e. at most 256 VGPRs, no scratch
+    shift = tmp_path / "s.hip"
+    shift.write_text('#define QM_SHIFT_TU 1\n#include <hip/hip_runtime.h>\n#include "qm_shift.hpp"\n')
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17",
+                           f"-I{ROOT / 'quakemigrate_amd' / 'csrc'}", "-c", str(shift), "-o",
+                           str(tmp_path / "s.o"), "--save-temps"], cwd=tmp_path,
+                          stderr=subprocess.DEVNULL)
+    sasm = next(tmp_path.glob("s-hip-amdgcn-*.s")).read_text()
+    m = re.search(r"\.set (\S*stack_shift_kernel\S*)\.num_vgpr, (\d+)", sasm)
+    assert m and int(m.group(2)) <= 256, m and m.groups()
+    sscr = re.search(re.escape(m.group(1)) + r"\.private_seg_size, (\d+)", sasm)
+    assert sscr is not None and int(sscr.group(1)) == 0
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17",
                            f"-I{ROOT / 'quakemigrate_amd' / 'csrc'}", "-c", str(src), "-o",
                            str(tmp_path / "k.o"), "--save-temps"], cwd=tmp_path,
