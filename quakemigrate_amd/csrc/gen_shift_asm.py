@@ -67,8 +67,9 @@ SNODE = ST + 7
 STAB = ST + 8            # stream base (pair, even)
 SOFF = ST + 10           # byte offset of the record loaded last
 SPF = ST + 12            # prefetch address (pair)
-SEND = ST + 14
-assert STAB % 2 == 0 and SB % 4 == 0
+SVA = ST + 14            # volume row address of the node in the epilogue (pair)
+SEND = ST + 16
+assert STAB % 2 == 0 and SB % 4 == 0 and SVA % 2 == 0 and SPF % 2 == 0
 
 
 def v2(r):
@@ -148,7 +149,7 @@ def row_iter(e, p, first):
             e(f"s_addc_u32 s{SPF + 1}, s{SPF + 1}, 0")
 
 
-def epilogue(e, degree):
+def epilogue(e, degree, volume):
     e("s_set_gpr_idx_off")
     # group-level running maximum (nodes of a group are visited in ascending flat index: strict >)
     for k in range(4):
@@ -184,6 +185,23 @@ def epilogue(e, degree):
                 e(f"v_fma_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, {v2(F + 2 * k)}, %[c{i}]")
         for k in range(4):
             e(f"v_ldexp_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, v{KI + k}")
+        if volume:
+            # the node's four values per lane are 32 contiguous bytes of its volume row (the tile's
+            # first sample is in the base): two 16-byte stores.  P is not written again before the
+            # next node's first Horner step, a dozen instructions away (gfx940+: 2 wait states
+            # between a store of more than 8 bytes and a VALU write to its data registers)
+            e(f"s_mul_i32 s{SVA}, s{SNODE}, %[vstride]")
+            e(f"s_mul_hi_u32 s{SVA + 1}, s{SNODE}, %[vstride]")
+            e(f"s_add_u32 s{SVA}, s{SVA}, %[vlo]")
+            e(f"s_addc_u32 s{SVA + 1}, s{SVA + 1}, %[vhi]")
+            # (re-dealing the dwords inside each quad of lanes with DPP moves so that one store
+            # writes whole 64-byte lines was measured too: same 5.95 ms -- the cost of the stores is
+            # their issue inside the CU, profiles/r03_ab_runs.txt)
+            nt = "" if "nont" in EXP else " nt"
+            if "nostore" not in EXP:
+                e(f"global_store_dwordx4 %[voff], v[{P}:{P + 3}], {s2(SVA)}{nt}")
+                if "halfstore" not in EXP:
+                    e(f"global_store_dwordx4 %[voff], v[{P + 4}:{P + 7}], {s2(SVA)} offset:16{nt}")
         for k in range(4):
             e(f"v_add_f64 %[sum{k}], %[sum{k}], {v2(P + 2 * k)}")
         for k in range(4):
@@ -203,7 +221,7 @@ def epilogue(e, degree):
         e(f"v_max_f64 %[max{k}], %[max{k}], {g_}")
 
 
-def body(degree):
+def body(degree, volume):
     e = Emitter()
     # leading coefficient into a VGPR pair (two different SGPR pairs cannot feed one VALU op)
     e(f"v_mov_b32 v{VC}, %[clo]")
@@ -233,7 +251,7 @@ def body(degree):
     e(f"s_sub_u32 s{SPAIRS}, s{SPAIRS}, 1")
     e(f"s_cbranch_scc0 {pair}")
     e(f"{nopair}:")
-    epilogue(e, degree)
+    epilogue(e, degree, volume)
     e("s_sub_u32 %[ng], %[ng], 1")
     e("s_cmp_lg_u32 %[ng], 0")
     e(f"s_cbranch_scc1 {group}")
@@ -249,22 +267,27 @@ def main():
     print(f"constexpr int kShiftPlane = {PLANE};        // bytes from plane A to plane B")
     print(f"constexpr int kShiftRec = {REC};            // bytes per stream record")
     print(f"constexpr int kShiftVgprs = {VEND};         // hard VGPRs reach v{VEND - 1}")
-    for degree, name in ((8, "shift_groups_d8"), (10, "shift_groups_d10")):
-        lines = body(degree)
+    for degree, volume, name in ((8, False, "shift_groups_detect"), (10, True, "shift_groups_volume")):
+        lines = body(degree, volume)
         # the stream pointer lives in a hard SGPR pair (the halves of an s[lo:hi] operand cannot be
         # named in inline asm): it is handed over as two 32-bit scalars
         text = "\\n\\t".join(lines)
         print()
-        print(f"// degree-{degree} 2^f; window of up to {WMAX} doubles; hard VGPRs v{VB}..v{VEND - 1}, "
-              f"SGPRs s{SB}..s{SEND - 1}")
+        print(f"// degree-{degree} 2^f{', values stored' if volume else ''}; window of up to {WMAX} doubles; "
+              f"hard VGPRs v{VB}..v{VEND - 1}, SGPRs s{SB}..s{SEND - 1}")
         print(f"__device__ __forceinline__ void {name}(double (&vmax)[4], double (&vsum)[4], "
               "int (&vidx)[4],")
         print("        const void *stream, int ngroups, int npairs, unsigned lane_addr, int nz, "
-              f"int nynz, double scale, const double (&c)[{degree + 1}]) {{")
+              f"int nynz, double scale, const double (&c)[{degree + 1}]"
+              + (", double *vol_tile, unsigned vol_stride_bytes, unsigned lane_bytes" if volume else "")
+              + ") {")
         print("    const unsigned long long sp = (unsigned long long)stream;")
         print("    const unsigned tablo = (unsigned)sp, tabhi = (unsigned)(sp >> 32);")
         print(f"    const unsigned long long cl = (unsigned long long)__double_as_longlong(c[{degree}]);")
         print("    const unsigned clo = (unsigned)cl, chi = (unsigned)(cl >> 32);")
+        if volume:
+            print("    const unsigned long long vp = (unsigned long long)vol_tile;")
+            print("    const unsigned vlo = (unsigned)vp, vhi = (unsigned)(vp >> 32);")
         outs = [f'[max{k}] "+v"(vmax[{k}])' for k in range(4)]
         outs += [f'[sum{k}] "+v"(vsum[{k}])' for k in range(4)]
         outs += [f'[idx{k}] "+v"(vidx[{k}])' for k in range(4)]
@@ -272,6 +295,9 @@ def main():
         ins = ['[tablo] "s"(tablo)', '[tabhi] "s"(tabhi)', '[lane] "v"(lane_addr)',
                '[npairs] "s"(npairs)', '[nz] "s"(nz)', '[nynz] "s"(nynz)', '[scale] "s"(scale)',
                '[clo] "s"(clo)', '[chi] "s"(chi)']
+        if volume:
+            ins += ['[vlo] "s"(vlo)', '[vhi] "s"(vhi)', '[vstride] "s"(vol_stride_bytes)',
+                    '[voff] "v"(lane_bytes)']
         ins += [f'[c{i}] "s"(c[{i}])' for i in range(degree)]
         clob = [f'"v{r}"' for r in range(VB, VEND)] + [f'"s{r}"' for r in range(SB, SEND)]
         clob += ['"vcc"', '"scc"', '"m0"', '"memory"']

@@ -521,15 +521,17 @@ int ensure_shift_tables(qm_engine *e) {
 
 // does this launch take the shift-reuse kernel?  (fused detect over whole 256-sample tiles' worth of
 // scan; short scans run on shorter tiles, run_j)
-bool shift_wanted(const qm_engine *e, int n_chunk, bool plain_detect) {
-    if (!plain_detect || e->cfg_shift == 0 || e->cfg_generic || e->cfg_force_direct ||
+bool shift_wanted(const qm_engine *e, int n_chunk, bool plain, bool volume, int64_t vol_stride) {
+    if (!plain || e->cfg_shift == 0 || e->cfg_generic || e->cfg_force_direct ||
         e->user_waves || e->user_lds || e->cfg_j > 0 || e->cfg_pair == 2)
         return false;
+    // volume-writing launches store whole tiles; the row stride goes into a 32-bit byte count
+    if (volume) return n_chunk >= qm::kShiftKT && vol_stride * 8 < ((int64_t)1 << 32);
     return n_chunk >= 192;
 }
 
 int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_direct,
-                      bool use_lds, bool use_direct) {
+                      bool use_lds, bool use_direct, bool volume) {
     if (use_lds) {
         a.ngroups = groups_lds;
         a.brick_list = nullptr;
@@ -543,7 +545,8 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         s.rows2 = e->shift_rows2;
         const qm::LaunchShape shape =
             stack_shape(e, a, a.ngroups, qm::kShiftWaves * qm::kWave, qm::kShiftLdsBytes);
-        QM_TABLE(qm::launch_shift_detect(s, shape));
+        if (volume) QM_TABLE(qm::launch_shift_volume(s, shape));
+        else QM_TABLE(qm::launch_shift_detect(s, shape));
         e->last_kernel = 3;
         e->last_j = 4;
         a.set0 += groups_lds;
@@ -554,7 +557,7 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         a.ngroups = groups_direct;
         a.brick_list = e->d_shwide.p;
         a.n_list = e->n_shwide;
-        if (launch_direct(e, a, 4, false, groups_direct, threads, publish_bytes)) return 1;
+        if (launch_direct(e, a, 4, volume, groups_direct, threads, publish_bytes)) return 1;
         a.set0 += groups_direct;
     }
     return 0;
@@ -621,7 +624,8 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         jp = 0;
     }
     // ---- the shift-reuse kernel (qm_shift.hpp): the fused detect's default where the table fits
-    bool shift = shift_wanted(e, n_chunk, !volume && !marginal && !accumulate && want_scan);
+    bool shift = shift_wanted(e, n_chunk, !marginal && !accumulate && (volume || want_scan),
+                              volume != nullptr, vol_stride);
     if (shift) {
         if (ensure_shift_tables(e)) return 1;
         shift = e->shift_ok;
@@ -694,7 +698,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
              ? launch_stack_j<JJ, true>(e, a, groups_lds, groups_direct, use_lds, use_direct)  \
                 : launch_stack_j<JJ, false>(e, a, groups_lds, groups_direct, use_lds, use_direct)
     if (shift)
-        rc = launch_shift_path(e, a, groups_lds, groups_direct, use_lds, use_direct);
+        rc = launch_shift_path(e, a, groups_lds, groups_direct, use_lds, use_direct, volume != nullptr);
     else if (jp == 2)
         rc = volume ? launch_pair_path<2, true>(e, a, groups_lds, groups_direct, use_lds, use_direct)
                     : launch_pair_path<2, false>(e, a, groups_lds, groups_direct, use_lds, use_direct);

@@ -34,7 +34,8 @@ constexpr int kShiftWaves = 4;                          // wavefronts per workgr
 constexpr int kShiftKT = 256;                           // samples per time tile
 constexpr int kShiftLdsBytes = 2 * kShiftPlane;         // both planes
 constexpr int kShiftMaxRows = 64;                       // table rows the stream builder handles
-static_assert(QM_EXP2_DEGREE_SUM == 8, "the generated loop carries the degree-8 2^f of the detect path");
+static_assert(QM_EXP2_DEGREE_SUM == 8 && QM_EXP2_DEGREE_VOLUME == 10,
+              "the generated loops carry the degree-8 (detect) and degree-10 (stored values) 2^f");
 
 // records per (brick, wave): lead-in + groups * rows2 + trailing pad; every (brick, wave) owns a
 // fixed-size run (a brick at the grid's edge uses a prefix of it)
@@ -56,6 +57,7 @@ struct ShiftArgs {
 
 struct LaunchShape;
 hipError_t launch_shift_detect(const ShiftArgs &a, const LaunchShape &s);   // qm_launch_shift.hip
+hipError_t launch_shift_volume(const ShiftArgs &a, const LaunchShape &s);
 
 // valid 2x2x2 groups of a brick form a box [0,cx) x [0,cy) x [0,cz) in group coordinates
 __device__ __forceinline__ void shift_group_box(const GridDesc &g, int b, int &x0, int &y0, int &z0,
@@ -240,6 +242,10 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
     }
 }
 
+// VOLUME: the 4-D volume is written too (whole 256-sample tiles only: a scan that is not a multiple
+// of the tile pulls its last tile back, and the overlap is stored twice with the same bits; scans
+// shorter than a tile stay with the other kernels)
+template <bool VOLUME>
 __global__ __launch_bounds__(kShiftWaves * kWave, 2) void stack_shift_kernel(ShiftArgs s) {
     extern __shared__ __attribute__((aligned(16))) double win[];
     const StackArgs &a = s.a;
@@ -266,9 +272,10 @@ __global__ __launch_bounds__(kShiftWaves * kWave, 2) void stack_shift_kernel(Shi
         vsum[k] = 0.0;
         vidx[k] = INT32_MAX;
     }
-    double c[9];
+    constexpr int D = Exp2Degree<VOLUME>::value;
+    double c[D + 1];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) c[i] = exp2_coeff<8>(i);
+    for (int i = 0; i <= D; ++i) c[i] = exp2_coeff<D>(i);
 
     const int64_t rpw = shift_recs_per_wave(g, s.rows2);
     for (int b = group; b < g.nbricks; b += a.ngroups) {
@@ -280,10 +287,16 @@ __global__ __launch_bounds__(kShiftWaves * kWave, 2) void stack_shift_kernel(Shi
         shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
         const int nvg = cx * cy * cz;
         const int mine = (nvg - wave + kShiftWaves - 1) / kShiftWaves;     // groups of this wave
-        if (mine > 0)
-            shift_groups_d8(vmax, vsum, vidx,
-                            s.stream + ((int64_t)b * kShiftWaves + wave) * rpw * kShiftRec, mine,
-                            s.rows2 / 2, lane_addr, g.nz, g.ny * g.nz, a.z_scale, c);
+        if (mine > 0) {
+            const char *run = s.stream + ((int64_t)b * kShiftWaves + wave) * rpw * kShiftRec;
+            if constexpr (VOLUME)
+                shift_groups_volume(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr, g.nz,
+                                    g.ny * g.nz, a.z_scale, c, a.volume + t_first,
+                                    (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u);
+            else
+                shift_groups_detect(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr, g.nz,
+                                    g.ny * g.nz, a.z_scale, c);
+        }
     }
     if (!a.want_scan) return;
     // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(NWAVES * 64, WPE) void model_kernel(const double *i
     for (int k = 0; k < 4; ++k) { vmax[k] = -__builtin_inf(); vsum[k] = 0.0; vidx[k] = INT32_MAX; }
     for (int b = 0; b < nbricks; ++b) {
         const char *p = stream + (long long)b * brick_stride + (long long)wave * wave_stride;
-        shift_groups_d8(vmax, vsum, vidx, p, ngroups, npairs, lane_addr, nz, nynz, scale, co.c);
+        shift_groups_detect(vmax, vsum, vidx, p, ngroups, npairs, lane_addr, nz, nynz, scale, co.c);
     }
     const long long o = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     for (int k = 0; k < 4; ++k) { omax[o + k] = vmax[k]; osum[o + k] = vsum[k]; oidx[o + k] = vidx[k]; }
