@@ -57,7 +57,9 @@ HBM_PEAK = 8.0e12           # B/s  (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 LDS_PEAK = 150.0e12         # B/s  aggregate ds_read_b64/b128
 FP64_PEAK = 39.3e12         # vector FP64 instructions-lanes / s (78.6 TFLOP/s FMA)
 EXP_F32_OPS = 8             # 32-bit ops per node-sample besides the S adds in the screening sweep
-EXP_FP64_OPS = 18           # FP64-rate VALU ops per node-sample besides the S adds (2^z, sum, max)
+EXP_FP64_OPS = 19           # FP64-rate VALU ops per node-sample besides the S adds (2^z, sum, max,
+                            # group merge / address: the shift-reuse kernel issues 19.2, the round-2
+                            # exact kernels 18 + 1 address add per row)
 
 
 def parse():
@@ -144,8 +146,10 @@ def cpu_baseline(case, budget_s):
     }
 
 
-def onchip(screened, local_ns, S, kern_s):
-    """The ceilings that bind the stacking kernel: LDS operand bytes and VALU issue."""
+def onchip(screened, local_ns, S, kern_s, operands_per_add=1.0):
+    """The ceilings that bind the stacking kernel: LDS operand bytes and VALU issue.
+    ``operands_per_add``: 8-byte LDS operands fetched per add -- 1 for the kernels that read every
+    operand from LDS, ~0.55 for the shift-reuse kernel (register windows shared by 8 nodes)."""
     if screened:
         # 4 operand bytes per add; v_add3_u32: two adds per lane-instruction
         ops = S + EXP_F32_OPS
@@ -155,10 +159,13 @@ def onchip(screened, local_ns, S, kern_s):
                                      "peak": 2 * FP64_PEAK / 1e12, "unit": "Tops/s",
                                      "frac": local_ns * ops / kern_s / (2 * FP64_PEAK),
                                      "ops_per_node_sample": ops}}
-    return {"lds": {"achieved": 8.0 * local_ns * S / kern_s / 1e12, "peak": LDS_PEAK / 1e12,
-                    "unit": "TB/s", "frac": 8.0 * local_ns * S / kern_s / LDS_PEAK},
+    lds_bytes = 8.0 * local_ns * S * operands_per_add
+    return {"lds": {"achieved": lds_bytes / kern_s / 1e12, "peak": LDS_PEAK / 1e12,
+                    "unit": "TB/s", "frac": lds_bytes / kern_s / LDS_PEAK,
+                    "operands_per_add": operands_per_add},
             "fp64_valu": {"achieved": local_ns * (S + EXP_FP64_OPS) / kern_s / 1e12,
-                          "peak": FP64_PEAK / 1e12, "unit": "Tinstr-lanes/s",
+                          "peak": FP64_PEAK / 1e12,
+                          "unit": "TFLOP/s (FP64 VALU instruction-lanes, one operation per instruction)",
                           "frac": local_ns * (S + EXP_FP64_OPS) / kern_s / FP64_PEAK,
                           "ops_per_node_sample": S + EXP_FP64_OPS}}
 
@@ -167,6 +174,8 @@ def stack_kernel_name(eng, S, volume=False):
     """Name of the stacking kernel the engine's last launch used (as rocprofv3 prints it)."""
     kind, j = eng.get("last_kernel"), eng.get("last_kernel_j")
     v = "true" if volume else "false"
+    if kind == 3:
+        return f"void qm::stack_shift_kernel<{v}>"
     if kind == 2:
         return f"qm::stack_pair_kernel<{j // 2}, {v}, {S}>"
     if kind == 1:
@@ -361,13 +370,26 @@ def main():
     kern_s = kern_ms / 1e3 / max(kern_calls, 1)         # avg stacking-kernel time, this rank
     local_ns = n_local * ns
     b_fused = 4.0 * n_local * S + 8.0 * S * t_samples + 24.0 * ns   # SURVEY 8d B_F
-    chip = onchip(screened, local_ns, S, kern_s)
+    shift_kernel = eng.get("last_kernel") == 3
+    # 8-byte LDS operands fetched per add: 1 for the round-2 kernels; the shift-reuse kernel shares
+    # a register window between the 8 nodes of a group (measured on the resident table)
+    per_add = eng.get("shift_operands_per_add_x1000") / 1000.0 if shift_kernel else 1.0
+    chip = onchip(screened, local_ns, S, kern_s, per_add)
+    valu_key = "int32_valu" if screened else "fp64_valu"
+    # the ceiling that binds: whichever on-chip unit is busier (the fused detect cannot be HBM
+    # bound: SURVEY.md section 8d); the HBM-compulsory figure is kept under its own key
+    bind = "lds" if chip["lds"]["frac"] >= chip[valu_key]["frac"] else valu_key
+    world_kernel_ms = [kern_s * 1e3]
+    if use_dist:                                        # where the imbalance is: every rank's kernel
+        gathered = [None] * world
+        dist.all_gather_object(gathered, kern_s * 1e3)
+        world_kernel_ms = [float(v) for v in gathered]
     result = {
         "metric": "grid-nodes x time-samples stacked /sec (detect sweep)",
         "value": value, "unit": "node-samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak" if (args.weak or time_sharded) else "strong",
+        "scaling": "weak" if (args.weak or streaming) else "strong",
         "vs_baseline": None,
         "dtype": "i32 fixed-point sweep + f64 refinement (opt-in screen=1)" if screened else "f64",
         "data": "synthetic",
@@ -385,6 +407,8 @@ def main():
                                  "allreduce": "3 x all_reduce(n_samples) per step"}[args.exchange]
                                 if use_dist and not time_sharded else "none"),
                    "collective_backend": backend, "ranks": world,
+                   "ranks_seen": dist.get_world_size() if use_dist else 1,
+                   "kernel_ms_per_rank": {"min": min(world_kernel_ms), "max": max(world_kernel_ms)},
                    "engine": dict(tunables, brick=[eng.get("brick_x"), eng.get("brick_y"),
                                                    eng.get("brick_z")],
                                   samples_per_lane=eng.get("samples_per_lane"),
@@ -392,18 +416,23 @@ def main():
         "kernel": {"name": (f"qm::screen_lds_kernel<{eng.get('screen_pairs')}, {(S + 7) // 8}>"
                             if screened else stack_kernel_name(eng, S)), "avg_ms": kern_s * 1e3,
                    "launches": kern_calls, "timing": "HIP events on the launch stream"},
-        "roofline": {"bound": "hbm", "achieved": b_fused / kern_s / 1e9,
-                     "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": b_fused / kern_s / HBM_PEAK,
+        "roofline": {"bound": bind, "achieved": chip[bind]["achieved"], "peak": chip[bind]["peak"],
+                     "unit": chip[bind]["unit"], "frac": chip[bind]["frac"],
                      "traffic": None,       # PMC passes are separate runs (profiles/, README there)
-                     "algorithmic_bytes_per_launch": b_fused,
-                     "lds_frac": chip["lds"]["frac"],
-                     "valu_frac": chip["int32_valu" if screened else "fp64_valu"]["frac"],
-                     "binding": "lds",
-                     "note": "fused detect never writes the volume: compulsory HBM bytes "
-                             "are the table, the onsets and the outputs only; the kernel is "
-                             "bound by LDS operand bytes (lds_frac of 150 TB/s) with the FP64 "
-                             "VALU co-saturated (valu_frac), see roofline_onchip"},
+                     "lds_frac": chip["lds"]["frac"], "valu_frac": chip[valu_key]["frac"],
+                     "hbm_compulsory": {"bound": "hbm", "achieved": b_fused / kern_s / 1e9,
+                                        "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                        "frac": b_fused / kern_s / HBM_PEAK,
+                                        "algorithmic_bytes_per_launch": b_fused},
+                     "note": "fused detect never writes the volume: compulsory HBM bytes are the "
+                             "table, the onsets and the outputs only (hbm_compulsory, far below 1 % "
+                             "by construction), so the roofline that binds is on the chip: "
+                             + ("FP64 VALU issue (S adds + ~19 epilogue instructions per node-"
+                                "sample against 39.3e12 instruction-lanes/s at 2.4 GHz), beside "
+                                "which the data returning from LDS costs the SIMDs 2 cycles per "
+                                "8-byte operand (DESIGN.md section 3.4)" if bind != "lds" else
+                                "LDS operand bytes (8 per add against 150 TB/s) with the FP64 "
+                                "VALU co-saturated")},
         "roofline_onchip": chip,
     }
 

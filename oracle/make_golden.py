@@ -299,6 +299,39 @@ def main():
     save("edges", onsets=on, traveltimes=tt, fsmp=fsmp, lsmp=lsmp,
          available=S - 2, map4d=m, max_coa=a, max_norm_coa=b, max_coa_idx=c)
 
+    # 4b. permuted twins: node pairs that stack the SAME multiset of log-onsets in a different row
+    #     order (every row carries the same trace; twin B's delays are a permutation of twin A's)
+    #     -- what a homogeneous table with a symmetric station layout produces.  Their float64
+    #     sums differ by 0-2 ulp; the reference compares exp(sum / available) (migratelib.c:100-105),
+    #     which usually merges them (lower index wins), sometimes not.  Recorded: the reference's
+    #     argmax, and "largest float64 sum, lowest index" computed from the same sums.
+    grid, S, ns, fsmp, lsmp = (8, 6, 4), 8, 512, 5, 40
+    n_nodes = int(np.prod(grid))
+    flat = np.zeros((n_nodes, S), dtype=np.int32)
+    for pair in range(n_nodes // 2):
+        d = rng.integers(0, lsmp + 1, size=S)
+        flat[2 * pair] = d
+        flat[2 * pair + 1] = rng.permutation(d)
+    tt = np.ascontiguousarray(flat.reshape(grid + (S,)))
+    trace = np.clip(rng.lognormal(0, 0.5, size=fsmp + ns + lsmp), 0.4, None)
+    on = np.ascontiguousarray(np.tile(trace, (S, 1)))
+    m, a, b, c = run(lib, on, tt, fsmp, lsmp, S)
+    logged = np.log(np.clip(on, 0.01, None))
+    sums = np.zeros((n_nodes, ns))
+    for r in range(S):                                  # ascending rows, one add each: the C loop
+        sums += logged[r][fsmp + flat[:, r][:, None] + np.arange(ns)[None, :]]
+    by_sum = np.argmax(sums, axis=0).astype(np.int64)   # first maximum = lowest index
+    twin_gap = np.abs(sums[0::2] - sums[1::2])
+    ulp = np.spacing(np.maximum(np.abs(sums[0::2]), np.abs(sums[1::2])))
+    gap_ulps = np.rint(twin_gap / ulp).astype(np.int64)
+    save("permuted_twins", onsets=on, traveltimes=tt, fsmp=fsmp, lsmp=lsmp, available=S,
+         max_coa=a, max_norm_coa=b, max_coa_idx=c, idx_by_largest_sum=by_sum,
+         reference_differs=np.array(float(np.mean(c != by_sum))),
+         twin_gap_ulps_hist=np.bincount(np.minimum(gap_ulps.ravel(), 5), minlength=6))
+    print("permuted_twins: the reference's argmax differs from 'largest sum, lowest index' on",
+          f"{100 * np.mean(c != by_sum):.1f} % of {ns} samples; twin gaps (ulps) histogram",
+          np.bincount(np.minimum(gap_ulps.ravel(), 5), minlength=6))
+
     # 5. ragged sizes (nothing a multiple of any tile), volume sampled -------
     grid, S, ns, fsmp, lsmp = (23, 17, 13), 7, 333, 19, 110
     tt = np.ascontiguousarray(

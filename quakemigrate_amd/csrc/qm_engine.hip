@@ -150,6 +150,7 @@ struct qm_engine {
     DevBuf<uint32_t> d_shstream;
     int n_shwide = 0, shift_rows2 = 0;
     bool shift_built = false, shift_ok = false;
+    int64_t shift_quads = 0, shift_group_rows = 0;   // register-window quads fetched / (group, row)s
 
     // float64 travel-time grids in seconds (optional; on-device table serving)
     DevBuf<double> d_grids;
@@ -473,19 +474,25 @@ int ensure_shift_tables(qm_engine *e) {
         g.brick_nodes = g.bx * g.by * g.bz;
         const size_t br = (size_t)g.nbricks * S;
         if (e->d_shraw.ensure(4 * br) || e->d_shmeta.ensure(4 * br) ||
-            e->d_shtotal.ensure(g.nbricks) || e->d_shfit.ensure(g.nbricks) || e->d_scalar.ensure(4))
+            e->d_shtotal.ensure(g.nbricks) || e->d_shfit.ensure(g.nbricks) || e->d_scalar.ensure(8))
             return 1;
-        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
+        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 8 * sizeof(int32_t), e->stream));
         hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
                            e->d_lut.p, reinterpret_cast<int4 *>(e->d_shraw.p), e->d_scalar.p);
         hipLaunchKernelGGL(qm::shift_need_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
                            e->d_lut.p, reinterpret_cast<const int4 *>(e->d_shraw.p),
-                           reinterpret_cast<int4 *>(e->d_shmeta.p), e->d_shtotal.p, e->d_shfit.p);
+                           reinterpret_cast<int4 *>(e->d_shmeta.p), e->d_shtotal.p, e->d_shfit.p,
+                           reinterpret_cast<unsigned long long *>(e->d_scalar.p + 4));
         QM_HIP(hipGetLastError());
         fit.resize(g.nbricks);
+        unsigned long long tally[2] = {0, 0};
         QM_HIP(hipMemcpyAsync(fit.data(), e->d_shfit.p, (size_t)g.nbricks * sizeof(int32_t),
                               hipMemcpyDeviceToHost, e->stream));
+        QM_HIP(hipMemcpyAsync(tally, e->d_scalar.p + 4, sizeof(tally), hipMemcpyDeviceToHost,
+                              e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
+        e->shift_quads = (int64_t)tally[0];
+        e->shift_group_rows = (int64_t)tally[1];
         wide.clear();
         for (int b = 0; b < g.nbricks; ++b)
             if (!fit[b]) wide.push_back(b);
@@ -1311,6 +1318,9 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "shift_ok") *v = e->shift_built && e->shift_ok ? 1 : 0;
     else if (k == "shift_brick_nodes") *v = e->shift_ok ? e->shg.brick_nodes : 0;
     else if (k == "shift_wide_bricks") *v = e->shift_ok ? e->n_shwide : 0;
+    else if (k == "shift_operands_per_add_x1000")   // 8-byte LDS operands fetched per add (x 1000)
+        *v = e->shift_ok && e->shift_group_rows > 0
+                 ? (e->shift_quads * 4 * 1000) / (e->shift_group_rows * 32) : 0;
     else if (k == "pair_brick_nodes") *v = e->pair_kt ? e->pg.brick_nodes : 0;
     else if (k == "pair_wide_bricks") *v = e->pair_kt ? e->n_pwide : 0;
     else if (k == "pair_tile") *v = e->pair_ok ? e->pair_kt : 0;

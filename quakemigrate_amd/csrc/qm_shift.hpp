@@ -110,7 +110,9 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
                                                          const int4 *__restrict__ meta_raw,
                                                          int4 *__restrict__ smeta,
                                                          int32_t *__restrict__ stotal,
-                                                         int32_t *__restrict__ sfit) {
+                                                         int32_t *__restrict__ sfit,
+                                                         unsigned long long *__restrict__ tally) {
+    // tally[0] += quads the loop fetches, tally[1] += (group, row) pairs: operands per add
     __shared__ int need[kShiftMaxRows];
     __shared__ int overflow;
     const int b = blockIdx.x, S = g.n_rows;
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
     if (threadIdx.x == 0) overflow = 0;
     __syncthreads();
     const int nvg = cx * cy * cz;
+    unsigned quads = 0;
     for (int i = threadIdx.x; i < nvg * S; i += blockDim.x) {
         const int j = i / S, r = i % S;
         const int gz = j % cz, gy = (j / cz) % cy, gx = j / (cz * cy);
@@ -128,10 +131,14 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
                            meta_raw[(int64_t)b * S + r].x, d);
         shift_window(d, e0, nq);
         if (nq > kShiftNqMax) atomicOr(&overflow, 1);
-        atomicMax(&need[r], e0 / 4 + 63 + (nq > kShiftNqMin ? nq : kShiftNqMin));
+        const int fetched = nq > kShiftNqMin ? nq : kShiftNqMin;
+        quads += (unsigned)fetched;
+        atomicMax(&need[r], e0 / 4 + 63 + fetched);
     }
+    atomicAdd(&tally[0], (unsigned long long)quads);
     __syncthreads();
     if (threadIdx.x == 0) {
+        atomicAdd(&tally[1], (unsigned long long)nvg * S);
         int run = 0;
         for (int r = 0; r < S; ++r) {
             const int4 raw = meta_raw[(int64_t)b * S + r];

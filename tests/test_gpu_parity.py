@@ -1630,3 +1630,135 @@ def test_shift_kernel_beside_the_direct_kernel_nan_and_shards(lib, oracle):
     assert np.array_equal(folded[2], single[2]) and np.array_equal(folded[0], single[0])
     np.testing.assert_allclose(folded[1], single[1], rtol=NORM)
     eng.close()
+
+
+def test_bench_self_launch_two_ranks_prints_one_json_line(tmp_path):
+    """`python bench.py --gpus 2` outside torch.distributed.run: starts its own two ranks (here
+    both on GPU 0 over gloo, QM_BENCH_ONE_DEVICE=1 -- RCCL refuses two ranks on one device),
+    shards the grid, exchanges the packed partials, and rank 0 prints exactly one JSON line on
+    stdout (the RCCL banner / anything else goes to stderr).  First contact with N GPUs should
+    be boring: this is the N > 1 code path end to end except for the transport."""
+    import json
+    import os
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = dict(os.environ, QM_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--config", "C2",
+                        "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
+                       cwd=tmp_path, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "strong"
+    cfg = line["config"]
+    assert cfg["ranks_seen"] == 2 and cfg["collective_backend"] == "gloo"
+    assert cfg["sharding"] == "x-plane slabs" and cfg["exchange"].startswith("1 x all_gather")
+    assert 0 < cfg["kernel_ms_per_rank"]["min"] <= cfg["kernel_ms_per_rank"]["max"]
+    assert line["value"] > 0 and line["unit"] == "node-samples/s" and line["dtype"] == "f64"
+    assert line["roofline"]["bound"] in ("lds", "fp64_valu") and 0 < line["roofline"]["frac"] < 1
+    assert line["roofline"]["hbm_compulsory"]["frac"] < 0.05
+
+
+def _alias_library_with_reference_argtypes():
+    """ctypes.CDLL of the alias file INTEGRATION.md tells a user to copy (qmlib<EXT_SUFFIX>),
+    argtypes set exactly as quakemigrate/core/lib.py:27-49 and :128 set them."""
+    import pathlib
+    import sysconfig
+
+    import numpy.ctypeslib as clib
+
+    root = pathlib.Path(__file__).resolve().parents[1]
+    so = ctypes.CDLL(str(root / "quakemigrate_amd" / "csrc" /
+                         ("qmlib" + sysconfig.get_config_var("EXT_SUFFIX"))))
+    c_int32, c_int64 = ctypes.c_int32, ctypes.c_int64
+    c_dPt = clib.ndpointer(dtype=np.double, flags="C_CONTIGUOUS")
+    c_i32Pt = clib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    c_i64Pt = clib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+    so.migrate.argtypes = [c_dPt, c_i32Pt, c_dPt, c_int32, c_int32, c_int32, c_int32, c_int32,
+                           c_int64, c_int64]
+    so.find_max_coa.argtypes = [c_dPt, c_dPt, c_dPt, c_i64Pt, c_int32, c_int64, c_int64]
+    so.qm_compat_status.restype = ctypes.c_int
+    so.qm_last_error.restype = ctypes.c_char_p
+    return so
+
+
+@pytest.mark.parametrize("name", ["small_random", "ties_twins", "edges"])
+def test_alias_library_raw_migrate_and_find_max_coa(name):
+    """The two drop-in symbols called the way the reference's binding calls them
+    (core/lib.py:112-123, :156-168), through the alias file, on goldens made by the reference."""
+    so = _alias_library_with_reference_argtypes()
+    g = load_golden(name)
+    lon = np.ascontiguousarray(np.log(np.clip(g["onsets"], 0.01, np.inf)))      # lib.py:93-94
+    tt = np.ascontiguousarray(g["traveltimes"])
+    fsmp, lsmp, avail = int(g["fsmp"]), int(g["lsmp"]), int(g["available"])
+    n_rows, t_samples = lon.shape
+    ns = t_samples - fsmp - lsmp
+    n_nodes = int(np.prod(tt.shape[:-1]))
+    vol = np.zeros(tt.shape[:-1] + (ns,), dtype=np.float64)                     # lib.py:101
+    so.migrate(lon, tt, vol, fsmp, lsmp, ns, n_rows, avail, n_nodes, 4)
+    assert so.qm_compat_status() == 0, so.qm_last_error()
+    np.testing.assert_allclose(vol, g["map4d"].reshape(vol.shape), rtol=TIGHT)
+    a, b, c = np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64)          # lib.py:152-154
+    so.find_max_coa(vol, a, b, c, ns, n_nodes, 4)
+    assert so.qm_compat_status() == 0, so.qm_last_error()
+    assert np.array_equal(c, g["max_coa_idx"])
+    np.testing.assert_allclose(a, g["max_coa"], rtol=TIGHT)
+    np.testing.assert_allclose(b, g["max_norm_coa"], rtol=NORM)
+    # scanning the REFERENCE's volume gives the reference's series exactly
+    ref_vol = np.ascontiguousarray(g["map4d"].reshape(vol.shape))
+    so.find_max_coa(ref_vol, a, b, c, ns, n_nodes, 4)
+    assert np.array_equal(c, g["max_coa_idx"]) and np.array_equal(a, g["max_coa"])
+    np.testing.assert_allclose(b, g["max_norm_coa"], rtol=1e-14)
+
+
+def test_alias_library_find_max_coa_failure_is_soft():
+    """A call the engine refuses (an empty volume): the outputs are NaN / 0, the status flag is
+    raised with a message, the interpreter lives, and the next good call clears the flag."""
+    so = _alias_library_with_reference_argtypes()
+    a, b, c = np.ones(4), np.ones(4), np.ones(4, dtype=np.int64)
+    so.find_max_coa(np.ones(8), a, b, c, 4, 0, 1)                               # n_nodes = 0
+    assert so.qm_compat_status() != 0 and b"empty" in so.qm_last_error()
+    assert np.isnan(a).all() and np.isnan(b).all() and (c == 0).all()
+    vol = np.arange(8.0).reshape(2, 4)
+    so.find_max_coa(vol, a, b, c, 4, 2, 1)
+    assert so.qm_compat_status() == 0
+    assert np.array_equal(a, vol[1]) and np.array_equal(c, np.ones(4, dtype=np.int64))
+    np.testing.assert_allclose(b, vol[1] * 2 / vol.sum(axis=0), rtol=1e-15)
+
+
+def test_permuted_twins_near_ties_are_quantified(lib, oracle):
+    """Node pairs that stack the same multiset of log-onsets in a different row order: sums 0-2
+    (sometimes more) ulp apart.  The reference compares the exponentiated values
+    (migratelib.c:100-105), which its libm usually rounds to the same double (lower index wins);
+    the engine keeps the larger float64 sum, lowest index on exact ties.
+    On this adversarial family the two rules pick a different TWIN on ~13 % of the samples
+    (recorded from the reference build in the fixture); values agree to the last bits, and the
+    engine's choice is exactly 'largest rounded z, lowest index'."""
+    g = load_golden("permuted_twins")
+    lon = oracle.log_onsets(g["onsets"])
+    tt, fsmp, lsmp, avail = g["traveltimes"], int(g["fsmp"]), int(g["lsmp"]), int(g["available"])
+    S = tt.shape[-1]
+    ns = lon.shape[1] - fsmp - lsmp
+    flat = tt.reshape(-1, S)
+    sums = np.zeros((flat.shape[0], ns))
+    for r in range(S):
+        sums += lon[r][fsmp + flat[:, r][:, None] + np.arange(ns)[None, :]]
+    z = sums * (1.4426950408889634074 / avail)              # the engine's rounded product
+    rule = np.argmax(z, axis=0)
+    ref_idx = g["max_coa_idx"]
+    assert abs(float(g["reference_differs"]) - np.mean(ref_idx != g["idx_by_largest_sum"])) < 1e-12
+    for cfg in ({}, {"shift": 0}, {"screen": 1}):
+        eng = lib.Engine(0, **cfg)
+        eng.load_lut(tt)
+        a, b, c = eng.detect(lon, fsmp, lsmp, avail)
+        eng.close()
+        assert np.array_equal(c, rule), cfg
+        np.testing.assert_allclose(a, g["max_coa"], rtol=TIGHT)
+        np.testing.assert_allclose(b, g["max_norm_coa"], rtol=NORM if not cfg.get("screen") else SCREEN_NORM)
+        differs = c != ref_idx
+        assert 0.02 < differs.mean() < 0.3                     # the measured deviation, ~0.13
+        assert np.array_equal(c[differs] // 2, ref_idx[differs] // 2)   # ... always the other twin
