@@ -355,6 +355,13 @@ def main():
         assert max(abs(int(a) - int(b)) for a, b in zip(found, ijk)) <= 2, \
             f"event at sample {t_ev}: node {found} is not at {ijk}"
 
+    # where the imbalance is: every rank's average stacking-kernel time
+    world_kernel_ms = [kern_ms / max(kern_calls, 1)]
+    if use_dist:
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = world_kernel_ms[0]
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        world_kernel_ms = [float(v) for v in t.cpu()]
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -379,11 +386,6 @@ def main():
     # the ceiling that binds: whichever on-chip unit is busier (the fused detect cannot be HBM
     # bound: SURVEY.md section 8d); the HBM-compulsory figure is kept under its own key
     bind = "lds" if chip["lds"]["frac"] >= chip[valu_key]["frac"] else valu_key
-    world_kernel_ms = [kern_s * 1e3]
-    if use_dist:                                        # where the imbalance is: every rank's kernel
-        gathered = [None] * world
-        dist.all_gather_object(gathered, kern_s * 1e3)
-        world_kernel_ms = [float(v) for v in gathered]
     result = {
         "metric": "grid-nodes x time-samples stacked /sec (detect sweep)",
         "value": value, "unit": "node-samples/s", "n_gpus": world, "steps": args.steps,
