@@ -49,10 +49,17 @@ void find_max_coa(double *map4d, double *max_coa, double *max_norm_coa,
  * a travel time beyond the post-pad, ...) it prints the reason to stderr, fills its outputs with
  * NaN (indices with 0) and leaves a non-zero status here until the next call (text:
  * qm_last_error()); QM_HIP_COMPAT_ON_ERROR=abort in the environment aborts the process instead.
- * The travel-time table is kept resident between calls and re-uploaded only when its content
- * (64-bit hash of every word) or shape changes; QM_HIP_ASSUME_ZERO_MAP=1 skips the scan of
- * map4d for non-zero content (the reference's binding always passes zeros, lib.py:101). */
+ * The travel-time table is kept resident between calls and re-uploaded only when its content or
+ * shape changes.  "Content" = two independent 64-bit hashes of every word (qm_table_hash): a stale
+ * table would need both to collide at once; callers who will not accept even that set
+ * QM_HIP_COMPAT_REUPLOAD=1 (upload on every call, the reference's cost model).
+ * QM_HIP_GRID=nx,ny,nz tells migrate() the grid shape its signature cannot carry (nx*ny*nz must be
+ * n_nodes): the table is then bricked in 3-D (8x8x8 where it fits) instead of 1x1x32 along the
+ * flat index.  QM_HIP_ASSUME_ZERO_MAP=1 skips the scan of map4d for non-zero content (the
+ * reference's binding always passes zeros, lib.py:101). */
 int qm_compat_status(void);
+/* the two content hashes the drop-in migrate() keys its resident table on (host code) */
+void qm_table_hash(const int32_t *table, int64_t n_words, uint64_t *hash_a, uint64_t *hash_b);
 
 typedef struct {
     int n;
@@ -133,8 +140,9 @@ int qm_engine_lut_download(qm_engine *e, int32_t *out);
 int qm_engine_lut_max(qm_engine *e, int32_t *max_delay);
 
 /* Fused detect step == migrate() + find_max_coa() of QuakeScan._compute
- * (quakemigrate/signal/scan.py:635-638) without the volume (screened by default, see
- * qm_engine_config; with device buffers the call never waits on the host).
+ * (quakemigrate/signal/scan.py:635-638) without the volume, float64 throughout (the screened
+ * sweep is opt-in: qm_engine_config "screen"; with device buffers the call never waits on the
+ * host).
  * n_nodes_total: node count of the FULL grid (normalisation, migratelib.c:108).
  * Outputs [n_samples]: max_coa f64, max_norm_coa f64, max_coa_idx i64. */
 int qm_engine_detect(qm_engine *e, const double *log_onsets, int onsets_on_device,

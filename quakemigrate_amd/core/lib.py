@@ -57,6 +57,9 @@ _vp = ctypes.c_void_p
 qmlib.qm_last_error.restype = ctypes.c_char_p
 qmlib.qm_device_count.restype = ctypes.c_int
 qmlib.qm_compat_status.restype = ctypes.c_int
+qmlib.qm_table_hash.restype = None
+qmlib.qm_table_hash.argtypes = [ctypes.c_void_p, c_int64, ctypes.POINTER(ctypes.c_uint64),
+                                ctypes.POINTER(ctypes.c_uint64)]
 qmlib.qm_engine_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
 qmlib.qm_engine_destroy.argtypes = [_vp]
 qmlib.qm_engine_destroy.restype = None
@@ -139,6 +142,7 @@ class Engine:
         self.grid = None
         self.n_rows = None
         self.node_offset = 0
+        self.table_generation = 0       # bumped whenever the resident table is replaced
         for k, v in config.items():
             self.config(k, v)
 
@@ -244,6 +248,7 @@ class Engine:
         self.grid = (nx, ny, nz)
         self.n_rows = rows
         self.node_offset = int(node_offset)
+        self.table_generation += 1
 
     # -- on-device serving (lut.py:502-538 / :102-140 moved to the GPU) ----------
     def set_traveltime_grids(self, grids):
@@ -272,6 +277,7 @@ class Engine:
         _check(qmlib.qm_engine_serve(self._h, float(sampling_rate), rows, len(rows), dfx, dfy,
                                      dfz, int(node_offset)))
         self.grid = (self.get("nx"), self.get("ny"), self.get("nz"))
+        self.table_generation += 1
         self.n_rows = len(rows)
         self.node_offset = int(node_offset)
 
@@ -509,11 +515,14 @@ class Engine:
 
 # --------------------------------------------------------------------------
 # module-level engine for the reference-signature functions.  They receive the
-# table on every call (lib.py:53-60) and upload it every call: the only safe
-# reading of that contract.  Callers that keep a table across timesteps use an
-# Engine (or quakemigrate_amd.scan.MigrationScan) and upload once.
+# table on every call (lib.py:53-60); like the C symbols beside them
+# (qm_engine.hip: migrate) they keep it resident and upload it again only when
+# its shape or content -- two independent 64-bit hashes of every word,
+# qm_table_hash -- changes (QM_HIP_COMPAT_REUPLOAD=1: on every call).  Callers
+# that keep a table across timesteps use an Engine (or
+# quakemigrate_amd.scan.MigrationScan) and never pay for the hash either.
 # --------------------------------------------------------------------------
-_default = {"engine": None}
+_default = {"engine": None, "table_key": None}
 
 
 def default_engine():
@@ -524,9 +533,23 @@ def default_engine():
     return _default["engine"]
 
 
+def _table_key(traveltimes):
+    a, b = ctypes.c_uint64(), ctypes.c_uint64()
+    qmlib.qm_table_hash(traveltimes.ctypes.data_as(ctypes.c_void_p), traveltimes.size,
+                        ctypes.byref(a), ctypes.byref(b))
+    return (tuple(traveltimes.shape), int(a.value), int(b.value))
+
+
 def _resident(traveltimes):
+    import os
+
     eng = default_engine()
-    eng.load_lut(traveltimes)
+    key = _table_key(traveltimes)
+    if (os.environ.get("QM_HIP_COMPAT_REUPLOAD", "0") not in ("", "0")
+            or _default["table_key"] != (key, eng.table_generation)):
+        _default["table_key"] = None
+        eng.load_lut(traveltimes)
+        _default["table_key"] = (key, eng.table_generation)
     return eng
 
 

@@ -68,8 +68,13 @@ STAB = ST + 8            # stream base (pair, even)
 SOFF = ST + 10           # byte offset of the record loaded last
 SPF = ST + 12            # prefetch address (pair)
 SVA = ST + 14            # volume row address of the node in the epilogue (pair)
-SEND = ST + 16
-assert STAB % 2 == 0 and SB % 4 == 0 and SVA % 2 == 0 and SPF % 2 == 0
+SKP = ST + 16            # scalar-cache prefetch base (pair)
+SDUMMY = ST + 18
+SEND = ST + 19
+KPF = int(os.environ.get("QM_SHIFT_KPF", "0"))        # records of the next group touched per epilogue
+                                                      # (experiment: no gain once the stream is
+                                                      # prefetched into L2, profiles/r03_ab_runs.txt)
+assert STAB % 2 == 0 and SB % 4 == 0 and SVA % 2 == 0 and SPF % 2 == 0 and SKP % 2 == 0
 
 
 def v2(r):
@@ -151,6 +156,15 @@ def row_iter(e, p, first):
 
 def epilogue(e, degree, volume):
     e("s_set_gpr_idx_off")
+    if KPF:
+        # The scalar loads of the row loop are waited for one row after their issue, and a scalar
+        # load that misses the scalar cache takes longer than a row.  The epilogue is ~600 VALU
+        # instructions without a wait: touch the next group's records now (one dword each pulls the
+        # 64-byte line into the scalar cache), so the row loop's loads hit.
+        e(f"s_add_u32 s{SKP}, s{STAB}, s{SOFF}")
+        e(f"s_addc_u32 s{SKP + 1}, s{STAB + 1}, 0")
+        for i in range(1, KPF + 1):
+            e(f"s_load_dword s{SDUMMY}, {s2(SKP)}, {i * REC}")
     # group-level running maximum (nodes of a group are visited in ascending flat index: strict >)
     for k in range(4):
         e(f"v_mov_b32 v{GMAX + 2 * k}, 0")

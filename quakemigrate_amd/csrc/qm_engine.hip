@@ -455,6 +455,9 @@ int ensure_shift_tables(qm_engine *e) {
     e->shift_ok = false;
     const int S = e->g.n_rows;
     if (S > qm::kShiftMaxRows) return 0;
+    // a grid one node thick has half-empty 2x2x2 groups everywhere (e.g. the flat 1 x 1 x N view
+    // of the reference-signature migrate): leave it to the other kernels unless asked explicitly
+    if (e->cfg_shift < 0 && (e->g.nx < 2 || e->g.ny < 2 || e->g.nz < 2)) return 0;
     static const int kShapes[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4}, {2, 4, 4}};
     const bool fixed = e->cfg_bx > 0;
     const int n_shapes = fixed ? 1 : (int)(sizeof(kShapes) / sizeof(kShapes[0]));
@@ -626,9 +629,10 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
 
     // ---- the paired (16-byte operand) kernel where it applies: own brick grid and tables
     int jp = (accumulate || marginal) ? 0 : pair_jp(e, n_chunk, volume != nullptr);
-    if (jp > 0 && (!pair_built(e->g.n_rows) || ensure_pair_tables(e, jp) != 0 || !e->pair_ok)) {
-        if (g_error.size() && !e->pair_kt) return 1;   // a HIP failure while building the tables
-        jp = 0;
+    if (jp > 0) {
+        if (!pair_built(e->g.n_rows)) jp = 0;
+        else if (ensure_pair_tables(e, jp) != 0) return 1;   // a HIP failure while building the tables
+        else if (!e->pair_ok) jp = 0;                         // the layout does not fit this table
     }
     // ---- the shift-reuse kernel (qm_shift.hpp): the fused detect's default where the table fits
     bool shift = shift_wanted(e, n_chunk, !marginal && !accumulate && (volume || want_scan),
@@ -2109,9 +2113,10 @@ static int g_compat_status = 0;
 // what the resident table of the compat engine was built from: the reference's caller passes the
 // served table on every call (scan.py:629-634 -> lib.py:53-60), usually with unchanged content
 struct CompatTable {
-    uint64_t hash = 0;
+    uint64_t hash = 0, hash2 = 0;       // two independent 64-bit content hashes (see table_hash)
     int64_t n_nodes = -1;
     int32_t n_rows = -1;
+    int32_t gx = 0, gy = 0, gz = 0;     // grid shape it was loaded with (QM_HIP_GRID), 0 = flat
     bool valid = false;
 };
 static CompatTable g_compat_table;
@@ -2137,21 +2142,31 @@ static void parallel_ranges(size_t n, size_t grain, F fn) {
     for (auto &th : pool) th.join();
 }
 
-// 64-bit content hash of the whole table (every word, order-sensitive), threads combined in order
-static uint64_t table_hash(const int32_t *p, size_t n) {
-    std::vector<uint64_t> part(32, 0);
+// Two independent 64-bit content hashes of the whole table (every word, order-sensitive; threads
+// combined in order): a multiply-xorshift chain and a rotate-add chain with other constants, read in
+// one pass.  The resident table is reused only if BOTH match (and the shape): a stale table would
+// need a simultaneous collision of two unrelated 64-bit functions.  QM_HIP_COMPAT_REUPLOAD=1
+// re-uploads on every call regardless.
+static void table_hash(const int32_t *p, size_t n, uint64_t *h1, uint64_t *h2) {
+    std::vector<uint64_t> part(32, 0), part2(32, 0);
     parallel_ranges(n, (size_t)1 << 22, [&](size_t lo, size_t hi, size_t t) {
         uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)lo;
+        uint64_t g = 0xD6E8FEB86659FD93ull + (uint64_t)lo * 0x2545F4914F6CDD1Dull;
         for (size_t i = lo; i < hi; ++i) {
-            h ^= (uint32_t)p[i];
+            const uint64_t w = (uint32_t)p[i];
+            h ^= w;
             h *= 0xFF51AFD7ED558CCDull;
             h ^= h >> 29;
+            g = ((g << 23) | (g >> 41)) + (w + 0x9FB21C651E98DF25ull) * 0xA24BAED4963EE407ull;
         }
         part[t] = h;
+        part2[t] = g;
     });
-    uint64_t h = n;
+    uint64_t h = n, g = ~(uint64_t)n;
     for (uint64_t v : part) h = (h ^ v) * 0xC4CEB9FE1A85EC53ull + 0x632BE59BD9B4E019ull;
-    return h;
+    for (uint64_t v : part2) g = ((g << 31) | (g >> 33)) ^ (v * 0x94D049BB133111EBull);
+    *h1 = h;
+    *h2 = g;
 }
 
 static bool any_nonzero(const double *p, size_t n) {
@@ -2189,6 +2204,13 @@ static bool compat_failed(int rc, const char *what) {
 
 int qm_compat_status(void) { return g_compat_status; }
 
+void qm_table_hash(const int32_t *table, int64_t n_words, uint64_t *hash_a, uint64_t *hash_b) {
+    uint64_t a = 0, b = 0;
+    if (table && n_words > 0) table_hash(table, (size_t)n_words, &a, &b);
+    if (hash_a) *hash_a = a;
+    if (hash_b) *hash_b = b;
+}
+
 void migrate(double *onsets, int32_t *lookup_tables, double *map4d, int32_t fsmp, int32_t lsmp,
              int32_t n_samples, int32_t n_stations, int32_t available, int64_t n_nodes,
              int64_t threads) {
@@ -2209,20 +2231,44 @@ void migrate(double *onsets, int32_t *lookup_tables, double *map4d, int32_t fsmp
                            n_stations), "migrate");
         return poison();
     }
+    // The reference's signature carries no grid shape (lib.py:112-123 passes the flat node count),
+    // so by default the table is bricked 1 x 1 x 32 along the flat index.  A caller who knows the
+    // shape can say so -- QM_HIP_GRID=nx,ny,nz (nx*ny*nz must equal n_nodes) -- and gets the
+    // engine's own 3-D bricks (8 x 8 x 8 where they fit) and the kernels that go with them.
+    int gx = 0, gy = 0, gz = 0;
+    if (const char *shape = getenv("QM_HIP_GRID")) {
+        long long a = 0, b = 0, c = 0;
+        if (sscanf(shape, "%lld,%lld,%lld", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0 &&
+            a * b * c == (long long)n_nodes) {
+            gx = (int)a; gy = (int)b; gz = (int)c;
+        } else {
+            compat_failed(fail("migrate: QM_HIP_GRID='%s' does not describe %lld nodes", shape,
+                               (long long)n_nodes), "migrate");
+            return poison();
+        }
+    }
     // table: re-uploaded (and its brick tables rebuilt) only when its content changed
-    const uint64_t h = table_hash(lookup_tables, (size_t)n_nodes * n_stations);
-    if (!(g_compat_table.valid && e->have_lut && g_compat_table.hash == h &&
-          g_compat_table.n_nodes == n_nodes && g_compat_table.n_rows == n_stations)) {
+    uint64_t h = 0, h2 = 0;
+    table_hash(lookup_tables, (size_t)n_nodes * n_stations, &h, &h2);
+    const char *reup = getenv("QM_HIP_COMPAT_REUPLOAD");
+    const bool force = reup && atoi(reup) != 0;
+    if (force || !(g_compat_table.valid && e->have_lut && g_compat_table.hash == h &&
+                   g_compat_table.hash2 == h2 && g_compat_table.n_nodes == n_nodes &&
+                   g_compat_table.n_rows == n_stations && g_compat_table.gx == gx &&
+                   g_compat_table.gy == gy && g_compat_table.gz == gz)) {
         g_compat_table.valid = false;
-        e->cfg_bx = 1;
-        e->cfg_by = 1;
-        e->cfg_bz = 32;
-        if (compat_failed(qm_engine_load_lut(e, lookup_tables, 0, 1, 1, (int32_t)n_nodes,
-                                             n_stations, 0), "migrate/load"))
+        e->cfg_bx = gx ? 0 : 1;
+        e->cfg_by = gx ? 0 : 1;
+        e->cfg_bz = gx ? 0 : 32;
+        if (compat_failed(qm_engine_load_lut(e, lookup_tables, 0, gx ? gx : 1, gx ? gy : 1,
+                                             gx ? gz : (int32_t)n_nodes, n_stations, 0),
+                          "migrate/load"))
             return poison();
         g_compat_table.hash = h;
+        g_compat_table.hash2 = h2;
         g_compat_table.n_nodes = n_nodes;
         g_compat_table.n_rows = n_stations;
+        g_compat_table.gx = gx; g_compat_table.gy = gy; g_compat_table.gz = gz;
         g_compat_table.valid = true;
     }
     // the reference adds on top of map4d; the Python binding always passes zeros (lib.py:101),

@@ -190,7 +190,16 @@ class ShardedDetector:
             self.engine.set_stream(ptr)
             self._bound = ptr
 
-    def detect(self, log_onsets, fsmp, lsmp, available):
+    def detect(self, log_onsets, fsmp, lsmp, available, out=None):
+        """
+        One sharded detect step; returns ``(max_coa, max_norm_coa, max_coa_idx)`` on every rank.
+
+        The result lands in ``out`` (three device tensors of length ``n_samples``) if given, else
+        in this detector's own buffers -- the SAME three tensors on every call, whichever
+        exchange is used: they are valid until the next ``detect``; callers that keep results
+        across steps pass ``out=`` or clone.
+        """
+        out = self.out if out is None else out
         self._bind_stream()
         if self.engine.n_rows is None:                       # empty slab: the neutral partial
             self.pmax.fill_(float("-inf"))
@@ -200,11 +209,14 @@ class ShardedDetector:
             self.engine.detect_partial(log_onsets, fsmp, lsmp, available,
                                        (self.pmax, self.pidx, self.psum))
         if self.exchange == "allreduce":
-            return exchange_partials(self.pmax, self.pidx, self.psum, self.n_nodes_total,
-                                     self.group)
+            got = exchange_partials(self.pmax, self.pidx, self.psum, self.n_nodes_total,
+                                    self.group)
+            for dst, src in zip(out, got):
+                dst.copy_(src)
+            return out
         all_gather_packed(self.packed, self.gathered, self.group)
         return self.engine.finalize_packed(self.gathered, self.world, self.n_samples,
-                                           self.n_nodes_total, out=self.out)
+                                           self.n_nodes_total, out=out)
 
     def marginal_map(self, log_onsets, fsmp, lsmp, available, first_sample, end_sample, nx_total,
                      plane_shape=None):

@@ -78,10 +78,11 @@ class MigrationScan:
         self.threads = threads
         self.engine = engine if engine is not None else lib.default_engine()
         # screen: None leaves the engine as configured (float64 throughout unless it was created
-        # with screen=1); True / False switch the opt-in screened detect (exact argmax and
-        # max_coa, max_coa_n within 6.7e-7 by a deterministic bound) on / off for this engine
-        if screen is not None:
-            self.engine.config("screen", 1 if screen else 0)
+        # with screen=1); True / False select the opt-in screened detect (exact argmax and
+        # max_coa, max_coa_n within 6.7e-7 by a deterministic bound) for THIS scan's steps only:
+        # the setting is applied around each call and the engine's own restored afterwards (the
+        # default engine is shared by every MigrationScan and by lib.migrate_and_find_max)
+        self.screen = None if screen is None else bool(screen)
         self._resident_key = None
         # device_serving: the float64 grids of ``lut.traveltimes`` ({station: {phase: grid}},
         # quakemigrate/lut/lut.py) are uploaded once and the int32 table of the available
@@ -161,7 +162,14 @@ class MigrationScan:
         series = (np.zeros(n_samples), np.zeros(n_samples),
                   np.zeros(n_samples, dtype=np.int64))
         if self.stage == "detect":
-            eng.detect(onsets, fsmp, lsmp, avail, out=series)
+            previous = eng.get("screen")
+            if self.screen is not None:
+                eng.config("screen", 1 if self.screen else 0)
+            try:
+                eng.detect(onsets, fsmp, lsmp, avail, out=series)
+            finally:
+                if self.screen is not None:
+                    eng.config("screen", previous)
             map4d = None
         else:
             map4d = np.zeros(tuple(eng.grid) + (n_samples,), dtype=np.double)

@@ -1762,3 +1762,93 @@ def test_permuted_twins_near_ties_are_quantified(lib, oracle):
         differs = c != ref_idx
         assert 0.02 < differs.mean() < 0.3                     # the measured deviation, ~0.13
         assert np.array_equal(c[differs] // 2, ref_idx[differs] // 2)   # ... always the other twin
+
+
+def test_spline_location_on_device_equals_scipy_rbf_on_map_windows(lib):
+    """`locate.spline_from_window(engine=...)` (Engine.rbf_peak: the cubic RBF's 41^3 values and
+    their first maximum on the GPU) against scipy.interpolate.Rbf ITSELF, called the way the
+    reference calls it (signal/scan.py:777-816), on 5^3 windows cut around the peaks of noisy
+    coalescence-like maps: same sub-node location.  (The three evaluations -- SciPy's BLAS dot, the
+    NumPy restatement, the GPU's sequential sum over the 125 centres -- round differently in the
+    last bits; a disagreement needs two fine-grid values closer than ~1e-13 relative AND both
+    maximal, which a map with structure does not produce: 40 windows here, none.)"""
+    from scipy.interpolate import Rbf
+
+    from quakemigrate_amd import locate
+
+    rng = np.random.default_rng(77)
+    eng = lib.Engine(0)
+    shape = (31, 27, 23)
+    g = np.indices(shape).astype(np.float64)
+    checked = 0
+    for trial in range(40):
+        centre = np.array([rng.uniform(4, n - 5) for n in shape])
+        width = rng.uniform(1.5, 6.0, size=3)
+        cmap = np.exp(-(((g[0] - centre[0]) / width[0]) ** 2 + ((g[1] - centre[1]) / width[1]) ** 2
+                        + ((g[2] - centre[2]) / width[2]) ** 2))
+        cmap += 0.03 * rng.random(shape)
+        cmap /= cmap.max()
+        peak = np.array(np.unravel_index(np.argmax(cmap), shape))
+        lo, hi = peak - 2, peak + 3
+        if (lo < 0).any() or (hi > np.array(shape)).any():
+            continue
+        window = cmap[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        got = locate.spline_from_window(window, peak, shape, engine=eng)
+        # the reference's call, verbatim in structure
+        xo = np.linspace(0, 4, 5)
+        xog, yog, zog = np.meshgrid(xo, xo, xo)
+        interp = Rbf(xog.flatten(), yog.flatten(), zog.flatten(), window.flatten(), function="cubic")
+        xx = np.linspace(0, 4, 41)
+        xxg, yyg, zzg = np.meshgrid(xx, xx, xx)
+        dense = interp(xxg.flatten(), yyg.flatten(), zzg.flatten()).reshape(xxg.shape)
+        want = np.array(np.unravel_index(np.nanargmax(dense), dense.shape)) / 10 + lo
+        if np.any(np.abs(peak - want) > 2):
+            want = peak.astype(np.float64)
+        assert np.array_equal(got, want), (trial, got, want)
+        checked += 1
+    assert checked >= 30
+    eng.close()
+
+
+def test_reference_signature_table_caching_and_grid_hint(lib, oracle, monkeypatch):
+    """The reference-signature functions receive the table on every call; both the Python ones
+    (lib.migrate) and the C symbol keep it resident, keyed by shape and two independent content
+    hashes, and upload again when one word changes or when QM_HIP_COMPAT_REUPLOAD=1.
+    QM_HIP_GRID=nx,ny,nz gives the C symbol the grid shape its signature cannot carry."""
+    g = load_golden("small_random")
+    on, tt = g["onsets"], np.ascontiguousarray(g["traveltimes"])
+    fsmp, lsmp, avail = int(g["fsmp"]), int(g["lsmp"]), int(g["available"])
+    eng = lib.default_engine()
+    first = lib.migrate(on, tt, fsmp, lsmp, avail)
+    gen = eng.table_generation
+    again = lib.migrate(on, tt.copy(), fsmp, lsmp, avail)             # same content, other buffer
+    assert eng.table_generation == gen and np.array_equal(again, first)
+    np.testing.assert_allclose(first, g["map4d"], rtol=TIGHT)
+    tt2 = tt.copy()
+    tt2[-1, -1, -1, -1] = (tt2[-1, -1, -1, -1] + 3) % lsmp
+    changed = lib.migrate(on, tt2, fsmp, lsmp, avail)
+    assert eng.table_generation == gen + 1
+    np.testing.assert_allclose(changed, oracle.c_migrate(on, tt2, fsmp, lsmp, avail, threads=2),
+                               rtol=TIGHT)
+    monkeypatch.setenv("QM_HIP_COMPAT_REUPLOAD", "1")
+    lib.migrate(on, tt2, fsmp, lsmp, avail)
+    assert eng.table_generation == gen + 2
+    monkeypatch.delenv("QM_HIP_COMPAT_REUPLOAD")
+    # another user of the shared engine replaces the table behind the cache's back
+    eng.load_lut(tt)
+    np.testing.assert_allclose(lib.migrate(on, tt2, fsmp, lsmp, avail), changed, rtol=0)
+    # the raw symbol with and without the grid hint: same volume
+    so = _alias_library_with_reference_argtypes()
+    lon = np.ascontiguousarray(np.log(np.clip(on, 0.01, np.inf)))
+    ns, n_nodes = lon.shape[1] - fsmp - lsmp, int(np.prod(tt.shape[:-1]))
+    flat = np.zeros((n_nodes, ns))
+    so.migrate(lon, tt, flat, fsmp, lsmp, ns, tt.shape[-1], avail, n_nodes, 1)
+    monkeypatch.setenv("QM_HIP_GRID", ",".join(str(v) for v in tt.shape[:-1]))
+    shaped = np.zeros((n_nodes, ns))
+    so.migrate(lon, tt, shaped, fsmp, lsmp, ns, tt.shape[-1], avail, n_nodes, 1)
+    assert so.qm_compat_status() == 0, so.qm_last_error()
+    assert np.array_equal(shaped, flat)
+    np.testing.assert_allclose(shaped.reshape(g["map4d"].shape), g["map4d"], rtol=TIGHT)
+    monkeypatch.setenv("QM_HIP_GRID", "3,3,3")
+    so.migrate(lon, tt, shaped, fsmp, lsmp, ns, tt.shape[-1], avail, n_nodes, 1)
+    assert so.qm_compat_status() != 0 and np.isnan(shaped).all()

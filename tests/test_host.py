@@ -380,16 +380,20 @@ def test_headline_kernels_stay_in_registers(tmp_path):
     # the shift-reuse detect kernel (C3 / C5 since round 3): two wavefronts per SIMD by design (64
     # accumulators + two register windows of 24 doubles), i.e. at most 256 VGPRs, no scratch
     shift = tmp_path / "s.hip"
-    shift.write_text('#define QM_SHIFT_TU 1\n#include <hip/hip_runtime.h>\n#include "qm_shift.hpp"\n')
+    shift.write_text('#define QM_SHIFT_TU 1\n#include <hip/hip_runtime.h>\n#include "qm_shift.hpp"\n'
+                     "template __global__ void qm::stack_shift_kernel<false>(qm::ShiftArgs);\n"
+                     "template __global__ void qm::stack_shift_kernel<true>(qm::ShiftArgs);\n")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17",
                            f"-I{ROOT / 'quakemigrate_amd' / 'csrc'}", "-c", str(shift), "-o",
                            str(tmp_path / "s.o"), "--save-temps"], cwd=tmp_path,
                           stderr=subprocess.DEVNULL)
     sasm = next(tmp_path.glob("s-hip-amdgcn-*.s")).read_text()
-    m = re.search(r"\.set (\S*stack_shift_kernel\S*)\.num_vgpr, (\d+)", sasm)
-    assert m and int(m.group(2)) <= 256, m and m.groups()
-    sscr = re.search(re.escape(m.group(1)) + r"\.private_seg_size, (\d+)", sasm)
-    assert sscr is not None and int(sscr.group(1)) == 0
+    found = re.findall(r"\.set (\S*stack_shift_kernel\S*)\.num_vgpr, (\d+)", sasm)
+    assert len(found) == 2, found
+    for name, vgprs in found:
+        assert int(vgprs) <= 256, (name, vgprs)
+        sscr = re.search(re.escape(name) + r"\.private_seg_size, (\d+)", sasm)
+        assert sscr is not None and int(sscr.group(1)) == 0, name
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17",
                            f"-I{ROOT / 'quakemigrate_amd' / 'csrc'}", "-c", str(src), "-o",
                            str(tmp_path / "k.o"), "--save-temps"], cwd=tmp_path,
