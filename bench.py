@@ -75,6 +75,10 @@ def parse():
     ap.add_argument("--weak", action="store_true",
                     help="N>1: weak scaling -- every rank holds a full slab of --config's size "
                          "(grid N times longer in x) instead of 1/N of it")
+    ap.add_argument("--partition", default="columns", choices=["columns", "planes"],
+                    help="N>1: contiguous flat-index ranges cut at (x, y)-column granularity "
+                         "(default: balanced to one column of nz nodes; a rank holds up to three "
+                         "boxes) or whole x-planes (201 planes over 8 ranks = 26 / 25)")
     ap.add_argument("--exchange", default="packed", choices=["packed", "allreduce"],
                     help="N>1: one packed all-gather + device fold (default) or three all-reduces")
     ap.add_argument("--no-screened", action="store_true",
@@ -270,28 +274,54 @@ def main():
     else:                                               # fixed grid, partitioned over the GPUs
         grid = (nx, ny, nz)
         x_range = qd.shard_planes(nx, part_world, part_rank)
+    # column partition (the default at N > 1): this rank's flat range as up to three boxes, the
+    # whole planes first in `boxes` (that engine is the one the kernel line describes)
+    by_columns = (world > 1 and not args.weak and not time_sharded and part_world == world
+                  and args.partition == "columns" and args.exchange == "packed")
+    boxes = []
+    if by_columns:
+        boxes = qd.column_boxes(*qd.shard_columns(nx, ny, world, rank), ny)
+        boxes.sort(key=lambda b: -(b[1] - b[0]) * (b[3] - b[2]))
+        x_range = (boxes[0][0], boxes[0][1]) if boxes else (0, 0)
     n_pool = 3                                          # distinct timesteps cycled through
-    cases = [synth.make_case(cfg_name, step=s, grid=grid, x_range=x_range, table=(s == 0))
+    cases = [synth.make_case(cfg_name, step=s, grid=grid, x_range=x_range,
+                             table=(s == 0 and x_range[1] > x_range[0]))
              for s in range(n_pool)]
     case = cases[0]
     S, ns = case.available, case.n_samples
     n_total = case.n_nodes_total
-    n_local = int(np.prod(case.traveltimes.shape[:-1]))
     t_samples = case.onsets.shape[1]
 
     tunables = {}                  # brick shape, samples per lane, workgroup layout: per table
     tunables.update(json.loads(args.engine))
     eng = lib.Engine(local_rank, **tunables)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.load_lut(case.traveltimes, node_offset=x_range[0] * ny * nz)
-    assert eng.lut_max <= case.lsmp
+    engines = []
+    if by_columns:
+        for k, (bx0, bx1, by0, by1) in enumerate(boxes):
+            tt = case.traveltimes if k == 0 else synth.make_case(
+                cfg_name, step=0, grid=grid, x_range=(bx0, bx1)).traveltimes
+            tt = np.ascontiguousarray(tt[:, by0:by1])
+            e_k = eng if k == 0 else lib.Engine(local_rank, **tunables)
+            e_k.set_stream(torch.cuda.current_stream().cuda_stream)
+            e_k.load_lut(tt, node_offset=(bx0 * ny + by0) * nz)
+            assert e_k.lut_max <= case.lsmp
+            engines.append(e_k)
+        n_local = sum((b[1] - b[0]) * (b[3] - b[2]) for b in boxes) * nz
+    else:
+        n_local = int(np.prod(case.traveltimes.shape[:-1]))
+        eng.load_lut(case.traveltimes, node_offset=x_range[0] * ny * nz)
+        assert eng.lut_max <= case.lsmp
     host_onsets = [np.ascontiguousarray(np.log(np.clip(c.onsets, 0.01, np.inf))) for c in cases]
     onsets_dev = [torch.from_numpy(h).to(dev) for h in host_onsets]
     out = (torch.empty(ns, dtype=torch.float64, device=dev),
            torch.empty(ns, dtype=torch.float64, device=dev),
            torch.empty(ns, dtype=torch.int64, device=dev))
-    sharded = (qd.ShardedDetector(eng, n_total, ns, dev, exchange=args.exchange)
-               if use_dist and not time_sharded else None)
+    if by_columns:
+        sharded = qd.ColumnShardedDetector(engines, n_total, ns, dev, fold_engine=eng)
+    else:
+        sharded = (qd.ShardedDetector(eng, n_total, ns, dev, exchange=args.exchange)
+                   if use_dist and not time_sharded else None)
 
     def step(i):
         on = onsets_dev[i % n_pool]
@@ -334,6 +364,8 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms, kern_calls = eng.kernel_log()
     eng.config("log_timing", 0)
+    for e_k in engines[1:]:                             # the partly owned planes' engines
+        e_k.config("log_timing", 0)
     screened = eng.get("screened_steps") > 0 and eng.get("fallback_steps") == 0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -375,8 +407,11 @@ def main():
         work_step *= world                              # every rank scanned its own timesteps
     value = work_step * args.steps / elapsed
     kern_s = kern_ms / 1e3 / max(kern_calls, 1)         # avg stacking-kernel time, this rank
-    local_ns = n_local * ns
-    b_fused = 4.0 * n_local * S + 8.0 * S * t_samples + 24.0 * ns   # SURVEY 8d B_F
+    # (column partition: the kernel line describes the engine holding the whole planes)
+    n_kernel = ((boxes[0][1] - boxes[0][0]) * (boxes[0][3] - boxes[0][2]) * nz
+                if by_columns and boxes else n_local)
+    local_ns = n_kernel * ns
+    b_fused = 4.0 * n_kernel * S + 8.0 * S * t_samples + 24.0 * ns  # SURVEY 8d B_F
     shift_kernel = eng.get("last_kernel") == 3
     # 8-byte LDS operands fetched per add: 1 for the round-2 kernels; the shift-reuse kernel shares
     # a register window between the 8 nodes of a group (measured on the resident table)
@@ -404,8 +439,13 @@ def main():
                                   if part_world > 1 else ""),
                    "n_nodes_per_gpu": n_local, "n_rows": S, "n_samples": ns,
                    "sharding": ("timesteps round-robin over the ranks, whole grid on every rank"
-                                if time_sharded else "x-plane slabs" if world > 1 else "none"),
-                   "exchange": ({"packed": "1 x all_gather([3][n_samples]) + device fold per step",
+                                if time_sharded else
+                                "flat-index ranges at (x, y)-column granularity (up to 3 boxes per "
+                                "rank)" if by_columns else "x-plane slabs" if world > 1 else "none"),
+                   "boxes_rank0": [list(b) for b in boxes] if by_columns else None,
+                   "exchange": ("1 x all_gather([3 boxes][3][n_samples]) + device fold per step"
+                                if by_columns else
+                                {"packed": "1 x all_gather([3][n_samples]) + device fold per step",
                                  "allreduce": "3 x all_reduce(n_samples) per step"}[args.exchange]
                                 if use_dist and not time_sharded else "none"),
                    "collective_backend": backend, "ranks": world,

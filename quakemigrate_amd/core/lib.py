@@ -513,6 +513,33 @@ class Engine:
                 f"{rows}:{self.n_rows}")
 
 
+def timeit(*args_, **kwargs_):
+    """
+    The reference's per-call wall-time log line (quakemigrate/util.py:651-669, applied at
+    core/lib.py:52,131 and signal/scan.py:593): same message, ``timeit("info")`` logs at info
+    level, ``timeit()`` at debug.  The wrapped functions here take host arrays and return host
+    arrays, so the elapsed time includes the copies and the wait for the GPU.
+    """
+    import functools
+    import time
+
+    def inner_function(func):
+        @functools.wraps(func)
+        def wrapper(*args, **kwargs):
+            ts = time.time()
+            result = func(*args, **kwargs)
+            msg = " " * 21 + f"Elapsed time: {time.time() - ts:6f} seconds."
+            if args_ and args_[0] == "info":
+                logging.info(msg)
+            else:
+                logging.debug(msg)
+            return result
+
+        return wrapper
+
+    return inner_function
+
+
 # --------------------------------------------------------------------------
 # module-level engine for the reference-signature functions.  They receive the
 # table on every call (lib.py:53-60); like the C symbols beside them
@@ -575,6 +602,7 @@ def _prepare(onsets, traveltimes, first_idx, last_idx):
     return onsets, tuple(grid_dimensions), n_samples
 
 
+@timeit()
 def migrate(onsets, traveltimes, first_idx, last_idx, available, threads=1):
     """
     Computes 4-D coalescence map by migrating seismic phase onset functions.
@@ -594,6 +622,7 @@ def migrate(onsets, traveltimes, first_idx, last_idx, available, threads=1):
     return map4d
 
 
+@timeit()
 def find_max_coa(map4d, threads=1):
     """
     Finds time series of the maximum coalescence/normalised coalescence in the
@@ -610,6 +639,7 @@ def find_max_coa(map4d, threads=1):
     return max_coa, max_norm_coa, max_coa_idx
 
 
+@timeit()
 def migrate_and_find_max(onsets, traveltimes, first_idx, last_idx, available,
                          threads=1, return_map=False):
     """

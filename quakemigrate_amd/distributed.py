@@ -46,6 +46,40 @@ def shard_planes(nx: int, world_size: int, rank: int):
     return x0, x0 + base + (1 if rank < extra else 0)
 
 
+def shard_columns(nx: int, ny: int, world_size: int, rank: int):
+    """
+    [c0, c1) of the (x, y) COLUMNS owned by ``rank``: the contiguous flat-index range
+    ``[c0 * nz, c1 * nz)`` of SURVEY.md section 8(e), balanced to one column (nz nodes).  Plane
+    slabs (:func:`shard_planes`) leave 201 planes over 8 ranks 26 / 25 -- 3.5 % of the step spent
+    waiting for the ranks with 26; columns leave 5051 / 5050.
+    """
+    return shard_planes(nx * ny, world_size, rank)
+
+
+def column_boxes(c0: int, c1: int, ny: int):
+    """
+    The column range [c0, c1) as at most three boxes ``(x0, x1, y0, y1)`` in ascending flat
+    order: the rest of a first, partly owned x-plane, the whole planes, the start of a last,
+    partly owned plane.  Each box is a contiguous flat range starting at ``(x0 * ny + y0) * nz``
+    (a partial box is one plane thick), i.e. something an Engine can hold with that node offset.
+    """
+    boxes = []
+    if c1 <= c0:
+        return boxes
+    xa, ya = divmod(c0, ny)
+    xb, yb = divmod(c1, ny)
+    if xa == xb:
+        return [(xa, xa + 1, ya, yb)]
+    if ya:
+        boxes.append((xa, xa + 1, ya, ny))
+        xa += 1
+    if xb > xa:
+        boxes.append((xa, xb, 0, ny))
+    if yb:
+        boxes.append((xb, xb + 1, 0, yb))
+    return boxes
+
+
 def combine_partials_local(pmax, pidx, psum, n_nodes_total):
     """
     Combine partial sets stacked along dim 0 ([n_sets, n_samples]) on one device;
@@ -236,3 +270,70 @@ class ShardedDetector:
         self.engine.marginal_map(log_onsets, fsmp, lsmp, available, first_sample, end_sample,
                                  out=local, n_nodes_total=self.n_nodes_total)
         return gather_planes(local, nx_total, self.group)
+
+
+MAX_BOXES = 3
+
+
+class ColumnShardedDetector:
+    """
+    One rank's share of a detect sweep sharded by flat-index ranges at column granularity
+    (:func:`shard_columns`): up to three engines, one per box of :func:`column_boxes`, each with
+    its box resident (``load_lut(box, node_offset=(x0 * ny + y0) * nz)``).  Per step every engine
+    writes its partial into one row block of a packed ``[3 boxes][3][n_samples]`` buffer (absent
+    boxes keep the neutral partial), ONE all-gather moves it to every rank, and the device fold of
+    ``Engine.finalize_packed`` over ``world * 3`` sets gives the global series -- the same exchange
+    as :class:`ShardedDetector`, three sets per rank instead of one.  A rank without any column
+    passes ``engines=[]`` and a ``fold_engine`` (an Engine without a table).
+
+    Stream discipline as :class:`ShardedDetector`: every engine is bound to torch's current stream
+    before the step.
+    """
+
+    def __init__(self, engines, n_nodes_total, n_samples, device, group=None, fold_engine=None):
+        import torch.distributed as dist
+
+        self.engines = list(engines)
+        if len(self.engines) > MAX_BOXES:
+            raise ValueError("a column range is at most three boxes")
+        self.fold_engine = fold_engine if fold_engine is not None else (
+            self.engines[0] if self.engines else None)
+        if self.fold_engine is None:
+            raise ValueError("a rank without columns needs a fold_engine")
+        self.n_nodes_total = int(n_nodes_total)
+        self.n_samples = ns = int(n_samples)
+        self.group = group
+        self.device = torch.device(device)
+        self.world = dist.get_world_size(group)
+        self.packed = torch.empty((MAX_BOXES, 3, ns), dtype=torch.float64, device=self.device)
+        self.packed[:, 0] = float("-inf")                    # neutral partials
+        self.packed[:, 1].view(torch.int64).fill_(INT64_MAX)
+        self.packed[:, 2] = 0.0
+        self.gathered = torch.empty((self.world, MAX_BOXES, 3, ns), dtype=torch.float64,
+                                    device=self.device)
+        self.out = (torch.empty(ns, dtype=torch.float64, device=self.device),
+                    torch.empty(ns, dtype=torch.float64, device=self.device),
+                    torch.empty(ns, dtype=torch.int64, device=self.device))
+        self._bound = None
+
+    def _bind_stream(self):
+        if self.device.type != "cuda":
+            return
+        ptr = torch.cuda.current_stream(self.device).cuda_stream
+        if self._bound != ptr:
+            for eng in {id(e): e for e in self.engines + [self.fold_engine]}.values():
+                eng.set_stream(ptr)
+            self._bound = ptr
+
+    def detect(self, log_onsets, fsmp, lsmp, available, out=None):
+        """Returns ``(max_coa, max_norm_coa, max_coa_idx)``; in ``out`` if given, else in this
+        detector's own buffers (valid until the next ``detect``)."""
+        out = self.out if out is None else out
+        self._bind_stream()
+        for k, eng in enumerate(self.engines):
+            eng.detect_partial(log_onsets, fsmp, lsmp, available,
+                               (self.packed[k, 0], self.packed[k, 1].view(torch.int64),
+                                self.packed[k, 2]))
+        all_gather_packed(self.packed, self.gathered, self.group)
+        return self.fold_engine.finalize_packed(self.gathered, self.world * MAX_BOXES,
+                                                self.n_samples, self.n_nodes_total, out=out)

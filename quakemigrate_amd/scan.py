@@ -136,6 +136,7 @@ class MigrationScan:
         return self.engine
 
     # -- the hot-path glue ------------------------------------------------------
+    @lib.timeit("info")
     def _compute(self, data, event=None):
         """
         Compute 3-D coalescence between two time stamps (reference scan.py:593-647).

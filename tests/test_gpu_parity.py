@@ -343,6 +343,79 @@ def test_sharded_detector_two_ranks_real_partials(lib, oracle, tmp_path, exchang
         np.testing.assert_allclose(got["cmap"], want_map, rtol=1e-13)
 
 
+def _column_rank(rank, world, port, tmp, grid):
+    """One rank of a column-sharded detect (flat-index ranges, up to three boxes = three engines
+    per rank), both ranks on GPU 0 over gloo."""
+    import os
+    import pathlib
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    from conftest import ROOT
+
+    sys.path.insert(0, str(ROOT))
+    from quakemigrate_amd import distributed as qd
+    from quakemigrate_amd.core import lib as _lib
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    case = synth.make_case("C3", step=3, grid=grid, rows=14, n_samples=777)
+    lon = torch.from_numpy(np.ascontiguousarray(
+        np.log(np.clip(case.onsets, 0.01, np.inf)))).cuda()
+    boxes = qd.column_boxes(*qd.shard_columns(grid[0], grid[1], world, rank), grid[1])
+    engines = []
+    for (x0, x1, y0, y1) in boxes:
+        eng = _lib.Engine(0)
+        eng.load_lut(np.ascontiguousarray(case.traveltimes[x0:x1, y0:y1]),
+                     node_offset=(x0 * grid[1] + y0) * grid[2])
+        engines.append(eng)
+    sd = qd.ColumnShardedDetector(engines, case.n_nodes_total, case.n_samples,
+                                  torch.device("cuda", 0), fold_engine=_lib.Engine(0))
+    first = tuple(t.clone() for t in sd.detect(lon, case.fsmp, case.lsmp, case.available))
+    again = sd.detect(lon, case.fsmp, case.lsmp, case.available)
+    torch.cuda.synchronize()
+    assert all(torch.equal(u, v) for u, v in zip(first, again))
+    np.savez(pathlib.Path(tmp) / f"col{rank}.npz", a=first[0].cpu().numpy(),
+             b=first[1].cpu().numpy(), c=first[2].cpu().numpy(), nbox=len(boxes),
+             kernels=np.array([e.get("last_kernel") for e in engines]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid", [(21, 17, 18), (2, 3, 20)], ids=["three-boxes", "fewer-columns"])
+def test_column_sharded_detector_two_ranks_real_partials(lib, oracle, tmp_path, grid):
+    """Flat-index ranges cut at (x, y)-column granularity (SURVEY.md section 8e as written): rank 0
+    of two holds whole planes + the start of a partly owned plane, rank 1 the rest of that plane
+    + whole planes; every box on its own Engine, one all-gather of [3 boxes][3][n_samples], fold
+    over world * 3 sets == the unsharded engine bit for bit (argmax, maximum) == the oracle."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_column_rank, args=(2, port, str(tmp_path), grid), nprocs=2, join=True)
+    case = synth.make_case("C3", step=3, grid=grid, rows=14, n_samples=777)
+    lon = oracle.log_onsets(case.onsets)
+    eng = lib.Engine(0)
+    eng.load_lut(case.traveltimes)
+    want = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+    eng.close()
+    _assert_series(want, oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp,
+                                       case.available, threads=4))
+    nbox = 0
+    for rank in range(2):
+        got = np.load(tmp_path / f"col{rank}.npz")
+        assert np.array_equal(got["c"], want[2]) and np.array_equal(got["a"], want[0])
+        np.testing.assert_allclose(got["b"], want[1], rtol=NORM)
+        nbox += int(got["nbox"])
+    assert nbox >= 3 if grid[0] > 2 else nbox >= 2           # the odd plane count is split
+
+
 # ---------------------------------------------------------------------------------
 # BASELINE.json's full sizes: oracle on a time chunk (the scan is independent per
 # sample, so a chunk of the full grid is an exact check) + size-independent properties
@@ -1656,7 +1729,8 @@ def test_bench_self_launch_two_ranks_prints_one_json_line(tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "strong"
     cfg = line["config"]
     assert cfg["ranks_seen"] == 2 and cfg["collective_backend"] == "gloo"
-    assert cfg["sharding"] == "x-plane slabs" and cfg["exchange"].startswith("1 x all_gather")
+    assert cfg["sharding"].startswith("flat-index ranges") and cfg["exchange"].startswith("1 x all_gather")
+    assert sum((b[1] - b[0]) * (b[3] - b[2]) for b in cfg["boxes_rank0"]) == (101 * 101 + 1) // 2
     assert 0 < cfg["kernel_ms_per_rank"]["min"] <= cfg["kernel_ms_per_rank"]["max"]
     assert line["value"] > 0 and line["unit"] == "node-samples/s" and line["dtype"] == "f64"
     assert line["roofline"]["bound"] in ("lds", "fp64_valu") and 0 < line["roofline"]["frac"] < 1

@@ -94,6 +94,29 @@ def test_engine_calls_fail_loudly_without_a_gpu(built):
                                  int(g["lsmp"]), int(g["available"]))
 
 
+def test_shard_columns_boxes_cover_the_flat_range():
+    """shard_columns / column_boxes: every rank's boxes tile its contiguous column range in
+    ascending flat order; ranks are balanced to one column; partial boxes are one plane thick."""
+    from quakemigrate_amd.distributed import column_boxes, shard_columns
+
+    for nx, ny, world in [(201, 201, 8), (401, 401, 8), (5, 3, 4), (2, 2, 8), (17, 9, 2), (1, 1, 3)]:
+        pos, sizes = 0, []
+        for r in range(world):
+            c0, c1 = shard_columns(nx, ny, world, r)
+            assert c0 == pos
+            boxes = column_boxes(c0, c1, ny)
+            assert len(boxes) <= 3
+            at = c0
+            for x0, x1, y0, y1 in boxes:
+                assert x0 * ny + y0 == at and x1 > x0 and y1 > y0
+                assert (y0, y1) == (0, ny) or x1 == x0 + 1
+                at += (x1 - x0) * (y1 - y0)
+            assert at == c1
+            pos = c1
+            sizes.append(c1 - c0)
+        assert pos == nx * ny and max(sizes) - min(sizes) <= 1
+
+
 def test_shard_planes_partition():
     from quakemigrate_amd.distributed import shard_planes
 
@@ -194,6 +217,32 @@ def _worker(rank, world, port, tmp):
     pa, pb, pc = qd.combine_packed_torch(gathered, int(np.prod(grid)))
     assert torch.equal(pc, c) and torch.equal(pa, a)
     assert torch.allclose(pb, b, rtol=1e-14, atol=0)
+    # the column partition (flat-index ranges, up to three boxes per rank): every box's partial
+    # from the oracle, one all-gather of [3 boxes][3][ns], fold over world * 3 sets
+    full = synth.make_case("C2", step=5, grid=grid, rows=6, n_samples=211)
+    boxes = qd.column_boxes(*qd.shard_columns(grid[0], grid[1], world, rank), grid[1])
+    assert 1 <= len(boxes) <= 3 and sum((b[1] - b[0]) * (b[3] - b[2]) for b in boxes) == \
+        qd.shard_columns(grid[0], grid[1], world, rank)[1] - qd.shard_columns(grid[0], grid[1], world, rank)[0]
+    cpacked = torch.empty((qd.MAX_BOXES, 3, vol.shape[1]), dtype=torch.float64)
+    cpacked[:, 0] = float("-inf")
+    cpacked[:, 1].view(torch.int64).fill_(qd.INT64_MAX)
+    cpacked[:, 2] = 0.0
+    for k, (bx0, bx1, by0, by1) in enumerate(boxes):
+        box_tt = np.ascontiguousarray(full.traveltimes[bx0:bx1, by0:by1])
+        bvol = qm_oracle.c_migrate(full.onsets, box_tt, full.fsmp, full.lsmp, full.available,
+                                   threads=2)
+        bvol = bvol.reshape(-1, bvol.shape[-1])
+        bi = np.argmax(bvol, axis=0)
+        cpacked[k, 0] = torch.from_numpy(np.log2(bvol[bi, np.arange(bvol.shape[1])]))
+        cpacked[k, 1].view(torch.int64).copy_(
+            torch.from_numpy(bi.astype(np.int64) + (bx0 * grid[1] + by0) * grid[2]))
+        cpacked[k, 2] = torch.from_numpy(bvol.sum(axis=0))
+    cgathered = torch.empty((world, qd.MAX_BOXES, 3, vol.shape[1]), dtype=torch.float64)
+    qd.all_gather_packed(cpacked, cgathered)
+    ca, cb, cc = qd.combine_packed_torch(cgathered.view(world * qd.MAX_BOXES, 3, -1),
+                                         int(np.prod(grid)))
+    assert torch.equal(cc, c) and torch.equal(ca, a)
+    assert torch.allclose(cb, b, rtol=1e-14, atol=0)
     # the marginalised map of a locate window, slab by slab, gathered on every rank
     marg = torch.from_numpy(vol[:, 40:150].sum(axis=1).reshape(x1 - x0, grid[1], grid[2]))
     whole = qd.gather_planes(marg, grid[0])
@@ -464,3 +513,25 @@ def test_reference_front_end_binds_the_drop_in_library(built):
         np.testing.assert_allclose(fn(toy, 2, 3), g[f"toy_{kind}"], rtol=1e-15)
         np.testing.assert_allclose(fn(g["signal"], int(g["nsta"]), int(g["nlta"])), g[kind],
                                    rtol=1e-12)
+
+
+def test_timeit_logs_the_references_line(caplog):
+    """quakemigrate/util.py:651-669: one 'Elapsed time' line per call, info or debug level."""
+    import logging
+
+    from quakemigrate_amd.core import lib
+
+    @lib.timeit("info")
+    def loud():
+        return 3
+
+    @lib.timeit()
+    def quiet():
+        return 4
+
+    with caplog.at_level(logging.DEBUG):
+        assert loud() == 3 and quiet() == 4
+    msgs = [(r.levelno, r.getMessage()) for r in caplog.records]
+    assert [lvl for lvl, _ in msgs] == [logging.INFO, logging.DEBUG]
+    assert all(m.startswith(" " * 21 + "Elapsed time: ") and m.endswith(" seconds.") for _, m in msgs)
+    assert lib.migrate.__wrapped__ is not None and lib.find_max_coa.__name__ == "find_max_coa"
