@@ -143,6 +143,31 @@ def row_iter(e, p, first):
     if "nosmem" not in EXP:
         e(f"s_add_u32 s{SOFF}, s{SOFF}, {REC}")
         e(f"s_load_dwordx16 s[{BUF[q]}:{BUF[q] + 15}], {s2(STAB)}, s{SOFF}")
+    if "interleave" in EXP:
+        # experiment: one body per quad count, the next row's reads dealt two per node behind the
+        # first nodes' adds (all issued by the row's middle)
+        e(f"v_add_u32 v{VADDR}, s{hdr}, %[lane]")
+        end = e.label("ri")
+        labels = {nq: e.label(f"q{nq}_") for nq in range(NQMIN + 1, NQMAX + 1)}
+        for nq in range(NQMAX, NQMIN, -1):
+            e(f"s_cmp_ge_u32 s{hdr + 1}, {nq}")
+            e(f"s_cbranch_scc1 {labels[nq]}")
+        for nq in range(NQMIN, NQMAX + 1):
+            if nq > NQMIN:
+                e(f"{labels[nq]}:")
+            pending = [r for m in range(nq) for r in quad_reads(WIN[q], m)]
+            for g in range(8):
+                node_adds(e, p, g, first)
+                for r in pending[2 * g:2 * g + 2]:
+                    e(r)
+                if g == 6 and PF_AHEAD:
+                    e(f"global_load_dword v{VPF}, v{VZERO}, {s2(SPF)}")
+                    e(f"s_add_u32 s{SPF}, s{SPF}, {REC}")
+                    e(f"s_addc_u32 s{SPF + 1}, s{SPF + 1}, 0")
+            if nq < NQMAX:
+                e(f"s_branch {end}")
+        e(f"{end}:")
+        return
     issue_window(e, q, hdr)
     for g in range(8):
         node_adds(e, p, g, first)
@@ -211,7 +236,8 @@ def epilogue(e, degree, volume):
             # (re-dealing the dwords inside each quad of lanes with DPP moves so that one store
             # writes whole 64-byte lines was measured too: same 5.95 ms -- the cost of the stores is
             # their issue inside the CU, profiles/r03_ab_runs.txt)
-            nt = "" if "nont" in EXP else " nt"
+            nt = os.environ.get("QM_SHIFT_STORE_POLICY", "nt").replace("_", " ")   # cache policy bits
+            nt = " " + nt if nt else ""
             if "nostore" not in EXP:
                 e(f"global_store_dwordx4 %[voff], v[{P}:{P + 3}], {s2(SVA)}{nt}")
                 if "halfstore" not in EXP:
