@@ -55,7 +55,8 @@ P = WIN[1] + 8
 KI = WIN[1] + 16
 GMAX = WIN[1] + 20
 GIDX = WIN[1] + 28
-assert GIDX + 4 <= WIN[1] + 2 * WMAX
+TT = WIN[1] + 32         # z + magic (4 pairs)
+assert TT + 8 <= WIN[1] + 2 * WMAX
 
 SB = 48                  # first hard SGPR (s_load_dwordx16 destinations)
 BUF = [SB, SB + 16]
@@ -68,13 +69,10 @@ STAB = ST + 8            # stream base (pair, even)
 SOFF = ST + 10           # byte offset of the record loaded last
 SPF = ST + 12            # prefetch address (pair)
 SVA = ST + 14            # volume row address of the node in the epilogue (pair)
-SKP = ST + 16            # scalar-cache prefetch base (pair)
-SDUMMY = ST + 18
-SEND = ST + 19
-KPF = int(os.environ.get("QM_SHIFT_KPF", "0"))        # records of the next group touched per epilogue
-                                                      # (experiment: no gain once the stream is
-                                                      # prefetched into L2, profiles/r03_ab_runs.txt)
-assert STAB % 2 == 0 and SB % 4 == 0 and SVA % 2 == 0 and SPF % 2 == 0 and SKP % 2 == 0
+SNEGINF = ST + 16        # -inf (pair)
+SMAGIC = ST + 18         # 1.5 * 2^52 (pair): z + magic has rint(z) in its low dword
+SEND = ST + 20
+assert STAB % 2 == 0 and SB % 4 == 0 and SVA % 2 == 0 and SPF % 2 == 0 and SNEGINF % 2 == 0 and SEND <= 102
 
 
 def v2(r):
@@ -179,18 +177,82 @@ def row_iter(e, p, first):
             e(f"s_addc_u32 s{SPF + 1}, s{SPF + 1}, 0")
 
 
+def epilogue_node(e, degree, volume, g, opens_group):
+    # flat index of node g: base + dx*ny*nz + dy*nz + dz (g = 4 dx + 2 dy + dz)
+    e(f"s_mov_b32 s{SNODE}, s{SBASE}")
+    if g & 4:
+        e(f"s_add_u32 s{SNODE}, s{SNODE}, %[nynz]")
+    if g & 2:
+        e(f"s_add_u32 s{SNODE}, s{SNODE}, %[nz]")
+    if g & 1:
+        e(f"s_add_u32 s{SNODE}, s{SNODE}, 1")
+    e(f"v_mov_b32 v{VNODE}, s{SNODE}")
+    A = [ACC + 8 * g + 2 * k for k in range(4)]
+    for k in range(4):                                          # z = stack * log2(e)/available
+        e(f"v_mul_f64 {v2(A[k])}, {v2(A[k])}, %[scale]")
+    # k = rint(z), f = z - k:  t = z + 1.5*2^52 holds k in its low dword (round half to even, as
+    # v_rndne_f64), t - 1.5*2^52 is k as a double -- two adds instead of rndne + the slower cvt
+    for k in range(4):
+        e(f"v_add_f64 {v2(TT + 2 * k)}, {v2(A[k])}, {s2(SMAGIC)}")
+    for k in range(4):
+        e(f"v_add_f64 {v2(F + 2 * k)}, {v2(TT + 2 * k)}, -{s2(SMAGIC)}")
+    for k in range(4):                                          # f = z - k
+        e(f"v_add_f64 {v2(F + 2 * k)}, {v2(A[k])}, -{v2(F + 2 * k)}")
+    for k in range(4):
+        e(f"v_fma_f64 {v2(P + 2 * k)}, {v2(VC)}, {v2(F + 2 * k)}, %[c{degree - 1}]")
+    for i in range(degree - 2, -1, -1):
+        for k in range(4):
+            e(f"v_fma_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, {v2(F + 2 * k)}, %[c{i}]")
+    for k in range(4):
+        e(f"v_ldexp_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, v{TT + 2 * k}")
+    if volume:
+        # the node's four values per lane are 32 contiguous bytes of its volume row (the tile's
+        # first sample is in the base): two 16-byte stores.  P is not written again before the
+        # next node's first Horner step, a dozen instructions away (gfx940+: 2 wait states
+        # between a store of more than 8 bytes and a VALU write to its data registers)
+        e(f"s_mul_i32 s{SVA}, s{SNODE}, %[vstride]")
+        e(f"s_mul_hi_u32 s{SVA + 1}, s{SNODE}, %[vstride]")
+        e(f"s_add_u32 s{SVA}, s{SVA}, %[vlo]")
+        e(f"s_addc_u32 s{SVA + 1}, s{SVA + 1}, %[vhi]")
+        # (re-dealing the dwords inside each quad of lanes with DPP moves so that one store
+        # writes whole 64-byte lines was measured too: same 5.95 ms -- the cost of the stores is
+        # their issue inside the CU, profiles/r03_ab_runs.txt)
+        nt = os.environ.get("QM_SHIFT_STORE_POLICY", "nt").replace("_", " ")   # cache policy bits
+        nt = " " + nt if nt else ""
+        if "nostore" not in EXP:
+            e(f"global_store_dwordx4 %[voff], v[{P}:{P + 3}], {s2(SVA)}{nt}")
+            if "halfstore" not in EXP:
+                e(f"global_store_dwordx4 %[voff], v[{P + 4}:{P + 7}], {s2(SVA)} offset:16{nt}")
+    for k in range(4):
+        e(f"v_add_f64 %[sum{k}], %[sum{k}], {v2(P + 2 * k)}")
+    for k in range(4):
+        if opens_group:
+            # the group's first node against the (-inf, none) start, without materialising it
+            # (a NaN or -inf z leaves (-inf, none), exactly as the strict '>' below would)
+            e(f"v_cmp_gt_f64 vcc, {v2(A[k])}, {s2(SNEGINF)}")
+            e(f"v_cndmask_b32 v{GIDX + k}, v{KI}, v{VNODE}, vcc")   # v[KI] = "none"
+            e(f"v_max_f64 {v2(GMAX + 2 * k)}, {v2(A[k])}, {s2(SNEGINF)}")
+        else:
+            e(f"v_cmp_gt_f64 vcc, {v2(A[k])}, {v2(GMAX + 2 * k)}")
+            e(f"v_cndmask_b32 v{GIDX + k}, v{GIDX + k}, v{VNODE}, vcc")
+            e(f"v_max_f64 {v2(GMAX + 2 * k)}, {v2(GMAX + 2 * k)}, {v2(A[k])}")
+
+
 def epilogue(e, degree, volume):
     e("s_set_gpr_idx_off")
-    if KPF:
-        # The scalar loads of the row loop are waited for one row after their issue, and a scalar
-        # load that misses the scalar cache takes longer than a row.  The epilogue is ~600 VALU
-        # instructions without a wait: touch the next group's records now (one dword each pulls the
-        # 64-byte line into the scalar cache), so the row loop's loads hit.
-        e(f"s_add_u32 s{SKP}, s{STAB}, s{SOFF}")
-        e(f"s_addc_u32 s{SKP + 1}, s{STAB + 1}, 0")
-        for i in range(1, KPF + 1):
-            e(f"s_load_dword s{SDUMMY}, {s2(SKP)}, {i * REC}")
-    # group-level running maximum (nodes of a group are visited in ascending flat index: strict >)
+    # Group-level running maximum (nodes of a group are visited in ascending flat index: strict >).
+    # A whole group (all eight nodes inside the grid, the common case) takes the first node's z
+    # as the starting maximum; a group cut by the grid's edge starts from (-inf, none) and skips
+    # the nodes outside.
+    partial = e.label("pg")
+    merge = e.label("mg")
+    e(f"s_cmp_lg_u32 s{SMASK}, 0xff")
+    e(f"s_cbranch_scc1 {partial}")
+    e(f"v_mov_b32 v{KI}, 0x7fffffff")                          # "no index" (a literal and vcc cannot
+    for g in range(8):                                         # feed one instruction)
+        epilogue_node(e, degree, volume, g, g == 0)
+    e(f"s_branch {merge}")
+    e(f"{partial}:")
     for k in range(4):
         e(f"v_mov_b32 v{GMAX + 2 * k}, 0")
         e(f"v_mov_b32 v{GMAX + 2 * k + 1}, 0xfff00000")        # -inf
@@ -199,56 +261,9 @@ def epilogue(e, degree, volume):
         skip = e.label("nd")
         e(f"s_bitcmp1_b32 s{SMASK}, {g}")
         e(f"s_cbranch_scc0 {skip}")
-        # flat index of node g: base + dx*ny*nz + dy*nz + dz (g = 4 dx + 2 dy + dz)
-        e(f"s_mov_b32 s{SNODE}, s{SBASE}")
-        if g & 4:
-            e(f"s_add_u32 s{SNODE}, s{SNODE}, %[nynz]")
-        if g & 2:
-            e(f"s_add_u32 s{SNODE}, s{SNODE}, %[nz]")
-        if g & 1:
-            e(f"s_add_u32 s{SNODE}, s{SNODE}, 1")
-        e(f"v_mov_b32 v{VNODE}, s{SNODE}")
-        A = [ACC + 8 * g + 2 * k for k in range(4)]
-        for k in range(4):                                      # z = stack * log2(e)/available
-            e(f"v_mul_f64 {v2(A[k])}, {v2(A[k])}, %[scale]")
-        for k in range(4):
-            e(f"v_rndne_f64 {v2(F + 2 * k)}, {v2(A[k])}")
-        for k in range(4):
-            e(f"v_cvt_i32_f64 v{KI + k}, {v2(F + 2 * k)}")
-        for k in range(4):                                      # f = z - k
-            e(f"v_add_f64 {v2(F + 2 * k)}, {v2(A[k])}, -{v2(F + 2 * k)}")
-        for k in range(4):
-            e(f"v_fma_f64 {v2(P + 2 * k)}, {v2(VC)}, {v2(F + 2 * k)}, %[c{degree - 1}]")
-        for i in range(degree - 2, -1, -1):
-            for k in range(4):
-                e(f"v_fma_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, {v2(F + 2 * k)}, %[c{i}]")
-        for k in range(4):
-            e(f"v_ldexp_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, v{KI + k}")
-        if volume:
-            # the node's four values per lane are 32 contiguous bytes of its volume row (the tile's
-            # first sample is in the base): two 16-byte stores.  P is not written again before the
-            # next node's first Horner step, a dozen instructions away (gfx940+: 2 wait states
-            # between a store of more than 8 bytes and a VALU write to its data registers)
-            e(f"s_mul_i32 s{SVA}, s{SNODE}, %[vstride]")
-            e(f"s_mul_hi_u32 s{SVA + 1}, s{SNODE}, %[vstride]")
-            e(f"s_add_u32 s{SVA}, s{SVA}, %[vlo]")
-            e(f"s_addc_u32 s{SVA + 1}, s{SVA + 1}, %[vhi]")
-            # (re-dealing the dwords inside each quad of lanes with DPP moves so that one store
-            # writes whole 64-byte lines was measured too: same 5.95 ms -- the cost of the stores is
-            # their issue inside the CU, profiles/r03_ab_runs.txt)
-            nt = os.environ.get("QM_SHIFT_STORE_POLICY", "nt").replace("_", " ")   # cache policy bits
-            nt = " " + nt if nt else ""
-            if "nostore" not in EXP:
-                e(f"global_store_dwordx4 %[voff], v[{P}:{P + 3}], {s2(SVA)}{nt}")
-                if "halfstore" not in EXP:
-                    e(f"global_store_dwordx4 %[voff], v[{P + 4}:{P + 7}], {s2(SVA)} offset:16{nt}")
-        for k in range(4):
-            e(f"v_add_f64 %[sum{k}], %[sum{k}], {v2(P + 2 * k)}")
-        for k in range(4):
-            e(f"v_cmp_gt_f64 vcc, {v2(A[k])}, {v2(GMAX + 2 * k)}")
-            e(f"v_cndmask_b32 v{GIDX + k}, v{GIDX + k}, v{VNODE}, vcc")
-            e(f"v_max_f64 {v2(GMAX + 2 * k)}, {v2(GMAX + 2 * k)}, {v2(A[k])}")
+        epilogue_node(e, degree, volume, g, False)
         e(f"{skip}:")
+    e(f"{merge}:")
     # merge into the wave's running pair: larger z, ties -> lower flat index
     for k in range(4):
         g_ = v2(GMAX + 2 * k)
@@ -272,6 +287,10 @@ def body(degree, volume):
     e(f"s_load_dwordx16 s[{BUF[1]}:{BUF[1] + 15}], {s2(STAB)}, 0")
     e(f"s_load_dwordx16 s[{BUF[0]}:{BUF[0] + 15}], {s2(STAB)}, {REC}")
     e(f"s_mov_b32 s{SOFF}, {REC}")
+    e(f"s_mov_b32 s{SNEGINF}, 0")
+    e(f"s_mov_b32 s{SNEGINF + 1}, 0xfff00000")
+    e(f"s_mov_b32 s{SMAGIC}, 0")
+    e(f"s_mov_b32 s{SMAGIC + 1}, 0x43380000")
     e(f"v_mov_b32 v{VZERO}, 0")
     e(f"s_add_u32 s{SPF}, s{STAB}, {PF_AHEAD * REC}")
     e(f"s_addc_u32 s{SPF + 1}, s{STAB + 1}, 0")
