@@ -37,26 +37,57 @@ EXP = set(filter(None, os.environ.get("QM_SHIFT_EXP", "").split(",")))   # timin
 NQMAX = int(os.environ.get("QM_SHIFT_NQMAX", "6"))    # window = 4 * NQMAX doubles
 NQMIN = int(os.environ.get("QM_SHIFT_NQMIN", "4"))    # quads fetched unconditionally
 WMAX = 4 * NQMAX
-PLANE = 40896            # plane A -> plane B, bytes: 128 q + 64 keeps the staging stores conflict-free
 REC = 64                 # bytes per stream record
-VB = int(os.environ.get("QM_SHIFT_VB", "32"))         # first hard VGPR
-ACC = VB                 # acc[g][k] = v[ACC + 8 g + 2 k : +1]
-WIN = [ACC + 64, ACC + 64 + 2 * WMAX]
-VADDR = WIN[1] + 2 * WMAX
-VNODE = VADDR + 1
-VC = VNODE + 1           # leading polynomial coefficient (pair)
-VPF = VC + 2             # L2 prefetch of the stream: dummy destination, zero offset
-VZERO = VPF + 1
-VEND = VZERO + 1
 PF_AHEAD = int(os.environ.get("QM_SHIFT_PF", "16"))   # records ahead (0: no prefetch)
-# epilogue temporaries live in window 1 (free between a group's last row and the next group's row 1)
-F = WIN[1]
-P = WIN[1] + 8
-KI = WIN[1] + 16
-GMAX = WIN[1] + 20
-GIDX = WIN[1] + 28
-TT = WIN[1] + 32         # z + magic (4 pairs)
-assert TT + 8 <= WIN[1] + 2 * WMAX
+PLANE2 = 40896           # plane A -> plane B, bytes (two 4-wave workgroups per CU, 80 KB each): 128 q + 64
+                         # keeps the staging stores conflict-free
+PLANE3 = 51136           # the same for the 12-wave workgroup (one per CU: 100 KB of windows + 60 KB of
+                         # per-wavefront running state)
+STATE_CHUNK = 1024       # running state in LDS: 5 chunks of 64 lanes x 16 bytes per wavefront
+
+
+def configure(lds_state):
+    """Register plan.  lds_state = False: the wavefront's running (max, sum, index) are inline-asm
+    operands (20 VGPRs the compiler places below VB).  True: they live in LDS and are read and
+    written by the group merge, the per-node temporaries move into window 1 -- 167 VGPRs in all,
+    three wavefronts per SIMD."""
+    global LDS_STATE, PLANE, VB, ACC, WIN, VADDR, VNODE, VC, VPF, VZERO, VEND
+    global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR
+    LDS_STATE = lds_state
+    PLANE = PLANE3 if lds_state else PLANE2
+    VB = 4 if lds_state else int(os.environ.get("QM_SHIFT_VB", "32"))    # first hard VGPR
+    ACC = VB                 # acc[g][k] = v[ACC + 8 g + 2 k : +1]
+    WIN = [ACC + 64, ACC + 64 + 2 * WMAX]
+    VADDR = WIN[1] + 2 * WMAX
+    # epilogue temporaries live in window 1 (free between a group's last row and the next group's
+    # row 1)
+    F = WIN[1]
+    P = WIN[1] + 8
+    TT = WIN[1] + 16         # z + magic (4 pairs)
+    GMAX = WIN[1] + 24
+    GIDX = WIN[1] + 32
+    GSUM = WIN[1] + 36       # (LDS state only) the group's sum of 2^z
+    KI = WIN[1] + 44         # "no index"
+    if lds_state:
+        VNODE = WIN[1] + 45
+        VC = WIN[1] + 46     # leading polynomial coefficient (pair), re-made per epilogue
+        VPF = VADDR + 1      # L2 prefetch of the stream: dummy destination, zero offset
+        assert VC + 2 <= WIN[1] + 2 * WMAX
+        # at the merge F / P / TT are dead: the state read from LDS lands there
+        MAXR = [v2(F + 2 * k) for k in range(4)]
+        SUMR = [v2(GSUM + 2 * k) for k in range(4)]
+        IDXR = [f"v{TT + k}" for k in range(4)]
+    else:
+        VNODE = VADDR + 1
+        VC = VNODE + 1
+        VPF = VC + 2
+        assert KI + 1 <= WIN[1] + 2 * WMAX
+        MAXR = [f"%[max{k}]" for k in range(4)]
+        SUMR = [f"%[sum{k}]" for k in range(4)]
+        IDXR = [f"%[idx{k}]" for k in range(4)]
+    VZERO = VPF + 1
+    VEND = VZERO + 1
+
 
 SB = 48                  # first hard SGPR (s_load_dwordx16 destinations)
 BUF = [SB, SB + 16]
@@ -204,7 +235,8 @@ def epilogue_node(e, degree, volume, g, opens_group):
         for k in range(4):
             e(f"v_fma_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, {v2(F + 2 * k)}, %[c{i}]")
     for k in range(4):
-        e(f"v_ldexp_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, v{TT + 2 * k}")
+        dst = SUMR[k] if (LDS_STATE and opens_group) else v2(P + 2 * k)   # the group's sum starts here
+        e(f"v_ldexp_f64 {dst}, {v2(P + 2 * k)}, v{TT + 2 * k}")
     if volume:
         # the node's four values per lane are 32 contiguous bytes of its volume row (the tile's
         # first sample is in the base): two 16-byte stores.  P is not written again before the
@@ -223,8 +255,9 @@ def epilogue_node(e, degree, volume, g, opens_group):
             e(f"global_store_dwordx4 %[voff], v[{P}:{P + 3}], {s2(SVA)}{nt}")
             if "halfstore" not in EXP:
                 e(f"global_store_dwordx4 %[voff], v[{P + 4}:{P + 7}], {s2(SVA)} offset:16{nt}")
-    for k in range(4):
-        e(f"v_add_f64 %[sum{k}], %[sum{k}], {v2(P + 2 * k)}")
+    if not (LDS_STATE and opens_group):
+        for k in range(4):
+            e(f"v_add_f64 {SUMR[k]}, {SUMR[k]}, {v2(P + 2 * k)}")
     for k in range(4):
         if opens_group:
             # the group's first node against the (-inf, none) start, without materialising it
@@ -246,6 +279,9 @@ def epilogue(e, degree, volume):
     # the nodes outside.
     partial = e.label("pg")
     merge = e.label("mg")
+    if LDS_STATE:
+        e(f"v_mov_b32 v{VC}, %[clo]")
+        e(f"v_mov_b32 v{VC + 1}, %[chi]")
     e(f"s_cmp_lg_u32 s{SMASK}, 0xff")
     e(f"s_cbranch_scc1 {partial}")
     e(f"v_mov_b32 v{KI}, 0x7fffffff")                          # "no index" (a literal and vcc cannot
@@ -257,6 +293,9 @@ def epilogue(e, degree, volume):
         e(f"v_mov_b32 v{GMAX + 2 * k}, 0")
         e(f"v_mov_b32 v{GMAX + 2 * k + 1}, 0xfff00000")        # -inf
         e(f"v_mov_b32 v{GIDX + k}, 0x7fffffff")
+        if LDS_STATE:
+            e(f"v_mov_b32 v{GSUM + 2 * k}, 0")
+            e(f"v_mov_b32 v{GSUM + 2 * k + 1}, 0")
     for g in range(8):
         skip = e.label("nd")
         e(f"s_bitcmp1_b32 s{SMASK}, {g}")
@@ -265,22 +304,34 @@ def epilogue(e, degree, volume):
         e(f"{skip}:")
     e(f"{merge}:")
     # merge into the wave's running pair: larger z, ties -> lower flat index
+    if LDS_STATE:
+        # the wavefront's running state lives in LDS (5 chunks of 64 lanes x 16 bytes): maxima into
+        # the dead F registers, sums into P, indices into TT
+        for c, reg in enumerate((F, F + 4, P, P + 4, TT)):
+            e(f"ds_read_b128 v[{reg}:{reg + 3}], %[state] offset:{c * STATE_CHUNK}")
+        e("s_waitcnt lgkmcnt(0)")
     for k in range(4):
         g_ = v2(GMAX + 2 * k)
-        e(f"v_cmp_gt_f64 {s2(ST)}, {g_}, %[max{k}]")
-        e(f"v_cmp_eq_f64 {s2(ST + 2)}, {g_}, %[max{k}]")
-        e(f"v_cmp_lt_i32 vcc, v{GIDX + k}, %[idx{k}]")
+        e(f"v_cmp_gt_f64 {s2(ST)}, {g_}, {MAXR[k]}")
+        e(f"v_cmp_eq_f64 {s2(ST + 2)}, {g_}, {MAXR[k]}")
+        e(f"v_cmp_lt_i32 vcc, v{GIDX + k}, {IDXR[k]}")
         e(f"s_and_b64 {s2(ST + 2)}, {s2(ST + 2)}, vcc")
         e(f"s_or_b64 vcc, {s2(ST)}, {s2(ST + 2)}")
-        e(f"v_cndmask_b32 %[idx{k}], %[idx{k}], v{GIDX + k}, vcc")
-        e(f"v_max_f64 %[max{k}], %[max{k}], {g_}")
+        e(f"v_cndmask_b32 {IDXR[k]}, {IDXR[k]}, v{GIDX + k}, vcc")
+        e(f"v_max_f64 {MAXR[k]}, {MAXR[k]}, {g_}")
+    if LDS_STATE:
+        for k in range(4):
+            e(f"v_add_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, {SUMR[k]}")
+        for c, reg in enumerate((F, F + 4, P, P + 4, TT)):
+            e(f"ds_write_b128 %[state], v[{reg}:{reg + 3}] offset:{c * STATE_CHUNK}")
 
 
 def body(degree, volume):
     e = Emitter()
-    # leading coefficient into a VGPR pair (two different SGPR pairs cannot feed one VALU op)
-    e(f"v_mov_b32 v{VC}, %[clo]")
-    e(f"v_mov_b32 v{VC + 1}, %[chi]")
+    if not LDS_STATE:
+        # leading coefficient into a VGPR pair (two different SGPR pairs cannot feed one VALU op)
+        e(f"v_mov_b32 v{VC}, %[clo]")
+        e(f"v_mov_b32 v{VC + 1}, %[chi]")
     e(f"s_mov_b32 s{STAB}, %[tablo]")
     e(f"s_mov_b32 s{STAB + 1}, %[tabhi]")
     # prologue: lead-in record (header of row 0) and row 0's record; window of row 0
@@ -321,22 +372,29 @@ def body(degree, volume):
 def main():
     print("// GENERATED by gen_shift_asm.py -- do not edit.  See that file for the schedule and the")
     print("// stream format.")
+    configure(False)
     print(f"constexpr int kShiftNqMax = {NQMAX};          // quads (4 samples) a register window holds")
     print(f"constexpr int kShiftNqMin = {NQMIN};          // quads fetched unconditionally")
-    print(f"constexpr int kShiftPlane = {PLANE};        // bytes from plane A to plane B")
+    print(f"constexpr int kShiftPlane = {PLANE2};        // bytes from plane A to plane B (4-wave workgroups)")
+    print(f"constexpr int kShiftPlane3 = {PLANE3};       // ... of the 12-wave workgroup")
+    print(f"constexpr int kShiftStateChunk = {STATE_CHUNK};   // LDS running state: 5 chunks per wavefront")
     print(f"constexpr int kShiftRec = {REC};            // bytes per stream record")
-    print(f"constexpr int kShiftVgprs = {VEND};         // hard VGPRs reach v{VEND - 1}")
-    for degree, volume, name in ((8, False, "shift_groups_detect"), (10, True, "shift_groups_volume")):
+    for degree, volume, lds_state, name in ((8, False, False, "shift_groups_detect"),
+                                            (10, True, False, "shift_groups_volume"),
+                                            (8, False, True, "shift_groups_detect3")):
+        configure(lds_state)
         lines = body(degree, volume)
         # the stream pointer lives in a hard SGPR pair (the halves of an s[lo:hi] operand cannot be
         # named in inline asm): it is handed over as two 32-bit scalars
         text = "\\n\\t".join(lines)
         print()
-        print(f"// degree-{degree} 2^f{', values stored' if volume else ''}; window of up to {WMAX} doubles; "
+        print(f"// degree-{degree} 2^f{', values stored' if volume else ''}"
+              f"{', running state in LDS' if lds_state else ''}; window of up to {WMAX} doubles; "
               f"hard VGPRs v{VB}..v{VEND - 1}, SGPRs s{SB}..s{SEND - 1}")
-        print(f"__device__ __forceinline__ void {name}(double (&vmax)[4], double (&vsum)[4], "
-              "int (&vidx)[4],")
-        print("        const void *stream, int ngroups, int npairs, unsigned lane_addr, int nz, "
+        print(f"__device__ __forceinline__ void {name}("
+              + ("" if lds_state else "double (&vmax)[4], double (&vsum)[4], int (&vidx)[4],"))
+        print("        const void *stream, int ngroups, int npairs, unsigned lane_addr, "
+              + ("unsigned state_addr, " if lds_state else "") + "int nz, "
               f"int nynz, double scale, const double (&c)[{degree + 1}]"
               + (", double *vol_tile, unsigned vol_stride_bytes, unsigned lane_bytes" if volume else "")
               + ") {")
@@ -347,13 +405,17 @@ def main():
         if volume:
             print("    const unsigned long long vp = (unsigned long long)vol_tile;")
             print("    const unsigned vlo = (unsigned)vp, vhi = (unsigned)(vp >> 32);")
-        outs = [f'[max{k}] "+v"(vmax[{k}])' for k in range(4)]
-        outs += [f'[sum{k}] "+v"(vsum[{k}])' for k in range(4)]
-        outs += [f'[idx{k}] "+v"(vidx[{k}])' for k in range(4)]
+        outs = []
+        if not lds_state:
+            outs += [f'[max{k}] "+v"(vmax[{k}])' for k in range(4)]
+            outs += [f'[sum{k}] "+v"(vsum[{k}])' for k in range(4)]
+            outs += [f'[idx{k}] "+v"(vidx[{k}])' for k in range(4)]
         outs += ['[ng] "+s"(ngroups)']
         ins = ['[tablo] "s"(tablo)', '[tabhi] "s"(tabhi)', '[lane] "v"(lane_addr)',
                '[npairs] "s"(npairs)', '[nz] "s"(nz)', '[nynz] "s"(nynz)', '[scale] "s"(scale)',
                '[clo] "s"(clo)', '[chi] "s"(chi)']
+        if lds_state:
+            ins += ['[state] "v"(state_addr)']
         if volume:
             ins += ['[vlo] "s"(vlo)', '[vhi] "s"(vhi)', '[vstride] "s"(vol_stride_bytes)',
                     '[voff] "v"(lane_bytes)']

@@ -145,6 +145,8 @@ struct qm_engine {
     // shift-reuse layout of the fused float64 detect (qm_shift.hpp): own brick grid, row-window
     // slots, record stream
     int cfg_shift = -1;                     // -1: where the table qualifies, 0: never, 1: as -1 (explicit)
+    int cfg_shift_waves = 0;                // workgroup shape: 4 (two per CU), 12 (one per CU), 0 = automatic
+    int shift_nw = 0;                       // ... the tables were built for
     qm::GridDesc shg{};
     DevBuf<int32_t> d_shraw, d_shmeta, d_shtotal, d_shfit, d_shwide;
     DevBuf<uint32_t> d_shstream;
@@ -458,9 +460,14 @@ int ensure_shift_tables(qm_engine *e) {
     // a grid one node thick has half-empty 2x2x2 groups everywhere (e.g. the flat 1 x 1 x N view
     // of the reference-signature migrate): leave it to the other kernels unless asked explicitly
     if (e->cfg_shift < 0 && (e->g.nx < 2 || e->g.ny < 2 || e->g.nz < 2)) return 0;
-    static const int kShapes[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4}, {2, 4, 4}};
+    // workgroup shape: 12 waves (one workgroup per CU, three wavefronts per SIMD, running state in
+    // LDS) wants bricks whose 2x2x2 groups deal evenly over 12 wavefronts
+    const int nw = e->cfg_shift_waves == qm::kShiftWaves3 ? qm::kShiftWaves3 : qm::kShiftWaves;
+    static const int kShapes4[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4}, {2, 4, 4}};
+    static const int kShapes12[][3] = {{8, 8, 12}, {8, 8, 6}, {4, 8, 6}, {4, 4, 6}, {2, 4, 6}};
+    const int (*kShapes)[3] = nw == qm::kShiftWaves3 ? kShapes12 : kShapes4;
     const bool fixed = e->cfg_bx > 0;
-    const int n_shapes = fixed ? 1 : (int)(sizeof(kShapes) / sizeof(kShapes[0]));
+    const int n_shapes = fixed ? 1 : 5;
     qm::GridDesc g = e->g;
     std::vector<int32_t> fit, wide;
     bool ok = false;
@@ -485,7 +492,8 @@ int ensure_shift_tables(qm_engine *e) {
         hipLaunchKernelGGL(qm::shift_need_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
                            e->d_lut.p, reinterpret_cast<const int4 *>(e->d_shraw.p),
                            reinterpret_cast<int4 *>(e->d_shmeta.p), e->d_shtotal.p, e->d_shfit.p,
-                           reinterpret_cast<unsigned long long *>(e->d_scalar.p + 4));
+                           reinterpret_cast<unsigned long long *>(e->d_scalar.p + 4),
+                           qm::shift_plane(nw));
         QM_HIP(hipGetLastError());
         fit.resize(g.nbricks);
         unsigned long long tally[2] = {0, 0};
@@ -504,7 +512,7 @@ int ensure_shift_tables(qm_engine *e) {
     }
     if (!ok) return 0;                                   // an incoherent table: the other kernels
     const int rows2 = S + (S & 1);
-    const int64_t words = (int64_t)g.nbricks * qm::kShiftWaves * qm::shift_recs_per_wave(g, rows2) *
+    const int64_t words = (int64_t)g.nbricks * nw * qm::shift_recs_per_wave(g, rows2, nw) *
                           (qm::kShiftRec / 4);
     // (+ one record of slack: the loop's last prefetch of a wave's run reads one record past it)
     if (e->d_shstream.ensure((size_t)words + 64)) return 1;
@@ -513,7 +521,7 @@ int ensure_shift_tables(qm_engine *e) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_bytes));
     hipLaunchKernelGGL(qm::shift_stream_kernel, dim3(g.nbricks), dim3(256), hdr_bytes, e->stream, g,
                        e->d_lut.p, reinterpret_cast<const int4 *>(e->d_shmeta.p), e->d_shtotal.p,
-                       e->d_shfit.p, rows2, e->d_shstream.p);
+                       e->d_shfit.p, rows2, nw, e->d_shstream.p);
     QM_HIP(hipGetLastError());
     e->n_shwide = (int)wide.size();
     if (e->n_shwide) {
@@ -525,6 +533,7 @@ int ensure_shift_tables(qm_engine *e) {
     e->d_shraw.release();
     e->shg = g;
     e->shift_rows2 = rows2;
+    e->shift_nw = nw;
     e->shift_ok = true;
     return 0;
 }
@@ -553,9 +562,12 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         s.sfit = e->d_shfit.p;
         s.stream = reinterpret_cast<const char *>(e->d_shstream.p);
         s.rows2 = e->shift_rows2;
-        const qm::LaunchShape shape =
-            stack_shape(e, a, a.ngroups, qm::kShiftWaves * qm::kWave, qm::kShiftLdsBytes);
+        s.nw = e->shift_nw;
+        const bool big = e->shift_nw == qm::kShiftWaves3;
+        const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, e->shift_nw * qm::kWave,
+                                                  big ? qm::kShiftLdsBytes3 : qm::kShiftLdsBytes);
         if (volume) QM_TABLE(qm::launch_shift_volume(s, shape));
+        else if (big) QM_TABLE(qm::launch_shift_detect3(s, shape));
         else QM_TABLE(qm::launch_shift_detect(s, shape));
         e->last_kernel = 3;
         e->last_j = 4;
@@ -639,7 +651,8 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
                               volume != nullptr, vol_stride);
     if (shift) {
         if (ensure_shift_tables(e)) return 1;
-        shift = e->shift_ok;
+        // (the 12-wave shape is built for the fused detect only)
+        shift = e->shift_ok && !(volume != nullptr && e->shift_nw == qm::kShiftWaves3);
     }
     if (shift) {
         jp = 0;
@@ -665,7 +678,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     const bool use_lds = !e->cfg_force_direct && n_wide_now < nbricks_now;
     const int threads = shift ? 512 : jp > 0 ? 1024 : e->cfg_waves * qm::kWave;   // (direct launch)
     const int lds_blocks_per_cu =
-        shift ? 2 : jp > 0 ? 1
+        shift ? (e->shift_nw == qm::kShiftWaves3 ? 1 : 2) : jp > 0 ? 1
                : std::max(1, std::min(160 * 1024 / std::max(1, e->cfg_lds_bytes), 2048 / threads));
     int groups_lds = 0, groups_direct = 0;
     if (use_lds)
@@ -1269,6 +1282,11 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
     } else if (k == "shift") {
         if (v < -1 || v > 1) return fail("shift must be -1 (automatic), 0 (off) or 1");
         e->cfg_shift = (int)v;
+    } else if (k == "shift_waves") {
+        if (v != 0 && v != qm::kShiftWaves && v != qm::kShiftWaves3)
+            return fail("shift_waves must be 0 (automatic), 4 or 12");
+        e->cfg_shift_waves = (int)v;
+        e->shift_built = false;
     } else if (k == "screen") {
         e->cfg_screen = v ? 1 : 0;
     } else if (k == "screen_pairs") {
@@ -1320,6 +1338,7 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "last_kernel_j") *v = e->last_j;
     else if (k == "shift") *v = e->cfg_shift;
     else if (k == "shift_ok") *v = e->shift_built && e->shift_ok ? 1 : 0;
+    else if (k == "shift_waves") *v = e->shift_ok ? e->shift_nw : e->cfg_shift_waves;
     else if (k == "shift_brick_nodes") *v = e->shift_ok ? e->shg.brick_nodes : 0;
     else if (k == "shift_wide_bricks") *v = e->shift_ok ? e->n_shwide : 0;
     else if (k == "shift_operands_per_add_x1000")   // 8-byte LDS operands fetched per add (x 1000)

@@ -30,9 +30,17 @@ namespace qm {
 #endif
 #include QM_SHIFT_ASM_INC
 
-constexpr int kShiftWaves = 4;                          // wavefronts per workgroup
+// Two workgroup shapes: two 4-wave workgroups per CU with 80 KB each (running state in registers,
+// two wavefronts per SIMD), or ONE 12-wave workgroup per CU (three per SIMD: the running state of
+// every wavefront lives in LDS behind the windows so that the loop fits 168 VGPRs).
+constexpr int kShiftWaves = 4;                          // wavefronts per workgroup (default shape)
+constexpr int kShiftWaves3 = 12;
 constexpr int kShiftKT = 256;                           // samples per time tile
 constexpr int kShiftLdsBytes = 2 * kShiftPlane;         // both planes
+constexpr int kShiftStateBytes = 5 * kShiftStateChunk;  // per wavefront (12-wave shape)
+constexpr int kShiftLdsBytes3 = 2 * kShiftPlane3 + kShiftWaves3 * kShiftStateBytes;
+static_assert(kShiftLdsBytes3 <= 160 * 1024, "the 12-wave workgroup's LDS exceeds a CU's");
+__host__ __device__ constexpr int shift_plane(int nw) { return nw == kShiftWaves3 ? kShiftPlane3 : kShiftPlane; }
 constexpr int kShiftMaxRows = 64;                       // table rows the stream builder handles
 static_assert(QM_EXP2_DEGREE_SUM == 8 && QM_EXP2_DEGREE_VOLUME == 10,
               "the generated loops carry the degree-8 (detect) and degree-10 (stored values) 2^f");
@@ -42,8 +50,8 @@ static_assert(QM_EXP2_DEGREE_SUM == 8 && QM_EXP2_DEGREE_VOLUME == 10,
 __host__ __device__ __forceinline__ int shift_groups_per_brick(const GridDesc &g) {
     return (g.bx / 2) * (g.by / 2) * (g.bz / 2);
 }
-__host__ __device__ __forceinline__ int64_t shift_recs_per_wave(const GridDesc &g, int rows2) {
-    return (int64_t)((shift_groups_per_brick(g) + kShiftWaves - 1) / kShiftWaves) * rows2 + 2;
+__host__ __device__ __forceinline__ int64_t shift_recs_per_wave(const GridDesc &g, int rows2, int nw) {
+    return (int64_t)((shift_groups_per_brick(g) + nw - 1) / nw) * rows2 + 2;
 }
 
 struct ShiftArgs {
@@ -51,13 +59,15 @@ struct ShiftArgs {
     const int4 *smeta;           // [nbricks][S] (min delay, span, first slot, slots) per row window
     const int32_t *stotal;       // [nbricks] slots of all rows (the zero row of an odd S follows)
     const int32_t *sfit;         // [nbricks] 1: the brick runs here, 0: direct kernel
-    const char *stream;          // records, [nbricks][kShiftWaves][shift_recs_per_wave]
+    const char *stream;          // records, [nbricks][nw][shift_recs_per_wave]
     int rows2;                   // stream rows per group: S rounded up to even
+    int nw;                      // wavefronts per workgroup the stream was dealt for
 };
 
 struct LaunchShape;
 hipError_t launch_shift_detect(const ShiftArgs &a, const LaunchShape &s);   // qm_launch_shift.hip
 hipError_t launch_shift_volume(const ShiftArgs &a, const LaunchShape &s);
+hipError_t launch_shift_detect3(const ShiftArgs &a, const LaunchShape &s);  // the 12-wave shape
 
 // valid 2x2x2 groups of a brick form a box [0,cx) x [0,cy) x [0,cz) in group coordinates
 __device__ __forceinline__ void shift_group_box(const GridDesc &g, int b, int &x0, int &y0, int &z0,
@@ -111,7 +121,8 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
                                                          int4 *__restrict__ smeta,
                                                          int32_t *__restrict__ stotal,
                                                          int32_t *__restrict__ sfit,
-                                                         unsigned long long *__restrict__ tally) {
+                                                         unsigned long long *__restrict__ tally,
+                                                         int plane_bytes) {
     // tally[0] += quads the loop fetches, tally[1] += (group, row) pairs: operands per add
     __shared__ int need[kShiftMaxRows];
     __shared__ int overflow;
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
         }
         stotal[b] = run;
         const int zero_row = (S & 1) ? 64 + kShiftNqMin : 0;   // all-zero window of the padding row
-        sfit[b] = (!overflow && (int64_t)(run + zero_row) * 16 <= kShiftPlane) ? 1 : 0;
+        sfit[b] = (!overflow && (int64_t)(run + zero_row) * 16 <= plane_bytes) ? 1 : 0;
     }
 }
 
@@ -156,18 +167,18 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
                                                            const int4 *__restrict__ smeta,
                                                            const int32_t *__restrict__ stotal,
                                                            const int32_t *__restrict__ sfit, int rows2,
-                                                           uint32_t *__restrict__ stream) {
+                                                           int nw, uint32_t *__restrict__ stream) {
     extern __shared__ uint2 hdr[];                      // [group j][row] (LDS address, quads)
     const int b = blockIdx.x, S = g.n_rows;
     if (!sfit[b]) return;
     int x0, y0, z0, vx, vy, vz, cx, cy, cz;
     shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
     const int nvg = cx * cy * cz;
-    const int64_t rpw = shift_recs_per_wave(g, rows2);
-    uint32_t *base = stream + (int64_t)b * kShiftWaves * rpw * (kShiftRec / 4);
+    const int64_t rpw = shift_recs_per_wave(g, rows2, nw);
+    uint32_t *base = stream + (int64_t)b * nw * rpw * (kShiftRec / 4);
     for (int i = threadIdx.x; i < nvg * rows2; i += blockDim.x) {
         const int j = i / rows2, r = i % rows2;
-        const int w = j % kShiftWaves, pos = j / kShiftWaves;
+        const int w = j % nw, pos = j / nw;
         uint32_t *rec = base + ((int64_t)w * rpw + 1 + (int64_t)pos * rows2 + r) * (kShiftRec / 4);
         if (r >= S) {                                   // padding row of an odd S: adds 0.0
             for (int n = 0; n < 8; ++n) rec[n] = 0;
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
     }
     __syncthreads();
     // headers travel one record ahead of their row
-    for (int i = threadIdx.x; i < nvg * rows2 + kShiftWaves; i += blockDim.x) {
+    for (int i = threadIdx.x; i < nvg * rows2 + nw; i += blockDim.x) {
         if (i >= nvg * rows2) {                          // lead-in record of wave w
             const int w = i - nvg * rows2;
             if (w < nvg) {
@@ -200,11 +211,11 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
             continue;
         }
         const int j = i / rows2, r = i % rows2;
-        const int w = j % kShiftWaves, pos = j / kShiftWaves;
+        const int w = j % nw, pos = j / nw;
         uint32_t *rec = base + ((int64_t)w * rpw + 1 + (int64_t)pos * rows2 + r) * (kShiftRec / 4);
         uint2 h = make_uint2(0u, 2u);                    // after the wave's last row: harmless
         if (r + 1 < rows2) h = hdr[j * rows2 + r + 1];
-        else if (j + kShiftWaves < nvg) h = hdr[(j + kShiftWaves) * rows2];
+        else if (j + nw < nvg) h = hdr[(j + nw) * rows2];
         rec[8] = h.x;
         rec[9] = h.y;
     }
@@ -215,45 +226,71 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
 // Stage the row windows of brick b for the tile starting at t_first: window sample u of row r goes
 // to plane (u & 2) / 2, slot first_r + u / 4, half u & 1.  Every slot of the row is written (zero
 // past the data the brick can touch and past the rows' end): a lane may fetch whole quads.
+template <int NW>
 __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *win, int b, int wave,
                                                     int lane, int t_first) {
     const StackArgs &a = s.a;
     const int S = a.g.n_rows;
-    constexpr int U = 5;
-    for (int r = wave; r < S; r += kShiftWaves) {
-        const int4 m = s.smeta[(int64_t)b * S + r];
-        const int len = m.y + kShiftKT;                            // samples the brick can touch
-        const int first = m.x + a.fsmp + a.sample0 + t_first;      // index inside the row
-        const int room = a.T - first;
-        const double *src = a.onsets + (int64_t)r * a.T + first;
-        const int total = 4 * m.w;
-        for (int u0 = 0; u0 < total; u0 += kWave * U) {
-            double v[U];
+    // A wavefront stages rows wave, wave + NW, ...: the loads of ALL its rows (up to RB x U x 64
+    // samples) are issued before the first LDS store, so the brick's staging costs one round trip
+    // to L2 instead of one per row (while a workgroup stages, its SIMDs' other wavefronts run at
+    // half rate: a wavefront alone issues one float64 instruction per 8 cycles).
+    constexpr int RB = NW == kShiftWaves ? 8 : 3;                  // rows per wavefront and pass
+    constexpr int U = 6;                                           // 64-sample chunks per row and pass
+    constexpr int kPlane = shift_plane(NW);
+    for (int r0 = wave; r0 < S; r0 += NW * RB) {
+        double v[RB][U];
+        int4 m[RB];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            const int r = r0 + k * NW;
+            m[k] = r < S ? s.smeta[(int64_t)b * S + r] : make_int4(0, 0, 0, 0);
+            const int len = m[k].y + kShiftKT;                     // samples the brick can touch
+            const int first = m[k].x + a.fsmp + a.sample0 + t_first;   // index inside the row
+            const int room = a.T - first;
+            const double *src = a.onsets + (int64_t)(r < S ? r : 0) * a.T + first;
 #pragma unroll
             for (int i = 0; i < U; ++i) {
-                const int u = u0 + kWave * i + lane;
-                v[i] = (u < len && u < room) ? src[u] : 0.0;
+                const int u = kWave * i + lane;
+                v[k][i] = (r < S && u < len && u < room) ? src[u] : 0.0;
             }
+        }
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            const int total = 4 * m[k].w;                          // every slot of the row is written
 #pragma unroll
             for (int i = 0; i < U; ++i) {
-                const int u = u0 + kWave * i + lane;
+                const int u = kWave * i + lane;
                 if (u < total)
-                    win[((u & 2) ? kShiftPlane / 8 : 0) + 2 * (m.z + (u >> 2)) + (u & 1)] = v[i];
+                    win[((u & 2) ? kPlane / 8 : 0) + 2 * (m[k].z + (u >> 2)) + (u & 1)] = v[k][i];
+            }
+            // (a row window longer than U x 64 samples: the rest, one load at a time)
+            if (total > kWave * U) {
+                const int r = r0 + k * NW;
+                const int len = m[k].y + kShiftKT;
+                const int first = m[k].x + a.fsmp + a.sample0 + t_first;
+                const int room = a.T - first;
+                const double *src = a.onsets + (int64_t)r * a.T + first;
+                for (int u = kWave * U + lane; u < total; u += kWave)
+                    win[((u & 2) ? kPlane / 8 : 0) + 2 * (m[k].z + (u >> 2)) + (u & 1)] =
+                        (u < len && u < room) ? src[u] : 0.0;
             }
         }
     }
     if ((S & 1) && wave == 0) {                                    // the padding row's zero window
         const int z = s.stotal[b];
         for (int u = lane; u < 4 * (64 + kShiftNqMin); u += kWave)
-            win[((u & 2) ? kShiftPlane / 8 : 0) + 2 * (z + (u >> 2)) + (u & 1)] = 0.0;
+            win[((u & 2) ? kPlane / 8 : 0) + 2 * (z + (u >> 2)) + (u & 1)] = 0.0;
     }
 }
 
 // VOLUME: the 4-D volume is written too (whole 256-sample tiles only: a scan that is not a multiple
 // of the tile pulls its last tile back, and the overlap is stored twice with the same bits; scans
 // shorter than a tile stay with the other kernels)
-template <bool VOLUME>
-__global__ __launch_bounds__(kShiftWaves * kWave, 2) void stack_shift_kernel(ShiftArgs s) {
+template <bool VOLUME, int NW>
+__global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_shift_kernel(ShiftArgs s) {
+    static_assert(NW == kShiftWaves || (NW == kShiftWaves3 && !VOLUME), "workgroup shapes: 4 waves, or 12 (detect)");
+    constexpr bool kLdsState = NW == kShiftWaves3;
     extern __shared__ __attribute__((aligned(16))) double win[];
     const StackArgs &a = s.a;
     const GridDesc &g = a.g;
@@ -279,24 +316,39 @@ __global__ __launch_bounds__(kShiftWaves * kWave, 2) void stack_shift_kernel(Shi
         vsum[k] = 0.0;
         vidx[k] = INT32_MAX;
     }
+    // 12-wave shape: the running state lives in LDS behind the windows, 5 chunks of 64 lanes x 16
+    // bytes per wavefront (maxima 0-1 / 2-3, sums 0-1 / 2-3, indices)
+    double *state = win + (2 * shift_plane(NW) + wave * kShiftStateBytes) / 8 + 2 * lane;
+    const unsigned state_addr = (unsigned)(uintptr_t)((lds_f64 *)state);
+    if constexpr (kLdsState) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            state[(k / 2) * (kShiftStateChunk / 8) + (k & 1)] = vmax[k];
+            state[(2 + k / 2) * (kShiftStateChunk / 8) + (k & 1)] = vsum[k];
+            reinterpret_cast<int *>(state + 4 * (kShiftStateChunk / 8))[k] = vidx[k];
+        }
+    }
     constexpr int D = Exp2Degree<VOLUME>::value;
     double c[D + 1];
 #pragma unroll
     for (int i = 0; i <= D; ++i) c[i] = exp2_coeff<D>(i);
 
-    const int64_t rpw = shift_recs_per_wave(g, s.rows2);
+    const int64_t rpw = shift_recs_per_wave(g, s.rows2, NW);
     for (int b = group; b < g.nbricks; b += a.ngroups) {
         if (!s.sfit[b]) continue;                     // direct kernel's job
         __syncthreads();                              // previous brick fully consumed
-        stage_shift_windows(s, win, b, wave, lane, t_first);
+        stage_shift_windows<NW>(s, win, b, wave, lane, t_first);
         __syncthreads();
         int x0, y0, z0, vx, vy, vz, cx, cy, cz;
         shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
         const int nvg = cx * cy * cz;
-        const int mine = (nvg - wave + kShiftWaves - 1) / kShiftWaves;     // groups of this wave
+        const int mine = (nvg - wave + NW - 1) / NW;                       // groups of this wave
         if (mine > 0) {
-            const char *run = s.stream + ((int64_t)b * kShiftWaves + wave) * rpw * kShiftRec;
-            if constexpr (VOLUME)
+            const char *run = s.stream + ((int64_t)b * NW + wave) * rpw * kShiftRec;
+            if constexpr (kLdsState)
+                shift_groups_detect3(run, mine, s.rows2 / 2, lane_addr, state_addr, g.nz,
+                                     g.ny * g.nz, a.z_scale, c);
+            else if constexpr (VOLUME)
                 shift_groups_volume(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr, g.nz,
                                     g.ny * g.nz, a.z_scale, c, a.volume + t_first,
                                     (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u);
@@ -306,10 +358,18 @@ __global__ __launch_bounds__(kShiftWaves * kWave, 2) void stack_shift_kernel(Shi
         }
     }
     if (!a.want_scan) return;
+    if constexpr (kLdsState) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            vmax[k] = state[(k / 2) * (kShiftStateChunk / 8) + (k & 1)];
+            vsum[k] = state[(2 + k / 2) * (kShiftStateChunk / 8) + (k & 1)];
+            vidx[k] = reinterpret_cast<int *>(state + 4 * (kShiftStateChunk / 8))[k];
+        }
+    }
     // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
     __syncthreads();
-    double *smax = win, *ssum = win + kShiftWaves * kShiftKT;
-    int *sidx = reinterpret_cast<int *>(win + 2 * kShiftWaves * kShiftKT);
+    double *smax = win, *ssum = win + NW * kShiftKT;
+    int *sidx = reinterpret_cast<int *>(win + 2 * NW * kShiftKT);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int o = wave * kShiftKT + 4 * lane + k;
@@ -319,9 +379,10 @@ __global__ __launch_bounds__(kShiftWaves * kWave, 2) void stack_shift_kernel(Shi
     }
     __syncthreads();
     const int k = threadIdx.x;
+    if (k >= kShiftKT) return;                        // (a 12-wave workgroup has more threads than samples)
     double best = smax[k], total = ssum[k];
     int bi = sidx[k];
-    for (int w = 1; w < kShiftWaves; ++w) {
+    for (int w = 1; w < NW; ++w) {
         const double v = smax[w * kShiftKT + k];
         const int i = sidx[w * kShiftKT + k];
         total += ssum[w * kShiftKT + k];

@@ -1626,6 +1626,22 @@ def test_shift_kernel_equals_round2_kernels_and_oracle(lib, oracle, recipe, grid
     np.testing.assert_allclose(r["shift"][1], r["round2"][1], rtol=NORM)
 
 
+@pytest.mark.parametrize("recipe,grid,rows,ns", [SHIFT_SHAPES[0], SHIFT_SHAPES[2], SHIFT_SHAPES[5]])
+def test_shift_kernel_twelve_wave_shape_gives_the_same_bits(lib, oracle, recipe, grid, rows, ns):
+    """Engine(shift_waves=12): one 12-wave workgroup per CU, three wavefronts per SIMD, the
+    wavefronts' running (max, sum, index) in LDS, bricks of 8x8x12 -- an opt-in shape (measured no
+    faster than two 4-wave workgroups) that must give the same series."""
+    case = synth.make_case(recipe, step=1, grid=grid, rows=rows, n_samples=ns)
+    lon = oracle.log_onsets(case.onsets)
+    r = _detect_both(lib, lon, case.traveltimes, case.fsmp, case.lsmp, case.available, shift_waves=12)
+    assert r["shift_kernel"] == 3, r
+    want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
+                         threads=4)
+    _assert_series(r["shift"], want)
+    assert np.array_equal(r["shift"][2], r["round2"][2]) and np.array_equal(r["shift"][0], r["round2"][0])
+    np.testing.assert_allclose(r["shift"][1], r["round2"][1], rtol=NORM)
+
+
 def test_shift_kernel_exact_ties_resolve_to_the_lowest_index(lib, oracle):
     """Quantised log-onsets (every partial sum exact): many nodes reach exactly the same maximum;
     the 2x2x2 groups of a wavefront are NOT visited in ascending flat index, so the lowest index

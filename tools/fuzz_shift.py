@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Randomised differential campaign for the shift-reuse kernel (development aid).
+
+Random grids (every dimension >= 2), 1-34 rows, 192-900 scanned samples, coherent tables of random
+steepness (so that some trials put bricks on the direct kernel and some tables do not qualify at
+all), quantised onsets in half of the trials (exact ties), negative delays, random `available` and
+group counts: the automatic engine against Engine(shift=0) (maxima bit for bit, indices) and the
+oracle; every fourth trial also the volume-writing variant against the oracle's volume.
+usage: fuzz_shift.py [trials] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import qm_oracle  # noqa: E402
+from quakemigrate_amd.core import lib  # noqa: E402
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+used = wide = 0
+for trial in range(trials):
+    grid = tuple(int(v) for v in rng.integers(2, 34, size=3))
+    if np.prod(grid) > 12000:
+        grid = (grid[0], grid[1], max(2, 12000 // (grid[0] * grid[1])))
+    S = int(rng.integers(1, 35))
+    ns = int(rng.integers(192, 900))
+    fsmp, lsmp = int(rng.integers(0, 30)), int(rng.integers(30, 160))
+    # coherent table: distance-like delays from random "stations", steepness up to ~7 samples per node, a fifth of the rows up to 30
+    ijk = np.stack(np.indices(grid), axis=-1).astype(np.float64)
+    tt = np.empty(grid + (S,), dtype=np.int32)
+    for r in range(S):
+        src = rng.uniform(-5, np.array(grid) + 5)
+        steep = rng.uniform(0.2, 7.0) if rng.random() < 0.8 else rng.uniform(7.0, 30.0)
+        d = np.sqrt(((ijk - src) ** 2).sum(-1)) * steep
+        tt[..., r] = np.minimum(np.rint(d - d.min() + rng.integers(0, 5)), lsmp).astype(np.int32)
+    if trial % 3 == 0:
+        tt[(tt <= 1) & (rng.random(tt.shape) < 0.5)] = -3          # clamp to 0 (migratelib.c:55)
+    T = fsmp + ns + lsmp
+    if trial % 2:
+        lon = rng.choice([-48, -16, 0, 16, 80], size=(S, T), p=[0.45, 0.25, 0.15, 0.1, 0.05]) / 64.0
+    else:
+        lon = np.log(np.clip(rng.lognormal(0, 0.6, size=(S, T)), 0.01, None))
+    avail = int(2 ** rng.integers(0, 5)) if trial % 2 else int(rng.integers(1, S + 1))
+    cfg = dict(groups=int(rng.choice([0, 1, 3, 9])))
+    want = qm_oracle.detect(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True)
+    res = {}
+    for tag, extra in (("shift", {}), ("round2", {"shift": 0})):
+        eng = lib.Engine(0, **cfg, **extra)
+        eng.load_lut(tt)
+        res[tag] = eng.detect(lon, fsmp, lsmp, avail)
+        if tag == "shift":
+            kern, nwide = eng.get("last_kernel"), eng.get("shift_wide_bricks")
+            if trial % 4 == 0:
+                vol = np.zeros(grid + (ns,))
+                series = (np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64))
+                eng.migrate(lon, fsmp, lsmp, avail, vol, scan_out=series)
+                ref = qm_oracle.c_migrate(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True)
+                np.testing.assert_allclose(vol, ref, rtol=1e-13, err_msg=str((trial, grid, S, ns)))
+                assert np.array_equal(series[2], want[2]), (trial, "volume scan idx")
+        eng.close()
+    used += kern == 3
+    wide += kern == 3 and nwide > 0
+    a, b, c = res["shift"]
+    assert np.array_equal(c, want[2]), (trial, grid, S, ns, cfg, kern)
+    assert np.array_equal(c, res["round2"][2]) and np.array_equal(a, res["round2"][0]), (trial, grid, S, ns)
+    np.testing.assert_allclose(a, want[0], rtol=1e-13)
+    np.testing.assert_allclose(b, want[1], rtol=1e-12)
+    np.testing.assert_allclose(b, res["round2"][1], rtol=1e-12)
+print(f"{trials} trials ok; shift kernel used in {used}, of which {wide} with bricks on the direct kernel")

@@ -16,7 +16,7 @@ for name, kw in cases:
     case = synth.make_case(name, step=0, **kw)
     lon = np.log(np.clip(case.onsets, 0.01, np.inf))
     res = {}
-    for tag, cfg in (("shift", {}), ("round2", {"shift": 0})):
+    for tag, cfg in (("shift", {"shift_waves": int(os.environ.get("QM_CHECK_WAVES", "0"))}), ("round2", {"shift": 0})):
         eng = lib.Engine(0, **cfg)
         eng.load_lut(case.traveltimes)
         res[tag] = eng.detect(lon, case.fsmp, case.lsmp, case.available)
