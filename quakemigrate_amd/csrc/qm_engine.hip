@@ -514,8 +514,9 @@ int ensure_shift_tables(qm_engine *e) {
     const int rows2 = S + (S & 1);
     const int64_t words = (int64_t)g.nbricks * nw * qm::shift_recs_per_wave(g, rows2, nw) *
                           (qm::kShiftRec / 4);
-    // (+ one record of slack: the loop's last prefetch of a wave's run reads one record past it)
-    if (e->d_shstream.ensure((size_t)words + 64)) return 1;
+    // (+ slack: the loop loads one record past a wavefront's run and touches the line 16 records
+    // ahead with its L2 prefetch -- after the last run of the last brick that is past the stream)
+    if (e->d_shstream.ensure((size_t)words + 4096)) return 1;
     const size_t hdr_bytes = (size_t)qm::shift_groups_per_brick(g) * rows2 * sizeof(uint2);
     QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(qm::shift_stream_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_bytes));

@@ -336,9 +336,17 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
     const int64_t rpw = shift_recs_per_wave(g, s.rows2, NW);
     for (int b = group; b < g.nbricks; b += a.ngroups) {
         if (!s.sfit[b]) continue;                     // direct kernel's job
+#ifdef QM_SHIFT_EXP_NOSTAGE                            // timing experiment (wrong results): the first
+                                                      // brick's windows for all, no barriers
+        if (b == group) {
+            stage_shift_windows<NW>(s, win, b, wave, lane, t_first);
+            __syncthreads();
+        }
+#else
         __syncthreads();                              // previous brick fully consumed
         stage_shift_windows<NW>(s, win, b, wave, lane, t_first);
         __syncthreads();
+#endif
         int x0, y0, z0, vx, vy, vz, cx, cy, cz;
         shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
         const int nvg = cx * cy * cz;
