@@ -107,12 +107,21 @@ int qm_engine_synchronize(qm_engine *e);
  * is within 6.7e-7 relative of it by a deterministic bound whose preconditions are checked per
  * step on the device; a step that fails one is redone in float64), "screen_pairs" /
  * "screen_big" (sweep launch shape, 0 / -1 = automatic), "exact" (default 1: the
- * exact-row-count float64 kernel), "pair" (default 1: the 16-byte-operand kernel for
- * volume-writing launches; 2 = for every launch, 0 = off), "rounds" (grid size of the automatic
+ * exact-row-count float64 kernel), "shift" (default -1: the fused detect and volume-writing
+ * launches of whole 256-sample tiles run the shift-reuse kernel, qm_shift.hpp -- 2x2x2 node groups
+ * stacked from register windows, 0.56 LDS operands per add at C3 -- where the table qualifies: up
+ * to ~32 rows, every group's delay spread within 20 samples for >= 99.5 % of the bricks, no grid
+ * dimension of 1; 0 = never, i.e. the round-2 kernels; 1 = as -1, also on grids one node thick),
+ * "shift_waves" (0 / 4 = two 4-wave workgroups per CU; 12 = one 12-wave workgroup with the
+ * wavefronts' running state in LDS: same bits, measured no faster),
+ * "pair" (default 1: the 16-byte-operand kernel for volume-writing launches the shift-reuse
+ * kernel does not take; 2 = for every launch, 0 = off), "rounds" (grid size of the automatic
  * group count), "scan_waves" (find_max_coa of a volume: wavefronts per CU over the whole grid).
  * qm_engine_get additionally reports "screened_steps", "fallback_steps" (steps redone in
  * float64 on the device: too many candidate cells -- flat all-ties data --, non-finite onsets,
- * a dynamic range outside the bound's preconditions), "last_candidates". */
+ * a dynamic range outside the bound's preconditions), "last_candidates", and of the shift-reuse
+ * layout once built: "shift_ok", "shift_brick_nodes", "shift_wide_bricks" (bricks left to the direct
+ * kernel), "shift_operands_per_add_x1000"; "last_kernel" = 3 when the last launch used it. */
 int qm_engine_config(qm_engine *e, const char *key, int64_t value);
 int qm_engine_get(qm_engine *e, const char *key, int64_t *value);
 
