@@ -43,22 +43,27 @@ PLANE2 = 40896           # plane A -> plane B, bytes (two 4-wave workgroups per 
                          # keeps the staging stores conflict-free
 PLANE3 = 51136           # the same for the 12-wave workgroup (one per CU: 100 KB of windows + 60 KB of
                          # per-wavefront running state)
+PLANE8 = 81856           # ... for the 8-wave workgroup that owns a CU's whole LDS (tables of 33-64 rows):
+                         # beyond the 16-bit offset of a DS instruction, so plane B gets its own
+                         # address register ("far plane")
 STATE_CHUNK = 1024       # running state in LDS: 5 chunks of 64 lanes x 16 bytes per wavefront
 
 
-def configure(lds_state):
-    """Register plan.  lds_state = False: the wavefront's running (max, sum, index) are inline-asm
+def configure(lds_state, far=False):
+    """Register plan.  far: plane B is addressed through a second register (see PLANE8).  lds_state = False: the wavefront's running (max, sum, index) are inline-asm
     operands (20 VGPRs the compiler places below VB).  True: they live in LDS and are read and
     written by the group merge, the per-node temporaries move into window 1 -- 167 VGPRs in all,
     three wavefronts per SIMD."""
-    global LDS_STATE, PLANE, VB, ACC, WIN, VADDR, VNODE, VC, VPF, VZERO, VEND
+    global LDS_STATE, FAR, PLANE, VB, ACC, WIN, VADDR, VADDRB, VNODE, VC, VPF, VZERO, VEND
     global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR
     LDS_STATE = lds_state
-    PLANE = PLANE3 if lds_state else PLANE2
+    FAR = far
+    PLANE = PLANE3 if lds_state else PLANE8 if far else PLANE2
     VB = 4 if lds_state else int(os.environ.get("QM_SHIFT_VB", "32"))    # first hard VGPR
     ACC = VB                 # acc[g][k] = v[ACC + 8 g + 2 k : +1]
     WIN = [ACC + 64, ACC + 64 + 2 * WMAX]
     VADDR = WIN[1] + 2 * WMAX
+    VADDRB = VADDR + 1 if far else VADDR     # plane B's address register (far plane only)
     # epilogue temporaries live in window 1 (free between a group's last row and the next group's
     # row 1)
     F = WIN[1]
@@ -71,15 +76,15 @@ def configure(lds_state):
     if lds_state:
         VNODE = WIN[1] + 45
         VC = WIN[1] + 46     # leading polynomial coefficient (pair), re-made per epilogue
-        VPF = VADDR + 1      # L2 prefetch of the stream: dummy destination, zero offset
+        VPF = VADDRB + 1     # L2 prefetch of the stream: dummy destination, zero offset
         assert VC + 2 <= WIN[1] + 2 * WMAX
         # at the merge F / P / TT are dead: the state read from LDS lands there
         MAXR = [v2(F + 2 * k) for k in range(4)]
         SUMR = [v2(GSUM + 2 * k) for k in range(4)]
         IDXR = [f"v{TT + k}" for k in range(4)]
     else:
-        VNODE = VADDR + 1
-        VC = VNODE + 1
+        VNODE = VADDRB + 1
+        VC = (VNODE + 2) & ~1    # (64-bit register tuples are even-aligned on gfx90a+)
         VPF = VC + 2
         assert KI + 1 <= WIN[1] + 2 * WMAX
         MAXR = [f"%[max{k}]" for k in range(4)]
@@ -128,13 +133,20 @@ class Emitter:
 
 
 def quad_reads(win, m):
+    plane_b = f"v{VADDRB} offset:{16 * m}" if FAR else f"v{VADDR} offset:{PLANE + 16 * m}"
     return [f"ds_read_b128 v[{win + 8 * m}:{win + 8 * m + 3}], v{VADDR} offset:{16 * m}",
-            f"ds_read_b128 v[{win + 8 * m + 4}:{win + 8 * m + 7}], v{VADDR} offset:{PLANE + 16 * m}"]
+            f"ds_read_b128 v[{win + 8 * m + 4}:{win + 8 * m + 7}], {plane_b}"]
+
+
+def window_address(e, hdr):
+    e(f"v_add_u32 v{VADDR}, s{hdr}, %[lane]")          # src0 scalar: untouched by SRC0-relative mode
+    if FAR:
+        e(f"v_add_u32 v{VADDRB}, s{hdr}, %[laneb]")
 
 
 def issue_window(e, q, hdr):
     """block form (prologue only): reads of the row whose header is s[hdr], s[hdr+1] into WIN[q]"""
-    e(f"v_add_u32 v{VADDR}, s{hdr}, %[lane]")          # src0 scalar: untouched by SRC0-relative mode
+    window_address(e, hdr)
     for m in range(NQMIN):
         for line in quad_reads(WIN[q], m):
             e(line)
@@ -175,7 +187,7 @@ def row_iter(e, p, first):
     if "interleave" in EXP:
         # experiment: one body per quad count, the next row's reads dealt two per node behind the
         # first nodes' adds (all issued by the row's middle)
-        e(f"v_add_u32 v{VADDR}, s{hdr}, %[lane]")
+        window_address(e, hdr)
         end = e.label("ri")
         labels = {nq: e.label(f"q{nq}_") for nq in range(NQMIN + 1, NQMAX + 1)}
         for nq in range(NQMAX, NQMIN, -1):
@@ -377,24 +389,28 @@ def main():
     print(f"constexpr int kShiftNqMin = {NQMIN};          // quads fetched unconditionally")
     print(f"constexpr int kShiftPlane = {PLANE2};        // bytes from plane A to plane B (4-wave workgroups)")
     print(f"constexpr int kShiftPlane3 = {PLANE3};       // ... of the 12-wave workgroup")
+    print(f"constexpr int kShiftPlane8 = {PLANE8};       // ... of the 8-wave workgroup (33-64 rows)")
     print(f"constexpr int kShiftStateChunk = {STATE_CHUNK};   // LDS running state: 5 chunks per wavefront")
     print(f"constexpr int kShiftRec = {REC};            // bytes per stream record")
-    for degree, volume, lds_state, name in ((8, False, False, "shift_groups_detect"),
-                                            (10, True, False, "shift_groups_volume"),
-                                            (8, False, True, "shift_groups_detect3")):
-        configure(lds_state)
+    for degree, volume, lds_state, far, name in ((8, False, False, False, "shift_groups_detect"),
+                                                 (10, True, False, False, "shift_groups_volume"),
+                                                 (8, False, True, False, "shift_groups_detect3"),
+                                                 (8, False, False, True, "shift_groups_detect8")):
+        configure(lds_state, far)
         lines = body(degree, volume)
         # the stream pointer lives in a hard SGPR pair (the halves of an s[lo:hi] operand cannot be
         # named in inline asm): it is handed over as two 32-bit scalars
         text = "\\n\\t".join(lines)
         print()
         print(f"// degree-{degree} 2^f{', values stored' if volume else ''}"
-              f"{', running state in LDS' if lds_state else ''}; window of up to {WMAX} doubles; "
+              f"{', running state in LDS' if lds_state else ''}{', far plane' if far else ''}; "
+              f"window of up to {WMAX} doubles; "
               f"hard VGPRs v{VB}..v{VEND - 1}, SGPRs s{SB}..s{SEND - 1}")
         print(f"__device__ __forceinline__ void {name}("
               + ("" if lds_state else "double (&vmax)[4], double (&vsum)[4], int (&vidx)[4],"))
         print("        const void *stream, int ngroups, int npairs, unsigned lane_addr, "
-              + ("unsigned state_addr, " if lds_state else "") + "int nz, "
+              + ("unsigned state_addr, " if lds_state else "")
+              + ("unsigned lane_addr_b, " if far else "") + "int nz, "
               f"int nynz, double scale, const double (&c)[{degree + 1}]"
               + (", double *vol_tile, unsigned vol_stride_bytes, unsigned lane_bytes" if volume else "")
               + ") {")
@@ -416,6 +432,8 @@ def main():
                '[clo] "s"(clo)', '[chi] "s"(chi)']
         if lds_state:
             ins += ['[state] "v"(state_addr)']
+        if far:
+            ins += ['[laneb] "v"(lane_addr_b)']
         if volume:
             ins += ['[vlo] "s"(vlo)', '[vhi] "s"(vhi)', '[vstride] "s"(vol_stride_bytes)',
                     '[voff] "v"(lane_bytes)']

@@ -460,18 +460,31 @@ int ensure_shift_tables(qm_engine *e) {
     // a grid one node thick has half-empty 2x2x2 groups everywhere (e.g. the flat 1 x 1 x N view
     // of the reference-signature migrate): leave it to the other kernels unless asked explicitly
     if (e->cfg_shift < 0 && (e->g.nx < 2 || e->g.ny < 2 || e->g.nz < 2)) return 0;
-    // workgroup shape: 12 waves (one workgroup per CU, three wavefronts per SIMD, running state in
-    // LDS) wants bricks whose 2x2x2 groups deal evenly over 12 wavefronts
-    const int nw = e->cfg_shift_waves == qm::kShiftWaves3 ? qm::kShiftWaves3 : qm::kShiftWaves;
+    // Workgroup shape (qm_shift.hpp): two 4-wave workgroups per CU up to ~32 rows; beyond, ONE 8-wave
+    // workgroup with all 160 KB (smaller bricks, 33-64 rows); 12 waves only on request.  Bricks are
+    // shaped so that their 2x2x2 groups deal evenly over the wavefronts.
     static const int kShapes4[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4}, {2, 4, 4}};
+    static const int kShapes8[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4}, {4, 4, 4}};
     static const int kShapes12[][3] = {{8, 8, 12}, {8, 8, 6}, {4, 8, 6}, {4, 4, 6}, {2, 4, 6}};
-    const int (*kShapes)[3] = nw == qm::kShiftWaves3 ? kShapes12 : kShapes4;
+    int candidates[2] = {qm::kShiftWaves, qm::kShiftWaves8};
+    int n_candidates = 2;
+    if (e->cfg_shift_waves != 0) {
+        candidates[0] = e->cfg_shift_waves;
+        n_candidates = 1;
+    } else if (S > 40) {                               // (80 KB cannot hold that many row windows)
+        candidates[0] = qm::kShiftWaves8;
+        n_candidates = 1;
+    }
     const bool fixed = e->cfg_bx > 0;
     const int n_shapes = fixed ? 1 : 5;
+    int nw = candidates[0];
     qm::GridDesc g = e->g;
     std::vector<int32_t> fit, wide;
     bool ok = false;
     auto even_up = [](int v) { return v + (v & 1); };
+    for (int cand = 0; cand < n_candidates && !ok; ++cand) {
+    nw = candidates[cand];
+    const int (*kShapes)[3] = nw == qm::kShiftWaves3 ? kShapes12 : nw == qm::kShiftWaves8 ? kShapes8 : kShapes4;
     for (int s = 0; s < n_shapes; ++s) {
         g = e->g;
         g.bx = std::min(even_up(fixed ? e->cfg_bx : kShapes[s][0]), even_up(g.nx));
@@ -509,6 +522,7 @@ int ensure_shift_tables(qm_engine *e) {
             if (!fit[b]) wide.push_back(b);
         ok = fixed ? (int)wide.size() < g.nbricks : (int64_t)wide.size() * 200 <= g.nbricks;
         if (ok) break;
+    }
     }
     if (!ok) return 0;                                   // an incoherent table: the other kernels
     const int rows2 = S + (S & 1);
@@ -564,11 +578,11 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         s.stream = reinterpret_cast<const char *>(e->d_shstream.p);
         s.rows2 = e->shift_rows2;
         s.nw = e->shift_nw;
-        const bool big = e->shift_nw == qm::kShiftWaves3;
         const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, e->shift_nw * qm::kWave,
-                                                  big ? qm::kShiftLdsBytes3 : qm::kShiftLdsBytes);
+                                                  qm::shift_lds_bytes(e->shift_nw));
         if (volume) QM_TABLE(qm::launch_shift_volume(s, shape));
-        else if (big) QM_TABLE(qm::launch_shift_detect3(s, shape));
+        else if (e->shift_nw == qm::kShiftWaves3) QM_TABLE(qm::launch_shift_detect3(s, shape));
+        else if (e->shift_nw == qm::kShiftWaves8) QM_TABLE(qm::launch_shift_detect8(s, shape));
         else QM_TABLE(qm::launch_shift_detect(s, shape));
         e->last_kernel = 3;
         e->last_j = 4;
@@ -652,8 +666,8 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
                               volume != nullptr, vol_stride);
     if (shift) {
         if (ensure_shift_tables(e)) return 1;
-        // (the 12-wave shape is built for the fused detect only)
-        shift = e->shift_ok && !(volume != nullptr && e->shift_nw == qm::kShiftWaves3);
+        // (the 8- and 12-wave shapes are built for the fused detect only)
+        shift = e->shift_ok && !(volume != nullptr && e->shift_nw != qm::kShiftWaves);
     }
     if (shift) {
         jp = 0;
@@ -679,7 +693,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     const bool use_lds = !e->cfg_force_direct && n_wide_now < nbricks_now;
     const int threads = shift ? 512 : jp > 0 ? 1024 : e->cfg_waves * qm::kWave;   // (direct launch)
     const int lds_blocks_per_cu =
-        shift ? (e->shift_nw == qm::kShiftWaves3 ? 1 : 2) : jp > 0 ? 1
+        shift ? (e->shift_nw == qm::kShiftWaves ? 2 : 1) : jp > 0 ? 1
                : std::max(1, std::min(160 * 1024 / std::max(1, e->cfg_lds_bytes), 2048 / threads));
     int groups_lds = 0, groups_direct = 0;
     if (use_lds)
@@ -1284,8 +1298,8 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
         if (v < -1 || v > 1) return fail("shift must be -1 (automatic), 0 (off) or 1");
         e->cfg_shift = (int)v;
     } else if (k == "shift_waves") {
-        if (v != 0 && v != qm::kShiftWaves && v != qm::kShiftWaves3)
-            return fail("shift_waves must be 0 (automatic), 4 or 12");
+        if (v != 0 && v != qm::kShiftWaves && v != qm::kShiftWaves8 && v != qm::kShiftWaves3)
+            return fail("shift_waves must be 0 (automatic), 4, 8 or 12");
         e->cfg_shift_waves = (int)v;
         e->shift_built = false;
     } else if (k == "screen") {

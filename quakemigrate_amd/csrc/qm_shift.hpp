@@ -30,17 +30,27 @@ namespace qm {
 #endif
 #include QM_SHIFT_ASM_INC
 
-// Two workgroup shapes: two 4-wave workgroups per CU with 80 KB each (running state in registers,
-// two wavefronts per SIMD), or ONE 12-wave workgroup per CU (three per SIMD: the running state of
-// every wavefront lives in LDS behind the windows so that the loop fits 168 VGPRs).
+// Three workgroup shapes: two 4-wave workgroups per CU with 80 KB each (tables of up to ~32 rows;
+// running state in registers, two wavefronts per SIMD); ONE 8-wave workgroup that owns all 160 KB
+// (33-64 rows: twice the rows' windows; plane B lies beyond a DS instruction's 16-bit offset and
+// gets its own address register); or ONE 12-wave workgroup per CU (opt-in: three per SIMD, the
+// running state of every wavefront in LDS behind the windows so that the loop fits 168 VGPRs).
 constexpr int kShiftWaves = 4;                          // wavefronts per workgroup (default shape)
+constexpr int kShiftWaves8 = 8;
 constexpr int kShiftWaves3 = 12;
 constexpr int kShiftKT = 256;                           // samples per time tile
 constexpr int kShiftLdsBytes = 2 * kShiftPlane;         // both planes
 constexpr int kShiftStateBytes = 5 * kShiftStateChunk;  // per wavefront (12-wave shape)
 constexpr int kShiftLdsBytes3 = 2 * kShiftPlane3 + kShiftWaves3 * kShiftStateBytes;
 static_assert(kShiftLdsBytes3 <= 160 * 1024, "the 12-wave workgroup's LDS exceeds a CU's");
-__host__ __device__ constexpr int shift_plane(int nw) { return nw == kShiftWaves3 ? kShiftPlane3 : kShiftPlane; }
+constexpr int kShiftLdsBytes8 = 2 * kShiftPlane8;
+static_assert(kShiftLdsBytes8 <= 160 * 1024, "the 8-wave workgroup's LDS exceeds a CU's");
+__host__ __device__ constexpr int shift_plane(int nw) {
+    return nw == kShiftWaves3 ? kShiftPlane3 : nw == kShiftWaves8 ? kShiftPlane8 : kShiftPlane;
+}
+__host__ __device__ constexpr int shift_lds_bytes(int nw) {
+    return nw == kShiftWaves3 ? kShiftLdsBytes3 : nw == kShiftWaves8 ? kShiftLdsBytes8 : kShiftLdsBytes;
+}
 constexpr int kShiftMaxRows = 64;                       // table rows the stream builder handles
 static_assert(QM_EXP2_DEGREE_SUM == 8 && QM_EXP2_DEGREE_VOLUME == 10,
               "the generated loops carry the degree-8 (detect) and degree-10 (stored values) 2^f");
@@ -68,6 +78,7 @@ struct LaunchShape;
 hipError_t launch_shift_detect(const ShiftArgs &a, const LaunchShape &s);   // qm_launch_shift.hip
 hipError_t launch_shift_volume(const ShiftArgs &a, const LaunchShape &s);
 hipError_t launch_shift_detect3(const ShiftArgs &a, const LaunchShape &s);  // the 12-wave shape
+hipError_t launch_shift_detect8(const ShiftArgs &a, const LaunchShape &s);  // the 8-wave shape
 
 // valid 2x2x2 groups of a brick form a box [0,cx) x [0,cy) x [0,cz) in group coordinates
 __device__ __forceinline__ void shift_group_box(const GridDesc &g, int b, int &x0, int &y0, int &z0,
@@ -235,7 +246,7 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
     // samples) are issued before the first LDS store, so the brick's staging costs one round trip
     // to L2 instead of one per row (while a workgroup stages, its SIMDs' other wavefronts run at
     // half rate: a wavefront alone issues one float64 instruction per 8 cycles).
-    constexpr int RB = NW == kShiftWaves ? 8 : 3;                  // rows per wavefront and pass
+    constexpr int RB = NW == kShiftWaves3 ? 3 : 8;                 // rows per wavefront and pass
     constexpr int U = 6;                                           // 64-sample chunks per row and pass
     constexpr int kPlane = shift_plane(NW);
     for (int r0 = wave; r0 < S; r0 += NW * RB) {
@@ -289,7 +300,8 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
 // shorter than a tile stay with the other kernels)
 template <bool VOLUME, int NW>
 __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_shift_kernel(ShiftArgs s) {
-    static_assert(NW == kShiftWaves || (NW == kShiftWaves3 && !VOLUME), "workgroup shapes: 4 waves, or 12 (detect)");
+    static_assert(NW == kShiftWaves || ((NW == kShiftWaves3 || NW == kShiftWaves8) && !VOLUME),
+                  "workgroup shapes: 4 waves, or 8 / 12 (detect only)");
     constexpr bool kLdsState = NW == kShiftWaves3;
     extern __shared__ __attribute__((aligned(16))) double win[];
     const StackArgs &a = s.a;
@@ -356,6 +368,10 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
             if constexpr (kLdsState)
                 shift_groups_detect3(run, mine, s.rows2 / 2, lane_addr, state_addr, g.nz,
                                      g.ny * g.nz, a.z_scale, c);
+            else if constexpr (NW == kShiftWaves8)
+                shift_groups_detect8(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr,
+                                     lane_addr + (unsigned)kShiftPlane8, g.nz, g.ny * g.nz,
+                                     a.z_scale, c);
             else if constexpr (VOLUME)
                 shift_groups_volume(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr, g.nz,
                                     g.ny * g.nz, a.z_scale, c, a.volume + t_first,

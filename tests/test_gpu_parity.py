@@ -1607,6 +1607,9 @@ SHIFT_SHAPES = [  # recipe, grid, rows, scanned samples
     ("C1", (23, 20, 19), 24, 625),       # the Icequake geometry's spacing / rates
     ("C3", (3, 2, 70), 31, 700),         # a grid thinner than a brick in two axes
     ("C3", (25, 24, 10), 32, 450),       # 32 rows: about the widest table whose windows fit 80 KB
+    ("C3", (25, 24, 10), 36, 450),       # ... beyond: one 8-wave workgroup per CU with all 160 KB
+    ("C4", (33, 26, 18), 47, 513),       # (plane B through its own address register)
+    ("C4", (20, 21, 22), 64, 300),       # the widest table the shift-reuse kernel takes
 ]
 
 

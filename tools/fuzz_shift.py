@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential campaign for the shift-reuse kernel (development aid).
 
-Random grids (every dimension >= 2), 1-34 rows, 192-900 scanned samples, coherent tables of random
+Random grids (every dimension >= 2), 1-64 rows (both workgroup shapes), 192-900 scanned samples, coherent tables of random
 steepness (so that some trials put bricks on the direct kernel and some tables do not qualify at
 all), quantised onsets in half of the trials (exact ties), negative delays, random `available` and
 group counts: the automatic engine against Engine(shift=0) (maxima bit for bit, indices) and the
@@ -23,7 +23,7 @@ for trial in range(trials):
     grid = tuple(int(v) for v in rng.integers(2, 34, size=3))
     if np.prod(grid) > 12000:
         grid = (grid[0], grid[1], max(2, 12000 // (grid[0] * grid[1])))
-    S = int(rng.integers(1, 35))
+    S = int(rng.integers(1, 65))
     ns = int(rng.integers(192, 900))
     fsmp, lsmp = int(rng.integers(0, 30)), int(rng.integers(30, 160))
     # coherent table: distance-like delays from random "stations", steepness up to ~7 samples per node, a fifth of the rows up to 30

@@ -11,7 +11,9 @@ bad = 0
 cases = [("C2", dict(grid=(26, 25, 14), n_samples=700)), ("C2", dict(grid=(17, 9, 11), n_samples=300, rows=7)),
          ("C3", dict(grid=(40, 33, 21), n_samples=1000)), ("C1", dict(grid=(23, 20, 19), n_samples=625)),
          ("C3", dict(grid=(16, 16, 16), n_samples=256, rows=1)), ("C3", dict(grid=(33, 18, 9), n_samples=513, rows=31)),
-         ("C4", dict(grid=(24, 24, 16), n_samples=900, rows=60)), ("C2", dict(grid=(5, 3, 2), n_samples=260, rows=4))]
+         ("C4", dict(grid=(24, 24, 16), n_samples=900, rows=60)), ("C2", dict(grid=(5, 3, 2), n_samples=260, rows=4)),
+         ("C4", dict(grid=(33, 26, 18), n_samples=513, rows=47)), ("C4", dict(grid=(20, 21, 22), n_samples=300, rows=64)),
+         ("C3", dict(grid=(18, 17, 16), n_samples=400, rows=33))]
 for name, kw in cases:
     case = synth.make_case(name, step=0, **kw)
     lon = np.log(np.clip(case.onsets, 0.01, np.inf))
