@@ -179,7 +179,7 @@ def stack_kernel_name(eng, S, volume=False):
     kind, j = eng.get("last_kernel"), eng.get("last_kernel_j")
     v = "true" if volume else "false"
     if kind == 3:
-        return f"void qm::stack_shift_kernel<{v}>"
+        return f"void qm::stack_shift_kernel<{v}, {eng.get('shift_waves')}>"
     if kind == 2:
         return f"qm::stack_pair_kernel<{j // 2}, {v}, {S}>"
     if kind == 1:

@@ -395,7 +395,8 @@ def main():
     for degree, volume, lds_state, far, name in ((8, False, False, False, "shift_groups_detect"),
                                                  (10, True, False, False, "shift_groups_volume"),
                                                  (8, False, True, False, "shift_groups_detect3"),
-                                                 (8, False, False, True, "shift_groups_detect8")):
+                                                 (8, False, False, True, "shift_groups_detect8"),
+                                                 (10, True, False, True, "shift_groups_volume8")):
         configure(lds_state, far)
         lines = body(degree, volume)
         # the stream pointer lives in a hard SGPR pair (the halves of an s[lo:hi] operand cannot be

@@ -580,7 +580,8 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         s.nw = e->shift_nw;
         const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, e->shift_nw * qm::kWave,
                                                   qm::shift_lds_bytes(e->shift_nw));
-        if (volume) QM_TABLE(qm::launch_shift_volume(s, shape));
+        if (volume && e->shift_nw == qm::kShiftWaves8) QM_TABLE(qm::launch_shift_volume8(s, shape));
+        else if (volume) QM_TABLE(qm::launch_shift_volume(s, shape));
         else if (e->shift_nw == qm::kShiftWaves3) QM_TABLE(qm::launch_shift_detect3(s, shape));
         else if (e->shift_nw == qm::kShiftWaves8) QM_TABLE(qm::launch_shift_detect8(s, shape));
         else QM_TABLE(qm::launch_shift_detect(s, shape));
@@ -666,8 +667,8 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
                               volume != nullptr, vol_stride);
     if (shift) {
         if (ensure_shift_tables(e)) return 1;
-        // (the 8- and 12-wave shapes are built for the fused detect only)
-        shift = e->shift_ok && !(volume != nullptr && e->shift_nw != qm::kShiftWaves);
+        // (the 12-wave shape is built for the fused detect only)
+        shift = e->shift_ok && !(volume != nullptr && e->shift_nw == qm::kShiftWaves3);
     }
     if (shift) {
         jp = 0;

@@ -79,6 +79,7 @@ hipError_t launch_shift_detect(const ShiftArgs &a, const LaunchShape &s);   // q
 hipError_t launch_shift_volume(const ShiftArgs &a, const LaunchShape &s);
 hipError_t launch_shift_detect3(const ShiftArgs &a, const LaunchShape &s);  // the 12-wave shape
 hipError_t launch_shift_detect8(const ShiftArgs &a, const LaunchShape &s);  // the 8-wave shape
+hipError_t launch_shift_volume8(const ShiftArgs &a, const LaunchShape &s);
 
 // valid 2x2x2 groups of a brick form a box [0,cx) x [0,cy) x [0,cz) in group coordinates
 __device__ __forceinline__ void shift_group_box(const GridDesc &g, int b, int &x0, int &y0, int &z0,
@@ -300,8 +301,8 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
 // shorter than a tile stay with the other kernels)
 template <bool VOLUME, int NW>
 __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_shift_kernel(ShiftArgs s) {
-    static_assert(NW == kShiftWaves || ((NW == kShiftWaves3 || NW == kShiftWaves8) && !VOLUME),
-                  "workgroup shapes: 4 waves, or 8 / 12 (detect only)");
+    static_assert(NW == kShiftWaves || NW == kShiftWaves8 || (NW == kShiftWaves3 && !VOLUME),
+                  "workgroup shapes: 4 or 8 waves, or 12 (detect only)");
     constexpr bool kLdsState = NW == kShiftWaves3;
     extern __shared__ __attribute__((aligned(16))) double win[];
     const StackArgs &a = s.a;
@@ -368,6 +369,11 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
             if constexpr (kLdsState)
                 shift_groups_detect3(run, mine, s.rows2 / 2, lane_addr, state_addr, g.nz,
                                      g.ny * g.nz, a.z_scale, c);
+            else if constexpr (NW == kShiftWaves8 && VOLUME)
+                shift_groups_volume8(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr,
+                                     lane_addr + (unsigned)kShiftPlane8, g.nz, g.ny * g.nz,
+                                     a.z_scale, c, a.volume + t_first,
+                                     (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u);
             else if constexpr (NW == kShiftWaves8)
                 shift_groups_detect8(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr,
                                      lane_addr + (unsigned)kShiftPlane8, g.nz, g.ny * g.nz,

@@ -1629,6 +1629,35 @@ def test_shift_kernel_equals_round2_kernels_and_oracle(lib, oracle, recipe, grid
     np.testing.assert_allclose(r["shift"][1], r["round2"][1], rtol=NORM)
 
 
+@pytest.mark.parametrize("recipe,grid,rows,ns", [SHIFT_SHAPES[0], SHIFT_SHAPES[1], SHIFT_SHAPES[4],
+                                                 SHIFT_SHAPES[9], SHIFT_SHAPES[10]])
+def test_shift_kernel_volume_variant_both_workgroup_shapes(lib, oracle, recipe, grid, rows, ns):
+    """The volume-writing variant (4-wave shape up to ~32 rows, 8-wave shape for 33-64): every
+    element of the 4-D map against the oracle's, the same bits as the round-2 volume kernels, and
+    the series that comes with it (ragged last tile pulled back: overlapping stores agree)."""
+    case = synth.make_case(recipe, step=1, grid=grid, rows=rows, n_samples=ns)
+    lon = oracle.log_onsets(case.onsets)
+    want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
+                         threads=4)
+    ref = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
+                           threads=4)
+    vols = {}
+    for tag, extra in (("shift", {}), ("round2", {"shift": 0})):
+        eng = lib.Engine(0, **extra)
+        eng.load_lut(case.traveltimes)
+        vol = np.full((case.n_nodes_total, ns), np.nan)
+        series = (np.full(ns, np.nan), np.full(ns, np.nan), np.full(ns, -1, dtype=np.int64))
+        eng.migrate(lon, case.fsmp, case.lsmp, case.available, vol, scan_out=series)
+        assert (eng.get("last_kernel") == 3) == (tag == "shift"), (tag, eng.get("last_kernel"))
+        if tag == "shift":
+            assert eng.get("shift_waves") == (4 if rows <= 32 else 8)
+        _assert_series(series, want)
+        np.testing.assert_allclose(vol, ref.reshape(vol.shape), rtol=TIGHT)
+        vols[tag] = vol
+        eng.close()
+    assert np.array_equal(vols["shift"], vols["round2"])
+
+
 @pytest.mark.parametrize("recipe,grid,rows,ns", [SHIFT_SHAPES[0], SHIFT_SHAPES[2], SHIFT_SHAPES[5]])
 def test_shift_kernel_twelve_wave_shape_gives_the_same_bits(lib, oracle, recipe, grid, rows, ns):
     """Engine(shift_waves=12): one 12-wave workgroup per CU, three wavefronts per SIMD, the

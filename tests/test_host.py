@@ -433,6 +433,7 @@ def test_headline_kernels_stay_in_registers(tmp_path):
                      "template __global__ void qm::stack_shift_kernel<false, 4>(qm::ShiftArgs);\n"
                      "template __global__ void qm::stack_shift_kernel<true, 4>(qm::ShiftArgs);\n"
                      "template __global__ void qm::stack_shift_kernel<false, 8>(qm::ShiftArgs);\n"
+                     "template __global__ void qm::stack_shift_kernel<true, 8>(qm::ShiftArgs);\n"
                      "template __global__ void qm::stack_shift_kernel<false, 12>(qm::ShiftArgs);\n")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17",
                            f"-I{ROOT / 'quakemigrate_amd' / 'csrc'}", "-c", str(shift), "-o",
@@ -440,7 +441,7 @@ def test_headline_kernels_stay_in_registers(tmp_path):
                           stderr=subprocess.DEVNULL)
     sasm = next(tmp_path.glob("s-hip-amdgcn-*.s")).read_text()
     found = re.findall(r"\.set (\S*stack_shift_kernel\S*)\.num_vgpr, (\d+)", sasm)
-    assert len(found) == 4, found
+    assert len(found) == 5, found
     for name, vgprs in found:
         if "Li12E" in name:                                # the opt-in 12-wave shape: three per SIMD
             assert int(vgprs) <= 168, (name, vgprs)
