@@ -110,11 +110,14 @@ int qm_engine_synchronize(qm_engine *e);
  * exact-row-count float64 kernel), "shift" (default -1: the fused detect and volume-writing
  * launches of whole 256-sample tiles run the shift-reuse kernel, qm_shift.hpp -- 2x2x2 node groups
  * stacked from register windows, 0.56 LDS operands per add at C3 -- where the table qualifies: up
- * to 64 rows (volume-writing: ~32), every group's delay spread within 20 samples for >= 99.5 % of
+ * to 64 rows, every group's delay spread within 20 samples for >= 99.5 % of
  * the bricks, no grid dimension of 1; 0 = never, i.e. the round-2 kernels; 1 = as -1, also on grids
  * one node thick), "shift_waves" (0 = automatic: two 4-wave workgroups per CU up to ~32 rows, one
  * 8-wave workgroup with all 160 KB beyond; 4 / 8 force one; 12 = one 12-wave workgroup with the
- * wavefronts' running state in LDS: same bits, measured no faster),
+ * wavefronts' running state in LDS: same bits, measured no faster), "shift_lazy" (default -1: the
+ * detect loop keeps only the group maximum per node and recovers the arg-max where a group
+ * reaches the wavefront's running maximum, when a wavefront sees >= 160 groups per launch -- same
+ * bits, -2 % at C3; 0 / 1 force the eager / lazy flavour; read back = what the last launch took),
  * "pair" (default 1: the 16-byte-operand kernel for volume-writing launches the shift-reuse
  * kernel does not take; 2 = for every launch, 0 = off), "rounds" (grid size of the automatic
  * group count), "scan_waves" (find_max_coa of a volume: wavefronts per CU over the whole grid).

@@ -49,14 +49,15 @@ PLANE8 = 81856           # ... for the 8-wave workgroup that owns a CU's whole L
 STATE_CHUNK = 1024       # running state in LDS: 5 chunks of 64 lanes x 16 bytes per wavefront
 
 
-def configure(lds_state, far=False):
+def configure(lds_state, far=False, lazy=False):
     """Register plan.  far: plane B is addressed through a second register (see PLANE8).  lds_state = False: the wavefront's running (max, sum, index) are inline-asm
     operands (20 VGPRs the compiler places below VB).  True: they live in LDS and are read and
     written by the group merge, the per-node temporaries move into window 1 -- 167 VGPRs in all,
     three wavefronts per SIMD."""
     global LDS_STATE, FAR, PLANE, VB, ACC, WIN, VADDR, VADDRB, VNODE, VC, VPF, VZERO, VEND
-    global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR
+    global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR, LAZY
     LDS_STATE = lds_state
+    LAZY = lazy
     FAR = far
     PLANE = PLANE3 if lds_state else PLANE8 if far else PLANE2
     VB = 4 if lds_state else int(os.environ.get("QM_SHIFT_VB", "32"))    # first hard VGPR
@@ -220,7 +221,7 @@ def row_iter(e, p, first):
             e(f"s_addc_u32 s{SPF + 1}, s{SPF + 1}, 0")
 
 
-def epilogue_node(e, degree, volume, g, opens_group):
+def node_index(e, g, to_vgpr=True):
     # flat index of node g: base + dx*ny*nz + dy*nz + dz (g = 4 dx + 2 dy + dz)
     e(f"s_mov_b32 s{SNODE}, s{SBASE}")
     if g & 4:
@@ -229,7 +230,20 @@ def epilogue_node(e, degree, volume, g, opens_group):
         e(f"s_add_u32 s{SNODE}, s{SNODE}, %[nz]")
     if g & 1:
         e(f"s_add_u32 s{SNODE}, s{SNODE}, 1")
-    e(f"v_mov_b32 v{VNODE}, s{SNODE}")
+    if to_vgpr:
+        e(f"v_mov_b32 v{VNODE}, s{SNODE}")
+
+
+def epilogue_node(e, degree, volume, g, opens_group):
+    """LAZY flavour: only the group's maximum is kept per node (v_max_f64); WHICH node holds it is
+    recovered after the eight nodes, per sample slot, and only where the group's maximum reaches
+    the wavefront's running one (epilogue) -- one instead of three instructions per node-sample
+    for the arg-max where that is rare: a lane's running maximum changes about ln(n) times in n
+    groups, so the flavour pays for wavefronts that see hundreds of groups (C3: 549, -2 %) and
+    costs where they see a few dozen (C1: 48, +1 %); the kernel takes it from kShiftLazyGroups
+    on."""
+    if volume or not LAZY:
+        node_index(e, g, not LAZY)
     A = [ACC + 8 * g + 2 * k for k in range(4)]
     for k in range(4):                                          # z = stack * log2(e)/available
         e(f"v_mul_f64 {v2(A[k])}, {v2(A[k])}, %[scale]")
@@ -270,6 +284,13 @@ def epilogue_node(e, degree, volume, g, opens_group):
     if not (LDS_STATE and opens_group):
         for k in range(4):
             e(f"v_add_f64 {SUMR[k]}, {SUMR[k]}, {v2(P + 2 * k)}")
+    if LAZY:
+        if opens_group:
+            return                                             # node 1 takes max(z0, z1)
+        for k in range(4):
+            prev = v2(ACC + 2 * k) if opens_group is None else v2(GMAX + 2 * k)
+            e(f"v_max_f64 {v2(GMAX + 2 * k)}, {prev}, {v2(A[k])}")       # a NaN never wins
+        return
     for k in range(4):
         if opens_group:
             # the group's first node against the (-inf, none) start, without materialising it
@@ -296,25 +317,76 @@ def epilogue(e, degree, volume):
         e(f"v_mov_b32 v{VC + 1}, %[chi]")
     e(f"s_cmp_lg_u32 s{SMASK}, 0xff")
     e(f"s_cbranch_scc1 {partial}")
-    e(f"v_mov_b32 v{KI}, 0x7fffffff")                          # "no index" (a literal and vcc cannot
+    if not LAZY:
+        e(f"v_mov_b32 v{KI}, 0x7fffffff")                      # "no index" (a literal and vcc cannot
     for g in range(8):                                         # feed one instruction)
-        epilogue_node(e, degree, volume, g, g == 0)
+        epilogue_node(e, degree, volume, g, g == 0 if not LAZY else (True if g == 0 else None if g == 1 else False))
     e(f"s_branch {merge}")
     e(f"{partial}:")
     for k in range(4):
         e(f"v_mov_b32 v{GMAX + 2 * k}, 0")
         e(f"v_mov_b32 v{GMAX + 2 * k + 1}, 0xfff00000")        # -inf
-        e(f"v_mov_b32 v{GIDX + k}, 0x7fffffff")
+        if not LAZY:
+            e(f"v_mov_b32 v{GIDX + k}, 0x7fffffff")
         if LDS_STATE:
             e(f"v_mov_b32 v{GSUM + 2 * k}, 0")
             e(f"v_mov_b32 v{GSUM + 2 * k + 1}, 0")
     for g in range(8):
         skip = e.label("nd")
         e(f"s_bitcmp1_b32 s{SMASK}, {g}")
-        e(f"s_cbranch_scc0 {skip}")
+        if LAZY:
+            # a node outside the grid: NaN, so that it never equals the group's maximum below
+            inside = e.label("in")
+            e(f"s_cbranch_scc1 {inside}")
+            for k in range(4):
+                e(f"v_mov_b32 v{ACC + 8 * g + 2 * k + 1}, 0x7ff80000")
+            e(f"s_branch {skip}")
+            e(f"{inside}:")
+        else:
+            e(f"s_cbranch_scc0 {skip}")
         epilogue_node(e, degree, volume, g, False)
         e(f"{skip}:")
     e(f"{merge}:")
+    done = e.label("dn")
+    if LAZY:
+        # does any lane's group maximum reach its running maximum?  (>=: groups are not visited in
+        # ascending flat index, an equal value may have to hand over a lower index)
+        e(f"v_cmp_ge_f64 {s2(ST)}, {v2(GMAX)}, {MAXR[0]}")
+        for k in range(1, 4):
+            e(f"v_cmp_ge_f64 vcc, {v2(GMAX + 2 * k)}, {MAXR[k]}")
+            e(f"s_or_b64 {s2(ST)}, {s2(ST)}, vcc")
+        e(f"s_cmp_eq_u64 {s2(ST)}, 0")
+        e(f"s_cbranch_scc1 {done}")
+        # yes: the eight nodes' flat indices into the (dead) F registers, then per sample slot k
+        # that reached: the lowest node whose z equals the group's maximum (descending, so the
+        # lowest is written last; nodes outside the grid hold NaN); a maximum of -inf has no node
+        # (as the strict '>' from a (-inf, none) start); then the merge into the running pair:
+        # larger z, ties -> lower flat index
+        e(f"v_mov_b32 v{KI}, 0x7fffffff")                      # "no index"
+        for g in range(8):
+            node_index(e, g, False)
+            e(f"v_mov_b32 v{F + g}, s{SNODE}")
+        for k in range(4):
+            nxt = e.label("nk")
+            g_ = v2(GMAX + 2 * k)
+            e(f"v_cmp_ge_f64 vcc, {g_}, {MAXR[k]}")
+            e(f"s_cbranch_vccz {nxt}")
+            e(f"v_mov_b32 v{GIDX + k}, v{KI}")
+            for g in range(7, -1, -1):
+                e(f"v_cmp_eq_f64 vcc, {v2(ACC + 8 * g + 2 * k)}, {g_}")
+                e(f"v_cndmask_b32 v{GIDX + k}, v{GIDX + k}, v{F + g}, vcc")
+            e(f"v_cmp_gt_f64 vcc, {g_}, {s2(SNEGINF)}")
+            e(f"v_cndmask_b32 v{GIDX + k}, v{KI}, v{GIDX + k}, vcc")
+            e(f"v_cmp_gt_f64 {s2(ST)}, {g_}, {MAXR[k]}")
+            e(f"v_cmp_eq_f64 {s2(ST + 2)}, {g_}, {MAXR[k]}")
+            e(f"v_cmp_lt_i32 vcc, v{GIDX + k}, {IDXR[k]}")
+            e(f"s_and_b64 {s2(ST + 2)}, {s2(ST + 2)}, vcc")
+            e(f"s_or_b64 vcc, {s2(ST)}, {s2(ST + 2)}")
+            e(f"v_cndmask_b32 {IDXR[k]}, {IDXR[k]}, v{GIDX + k}, vcc")
+            e(f"v_max_f64 {MAXR[k]}, {MAXR[k]}, {g_}")
+            e(f"{nxt}:")
+        e(f"{done}:")
+        return
     # merge into the wave's running pair: larger z, ties -> lower flat index
     if LDS_STATE:
         # the wavefront's running state lives in LDS (5 chunks of 64 lanes x 16 bytes): maxima into
@@ -336,6 +408,7 @@ def epilogue(e, degree, volume):
             e(f"v_add_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, {SUMR[k]}")
         for c, reg in enumerate((F, F + 4, P, P + 4, TT)):
             e(f"ds_write_b128 %[state], v[{reg}:{reg + 3}] offset:{c * STATE_CHUNK}")
+    e(f"{done}:")
 
 
 def body(degree, volume):
@@ -392,19 +465,23 @@ def main():
     print(f"constexpr int kShiftPlane8 = {PLANE8};       // ... of the 8-wave workgroup (33-64 rows)")
     print(f"constexpr int kShiftStateChunk = {STATE_CHUNK};   // LDS running state: 5 chunks per wavefront")
     print(f"constexpr int kShiftRec = {REC};            // bytes per stream record")
-    for degree, volume, lds_state, far, name in ((8, False, False, False, "shift_groups_detect"),
-                                                 (10, True, False, False, "shift_groups_volume"),
-                                                 (8, False, True, False, "shift_groups_detect3"),
-                                                 (8, False, False, True, "shift_groups_detect8"),
-                                                 (10, True, False, True, "shift_groups_volume8")):
-        configure(lds_state, far)
+    for degree, volume, lds_state, far, lazy, name in (
+            (8, False, False, False, False, "shift_groups_detect"),
+            (8, False, False, False, True, "shift_groups_detect_lazy"),
+            (10, True, False, False, False, "shift_groups_volume"),
+            (8, False, True, False, False, "shift_groups_detect3"),
+            (8, False, False, True, False, "shift_groups_detect8"),
+            (8, False, False, True, True, "shift_groups_detect8_lazy"),
+            (10, True, False, True, False, "shift_groups_volume8")):
+        configure(lds_state, far, lazy)
         lines = body(degree, volume)
         # the stream pointer lives in a hard SGPR pair (the halves of an s[lo:hi] operand cannot be
         # named in inline asm): it is handed over as two 32-bit scalars
         text = "\\n\\t".join(lines)
         print()
         print(f"// degree-{degree} 2^f{', values stored' if volume else ''}"
-              f"{', running state in LDS' if lds_state else ''}{', far plane' if far else ''}; "
+              f"{', running state in LDS' if lds_state else ''}{', far plane' if far else ''}"
+              f"{', arg-max recovered lazily' if lazy else ''}; "
               f"window of up to {WMAX} doubles; "
               f"hard VGPRs v{VB}..v{VEND - 1}, SGPRs s{SB}..s{SEND - 1}")
         print(f"__device__ __forceinline__ void {name}("

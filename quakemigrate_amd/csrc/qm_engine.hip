@@ -146,6 +146,8 @@ struct qm_engine {
     // slots, record stream
     int cfg_shift = -1;                     // -1: where the table qualifies, 0: never, 1: as -1 (explicit)
     int cfg_shift_waves = 0;                // workgroup shape: 4 (two per CU), 12 (one per CU), 0 = automatic
+    int cfg_shift_lazy = -1;                // detect loop flavour: -1 automatic, 0 eager, 1 lazy arg-max
+    int shift_lazy_last = 0;                // ... the last launch took
     int shift_nw = 0;                       // ... the tables were built for
     qm::GridDesc shg{};
     DevBuf<int32_t> d_shraw, d_shmeta, d_shtotal, d_shfit, d_shwide;
@@ -578,6 +580,12 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         s.stream = reinterpret_cast<const char *>(e->d_shstream.p);
         s.rows2 = e->shift_rows2;
         s.nw = e->shift_nw;
+        // groups a wavefront sees before its running maximum is reset: bricks per workgroup x
+        // groups per (brick, wavefront)
+        const int64_t life = ((int64_t)e->shg.nbricks / std::max(1, a.ngroups)) *
+                             std::max(1, e->shg.brick_nodes / 8 / e->shift_nw);
+        s.lazy = e->cfg_shift_lazy >= 0 ? e->cfg_shift_lazy : (life >= qm::kShiftLazyGroups ? 1 : 0);
+        e->shift_lazy_last = s.lazy;
         const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, e->shift_nw * qm::kWave,
                                                   qm::shift_lds_bytes(e->shift_nw));
         if (volume && e->shift_nw == qm::kShiftWaves8) QM_TABLE(qm::launch_shift_volume8(s, shape));
@@ -1303,6 +1311,9 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
             return fail("shift_waves must be 0 (automatic), 4, 8 or 12");
         e->cfg_shift_waves = (int)v;
         e->shift_built = false;
+    } else if (k == "shift_lazy") {
+        if (v < -1 || v > 1) return fail("shift_lazy must be -1 (automatic), 0 or 1");
+        e->cfg_shift_lazy = (int)v;
     } else if (k == "screen") {
         e->cfg_screen = v ? 1 : 0;
     } else if (k == "screen_pairs") {
@@ -1355,6 +1366,7 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "shift") *v = e->cfg_shift;
     else if (k == "shift_ok") *v = e->shift_built && e->shift_ok ? 1 : 0;
     else if (k == "shift_waves") *v = e->shift_ok ? e->shift_nw : e->cfg_shift_waves;
+    else if (k == "shift_lazy") *v = e->shift_lazy_last;
     else if (k == "shift_brick_nodes") *v = e->shift_ok ? e->shg.brick_nodes : 0;
     else if (k == "shift_wide_bricks") *v = e->shift_ok ? e->n_shwide : 0;
     else if (k == "shift_operands_per_add_x1000")   // 8-byte LDS operands fetched per add (x 1000)

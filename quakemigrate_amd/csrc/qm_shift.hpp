@@ -72,7 +72,12 @@ struct ShiftArgs {
     const char *stream;          // records, [nbricks][nw][shift_recs_per_wave]
     int rows2;                   // stream rows per group: S rounded up to even
     int nw;                      // wavefronts per workgroup the stream was dealt for
+    int lazy;                    // detect: the loop flavour that recovers the arg-max lazily
 };
+
+// a wavefront that sees at least this many 2x2x2 groups between two resets of its running
+// maximum takes the lazy flavour (gen_shift_asm.py, epilogue_node)
+constexpr int kShiftLazyGroups = 160;
 
 struct LaunchShape;
 hipError_t launch_shift_detect(const ShiftArgs &a, const LaunchShape &s);   // qm_launch_shift.hip
@@ -374,14 +379,23 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
                                      lane_addr + (unsigned)kShiftPlane8, g.nz, g.ny * g.nz,
                                      a.z_scale, c, a.volume + t_first,
                                      (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u);
-            else if constexpr (NW == kShiftWaves8)
-                shift_groups_detect8(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr,
-                                     lane_addr + (unsigned)kShiftPlane8, g.nz, g.ny * g.nz,
-                                     a.z_scale, c);
+            else if constexpr (NW == kShiftWaves8) {
+                if (s.lazy)
+                    shift_groups_detect8_lazy(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr,
+                                              lane_addr + (unsigned)kShiftPlane8, g.nz, g.ny * g.nz,
+                                              a.z_scale, c);
+                else
+                    shift_groups_detect8(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr,
+                                         lane_addr + (unsigned)kShiftPlane8, g.nz, g.ny * g.nz,
+                                         a.z_scale, c);
+            }
             else if constexpr (VOLUME)
                 shift_groups_volume(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr, g.nz,
                                     g.ny * g.nz, a.z_scale, c, a.volume + t_first,
                                     (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u);
+            else if (s.lazy)
+                shift_groups_detect_lazy(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr, g.nz,
+                                         g.ny * g.nz, a.z_scale, c);
             else
                 shift_groups_detect(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr, g.nz,
                                     g.ny * g.nz, a.z_scale, c);

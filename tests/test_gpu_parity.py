@@ -1594,6 +1594,7 @@ def _detect_both(lib, lon, tt, fsmp, lsmp, avail, **cfg):
         if tag == "shift":
             out["wide"] = eng.get("shift_wide_bricks")
             out["brick_nodes"] = eng.get("shift_brick_nodes")
+            out["lazy"] = eng.get("shift_lazy")
         eng.close()
     return out
 
@@ -1619,14 +1620,18 @@ def test_shift_kernel_equals_round2_kernels_and_oracle(lib, oracle, recipe, grid
     stacking kernel: maxima and indices are the round-2 kernels' bits, and the oracle's argmax."""
     case = synth.make_case(recipe, step=1, grid=grid, rows=rows, n_samples=ns)
     lon = oracle.log_onsets(case.onsets)
-    r = _detect_both(lib, lon, case.traveltimes, case.fsmp, case.lsmp, case.available)
-    assert r["shift_kernel"] == 3 and r["round2_kernel"] != 3, r
     want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
                          threads=4)
-    _assert_series(r["shift"], want)
-    assert np.array_equal(r["shift"][2], r["round2"][2])
-    assert np.array_equal(r["shift"][0], r["round2"][0])            # same bits
-    np.testing.assert_allclose(r["shift"][1], r["round2"][1], rtol=NORM)
+    # both flavours of the loop (qmhip.h "shift_lazy"; the automatic choice depends on how many
+    # groups a wavefront sees, which these small grids keep low)
+    for lazy in (0, 1):
+        r = _detect_both(lib, lon, case.traveltimes, case.fsmp, case.lsmp, case.available,
+                         shift_lazy=lazy)
+        assert r["shift_kernel"] == 3 and r["round2_kernel"] != 3 and r["lazy"] == lazy, r
+        _assert_series(r["shift"], want)
+        assert np.array_equal(r["shift"][2], r["round2"][2])
+        assert np.array_equal(r["shift"][0], r["round2"][0])            # same bits
+        np.testing.assert_allclose(r["shift"][1], r["round2"][1], rtol=NORM)
 
 
 @pytest.mark.parametrize("recipe,grid,rows,ns", [SHIFT_SHAPES[0], SHIFT_SHAPES[1], SHIFT_SHAPES[4],
@@ -1696,8 +1701,11 @@ def test_shift_kernel_exact_ties_resolve_to_the_lowest_index(lib, oracle):
         want = oracle.detect(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True)
         ref = oracle.c_migrate(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True).reshape(-1, ns)
         n_ties += int((np.sum(ref == ref.max(axis=0)[None, :], axis=0) > 1).sum())
-        r = _detect_both(lib, lon, tt, fsmp, lsmp, avail, groups=int(rng.choice([0, 1, 5])))
-        assert r["shift_kernel"] == 3, (trial, grid, S, ns)
+        # (both flavours of the loop: arg-max kept per node, or recovered where a group reaches the
+        # wavefront's running maximum -- with these data nearly every group does)
+        r = _detect_both(lib, lon, tt, fsmp, lsmp, avail, groups=int(rng.choice([0, 1, 5])),
+                         shift_lazy=trial % 2)
+        assert r["shift_kernel"] == 3 and r["lazy"] == trial % 2, (trial, grid, S, ns)
         assert np.array_equal(r["shift"][2], want[2]), (trial, grid, S, ns)
         assert np.array_equal(r["shift"][0], r["round2"][0])
         np.testing.assert_allclose(r["shift"][1], want[1], rtol=NORM)

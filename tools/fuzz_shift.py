@@ -2,8 +2,8 @@
 """Randomised differential campaign for the shift-reuse kernel (development aid).
 
 Random grids (every dimension >= 2), 1-64 rows (both workgroup shapes), 192-900 scanned samples, coherent tables of random
-steepness (so that some trials put bricks on the direct kernel and some tables do not qualify at
-all), quantised onsets in half of the trials (exact ties), negative delays, random `available` and
+steepness (in 30 % of the trials with a few steep rows: bricks on the direct kernel, or a table that
+does not qualify at all), quantised onsets in half of the trials (exact ties), negative delays, random `available` and
 group counts: the automatic engine against Engine(shift=0) (maxima bit for bit, indices) and the
 oracle; every fourth trial also the volume-writing variant against the oracle's volume.
 usage: fuzz_shift.py [trials] [seed]"""
@@ -29,9 +29,10 @@ for trial in range(trials):
     # coherent table: distance-like delays from random "stations", steepness up to ~7 samples per node, a fifth of the rows up to 30
     ijk = np.stack(np.indices(grid), axis=-1).astype(np.float64)
     tt = np.empty(grid + (S,), dtype=np.int32)
+    rough = rng.random() < 0.3          # (a steep row disqualifies the table or sends bricks to the direct kernel)
     for r in range(S):
         src = rng.uniform(-5, np.array(grid) + 5)
-        steep = rng.uniform(0.2, 7.0) if rng.random() < 0.8 else rng.uniform(7.0, 30.0)
+        steep = rng.uniform(0.2, 7.0) if (not rough or rng.random() < 0.9) else rng.uniform(7.0, 30.0)
         d = np.sqrt(((ijk - src) ** 2).sum(-1)) * steep
         tt[..., r] = np.minimum(np.rint(d - d.min() + rng.integers(0, 5)), lsmp).astype(np.int32)
     if trial % 3 == 0:
@@ -42,11 +43,11 @@ for trial in range(trials):
     else:
         lon = np.log(np.clip(rng.lognormal(0, 0.6, size=(S, T)), 0.01, None))
     avail = int(2 ** rng.integers(0, 5)) if trial % 2 else int(rng.integers(1, S + 1))
-    cfg = dict(groups=int(rng.choice([0, 1, 3, 9])))
+    cfg = dict(groups=int(rng.choice([0, 1, 3, 9])), shift_lazy=int(rng.integers(-1, 2)))
     want = qm_oracle.detect(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True)
     res = {}
-    for tag, extra in (("shift", {}), ("round2", {"shift": 0})):
-        eng = lib.Engine(0, **cfg, **extra)
+    for tag, extra in (("shift", {}), ("round2", {"shift": 0, "shift_lazy": -1})):
+        eng = lib.Engine(0, **{**cfg, **extra})
         eng.load_lut(tt)
         res[tag] = eng.detect(lon, fsmp, lsmp, avail)
         if tag == "shift":
@@ -65,6 +66,6 @@ for trial in range(trials):
     assert np.array_equal(c, want[2]), (trial, grid, S, ns, cfg, kern)
     assert np.array_equal(c, res["round2"][2]) and np.array_equal(a, res["round2"][0]), (trial, grid, S, ns)
     np.testing.assert_allclose(a, want[0], rtol=1e-13)
-    np.testing.assert_allclose(b, want[1], rtol=1e-12)
+    np.testing.assert_allclose(b, want[1], rtol=2e-12)   # degree-8 2^f: truncation 7.8e-13 + rounding
     np.testing.assert_allclose(b, res["round2"][1], rtol=1e-12)
 print(f"{trials} trials ok; shift kernel used in {used}, of which {wide} with bricks on the direct kernel")
