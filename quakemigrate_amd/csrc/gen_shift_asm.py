@@ -278,9 +278,16 @@ def epilogue_node(e, degree, volume, g, opens_group):
         nt = os.environ.get("QM_SHIFT_STORE_POLICY", "nt").replace("_", " ")   # cache policy bits
         nt = " " + nt if nt else ""
         if "nostore" not in EXP:
+            # lanes whose four samples the previous tile has already stored (a last tile pulled
+            # back over its predecessor) are masked off: no HBM byte is written twice
+            if "nomask" not in EXP:
+                e("s_mov_b32 exec_lo, %[mlo]")
+                e("s_mov_b32 exec_hi, %[mhi]")
             e(f"global_store_dwordx4 %[voff], v[{P}:{P + 3}], {s2(SVA)}{nt}")
             if "halfstore" not in EXP:
                 e(f"global_store_dwordx4 %[voff], v[{P + 4}:{P + 7}], {s2(SVA)} offset:16{nt}")
+            if "nomask" not in EXP:
+                e("s_mov_b64 exec, -1")
     if not (LDS_STATE and opens_group):
         for k in range(4):
             e(f"v_add_f64 {SUMR[k]}, {SUMR[k]}, {v2(P + 2 * k)}")
@@ -490,7 +497,8 @@ def main():
               + ("unsigned state_addr, " if lds_state else "")
               + ("unsigned lane_addr_b, " if far else "") + "int nz, "
               f"int nynz, double scale, const double (&c)[{degree + 1}]"
-              + (", double *vol_tile, unsigned vol_stride_bytes, unsigned lane_bytes" if volume else "")
+              + (", double *vol_tile, unsigned vol_stride_bytes, unsigned lane_bytes, "
+                 "unsigned long long store_lanes" if volume else "")
               + ") {")
         print("    const unsigned long long sp = (unsigned long long)stream;")
         print("    const unsigned tablo = (unsigned)sp, tabhi = (unsigned)(sp >> 32);")
@@ -499,6 +507,7 @@ def main():
         if volume:
             print("    const unsigned long long vp = (unsigned long long)vol_tile;")
             print("    const unsigned vlo = (unsigned)vp, vhi = (unsigned)(vp >> 32);")
+            print("    const unsigned mlo = (unsigned)store_lanes, mhi = (unsigned)(store_lanes >> 32);")
         outs = []
         if not lds_state:
             outs += [f'[max{k}] "+v"(vmax[{k}])' for k in range(4)]
@@ -514,7 +523,7 @@ def main():
             ins += ['[laneb] "v"(lane_addr_b)']
         if volume:
             ins += ['[vlo] "s"(vlo)', '[vhi] "s"(vhi)', '[vstride] "s"(vol_stride_bytes)',
-                    '[voff] "v"(lane_bytes)']
+                    '[voff] "v"(lane_bytes)', '[mlo] "s"(mlo)', '[mhi] "s"(mhi)']
         ins += [f'[c{i}] "s"(c[{i}])' for i in range(degree)]
         clob = [f'"v{r}"' for r in range(VB, VEND)] + [f'"s{r}"' for r in range(SB, SEND)]
         clob += ['"vcc"', '"scc"', '"m0"', '"memory"']

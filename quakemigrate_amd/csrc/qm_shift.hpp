@@ -302,8 +302,8 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
 }
 
 // VOLUME: the 4-D volume is written too (whole 256-sample tiles only: a scan that is not a multiple
-// of the tile pulls its last tile back, and the overlap is stored twice with the same bits; scans
-// shorter than a tile stay with the other kernels)
+// of the tile pulls its last tile back; the lanes whose samples its predecessor stores are masked
+// off at the stores; scans shorter than a tile stay with the other kernels)
 template <bool VOLUME, int NW>
 __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_shift_kernel(ShiftArgs s) {
     static_assert(NW == kShiftWaves || NW == kShiftWaves8 || (NW == kShiftWaves3 && !VOLUME),
@@ -325,6 +325,10 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
     const int t_first =
         ((tile + 1) * kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT) ? a.n_chunk - kShiftKT : tile * kShiftKT;
     const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 16u;
+    // volume: lanes of a pulled-back tile whose four samples its predecessor stores are masked off
+    // at the stores (a lane that straddles the seam stores its four: same bits)
+    const int seam = tile * kShiftKT - t_first;                    // samples of overlap, 0 .. 255
+    const unsigned long long store_lanes = ~0ull << (seam / 4);
 
     double vmax[4], vsum[4];
     int vidx[4];
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
                 shift_groups_volume8(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr,
                                      lane_addr + (unsigned)kShiftPlane8, g.nz, g.ny * g.nz,
                                      a.z_scale, c, a.volume + t_first,
-                                     (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u);
+                                     (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u, store_lanes);
             else if constexpr (NW == kShiftWaves8) {
                 if (s.lazy)
                     shift_groups_detect8_lazy(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr,
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
             else if constexpr (VOLUME)
                 shift_groups_volume(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr, g.nz,
                                     g.ny * g.nz, a.z_scale, c, a.volume + t_first,
-                                    (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u);
+                                    (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u, store_lanes);
             else if (s.lazy)
                 shift_groups_detect_lazy(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr, g.nz,
                                          g.ny * g.nz, a.z_scale, c);
