@@ -47,20 +47,24 @@ PLANE8 = 81856           # ... for the 8-wave workgroup that owns a CU's whole L
                          # beyond the 16-bit offset of a DS instruction, so plane B gets its own
                          # address register ("far plane")
 STATE_CHUNK = 1024       # running state in LDS: 5 chunks of 64 lanes x 16 bytes per wavefront
+VB_BLOCK = 80            # first hard VGPR of the row-block flavour
 
 
-def configure(lds_state, far=False, lazy=False):
+def configure(lds_state, far=False, lazy=False, block=False):
     """Register plan.  far: plane B is addressed through a second register (see PLANE8).  lds_state = False: the wavefront's running (max, sum, index) are inline-asm
     operands (20 VGPRs the compiler places below VB).  True: they live in LDS and are read and
     written by the group merge, the per-node temporaries move into window 1 -- 167 VGPRs in all,
     three wavefronts per SIMD."""
     global LDS_STATE, FAR, PLANE, VB, ACC, WIN, VADDR, VADDRB, VNODE, VC, VPF, VZERO, VEND
-    global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR, LAZY
+    global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR, LAZY, BLOCK
+    BLOCK = block            # one group per call, accumulators kept between calls (row blocks)
     LDS_STATE = lds_state
     LAZY = lazy
     FAR = far
     PLANE = PLANE3 if lds_state else PLANE8 if far else PLANE2
-    VB = 4 if lds_state else int(os.environ.get("QM_SHIFT_VB", "32"))    # first hard VGPR
+    # first hard VGPR (row-block flavour: the accumulators must survive the compiler's code between
+    # two calls, which therefore has to stay below VB -- tests/test_host.py checks the ISA)
+    VB = 4 if lds_state else VB_BLOCK if block else int(os.environ.get("QM_SHIFT_VB", "32"))
     ACC = VB                 # acc[g][k] = v[ACC + 8 g + 2 k : +1]
     WIN = [ACC + 64, ACC + 64 + 2 * WMAX]
     VADDR = WIN[1] + 2 * WMAX
@@ -161,6 +165,7 @@ def issue_window(e, q, hdr):
 
 
 def node_adds(e, p, g, first):
+    first = first and not BLOCK          # (row blocks: the accumulators are zeroed, or carry on)
     if "noidx" in EXP:
         e("s_nop 0")
     else:
@@ -442,6 +447,15 @@ def body(degree, volume):
     group = e.label("grp")
     pair = e.label("pair")
     nopair = e.label("np")
+    if BLOCK:
+        # the first lines of this wavefront's next run (the next brick's first block), into L2
+        e(f"global_load_dword v{VPF}, %[nxoff], %[nxrun]")
+        carry = e.label("cy")
+        e("s_bitcmp1_b32 %[flags], 0")                         # first block of the brick: zero
+        e(f"s_cbranch_scc0 {carry}")
+        for r in range(ACC, ACC + 64):
+            e(f"v_mov_b32 v{r}, 0")
+        e(f"{carry}:")
     e(f"{group}:")
     row_iter(e, 0, True)
     row_iter(e, 1, False)
@@ -453,10 +467,18 @@ def body(degree, volume):
     e(f"s_sub_u32 s{SPAIRS}, s{SPAIRS}, 1")
     e(f"s_cbranch_scc0 {pair}")
     e(f"{nopair}:")
-    epilogue(e, degree, volume)
-    e("s_sub_u32 %[ng], %[ng], 1")
-    e("s_cmp_lg_u32 %[ng], 0")
-    e(f"s_cbranch_scc1 {group}")
+    if BLOCK:
+        more = e.label("mb")
+        e("s_set_gpr_idx_off")
+        e("s_bitcmp1_b32 %[flags], 1")                         # last block: exponentiate, reduce
+        e(f"s_cbranch_scc0 {more}")
+        epilogue(e, degree, volume)
+        e(f"{more}:")
+    else:
+        epilogue(e, degree, volume)
+        e("s_sub_u32 %[ng], %[ng], 1")
+        e("s_cmp_lg_u32 %[ng], 0")
+        e(f"s_cbranch_scc1 {group}")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     return e.lines
 
@@ -472,15 +494,17 @@ def main():
     print(f"constexpr int kShiftPlane8 = {PLANE8};       // ... of the 8-wave workgroup (33-64 rows)")
     print(f"constexpr int kShiftStateChunk = {STATE_CHUNK};   // LDS running state: 5 chunks per wavefront")
     print(f"constexpr int kShiftRec = {REC};            // bytes per stream record")
-    for degree, volume, lds_state, far, lazy, name in (
-            (8, False, False, False, False, "shift_groups_detect"),
-            (8, False, False, False, True, "shift_groups_detect_lazy"),
-            (10, True, False, False, False, "shift_groups_volume"),
-            (8, False, True, False, False, "shift_groups_detect3"),
-            (8, False, False, True, False, "shift_groups_detect8"),
-            (8, False, False, True, True, "shift_groups_detect8_lazy"),
-            (10, True, False, True, False, "shift_groups_volume8")):
-        configure(lds_state, far, lazy)
+    print(f"constexpr int kShiftBlockVgprs = {VB_BLOCK};   // row-block flavour: the compiler's own code stays below")
+    for degree, volume, lds_state, far, lazy, block, name in (
+            (8, False, False, False, False, False, "shift_groups_detect"),
+            (8, False, False, False, True, False, "shift_groups_detect_lazy"),
+            (10, True, False, False, False, False, "shift_groups_volume"),
+            (8, False, True, False, False, False, "shift_groups_detect3"),
+            (8, False, False, True, False, False, "shift_groups_detect8"),
+            (8, False, False, True, True, False, "shift_groups_detect8_lazy"),
+            (10, True, False, True, False, False, "shift_groups_volume8"),
+            (8, False, False, True, False, True, "shift_group_rows8")):
+        configure(lds_state, far, lazy, block)
         lines = body(degree, volume)
         # the stream pointer lives in a hard SGPR pair (the halves of an s[lo:hi] operand cannot be
         # named in inline asm): it is handed over as two 32-bit scalars
@@ -488,12 +512,14 @@ def main():
         print()
         print(f"// degree-{degree} 2^f{', values stored' if volume else ''}"
               f"{', running state in LDS' if lds_state else ''}{', far plane' if far else ''}"
-              f"{', arg-max recovered lazily' if lazy else ''}; "
+              f"{', arg-max recovered lazily' if lazy else ''}"
+              f"{', ONE group, one block of its rows per call (flags: 1 = first block, 2 = last)' if block else ''}; "
               f"window of up to {WMAX} doubles; "
               f"hard VGPRs v{VB}..v{VEND - 1}, SGPRs s{SB}..s{SEND - 1}")
         print(f"__device__ __forceinline__ void {name}("
               + ("" if lds_state else "double (&vmax)[4], double (&vsum)[4], int (&vidx)[4],"))
-        print("        const void *stream, int ngroups, int npairs, unsigned lane_addr, "
+        print("        const void *stream, " + ("unsigned flags, const void *next_run, unsigned next_off, "
+                                                if block else "int ngroups, ") + "int npairs, unsigned lane_addr, "
               + ("unsigned state_addr, " if lds_state else "")
               + ("unsigned lane_addr_b, " if far else "") + "int nz, "
               f"int nynz, double scale, const double (&c)[{degree + 1}]"
@@ -513,7 +539,8 @@ def main():
             outs += [f'[max{k}] "+v"(vmax[{k}])' for k in range(4)]
             outs += [f'[sum{k}] "+v"(vsum[{k}])' for k in range(4)]
             outs += [f'[idx{k}] "+v"(vidx[{k}])' for k in range(4)]
-        outs += ['[ng] "+s"(ngroups)']
+        if not block:
+            outs += ['[ng] "+s"(ngroups)']
         ins = ['[tablo] "s"(tablo)', '[tabhi] "s"(tabhi)', '[lane] "v"(lane_addr)',
                '[npairs] "s"(npairs)', '[nz] "s"(nz)', '[nynz] "s"(nynz)', '[scale] "s"(scale)',
                '[clo] "s"(clo)', '[chi] "s"(chi)']
@@ -521,6 +548,8 @@ def main():
             ins += ['[state] "v"(state_addr)']
         if far:
             ins += ['[laneb] "v"(lane_addr_b)']
+        if block:
+            ins += ['[flags] "s"(flags)', '[nxrun] "s"(next_run)', '[nxoff] "v"(next_off)']
         if volume:
             ins += ['[vlo] "s"(vlo)', '[vhi] "s"(vhi)', '[vstride] "s"(vol_stride_bytes)',
                     '[voff] "v"(lane_bytes)', '[mlo] "s"(mlo)', '[mhi] "s"(mhi)']

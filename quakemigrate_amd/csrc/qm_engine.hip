@@ -153,6 +153,7 @@ struct qm_engine {
     DevBuf<int32_t> d_shraw, d_shmeta, d_shtotal, d_shfit, d_shwide;
     DevBuf<uint32_t> d_shstream;
     int n_shwide = 0, shift_rows2 = 0;
+    int shift_nblk = 1, shift_sb = 0;       // row blocks (tables of more than 64 rows): blocks, rows per block
     bool shift_built = false, shift_ok = false;
     int64_t shift_quads = 0, shift_group_rows = 0;   // register-window quads fetched / (group, row)s
 
@@ -458,7 +459,16 @@ int ensure_shift_tables(qm_engine *e) {
     e->shift_built = true;
     e->shift_ok = false;
     const int S = e->g.n_rows;
-    if (S > qm::kShiftMaxRows) return 0;
+    // More rows than a CU's LDS holds windows for: row blocks (stack_shift_rows_kernel) -- bricks of
+    // 4x4x4 nodes = one 2x2x2 group per wavefront of the 8-wave workgroup, whose accumulators stay
+    // in registers while the rows are staged in nblk blocks of sb <= 64 rows.
+    const bool blocks = S > qm::kShiftMaxRows;
+    // (65-96 rows: two blocks of <= 48 rows stage as often as they compute; the chunked kernel with
+    // its 8x8x8 bricks is 4-5 % faster there -- profiles/r03_ab_runs.txt -- unless shift = 1)
+    if (blocks && S <= 96 && e->cfg_shift != 1) return 0;
+    const int nblk = blocks ? (S + qm::kShiftMaxRows - 1) / qm::kShiftMaxRows : 1;
+    const int sb = blocks ? ((S + nblk - 1) / nblk + 1) / 2 * 2 : S;
+    if (S > 1024 || (blocks && e->cfg_shift_waves != 0 && e->cfg_shift_waves != qm::kShiftWaves8)) return 0;
     // a grid one node thick has half-empty 2x2x2 groups everywhere (e.g. the flat 1 x 1 x N view
     // of the reference-signature migrate): leave it to the other kernels unless asked explicitly
     if (e->cfg_shift < 0 && (e->g.nx < 2 || e->g.ny < 2 || e->g.nz < 2)) return 0;
@@ -477,8 +487,9 @@ int ensure_shift_tables(qm_engine *e) {
         candidates[0] = qm::kShiftWaves8;
         n_candidates = 1;
     }
-    const bool fixed = e->cfg_bx > 0;
-    const int n_shapes = fixed ? 1 : 5;
+    const bool fixed = e->cfg_bx > 0 && !blocks;
+    const int n_shapes = fixed || blocks ? 1 : 5;
+    static const int kShapesBlocks[][3] = {{4, 4, 4}};
     int nw = candidates[0];
     qm::GridDesc g = e->g;
     std::vector<int32_t> fit, wide;
@@ -486,7 +497,8 @@ int ensure_shift_tables(qm_engine *e) {
     auto even_up = [](int v) { return v + (v & 1); };
     for (int cand = 0; cand < n_candidates && !ok; ++cand) {
     nw = candidates[cand];
-    const int (*kShapes)[3] = nw == qm::kShiftWaves3 ? kShapes12 : nw == qm::kShiftWaves8 ? kShapes8 : kShapes4;
+    const int (*kShapes)[3] = blocks ? kShapesBlocks : nw == qm::kShiftWaves3 ? kShapes12
+                              : nw == qm::kShiftWaves8 ? kShapes8 : kShapes4;
     for (int s = 0; s < n_shapes; ++s) {
         g = e->g;
         g.bx = std::min(even_up(fixed ? e->cfg_bx : kShapes[s][0]), even_up(g.nx));
@@ -498,21 +510,22 @@ int ensure_shift_tables(qm_engine *e) {
         g.nbricks = g.nbx * g.nby * g.nbz;
         g.brick_nodes = g.bx * g.by * g.bz;
         const size_t br = (size_t)g.nbricks * S;
-        if (e->d_shraw.ensure(4 * br) || e->d_shmeta.ensure(4 * br) ||
-            e->d_shtotal.ensure(g.nbricks) || e->d_shfit.ensure(g.nbricks) || e->d_scalar.ensure(8))
+        const size_t nvb = (size_t)g.nbricks * nblk;               // (brick, row block) pairs
+        if (e->d_shraw.ensure(4 * br) || e->d_shmeta.ensure(4 * nvb * sb) ||
+            e->d_shtotal.ensure(nvb) || e->d_shfit.ensure(nvb) || e->d_scalar.ensure(8))
             return 1;
         QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 8 * sizeof(int32_t), e->stream));
         hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
                            e->d_lut.p, reinterpret_cast<int4 *>(e->d_shraw.p), e->d_scalar.p);
-        hipLaunchKernelGGL(qm::shift_need_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
+        hipLaunchKernelGGL(qm::shift_need_kernel, dim3((unsigned)nvb), dim3(256), 0, e->stream, g,
                            e->d_lut.p, reinterpret_cast<const int4 *>(e->d_shraw.p),
                            reinterpret_cast<int4 *>(e->d_shmeta.p), e->d_shtotal.p, e->d_shfit.p,
                            reinterpret_cast<unsigned long long *>(e->d_scalar.p + 4),
-                           qm::shift_plane(nw));
+                           qm::shift_plane(nw), nblk, sb);
         QM_HIP(hipGetLastError());
-        fit.resize(g.nbricks);
+        fit.resize(nvb);
         unsigned long long tally[2] = {0, 0};
-        QM_HIP(hipMemcpyAsync(fit.data(), e->d_shfit.p, (size_t)g.nbricks * sizeof(int32_t),
+        QM_HIP(hipMemcpyAsync(fit.data(), e->d_shfit.p, nvb * sizeof(int32_t),
                               hipMemcpyDeviceToHost, e->stream));
         QM_HIP(hipMemcpyAsync(tally, e->d_scalar.p + 4, sizeof(tally), hipMemcpyDeviceToHost,
                               e->stream));
@@ -520,25 +533,33 @@ int ensure_shift_tables(qm_engine *e) {
         e->shift_quads = (int64_t)tally[0];
         e->shift_group_rows = (int64_t)tally[1];
         wide.clear();
-        for (int b = 0; b < g.nbricks; ++b)
-            if (!fit[b]) wide.push_back(b);
+        for (int b = 0; b < g.nbricks; ++b) {                      // a brick fits if all its blocks do
+            int all = 1;
+            for (int k = 0; k < nblk; ++k) all &= fit[(size_t)b * nblk + k];
+            fit[b] = all;
+            if (!all) wide.push_back(b);
+        }
         ok = fixed ? (int)wide.size() < g.nbricks : (int64_t)wide.size() * 200 <= g.nbricks;
         if (ok) break;
     }
     }
     if (!ok) return 0;                                   // an incoherent table: the other kernels
-    const int rows2 = S + (S & 1);
-    const int64_t words = (int64_t)g.nbricks * nw * qm::shift_recs_per_wave(g, rows2, nw) *
+    const int rows2 = sb + (sb & 1);
+    const int64_t words = (int64_t)g.nbricks * nw * nblk * qm::shift_recs_per_wave(g, rows2, nw) *
                           (qm::kShiftRec / 4);
+    if (blocks)                                          // per-brick verdicts for the kernels
+        QM_HIP(hipMemcpyAsync(e->d_shfit.p, fit.data(), (size_t)g.nbricks * sizeof(int32_t),
+                              hipMemcpyHostToDevice, e->stream));
     // (+ slack: the loop loads one record past a wavefront's run and touches the line 16 records
     // ahead with its L2 prefetch -- after the last run of the last brick that is past the stream)
     if (e->d_shstream.ensure((size_t)words + 4096)) return 1;
     const size_t hdr_bytes = (size_t)qm::shift_groups_per_brick(g) * rows2 * sizeof(uint2);
     QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(qm::shift_stream_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_bytes));
-    hipLaunchKernelGGL(qm::shift_stream_kernel, dim3(g.nbricks), dim3(256), hdr_bytes, e->stream, g,
-                       e->d_lut.p, reinterpret_cast<const int4 *>(e->d_shmeta.p), e->d_shtotal.p,
-                       e->d_shfit.p, rows2, nw, e->d_shstream.p);
+    hipLaunchKernelGGL(qm::shift_stream_kernel, dim3((unsigned)((size_t)g.nbricks * nblk)), dim3(256),
+                       hdr_bytes, e->stream, g, e->d_lut.p,
+                       reinterpret_cast<const int4 *>(e->d_shmeta.p), e->d_shtotal.p, e->d_shfit.p,
+                       rows2, nw, nblk, sb, e->d_shstream.p);
     QM_HIP(hipGetLastError());
     e->n_shwide = (int)wide.size();
     if (e->n_shwide) {
@@ -551,6 +572,8 @@ int ensure_shift_tables(qm_engine *e) {
     e->shg = g;
     e->shift_rows2 = rows2;
     e->shift_nw = nw;
+    e->shift_nblk = nblk;
+    e->shift_sb = sb;
     e->shift_ok = true;
     return 0;
 }
@@ -580,6 +603,8 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         s.stream = reinterpret_cast<const char *>(e->d_shstream.p);
         s.rows2 = e->shift_rows2;
         s.nw = e->shift_nw;
+        s.nblk = e->shift_nblk;
+        s.sb = e->shift_sb;
         // groups a wavefront sees before its running maximum is reset: bricks per workgroup x
         // groups per (brick, wavefront)
         const int64_t life = ((int64_t)e->shg.nbricks / std::max(1, a.ngroups)) *
@@ -588,7 +613,8 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         e->shift_lazy_last = s.lazy;
         const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, e->shift_nw * qm::kWave,
                                                   qm::shift_lds_bytes(e->shift_nw));
-        if (volume && e->shift_nw == qm::kShiftWaves8) QM_TABLE(qm::launch_shift_volume8(s, shape));
+        if (e->shift_nblk > 1) QM_TABLE(qm::launch_shift_rows8(s, shape));
+        else if (volume && e->shift_nw == qm::kShiftWaves8) QM_TABLE(qm::launch_shift_volume8(s, shape));
         else if (volume) QM_TABLE(qm::launch_shift_volume(s, shape));
         else if (e->shift_nw == qm::kShiftWaves3) QM_TABLE(qm::launch_shift_detect3(s, shape));
         else if (e->shift_nw == qm::kShiftWaves8) QM_TABLE(qm::launch_shift_detect8(s, shape));
@@ -675,8 +701,8 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
                               volume != nullptr, vol_stride);
     if (shift) {
         if (ensure_shift_tables(e)) return 1;
-        // (the 12-wave shape is built for the fused detect only)
-        shift = e->shift_ok && !(volume != nullptr && e->shift_nw == qm::kShiftWaves3);
+        // (the 12-wave shape and the row-block kernel are built for the fused detect only)
+        shift = e->shift_ok && !(volume != nullptr && (e->shift_nw == qm::kShiftWaves3 || e->shift_nblk > 1));
     }
     if (shift) {
         jp = 0;
@@ -1367,6 +1393,7 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "shift_ok") *v = e->shift_built && e->shift_ok ? 1 : 0;
     else if (k == "shift_waves") *v = e->shift_ok ? e->shift_nw : e->cfg_shift_waves;
     else if (k == "shift_lazy") *v = e->shift_lazy_last;
+    else if (k == "shift_row_blocks") *v = e->shift_ok ? e->shift_nblk : 0;
     else if (k == "shift_brick_nodes") *v = e->shift_ok ? e->shg.brick_nodes : 0;
     else if (k == "shift_wide_bricks") *v = e->shift_ok ? e->n_shwide : 0;
     else if (k == "shift_operands_per_add_x1000")   // 8-byte LDS operands fetched per add (x 1000)

@@ -63,6 +63,12 @@ __host__ __device__ __forceinline__ int shift_groups_per_brick(const GridDesc &g
 __host__ __device__ __forceinline__ int64_t shift_recs_per_wave(const GridDesc &g, int rows2, int nw) {
     return (int64_t)((shift_groups_per_brick(g) + nw - 1) / nw) * rows2 + 2;
 }
+// first record of the run of (brick b, wave w, row block k): a wavefront's blocks of one brick are
+// contiguous (the loop's L2 prefetch runs from one into the next)
+__host__ __device__ __forceinline__ int64_t shift_run_record(int64_t b, int w, int k, int nw, int nblk,
+                                                             int64_t rpw) {
+    return ((b * nw + w) * nblk + k) * rpw;
+}
 
 struct ShiftArgs {
     StackArgs a;                 // grid (shift bricks), onsets, scan geometry, partial sets
@@ -73,6 +79,8 @@ struct ShiftArgs {
     int rows2;                   // stream rows per group: S rounded up to even
     int nw;                      // wavefronts per workgroup the stream was dealt for
     int lazy;                    // detect: the loop flavour that recovers the arg-max lazily
+    int nblk;                    // row blocks per brick (1: all rows of a brick are staged at once)
+    int sb;                      // rows per block (even; the last block may hold fewer)
 };
 
 // a wavefront that sees at least this many 2x2x2 groups between two resets of its running
@@ -85,6 +93,7 @@ hipError_t launch_shift_volume(const ShiftArgs &a, const LaunchShape &s);
 hipError_t launch_shift_detect3(const ShiftArgs &a, const LaunchShape &s);  // the 12-wave shape
 hipError_t launch_shift_detect8(const ShiftArgs &a, const LaunchShape &s);  // the 8-wave shape
 hipError_t launch_shift_volume8(const ShiftArgs &a, const LaunchShape &s);
+hipError_t launch_shift_rows8(const ShiftArgs &a, const LaunchShape &s);    // row blocks (> 64 rows)
 
 // valid 2x2x2 groups of a brick form a box [0,cx) x [0,cy) x [0,cz) in group coordinates
 __device__ __forceinline__ void shift_group_box(const GridDesc &g, int b, int &x0, int &y0, int &z0,
@@ -139,11 +148,14 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
                                                          int32_t *__restrict__ stotal,
                                                          int32_t *__restrict__ sfit,
                                                          unsigned long long *__restrict__ tally,
-                                                         int plane_bytes) {
+                                                         int plane_bytes, int nblk, int sb) {
     // tally[0] += quads the loop fetches, tally[1] += (group, row) pairs: operands per add
+    // Row blocks (nblk > 1): workgroup vb = (brick, block) handles rows [k sb, k sb + S) of brick b;
+    // smeta / stotal / sfit are per (brick, block), sb rows apart.
     __shared__ int need[kShiftMaxRows];
     __shared__ int overflow;
-    const int b = blockIdx.x, S = g.n_rows;
+    const int vb = blockIdx.x, b = vb / nblk, r0 = (vb % nblk) * sb;
+    const int S = g.n_rows - r0 < sb ? g.n_rows - r0 : sb;
     int x0, y0, z0, vx, vy, vz, cx, cy, cz;
     shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
     for (int r = threadIdx.x; r < S; r += blockDim.x) need[r] = 0;
@@ -155,8 +167,8 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
         const int j = i / S, r = i % S;
         const int gz = j % cz, gy = (j / cz) % cy, gx = j / (cz * cy);
         int d[8], e0, nq;
-        shift_group_delays(g, lut, x0, y0, z0, vx, vy, vz, gx, gy, gz, r,
-                           meta_raw[(int64_t)b * S + r].x, d);
+        shift_group_delays(g, lut, x0, y0, z0, vx, vy, vz, gx, gy, gz, r0 + r,
+                           meta_raw[(int64_t)b * g.n_rows + r0 + r].x, d);
         shift_window(d, e0, nq);
         if (nq > kShiftNqMax) atomicOr(&overflow, 1);
         const int fetched = nq > kShiftNqMin ? nq : kShiftNqMin;
@@ -169,13 +181,13 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
         atomicAdd(&tally[1], (unsigned long long)nvg * S);
         int run = 0;
         for (int r = 0; r < S; ++r) {
-            const int4 raw = meta_raw[(int64_t)b * S + r];
-            smeta[(int64_t)b * S + r] = make_int4(raw.x, raw.y, run, need[r]);
+            const int4 raw = meta_raw[(int64_t)b * g.n_rows + r0 + r];
+            smeta[(int64_t)vb * sb + r] = make_int4(raw.x, raw.y, run, need[r]);
             run += need[r];
         }
-        stotal[b] = run;
+        stotal[vb] = run;
         const int zero_row = (S & 1) ? 64 + kShiftNqMin : 0;   // all-zero window of the padding row
-        sfit[b] = (!overflow && (int64_t)(run + zero_row) * 16 <= plane_bytes) ? 1 : 0;
+        sfit[vb] = (!overflow && (int64_t)(run + zero_row) * 16 <= plane_bytes) ? 1 : 0;
     }
 }
 
@@ -183,29 +195,35 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
 __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int32_t *__restrict__ lut,
                                                            const int4 *__restrict__ smeta,
                                                            const int32_t *__restrict__ stotal,
-                                                           const int32_t *__restrict__ sfit, int rows2,
-                                                           int nw, uint32_t *__restrict__ stream) {
+                                                           const int32_t *__restrict__ sfit, int rows2max,
+                                                           int nw, int nblk, int sb,
+                                                           uint32_t *__restrict__ stream) {
     extern __shared__ uint2 hdr[];                      // [group j][row] (LDS address, quads)
-    const int b = blockIdx.x, S = g.n_rows;
+    // (row blocks: workgroup vb = (brick, block); sfit is per brick -- all of its blocks fit)
+    const int vb = blockIdx.x, b = vb / nblk, k = vb % nblk, r0 = k * sb;
+    const int S = g.n_rows - r0 < sb ? g.n_rows - r0 : sb;
+    const int rows2 = S + (S & 1);
     if (!sfit[b]) return;
     int x0, y0, z0, vx, vy, vz, cx, cy, cz;
     shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
     const int nvg = cx * cy * cz;
-    const int64_t rpw = shift_recs_per_wave(g, rows2, nw);
-    uint32_t *base = stream + (int64_t)b * nw * rpw * (kShiftRec / 4);
+    const int64_t rpw = shift_recs_per_wave(g, rows2max, nw);
+    auto record = [&](int w, int64_t i) {
+        return stream + (shift_run_record(b, w, k, nw, nblk, rpw) + i) * (kShiftRec / 4);
+    };
     for (int i = threadIdx.x; i < nvg * rows2; i += blockDim.x) {
         const int j = i / rows2, r = i % rows2;
         const int w = j % nw, pos = j / nw;
-        uint32_t *rec = base + ((int64_t)w * rpw + 1 + (int64_t)pos * rows2 + r) * (kShiftRec / 4);
+        uint32_t *rec = record(w, 1 + (int64_t)pos * rows2 + r);
         if (r >= S) {                                   // padding row of an odd S: adds 0.0
             for (int n = 0; n < 8; ++n) rec[n] = 0;
-            hdr[j * rows2 + r] = make_uint2(16u * (unsigned)stotal[b], 2u);
+            hdr[j * rows2 + r] = make_uint2(16u * (unsigned)stotal[vb], 2u);
             continue;
         }
         const int gz = j % cz, gy = (j / cz) % cy, gx = j / (cz * cy);
-        const int4 m = smeta[(int64_t)b * S + r];
+        const int4 m = smeta[(int64_t)vb * sb + r];
         int d[8], e0, nq;
-        const unsigned mask = shift_group_delays(g, lut, x0, y0, z0, vx, vy, vz, gx, gy, gz, r, m.x, d);
+        const unsigned mask = shift_group_delays(g, lut, x0, y0, z0, vx, vy, vz, gx, gy, gz, r0 + r, m.x, d);
         shift_window(d, e0, nq);
         for (int n = 0; n < 8; ++n) rec[n] = 2u * (unsigned)(d[n] - e0);
         hdr[j * rows2 + r] = make_uint2(16u * (unsigned)(m.z + e0 / 4), (unsigned)nq);
@@ -221,7 +239,7 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
             const int w = i - nvg * rows2;
             if (w < nvg) {
                 const uint2 h = hdr[w * rows2];
-                uint32_t *rec = base + (int64_t)w * rpw * (kShiftRec / 4);
+                uint32_t *rec = record(w, 0);
                 rec[8] = h.x;
                 rec[9] = h.y;
             }
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
         }
         const int j = i / rows2, r = i % rows2;
         const int w = j % nw, pos = j / nw;
-        uint32_t *rec = base + ((int64_t)w * rpw + 1 + (int64_t)pos * rows2 + r) * (kShiftRec / 4);
+        uint32_t *rec = record(w, 1 + (int64_t)pos * rows2 + r);
         uint2 h = make_uint2(0u, 2u);                    // after the wave's last row: harmless
         if (r + 1 < rows2) h = hdr[j * rows2 + r + 1];
         else if (j + nw < nvg) h = hdr[(j + nw) * rows2];
@@ -243,17 +261,16 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
 // Stage the row windows of brick b for the tile starting at t_first: window sample u of row r goes
 // to plane (u & 2) / 2, slot first_r + u / 4, half u & 1.  Every slot of the row is written (zero
 // past the data the brick can touch and past the rows' end): a lane may fetch whole quads.
-template <int NW>
-__device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *win, int b, int wave,
-                                                    int lane, int t_first) {
+// Row blocks: vb = (brick, block), the block's S rows start at table row row0, metadata sb rows apart.
+template <int NW, int RB = (NW == 12 ? 3 : 8), int U = 6>
+__device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *win, int vb, int row0,
+                                                    int S, int sb, int wave, int lane, int t_first) {
     const StackArgs &a = s.a;
-    const int S = a.g.n_rows;
     // A wavefront stages rows wave, wave + NW, ...: the loads of ALL its rows (up to RB x U x 64
     // samples) are issued before the first LDS store, so the brick's staging costs one round trip
     // to L2 instead of one per row (while a workgroup stages, its SIMDs' other wavefronts run at
     // half rate: a wavefront alone issues one float64 instruction per 8 cycles).
-    constexpr int RB = NW == kShiftWaves3 ? 3 : 8;                 // rows per wavefront and pass
-    constexpr int U = 6;                                           // 64-sample chunks per row and pass
+    // (RB rows per wavefront and pass, U 64-sample chunks per row and pass)
     constexpr int kPlane = shift_plane(NW);
     for (int r0 = wave; r0 < S; r0 += NW * RB) {
         double v[RB][U];
@@ -261,11 +278,11 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
             const int r = r0 + k * NW;
-            m[k] = r < S ? s.smeta[(int64_t)b * S + r] : make_int4(0, 0, 0, 0);
+            m[k] = r < S ? s.smeta[(int64_t)vb * sb + r] : make_int4(0, 0, 0, 0);
             const int len = m[k].y + kShiftKT;                     // samples the brick can touch
             const int first = m[k].x + a.fsmp + a.sample0 + t_first;   // index inside the row
             const int room = a.T - first;
-            const double *src = a.onsets + (int64_t)(r < S ? r : 0) * a.T + first;
+            const double *src = a.onsets + (int64_t)(r < S ? row0 + r : 0) * a.T + first;
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 const int u = kWave * i + lane;
@@ -287,7 +304,7 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
                 const int len = m[k].y + kShiftKT;
                 const int first = m[k].x + a.fsmp + a.sample0 + t_first;
                 const int room = a.T - first;
-                const double *src = a.onsets + (int64_t)r * a.T + first;
+                const double *src = a.onsets + (int64_t)(row0 + r) * a.T + first;
                 for (int u = kWave * U + lane; u < total; u += kWave)
                     win[((u & 2) ? kPlane / 8 : 0) + 2 * (m[k].z + (u >> 2)) + (u & 1)] =
                         (u < len && u < room) ? src[u] : 0.0;
@@ -295,7 +312,7 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
         }
     }
     if ((S & 1) && wave == 0) {                                    // the padding row's zero window
-        const int z = s.stotal[b];
+        const int z = s.stotal[vb];
         for (int u = lane; u < 4 * (64 + kShiftNqMin); u += kWave)
             win[((u & 2) ? kPlane / 8 : 0) + 2 * (z + (u >> 2)) + (u & 1)] = 0.0;
     }
@@ -361,12 +378,12 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
 #ifdef QM_SHIFT_EXP_NOSTAGE                            // timing experiment (wrong results): the first
                                                       // brick's windows for all, no barriers
         if (b == group) {
-            stage_shift_windows<NW>(s, win, b, wave, lane, t_first);
+            stage_shift_windows<NW>(s, win, b, 0, g.n_rows, g.n_rows, wave, lane, t_first);
             __syncthreads();
         }
 #else
         __syncthreads();                              // previous brick fully consumed
-        stage_shift_windows<NW>(s, win, b, wave, lane, t_first);
+        stage_shift_windows<NW>(s, win, b, 0, g.n_rows, g.n_rows, wave, lane, t_first);
         __syncthreads();
 #endif
         int x0, y0, z0, vx, vy, vz, cx, cy, cz;
@@ -374,7 +391,7 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
         const int nvg = cx * cy * cz;
         const int mine = (nvg - wave + NW - 1) / NW;                       // groups of this wave
         if (mine > 0) {
-            const char *run = s.stream + ((int64_t)b * NW + wave) * rpw * kShiftRec;
+            const char *run = s.stream + shift_run_record(b, wave, 0, NW, 1, rpw) * kShiftRec;
             if constexpr (kLdsState)
                 shift_groups_detect3(run, mine, s.rows2 / 2, lane_addr, state_addr, g.nz,
                                      g.ny * g.nz, a.z_scale, c);
@@ -428,6 +445,114 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
     __syncthreads();
     const int k = threadIdx.x;
     if (k >= kShiftKT) return;                        // (a 12-wave workgroup has more threads than samples)
+    double best = smax[k], total = ssum[k];
+    int bi = sidx[k];
+    for (int w = 1; w < NW; ++w) {
+        const double v = smax[w * kShiftKT + k];
+        const int i = sidx[w * kShiftKT + k];
+        total += ssum[w * kShiftKT + k];
+        if (better(v, i, best, bi)) {
+            best = v;
+            bi = i;
+        }
+    }
+    const int t = t_first + k;
+    if (t < a.n_chunk) {
+        const int64_t o = (int64_t)(a.set0 + group) * a.n_chunk + t;
+        a.part_max[o] = best;
+        a.part_idx[o] = bi == INT32_MAX ? kNoIndex : (int64_t)bi;
+        a.part_sum[o] = total;
+    }
+}
+// Tables of more rows than a CU's LDS holds windows for (> 64): ROW BLOCKS.  A brick is as many
+// 2x2x2 groups as the workgroup has wavefronts (4x4x4 nodes for 8), each wavefront owns ONE group
+// and keeps its 64 accumulators in registers while the workgroup stages the brick's rows block by
+// block (<= 64 rows each): rows are still added one at a time in ascending order, so every sum has
+// the reference's bits.  The accumulators live in hard registers of the generated loop
+// (shift_group_rows8: v80 up) ACROSS its calls -- the compiler does not know, so its own code
+// between two calls must stay below kShiftBlockVgprs: see the kernel's attributes; the staging is
+// kept lean for that (half the rows in flight per pass) and tests/test_host.py checks the ISA.
+// (amdgpu_waves_per_eu(6, 6) is what keeps the compiler below v80 = kShiftBlockVgprs: it plans for
+// six wavefronts per SIMD, i.e. 80 registers, and treats the rest as reserved; the generated loop's
+// hard registers above bring the kernel to 248, two wavefronts per SIMD)
+#ifndef QM_ROWS_RB               // rows in flight per wavefront and staging pass, 64-sample chunks per row
+#define QM_ROWS_RB 3             // (3 x 5: the most that leaves the compiler without spills below v80)
+#define QM_ROWS_U 5
+#endif
+template <int NW>
+__global__ __attribute__((amdgpu_flat_work_group_size(NW * kWave, NW * kWave), amdgpu_waves_per_eu(6, 6)))
+void stack_shift_rows_kernel(ShiftArgs s) {
+    static_assert(NW == kShiftWaves8, "row blocks: the 8-wave workgroup");
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    const StackArgs &a = s.a;
+    const GridDesc &g = a.g;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = blockIdx.x >> 3;
+    const int tile = slot % a.ntiles;
+    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    if (group >= a.ngroups) return;
+    if (a.run_if != nullptr && *a.run_if == 0) return;
+    const int t_first =
+        ((tile + 1) * kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT) ? a.n_chunk - kShiftKT : tile * kShiftKT;
+    const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 16u;
+
+    double vmax[4], vsum[4];
+    int vidx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        vmax[k] = -__builtin_inf();
+        vsum[k] = 0.0;
+        vidx[k] = INT32_MAX;
+    }
+    constexpr int D = Exp2Degree<false>::value;
+    double c[D + 1];
+#pragma unroll
+    for (int i = 0; i <= D; ++i) c[i] = exp2_coeff<D>(i);
+
+    const int rows2max = s.sb + (s.sb & 1);
+    const int64_t rpw = shift_recs_per_wave(g, rows2max, NW);
+    for (int b = group; b < g.nbricks; b += a.ngroups) {
+        if (!s.sfit[b]) continue;                     // direct kernel's job
+        int x0, y0, z0, vx, vy, vz, cx, cy, cz;
+        shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
+        const bool mine = wave < cx * cy * cz;        // one group per wavefront
+        // this wavefront's next run: the first block of its next brick
+        int nb = b + a.ngroups;
+        while (nb < g.nbricks && !s.sfit[nb]) nb += a.ngroups;
+        const char *next_run = s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, s.nblk, rpw) * kShiftRec;
+        for (int k = 0; k < s.nblk; ++k) {
+            const int row0 = k * s.sb;
+            const int rows = g.n_rows - row0 < s.sb ? g.n_rows - row0 : s.sb;
+            __syncthreads();                          // previous block fully consumed
+            stage_shift_windows<NW, QM_ROWS_RB, QM_ROWS_U>(s, win, b * s.nblk + k, row0, rows, s.sb, wave,
+                                                           lane, t_first);
+            __syncthreads();
+            if (mine) {
+                const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRec;
+                const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
+                    (int)((k == 0 ? 1u : 0u) | (k == s.nblk - 1 ? 2u : 0u)));
+                shift_group_rows8(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                                  (rows + 1) / 2, lane_addr, lane_addr + (unsigned)kShiftPlane8, g.nz,
+                                  g.ny * g.nz, a.z_scale, c);
+            }
+        }
+    }
+    if (!a.want_scan) return;
+    // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
+    __syncthreads();
+    double *smax = win, *ssum = win + NW * kShiftKT;
+    int *sidx = reinterpret_cast<int *>(win + 2 * NW * kShiftKT);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int o = wave * kShiftKT + 4 * lane + k;
+        smax[o] = vmax[k];
+        ssum[o] = vsum[k];
+        sidx[o] = vidx[k];
+    }
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k >= kShiftKT) return;
     double best = smax[k], total = ssum[k];
     int bi = sidx[k];
     for (int w = 1; w < NW; ++w) {
