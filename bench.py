@@ -60,6 +60,9 @@ EXP_F32_OPS = 8             # 32-bit ops per node-sample besides the S adds in t
 EXP_FP64_OPS = 19           # FP64-rate VALU ops per node-sample besides the S adds (2^z, sum, max,
                             # group merge / address: the shift-reuse kernel issues 19.2, the round-2
                             # exact kernels 18 + 1 address add per row)
+EXP_FP64_OPS_LAZY = 17      # ... the shift-reuse kernel's lazy arg-max flavour (one max instead of
+                            # compare + select + max per node-sample; recovery and merge where a group
+                            # reaches the running maximum; profiles/r03_pmc_C3shift_*: SQ_INSTS_VALU)
 
 
 def parse():
@@ -150,7 +153,7 @@ def cpu_baseline(case, budget_s):
     }
 
 
-def onchip(screened, local_ns, S, kern_s, operands_per_add=1.0):
+def onchip(screened, local_ns, S, kern_s, operands_per_add=1.0, exp_ops=EXP_FP64_OPS):
     """The ceilings that bind the stacking kernel: LDS operand bytes and VALU issue.
     ``operands_per_add``: 8-byte LDS operands fetched per add -- 1 for the kernels that read every
     operand from LDS, ~0.55 for the shift-reuse kernel (register windows shared by 8 nodes)."""
@@ -167,11 +170,11 @@ def onchip(screened, local_ns, S, kern_s, operands_per_add=1.0):
     return {"lds": {"achieved": lds_bytes / kern_s / 1e12, "peak": LDS_PEAK / 1e12,
                     "unit": "TB/s", "frac": lds_bytes / kern_s / LDS_PEAK,
                     "operands_per_add": operands_per_add},
-            "fp64_valu": {"achieved": local_ns * (S + EXP_FP64_OPS) / kern_s / 1e12,
+            "fp64_valu": {"achieved": local_ns * (S + exp_ops) / kern_s / 1e12,
                           "peak": FP64_PEAK / 1e12,
                           "unit": "TFLOP/s (FP64 VALU instruction-lanes, one operation per instruction)",
-                          "frac": local_ns * (S + EXP_FP64_OPS) / kern_s / FP64_PEAK,
-                          "ops_per_node_sample": S + EXP_FP64_OPS}}
+                          "frac": local_ns * (S + exp_ops) / kern_s / FP64_PEAK,
+                          "ops_per_node_sample": S + exp_ops}}
 
 
 def stack_kernel_name(eng, S, volume=False):
@@ -416,7 +419,8 @@ def main():
     # 8-byte LDS operands fetched per add: 1 for the round-2 kernels; the shift-reuse kernel shares
     # a register window between the 8 nodes of a group (measured on the resident table)
     per_add = eng.get("shift_operands_per_add_x1000") / 1000.0 if shift_kernel else 1.0
-    chip = onchip(screened, local_ns, S, kern_s, per_add)
+    exp_ops = EXP_FP64_OPS_LAZY if shift_kernel and eng.get("shift_lazy") == 1 else EXP_FP64_OPS
+    chip = onchip(screened, local_ns, S, kern_s, per_add, exp_ops)
     valu_key = "int32_valu" if screened else "fp64_valu"
     # the ceiling that binds: whichever on-chip unit is busier (the fused detect cannot be HBM
     # bound: SURVEY.md section 8d); the HBM-compulsory figure is kept under its own key
@@ -469,7 +473,7 @@ def main():
                      "note": "fused detect never writes the volume: compulsory HBM bytes are the "
                              "table, the onsets and the outputs only (hbm_compulsory, far below 1 % "
                              "by construction), so the roofline that binds is on the chip: "
-                             + ("FP64 VALU issue (S adds + ~19 epilogue instructions per node-"
+                             + (f"FP64 VALU issue (S adds + ~{exp_ops} epilogue instructions per node-"
                                 "sample against 39.3e12 instruction-lanes/s at 2.4 GHz), beside "
                                 "which the data returning from LDS costs the SIMDs 2 cycles per "
                                 "8-byte operand (DESIGN.md section 3.4)" if bind != "lds" else

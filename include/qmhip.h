@@ -110,10 +110,12 @@ int qm_engine_synchronize(qm_engine *e);
  * exact-row-count float64 kernel), "shift" (default -1: the fused detect and volume-writing
  * launches of whole 256-sample tiles run the shift-reuse kernel, qm_shift.hpp -- 2x2x2 node groups
  * stacked from register windows, 0.56 LDS operands per add at C3 -- where the table qualifies: up
- * to 64 rows, every group's delay spread within 20 samples for >= 99.5 % of
- * the bricks, no grid dimension of 1; 0 = never, i.e. the round-2 kernels; 1 = as -1, also on grids
- * one node thick), "shift_waves" (0 = automatic: two 4-wave workgroups per CU up to ~32 rows, one
- * 8-wave workgroup with all 160 KB beyond; 4 / 8 force one; 12 = one 12-wave workgroup with the
+ * to 64 rows, every group's delay spread within 20 samples for >= 99.5 % of the bricks, no grid
+ * dimension of 1; fused detect of tables of more than 96 rows runs its row-block form -- 4x4x4
+ * bricks, the rows staged in blocks of <= 64 while the accumulators stay in registers; 0 = never,
+ * i.e. the round-2 kernels; 1 = as -1, also on grids one node thick and row blocks from 65 rows
+ * on), "shift_waves" (0 = automatic: two 4-wave workgroups per CU up to ~32 rows, one 8-wave
+ * workgroup with all 160 KB beyond; 4 / 8 force one; 12 = one 12-wave workgroup with the
  * wavefronts' running state in LDS: same bits, measured no faster), "shift_lazy" (default -1: the
  * detect loop keeps only the group maximum per node and recovers the arg-max where a group
  * reaches the wavefront's running maximum, when a wavefront sees >= 160 groups per launch -- same
@@ -125,7 +127,8 @@ int qm_engine_synchronize(qm_engine *e);
  * float64 on the device: too many candidate cells -- flat all-ties data --, non-finite onsets,
  * a dynamic range outside the bound's preconditions), "last_candidates", and of the shift-reuse
  * layout once built: "shift_ok", "shift_brick_nodes", "shift_wide_bricks" (bricks left to the direct
- * kernel), "shift_operands_per_add_x1000"; "last_kernel" = 3 when the last launch used it. */
+ * kernel), "shift_row_blocks" (1, or the blocks a brick's rows are staged in),
+ * "shift_operands_per_add_x1000"; "last_kernel" = 3 when the last launch used it. */
 int qm_engine_config(qm_engine *e, const char *key, int64_t value);
 int qm_engine_get(qm_engine *e, const char *key, int64_t *value);
 
