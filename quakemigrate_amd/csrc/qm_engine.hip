@@ -154,6 +154,8 @@ struct qm_engine {
     DevBuf<uint32_t> d_shstream;
     int n_shwide = 0, shift_rows2 = 0;
     int shift_nblk = 1, shift_sb = 0;       // row blocks (tables of more than 64 rows): blocks, rows per block
+    bool shift_direct = false;              // ... staged by LDS-direct loads (stack_shift_rows2_kernel)
+    int cfg_shift_rows_direct = 1;
     bool shift_built = false, shift_ok = false;
     int64_t shift_quads = 0, shift_group_rows = 0;   // register-window quads fetched / (group, row)s
 
@@ -463,10 +465,14 @@ int ensure_shift_tables(qm_engine *e) {
     // 4x4x4 nodes = one 2x2x2 group per wavefront of the 8-wave workgroup, whose accumulators stay
     // in registers while the rows are staged in nblk blocks of sb <= 64 rows.
     const bool blocks = S > qm::kShiftMaxRows;
-    // (65-96 rows: two blocks of <= 48 rows stage as often as they compute; the chunked kernel with
-    // its 8x8x8 bricks is 4-5 % faster there -- profiles/r03_ab_runs.txt -- unless shift = 1)
-    if (blocks && S <= 96 && e->cfg_shift != 1) return 0;
-    const int nblk = blocks ? (S + qm::kShiftMaxRows - 1) / qm::kShiftMaxRows : 1;
+    // two forms (qm_shift.hpp): blocks of <= 34 rows staged by LDS-direct loads into the idle half of
+    // a double-buffered LDS (default), or blocks of <= 64 staged through registers between two barriers
+    // (that one only from 97 rows on: at 65-96 two blocks of <= 48 rows stage as often as they
+    // compute and the chunked kernel with its 8x8x8 bricks is 4-5 % faster, profiles/r03_ab_runs.txt)
+    const bool direct = e->cfg_shift_rows_direct != 0;
+    if (blocks && !direct && S <= 96 && e->cfg_shift != 1) return 0;
+    const int block_rows = direct ? 34 : qm::kShiftMaxRows;
+    const int nblk = blocks ? (S + block_rows - 1) / block_rows : 1;
     const int sb = blocks ? ((S + nblk - 1) / nblk + 1) / 2 * 2 : S;
     if (S > 1024 || (blocks && e->cfg_shift_waves != 0 && e->cfg_shift_waves != qm::kShiftWaves8)) return 0;
     // a grid one node thick has half-empty 2x2x2 groups everywhere (e.g. the flat 1 x 1 x N view
@@ -521,7 +527,7 @@ int ensure_shift_tables(qm_engine *e) {
                            e->d_lut.p, reinterpret_cast<const int4 *>(e->d_shraw.p),
                            reinterpret_cast<int4 *>(e->d_shmeta.p), e->d_shtotal.p, e->d_shfit.p,
                            reinterpret_cast<unsigned long long *>(e->d_scalar.p + 4),
-                           qm::shift_plane(nw), nblk, sb);
+                           blocks && direct ? qm::kShiftPlane : qm::shift_plane(nw), nblk, sb);
         QM_HIP(hipGetLastError());
         fit.resize(nvb);
         unsigned long long tally[2] = {0, 0};
@@ -574,6 +580,7 @@ int ensure_shift_tables(qm_engine *e) {
     e->shift_nw = nw;
     e->shift_nblk = nblk;
     e->shift_sb = sb;
+    e->shift_direct = blocks && direct;
     e->shift_ok = true;
     return 0;
 }
@@ -613,7 +620,8 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         e->shift_lazy_last = s.lazy;
         const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, e->shift_nw * qm::kWave,
                                                   qm::shift_lds_bytes(e->shift_nw));
-        if (e->shift_nblk > 1) QM_TABLE(qm::launch_shift_rows8(s, shape));
+        if (e->shift_nblk > 1 && e->shift_direct) QM_TABLE(qm::launch_shift_rows2(s, shape));
+        else if (e->shift_nblk > 1) QM_TABLE(qm::launch_shift_rows8(s, shape));
         else if (volume && e->shift_nw == qm::kShiftWaves8) QM_TABLE(qm::launch_shift_volume8(s, shape));
         else if (volume) QM_TABLE(qm::launch_shift_volume(s, shape));
         else if (e->shift_nw == qm::kShiftWaves3) QM_TABLE(qm::launch_shift_detect3(s, shape));
@@ -1336,6 +1344,9 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
         if (v != 0 && v != qm::kShiftWaves && v != qm::kShiftWaves8 && v != qm::kShiftWaves3)
             return fail("shift_waves must be 0 (automatic), 4, 8 or 12");
         e->cfg_shift_waves = (int)v;
+        e->shift_built = false;
+    } else if (k == "shift_rows_direct") {
+        e->cfg_shift_rows_direct = v ? 1 : 0;
         e->shift_built = false;
     } else if (k == "shift_lazy") {
         if (v < -1 || v > 1) return fail("shift_lazy must be -1 (automatic), 0 or 1");

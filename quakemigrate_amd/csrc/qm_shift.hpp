@@ -94,6 +94,7 @@ hipError_t launch_shift_detect3(const ShiftArgs &a, const LaunchShape &s);  // t
 hipError_t launch_shift_detect8(const ShiftArgs &a, const LaunchShape &s);  // the 8-wave shape
 hipError_t launch_shift_volume8(const ShiftArgs &a, const LaunchShape &s);
 hipError_t launch_shift_rows8(const ShiftArgs &a, const LaunchShape &s);    // row blocks (> 64 rows)
+hipError_t launch_shift_rows2(const ShiftArgs &a, const LaunchShape &s);    // ... double-buffered, LDS-direct
 
 // valid 2x2x2 groups of a brick form a box [0,cx) x [0,cy) x [0,cz) in group coordinates
 __device__ __forceinline__ void shift_group_box(const GridDesc &g, int b, int &x0, int &y0, int &z0,
@@ -541,6 +542,160 @@ void stack_shift_rows_kernel(ShiftArgs s) {
     if (!a.want_scan) return;
     // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
     __syncthreads();
+    double *smax = win, *ssum = win + NW * kShiftKT;
+    int *sidx = reinterpret_cast<int *>(win + 2 * NW * kShiftKT);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int o = wave * kShiftKT + 4 * lane + k;
+        smax[o] = vmax[k];
+        ssum[o] = vsum[k];
+        sidx[o] = vidx[k];
+    }
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k >= kShiftKT) return;
+    double best = smax[k], total = ssum[k];
+    int bi = sidx[k];
+    for (int w = 1; w < NW; ++w) {
+        const double v = smax[w * kShiftKT + k];
+        const int i = sidx[w * kShiftKT + k];
+        total += ssum[w * kShiftKT + k];
+        if (better(v, i, best, bi)) {
+            best = v;
+            bi = i;
+        }
+    }
+    const int t = t_first + k;
+    if (t < a.n_chunk) {
+        const int64_t o = (int64_t)(a.set0 + group) * a.n_chunk + t;
+        a.part_max[o] = best;
+        a.part_idx[o] = bi == INT32_MAX ? kNoIndex : (int64_t)bi;
+        a.part_sum[o] = total;
+    }
+}
+// Row blocks, second form: the CU's LDS holds TWO halves of 80 KB (each laid out like the 4-wave
+// shape: plane B kShiftPlane bytes above plane A), the rows are staged in blocks of <= 34, and the
+// NEXT block is written into the idle half while the wavefronts add the current one -- by
+// LDS-direct loads (global_load_lds_dwordx4, gfx950: 16 bytes per lane from global memory straight
+// into LDS at M0 + 16 lane, no registers, counted by vmcnt).  A 16-byte slot of plane A is window
+// samples (4s, 4s+1), of plane B (4s+2, 4s+3): one instruction per plane and 64 slots.  One
+// barrier per block.  (Window slots past the row's end are left as they are: the loop fetches them
+// with the quads but never adds them.)
+constexpr int kShiftHalfBytes = 80 * 1024;
+static_assert(2 * kShiftPlane <= kShiftHalfBytes, "a half holds both planes");
+
+template <int NW>
+__device__ __forceinline__ void stage_shift_block_direct(const ShiftArgs &s, double *half, int vb,
+                                                         int row0, int S, int wave, int lane,
+                                                         int t_first) {
+    const StackArgs &a = s.a;
+    using lds_ptr = __attribute__((address_space(3))) void *;
+    using glb_ptr = const __attribute__((address_space(1))) void *;
+    for (int r = wave; r < S; r += NW) {
+        const int4 m = s.smeta[(int64_t)vb * s.sb + r];
+        const int first = m.x + a.fsmp + a.sample0 + t_first;      // index inside the row
+        const int room = a.T - first;
+        const double *src = a.onsets + (int64_t)(row0 + r) * a.T + first;
+        for (int c = 0; c * kWave < m.w; ++c) {
+            const int slot = c * kWave + lane;
+            if (slot < m.w) {
+                // samples of the slot's pair that lie inside the row: 2 -> one 16-byte load; 1 (the
+                // row's last sample, e.g. the scan's last sample at the largest delay) -> that
+                // sample alone, through a register; 0 -> nothing (never added, whatever is there)
+                const int u = 4 * slot;
+                double *la = half + 2 * (m.z + c * kWave);         // (+ 16 bytes x lane by the hardware)
+                double *lb = la + kShiftPlane / 8;
+                if (room - u >= 2)
+                    __builtin_amdgcn_global_load_lds((glb_ptr)(src + u), (lds_ptr)(lds_f64 *)la, 16, 0, 0);
+                else if (room - u == 1)
+                    la[2 * lane] = src[u];
+                if (room - u >= 4)
+                    __builtin_amdgcn_global_load_lds((glb_ptr)(src + u + 2), (lds_ptr)(lds_f64 *)lb, 16, 0, 0);
+                else if (room - u == 3)
+                    lb[2 * lane] = src[u + 2];
+            }
+        }
+    }
+    if ((S & 1) && wave == 0) {                                    // the padding row's zero window
+        const int z = s.stotal[vb];
+        for (int u = lane; u < 4 * (64 + kShiftNqMin); u += kWave)
+            half[((u & 2) ? kShiftPlane / 8 : 0) + 2 * (z + (u >> 2)) + (u & 1)] = 0.0;
+    }
+}
+
+template <int NW>
+__global__ __attribute__((amdgpu_flat_work_group_size(NW * kWave, NW * kWave), amdgpu_waves_per_eu(6, 6)))
+void stack_shift_rows2_kernel(ShiftArgs s) {
+    static_assert(NW == kShiftWaves8, "row blocks: the 8-wave workgroup");
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    const StackArgs &a = s.a;
+    const GridDesc &g = a.g;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = blockIdx.x >> 3;
+    const int tile = slot % a.ntiles;
+    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    if (group >= a.ngroups) return;
+    if (a.run_if != nullptr && *a.run_if == 0) return;
+    const int t_first =
+        ((tile + 1) * kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT) ? a.n_chunk - kShiftKT : tile * kShiftKT;
+    const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 16u;
+
+    double vmax[4], vsum[4];
+    int vidx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        vmax[k] = -__builtin_inf();
+        vsum[k] = 0.0;
+        vidx[k] = INT32_MAX;
+    }
+    constexpr int D = Exp2Degree<false>::value;
+    double c[D + 1];
+#pragma unroll
+    for (int i = 0; i <= D; ++i) c[i] = exp2_coeff<D>(i);
+
+    const int rows2max = s.sb + (s.sb & 1);
+    const int64_t rpw = shift_recs_per_wave(g, rows2max, NW);
+    auto rows_of = [&](int k) { return g.n_rows - k * s.sb < s.sb ? g.n_rows - k * s.sb : s.sb; };
+    int b = group;
+    while (b < g.nbricks && !s.sfit[b]) b += a.ngroups;            // (others: the direct kernel's job)
+    int cur = 0;                                                   // half the current block lies in
+    if (b < g.nbricks)
+        stage_shift_block_direct<NW>(s, win, b * s.nblk, 0, rows_of(0), wave, lane, t_first);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    while (b < g.nbricks) {
+        int nb = b + a.ngroups;
+        while (nb < g.nbricks && !s.sfit[nb]) nb += a.ngroups;
+        int x0, y0, z0, vx, vy, vz, cx, cy, cz;
+        shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
+        const bool mine = wave < cx * cy * cz;                     // one group per wavefront
+        const char *next_run =
+            s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, s.nblk, rpw) * kShiftRec;
+        for (int k = 0; k < s.nblk; ++k) {
+            // the next block (of this brick, or the first of the next) into the idle half
+            double *idle = win + (cur ^ 1) * (kShiftHalfBytes / 8);
+            if (k + 1 < s.nblk)
+                stage_shift_block_direct<NW>(s, idle, b * s.nblk + k + 1, (k + 1) * s.sb, rows_of(k + 1),
+                                             wave, lane, t_first);
+            else if (nb < g.nbricks)
+                stage_shift_block_direct<NW>(s, idle, nb * s.nblk, 0, rows_of(0), wave, lane, t_first);
+            if (mine) {
+                const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRec;
+                const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
+                    (int)((k == 0 ? 1u : 0u) | (k == s.nblk - 1 ? 2u : 0u)));
+                shift_group_rows(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                                 (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes), g.nz,
+                                 g.ny * g.nz, a.z_scale, c);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wavefront's loads are in LDS
+            __syncthreads();                                       // ... everyone's; the current half is free
+            cur ^= 1;
+        }
+        b = nb;
+    }
+    if (!a.want_scan) return;
+    // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
     double *smax = win, *ssum = win + NW * kShiftKT;
     int *sidx = reinterpret_cast<int *>(win + 2 * NW * kShiftKT);
 #pragma unroll

@@ -1664,34 +1664,44 @@ def test_shift_kernel_volume_variant_both_workgroup_shapes(lib, oracle, recipe, 
 
 
 @pytest.mark.parametrize("grid,rows,ns", [
-    ((21, 18, 17), 66, 300),      # two blocks of 34 / 32 rows; odd grid dimensions (groups cut by the edge)
-    ((16, 16, 12), 128, 513),     # two whole blocks of 64; the last tile pulled back
-    ((13, 12, 16), 129, 256),     # three blocks 44 / 44 / 41: an odd last block (padding row)
-    ((12, 9, 10), 200, 700),      # four blocks of 50
+    ((21, 18, 17), 66, 300),      # two blocks; odd grid dimensions (groups cut by the edge)
+    ((16, 16, 12), 128, 513),     # four blocks of 32 / two of 64; the last tile pulled back
+    ((13, 12, 16), 129, 256),     # an odd last block (padding row): 34 34 34 27 / 44 44 41
+    ((12, 9, 10), 200, 700),      # six blocks of 34 .. 30 / four of 50
     ((6, 5, 4), 67, 193),         # a scan shorter than a tile; bricks smaller than 4x4x4
+    ((9, 8, 7), 65, 257),         # 34 + 31 rows
+    ((8, 13, 10), 110, 580),      # (the scan's last sample at the largest delay is the row's last: below)
 ])
 def test_shift_kernel_row_blocks_beyond_64_rows(lib, oracle, grid, rows, ns):
-    """Tables of more than 64 rows: stack_shift_rows_kernel -- 4x4x4 bricks, one 2x2x2 group per
-    wavefront whose accumulators stay in registers while the rows are staged block by block; the
-    same bits as the chunked kernel (Engine(shift=0)) and the oracle's argmax."""
+    """Tables of more than 64 rows: 4x4x4 bricks, one 2x2x2 group per wavefront whose accumulators
+    stay in registers while the rows are staged block by block -- by LDS-direct loads into the idle
+    half of a double-buffered LDS (blocks of <= 34 rows, the default), or through registers between
+    two barriers (blocks of <= 64): the same bits as the chunked kernel (Engine(shift=0)) and the
+    oracle's argmax."""
     case = synth.make_case("C3", step=2, grid=grid, rows=rows, n_samples=ns)
-    lon = oracle.log_onsets(case.onsets)
-    want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
-                         threads=4)
+    # rows cut right behind the largest delay (lsmp = the table's maximum): the scan's last sample
+    # then reads a row's very last element, which may sit alone in its 16-byte LDS slot
+    tt = case.traveltimes
+    lsmp = int(tt.max())
+    onsets = np.ascontiguousarray(case.onsets[:, :case.fsmp + ns + lsmp])
+    lon = oracle.log_onsets(onsets)
+    want = oracle.detect(onsets, tt, case.fsmp, lsmp, case.available, threads=4)
     out = {}
-    # (automatic from 97 rows on; shift=1 asks for it from 65)
-    for tag, extra in (("shift", {"shift": 1 if rows <= 96 else -1}), ("round2", {"shift": 0})):
+    # (the register form is automatic from 97 rows on; shift=1 asks for it from 65)
+    for tag, extra, per_block in (("direct", {}, 34), ("registers", {"shift_rows_direct": 0, "shift": 1}, 64),
+                                  ("round2", {"shift": 0}, 0)):
         eng = lib.Engine(0, **extra)
-        eng.load_lut(case.traveltimes)
-        out[tag] = eng.detect(lon, case.fsmp, case.lsmp, case.available)
-        if tag == "shift":
-            assert eng.get("last_kernel") == 3 and eng.get("shift_row_blocks") == -(-rows // 64), \
-                (eng.get("last_kernel"), eng.get("shift_row_blocks"))
+        eng.load_lut(tt)
+        out[tag] = eng.detect(lon, case.fsmp, lsmp, case.available)
+        if per_block:
+            assert eng.get("last_kernel") == 3 and eng.get("shift_row_blocks") == -(-rows // per_block), \
+                (tag, eng.get("last_kernel"), eng.get("shift_row_blocks"))
         eng.close()
-    _assert_series(out["shift"], want)
-    assert np.array_equal(out["shift"][2], out["round2"][2])
-    assert np.array_equal(out["shift"][0], out["round2"][0])            # same bits
-    np.testing.assert_allclose(out["shift"][1], out["round2"][1], rtol=NORM)
+    for tag in ("direct", "registers"):
+        _assert_series(out[tag], want)
+        assert np.array_equal(out[tag][2], out["round2"][2])
+        assert np.array_equal(out[tag][0], out["round2"][0])            # same bits
+        np.testing.assert_allclose(out[tag][1], out["round2"][1], rtol=NORM)
 
 
 @pytest.mark.parametrize("recipe,grid,rows,ns", [SHIFT_SHAPES[0], SHIFT_SHAPES[2], SHIFT_SHAPES[5]])

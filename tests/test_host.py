@@ -435,14 +435,15 @@ def test_headline_kernels_stay_in_registers(tmp_path):
                      "template __global__ void qm::stack_shift_kernel<false, 8>(qm::ShiftArgs);\n"
                      "template __global__ void qm::stack_shift_kernel<true, 8>(qm::ShiftArgs);\n"
                      "template __global__ void qm::stack_shift_kernel<false, 12>(qm::ShiftArgs);\n"
-                     "template __global__ void qm::stack_shift_rows_kernel<8>(qm::ShiftArgs);\n")
+                     "template __global__ void qm::stack_shift_rows_kernel<8>(qm::ShiftArgs);\n"
+                     "template __global__ void qm::stack_shift_rows2_kernel<8>(qm::ShiftArgs);\n")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17",
                            f"-I{ROOT / 'quakemigrate_amd' / 'csrc'}", "-c", str(shift), "-o",
                            str(tmp_path / "s.o"), "--save-temps"], cwd=tmp_path,
                           stderr=subprocess.DEVNULL)
     sasm = next(tmp_path.glob("s-hip-amdgcn-*.s")).read_text()
     found = re.findall(r"\.set (\S*stack_shift\w*_kernel\S*)\.num_vgpr, (\d+)", sasm)
-    assert len(found) == 6, found
+    assert len(found) == 7, found
     for name, vgprs in found:
         if "Li12E" in name:                                # the opt-in 12-wave shape: three per SIMD
             assert int(vgprs) <= 168, (name, vgprs)
@@ -455,21 +456,24 @@ def test_headline_kernels_stay_in_registers(tmp_path):
     # register from kShiftBlockVgprs up.  Its attributes make those reserved; check the ISA.
     first_hard = int(re.search(r"kShiftBlockVgprs = (\d+);",
                                (ROOT / "quakemigrate_amd" / "csrc" / "qm_shift_asm.inc").read_text()).group(1))
-    body = sasm[sasm.index("_ZN2qm23stack_shift_rows_kernelILi8EEEvNS_9ShiftArgsE:"):]
-    body = body[:body.index("s_endpgm")]
-    inside, checked = False, 0
-    for line in body.splitlines():
-        if ";;#ASMSTART" in line or ";;#ASMEND" in line:
-            inside = ";;#ASMSTART" in line
-            continue
-        if inside:
-            continue
-        code = line.split(";")[0]
-        regs = [int(x) for x in re.findall(r"\bv(\d+)\b", code)]
-        regs += [int(b) for _, b in re.findall(r"\bv\[(\d+):(\d+)\]", code)]
-        assert all(r < first_hard for r in regs), (first_hard, line.strip())
-        checked += bool(regs)
-    assert checked > 100
+    for symbol in ("_ZN2qm23stack_shift_rows_kernelILi8EEEvNS_9ShiftArgsE:",
+                   "_ZN2qm24stack_shift_rows2_kernelILi8EEEvNS_9ShiftArgsE:"):
+        body = sasm[sasm.index(symbol):]
+        body = body[:body.index("s_endpgm")]
+        inside, checked = False, 0
+        for line in body.splitlines():
+            if ";;#ASMSTART" in line or ";;#ASMEND" in line:
+                inside = ";;#ASMSTART" in line
+                continue
+            if inside:
+                continue
+            code = line.split(";")[0]
+            regs = [int(x) for x in re.findall(r"\bv(\d+)\b", code)]
+            regs += [int(b) for _, b in re.findall(r"\bv\[(\d+):(\d+)\]", code)]
+            assert all(r < first_hard for r in regs), (first_hard, line.strip())
+            checked += bool(regs)
+        assert checked > 100
+    assert sasm.count("global_load_lds_dwordx4") >= 6      # the second form stages straight into LDS
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17",
                            f"-I{ROOT / 'quakemigrate_amd' / 'csrc'}", "-c", str(src), "-o",
                            str(tmp_path / "k.o"), "--save-temps"], cwd=tmp_path,

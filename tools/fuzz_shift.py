@@ -44,8 +44,22 @@ for trial in range(trials):
         lon = np.log(np.clip(rng.lognormal(0, 0.6, size=(S, T)), 0.01, None))
     avail = int(2 ** rng.integers(0, 5)) if trial % 2 else int(rng.integers(1, S + 1))
     cfg = dict(groups=int(rng.choice([0, 1, 3, 9])), shift_lazy=int(rng.integers(-1, 2)),
-               shift=1 if 64 < S <= 96 else -1)
+               shift=1 if 64 < S <= 96 else -1, shift_rows_direct=int(rng.integers(0, 2)))
+    if os.environ.get("QM_FUZZ_ONLY") and trial != int(os.environ["QM_FUZZ_ONLY"]):
+        continue                                                    # (replay one trial of a seed)
     want = qm_oracle.detect(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True)
+    if os.environ.get("QM_FUZZ_ONLY"):                              # ... with a diagnosis
+        print("trial", trial, "grid", grid, "S", S, "ns", ns, "fsmp", fsmp, "lsmp", lsmp, "avail", avail, cfg)
+        for direct in (1, 0):
+            eng = lib.Engine(0, **{**cfg, "shift_rows_direct": direct})
+            eng.load_lut(tt)
+            got = eng.detect(lon, fsmp, lsmp, avail)
+            bad = np.flatnonzero((got[2] != want[2]) | ~np.isclose(got[0], want[0], rtol=1e-12, atol=0))
+            print(" direct", direct, "kernel", eng.get("last_kernel"), "blocks", eng.get("shift_row_blocks"),
+                  "wide", eng.get("shift_wide_bricks"), "bad samples", bad.size, bad[:24],
+                  "got idx", got[2][bad[:6]], "want idx", want[2][bad[:6]],
+                  "got", got[0][bad[:4]], "want", want[0][bad[:4]])
+            eng.close()
     res = {}
     for tag, extra in (("shift", {}), ("round2", {"shift": 0, "shift_lazy": -1})):
         eng = lib.Engine(0, **{**cfg, **extra})
