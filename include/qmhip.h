@@ -111,10 +111,11 @@ int qm_engine_synchronize(qm_engine *e);
  * launches of whole 256-sample tiles run the shift-reuse kernel, qm_shift.hpp -- 2x2x2 node groups
  * stacked from register windows, 0.56 LDS operands per add at C3 -- where the table qualifies: up
  * to 64 rows, every group's delay spread within 20 samples for >= 99.5 % of the bricks, no grid
- * dimension of 1; fused detect of tables of more than 96 rows runs its row-block form -- 4x4x4
- * bricks, the rows staged in blocks of <= 64 while the accumulators stay in registers; 0 = never,
- * i.e. the round-2 kernels; 1 = as -1, also on grids one node thick and row blocks from 65 rows
- * on), "shift_waves" (0 = automatic: two 4-wave workgroups per CU up to ~32 rows, one 8-wave
+ * dimension of 1; fused detect of tables of more than 64 rows runs its row-block form -- 4x4x4
+ * bricks, the accumulators in registers while the rows pass through a double-buffered LDS in blocks
+ * of <= 34, staged by LDS-direct loads ("shift_rows_direct" = 0: blocks of <= 64 staged through
+ * registers instead, from 97 rows on); 0 = never, i.e. the round-2 kernels; 1 = as -1, also on
+ * grids one node thick), "shift_waves" (0 = automatic: two 4-wave workgroups per CU up to ~32 rows, one 8-wave
  * workgroup with all 160 KB beyond; 4 / 8 force one; 12 = one 12-wave workgroup with the
  * wavefronts' running state in LDS: same bits, measured no faster), "shift_lazy" (default -1: the
  * detect loop keeps only the group maximum per node and recovers the arg-max where a group
