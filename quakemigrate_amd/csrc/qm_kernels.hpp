@@ -1548,7 +1548,9 @@ __global__ __launch_bounds__(kCombineWaves * kWave) void combine_kernel(
         out_norm_or_sum[t] = total;
         out_idx[t] = bi;
     } else {
-        const double peak = (mode == 1) ? qm_exp2_peak(best) : best;
+        // (no finite sum at this sample -- only possible with -inf onsets, i.e. log(0), which
+        // core/lib.py:93 clips away: the reference's exp(-inf) = 0, not rint's NaN)
+        const double peak = (mode != 1) ? best : best == -__builtin_inf() ? 0.0 : qm_exp2_peak(best);
         out_max[t] = peak;
         out_norm_or_sum[t] = peak * n_nodes_total / total;     // migratelib.c:108
         out_idx[t] = (bi == kNoIndex) ? 0 : bi;
