@@ -55,7 +55,7 @@ def configure(lds_state, far=False, lazy=False, block=False):
     operands (20 VGPRs the compiler places below VB).  True: they live in LDS and are read and
     written by the group merge, the per-node temporaries move into window 1 -- 167 VGPRs in all,
     three wavefronts per SIMD."""
-    global LDS_STATE, FAR, PLANE, VB, ACC, WIN, VADDR, VADDRB, VNODE, VC, VPF, VZERO, VEND
+    global LDS_STATE, FAR, PLANE, VB, ACC, WIN, VADDR, VADDRB, VNODE, VC, VPF, VZERO, VEND, VMAG
     global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR, LAZY, BLOCK
     BLOCK = block            # one group per call, accumulators kept between calls (row blocks)
     LDS_STATE = lds_state
@@ -96,7 +96,8 @@ def configure(lds_state, far=False, lazy=False, block=False):
         SUMR = [f"%[sum{k}]" for k in range(4)]
         IDXR = [f"%[idx{k}]" for k in range(4)]
     VZERO = VPF + 1
-    VEND = VZERO + 1
+    VMAG = (VZERO + 2) & ~1      # 1.5 * 2^52 as a VGPR pair (lazy flavour: z is folded into FMAs)
+    VEND = VMAG + 2 if lazy else VZERO + 1
 
 
 SB = 48                  # first hard SGPR (s_load_dwordx16 destinations)
@@ -250,16 +251,28 @@ def epilogue_node(e, degree, volume, g, opens_group):
     if volume or not LAZY:
         node_index(e, g, not LAZY)
     A = [ACC + 8 * g + 2 * k for k in range(4)]
-    for k in range(4):                                          # z = stack * log2(e)/available
-        e(f"v_mul_f64 {v2(A[k])}, {v2(A[k])}, %[scale]")
-    # k = rint(z), f = z - k:  t = z + 1.5*2^52 holds k in its low dword (round half to even, as
-    # v_rndne_f64), t - 1.5*2^52 is k as a double -- two adds instead of rndne + the slower cvt
-    for k in range(4):
-        e(f"v_add_f64 {v2(TT + 2 * k)}, {v2(A[k])}, {s2(SMAGIC)}")
-    for k in range(4):
-        e(f"v_add_f64 {v2(F + 2 * k)}, {v2(TT + 2 * k)}, -{s2(SMAGIC)}")
-    for k in range(4):                                          # f = z - k
-        e(f"v_add_f64 {v2(F + 2 * k)}, {v2(A[k])}, -{v2(F + 2 * k)}")
+    if LAZY:
+        # z = stack * scale is never formed per node-sample: t = fma(stack, scale, 1.5*2^52),
+        # k = t - 1.5*2^52, f = fma(stack, scale, -k) (three instructions instead of four; the sum's
+        # terms differ from the other kernels' in the last bits, the maximum is taken over the raw
+        # stacks -- monotone in z -- and brought to z where a group is examined, epilogue)
+        for k in range(4):
+            e(f"v_fma_f64 {v2(TT + 2 * k)}, {v2(A[k])}, %[scale], {v2(VMAG)}")
+        for k in range(4):
+            e(f"v_add_f64 {v2(F + 2 * k)}, {v2(TT + 2 * k)}, -{s2(SMAGIC)}")
+        for k in range(4):
+            e(f"v_fma_f64 {v2(F + 2 * k)}, {v2(A[k])}, %[scale], -{v2(F + 2 * k)}")
+    else:
+        for k in range(4):                                      # z = stack * log2(e)/available
+            e(f"v_mul_f64 {v2(A[k])}, {v2(A[k])}, %[scale]")
+        # k = rint(z), f = z - k:  t = z + 1.5*2^52 holds k in its low dword (round half to even, as
+        # v_rndne_f64), t - 1.5*2^52 is k as a double -- two adds instead of rndne + the slower cvt
+        for k in range(4):
+            e(f"v_add_f64 {v2(TT + 2 * k)}, {v2(A[k])}, {s2(SMAGIC)}")
+        for k in range(4):
+            e(f"v_add_f64 {v2(F + 2 * k)}, {v2(TT + 2 * k)}, -{s2(SMAGIC)}")
+        for k in range(4):                                      # f = z - k
+            e(f"v_add_f64 {v2(F + 2 * k)}, {v2(A[k])}, -{v2(F + 2 * k)}")
     for k in range(4):
         e(f"v_fma_f64 {v2(P + 2 * k)}, {v2(VC)}, {v2(F + 2 * k)}, %[c{degree - 1}]")
     for i in range(degree - 2, -1, -1):
@@ -363,9 +376,13 @@ def epilogue(e, degree, volume):
     if LAZY:
         # does any lane's group maximum reach its running maximum?  (>=: groups are not visited in
         # ascending flat index, an equal value may have to hand over a lower index)
-        e(f"v_cmp_ge_f64 {s2(ST)}, {v2(GMAX)}, {MAXR[0]}")
+        # (the group maxima are raw stacks: z = stack * scale, the rounded product every kernel
+        # compares, once per group and sample slot -- into the dead TT registers)
+        for k in range(4):
+            e(f"v_mul_f64 {v2(TT + 2 * k)}, {v2(GMAX + 2 * k)}, %[scale]")
+        e(f"v_cmp_ge_f64 {s2(ST)}, {v2(TT)}, {MAXR[0]}")
         for k in range(1, 4):
-            e(f"v_cmp_ge_f64 vcc, {v2(GMAX + 2 * k)}, {MAXR[k]}")
+            e(f"v_cmp_ge_f64 vcc, {v2(TT + 2 * k)}, {MAXR[k]}")
             e(f"s_or_b64 {s2(ST)}, {s2(ST)}, vcc")
         e(f"s_cmp_eq_u64 {s2(ST)}, 0")
         e(f"s_cbranch_scc1 {done}")
@@ -380,12 +397,13 @@ def epilogue(e, degree, volume):
             e(f"v_mov_b32 v{F + g}, s{SNODE}")
         for k in range(4):
             nxt = e.label("nk")
-            g_ = v2(GMAX + 2 * k)
+            g_ = v2(TT + 2 * k)
             e(f"v_cmp_ge_f64 vcc, {g_}, {MAXR[k]}")
             e(f"s_cbranch_vccz {nxt}")
             e(f"v_mov_b32 v{GIDX + k}, v{KI}")
             for g in range(7, -1, -1):
-                e(f"v_cmp_eq_f64 vcc, {v2(ACC + 8 * g + 2 * k)}, {g_}")
+                e(f"v_mul_f64 {v2(P)}, {v2(ACC + 8 * g + 2 * k)}, %[scale]")      # the node's z
+                e(f"v_cmp_eq_f64 vcc, {v2(P)}, {g_}")
                 e(f"v_cndmask_b32 v{GIDX + k}, v{GIDX + k}, v{F + g}, vcc")
             e(f"v_cmp_gt_f64 vcc, {g_}, {s2(SNEGINF)}")
             e(f"v_cndmask_b32 v{GIDX + k}, v{KI}, v{GIDX + k}, vcc")
@@ -440,6 +458,9 @@ def body(degree, volume):
     e(f"s_mov_b32 s{SMAGIC}, 0")
     e(f"s_mov_b32 s{SMAGIC + 1}, 0x43380000")
     e(f"v_mov_b32 v{VZERO}, 0")
+    if LAZY:
+        e(f"v_mov_b32 v{VMAG}, 0")
+        e(f"v_mov_b32 v{VMAG + 1}, 0x43380000")
     e(f"s_add_u32 s{SPF}, s{STAB}, {PF_AHEAD * REC}")
     e(f"s_addc_u32 s{SPF + 1}, s{STAB + 1}, 0")
     e("s_waitcnt lgkmcnt(0)")
