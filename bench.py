@@ -60,9 +60,10 @@ EXP_F32_OPS = 8             # 32-bit ops per node-sample besides the S adds in t
 EXP_FP64_OPS = 19           # FP64-rate VALU ops per node-sample besides the S adds (2^z, sum, max,
                             # group merge / address: the shift-reuse kernel issues 19.2, the round-2
                             # exact kernels 18 + 1 address add per row)
-EXP_FP64_OPS_LAZY = 18      # ... the shift-reuse kernel's lazy arg-max flavour (one max instead of
-                            # compare + select + max per node-sample; recovery and merge where a group
-                            # reaches the running maximum; profiles/r03_pmc_C3shift_*: SQ_INSTS_VALU)
+EXP_FP64_OPS_LAZY = 17      # ... the shift-reuse kernel's lazy arg-max flavour (one max instead of
+                            # compare + select + max per node-sample, z folded into two FMAs; recovery
+                            # and merge where a group reaches the running maximum;
+                            # profiles/r03_pmc_C3shift_*: SQ_INSTS_VALU per computed node-sample - S)
 
 
 def parse():
