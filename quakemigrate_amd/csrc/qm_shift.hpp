@@ -319,6 +319,45 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
     }
 }
 
+// The workgroup's wavefronts hold (max, sum, index) of the tile's 256 samples, four per lane:
+// combine them through LDS (thread k owns sample k) and publish the workgroup's partial set.
+// Call after a barrier behind the last use of `win`.
+template <int NW>
+__device__ __forceinline__ void shift_publish(const StackArgs &a, double *win, const double (&vmax)[4],
+                                              const double (&vsum)[4], const int (&vidx)[4], int wave,
+                                              int lane, int group, int t_first) {
+    double *smax = win, *ssum = win + NW * kShiftKT;
+    int *sidx = reinterpret_cast<int *>(win + 2 * NW * kShiftKT);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int o = wave * kShiftKT + 4 * lane + k;
+        smax[o] = vmax[k];
+        ssum[o] = vsum[k];
+        sidx[o] = vidx[k];
+    }
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k >= kShiftKT) return;                        // (8- and 12-wave workgroups have more threads than samples)
+    double best = smax[k], total = ssum[k];
+    int bi = sidx[k];
+    for (int w = 1; w < NW; ++w) {
+        const double v = smax[w * kShiftKT + k];
+        const int i = sidx[w * kShiftKT + k];
+        total += ssum[w * kShiftKT + k];
+        if (better(v, i, best, bi)) {
+            best = v;
+            bi = i;
+        }
+    }
+    const int t = t_first + k;
+    if (t < a.n_chunk) {
+        const int64_t o = (int64_t)(a.set0 + group) * a.n_chunk + t;
+        a.part_max[o] = best;
+        a.part_idx[o] = bi == INT32_MAX ? kNoIndex : (int64_t)bi;
+        a.part_sum[o] = total;
+    }
+}
+
 // VOLUME: the 4-D volume is written too (whole 256-sample tiles only: a scan that is not a multiple
 // of the tile pulls its last tile back; the lanes whose samples its predecessor stores are masked
 // off at the stores; scans shorter than a tile stay with the other kernels)
@@ -434,37 +473,9 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
     }
     // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
     __syncthreads();
-    double *smax = win, *ssum = win + NW * kShiftKT;
-    int *sidx = reinterpret_cast<int *>(win + 2 * NW * kShiftKT);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int o = wave * kShiftKT + 4 * lane + k;
-        smax[o] = vmax[k];
-        ssum[o] = vsum[k];
-        sidx[o] = vidx[k];
-    }
-    __syncthreads();
-    const int k = threadIdx.x;
-    if (k >= kShiftKT) return;                        // (a 12-wave workgroup has more threads than samples)
-    double best = smax[k], total = ssum[k];
-    int bi = sidx[k];
-    for (int w = 1; w < NW; ++w) {
-        const double v = smax[w * kShiftKT + k];
-        const int i = sidx[w * kShiftKT + k];
-        total += ssum[w * kShiftKT + k];
-        if (better(v, i, best, bi)) {
-            best = v;
-            bi = i;
-        }
-    }
-    const int t = t_first + k;
-    if (t < a.n_chunk) {
-        const int64_t o = (int64_t)(a.set0 + group) * a.n_chunk + t;
-        a.part_max[o] = best;
-        a.part_idx[o] = bi == INT32_MAX ? kNoIndex : (int64_t)bi;
-        a.part_sum[o] = total;
-    }
+    shift_publish<NW>(a, win, vmax, vsum, vidx, wave, lane, group, t_first);
 }
+
 // Tables of more rows than a CU's LDS holds windows for (> 64): ROW BLOCKS.  A brick is as many
 // 2x2x2 groups as the workgroup has wavefronts (4x4x4 nodes for 8), each wavefront owns ONE group
 // and keeps its 64 accumulators in registers while the workgroup stages the brick's rows block by
@@ -542,37 +553,9 @@ void stack_shift_rows_kernel(ShiftArgs s) {
     if (!a.want_scan) return;
     // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
     __syncthreads();
-    double *smax = win, *ssum = win + NW * kShiftKT;
-    int *sidx = reinterpret_cast<int *>(win + 2 * NW * kShiftKT);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int o = wave * kShiftKT + 4 * lane + k;
-        smax[o] = vmax[k];
-        ssum[o] = vsum[k];
-        sidx[o] = vidx[k];
-    }
-    __syncthreads();
-    const int k = threadIdx.x;
-    if (k >= kShiftKT) return;
-    double best = smax[k], total = ssum[k];
-    int bi = sidx[k];
-    for (int w = 1; w < NW; ++w) {
-        const double v = smax[w * kShiftKT + k];
-        const int i = sidx[w * kShiftKT + k];
-        total += ssum[w * kShiftKT + k];
-        if (better(v, i, best, bi)) {
-            best = v;
-            bi = i;
-        }
-    }
-    const int t = t_first + k;
-    if (t < a.n_chunk) {
-        const int64_t o = (int64_t)(a.set0 + group) * a.n_chunk + t;
-        a.part_max[o] = best;
-        a.part_idx[o] = bi == INT32_MAX ? kNoIndex : (int64_t)bi;
-        a.part_sum[o] = total;
-    }
+    shift_publish<NW>(a, win, vmax, vsum, vidx, wave, lane, group, t_first);
 }
+
 // Row blocks, second form: the CU's LDS holds TWO halves of 80 KB (each laid out like the 4-wave
 // shape: plane B kShiftPlane bytes above plane A), the rows are staged in blocks of <= 34, and the
 // NEXT block is written into the idle half while the wavefronts add the current one -- by
@@ -696,36 +679,7 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
     }
     if (!a.want_scan) return;
     // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
-    double *smax = win, *ssum = win + NW * kShiftKT;
-    int *sidx = reinterpret_cast<int *>(win + 2 * NW * kShiftKT);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int o = wave * kShiftKT + 4 * lane + k;
-        smax[o] = vmax[k];
-        ssum[o] = vsum[k];
-        sidx[o] = vidx[k];
-    }
-    __syncthreads();
-    const int k = threadIdx.x;
-    if (k >= kShiftKT) return;
-    double best = smax[k], total = ssum[k];
-    int bi = sidx[k];
-    for (int w = 1; w < NW; ++w) {
-        const double v = smax[w * kShiftKT + k];
-        const int i = sidx[w * kShiftKT + k];
-        total += ssum[w * kShiftKT + k];
-        if (better(v, i, best, bi)) {
-            best = v;
-            bi = i;
-        }
-    }
-    const int t = t_first + k;
-    if (t < a.n_chunk) {
-        const int64_t o = (int64_t)(a.set0 + group) * a.n_chunk + t;
-        a.part_max[o] = best;
-        a.part_idx[o] = bi == INT32_MAX ? kNoIndex : (int64_t)bi;
-        a.part_sum[o] = total;
-    }
+    shift_publish<NW>(a, win, vmax, vsum, vidx, wave, lane, group, t_first);
 }
 #endif  // QM_SHIFT_TU
 
