@@ -617,6 +617,7 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         const int64_t life = ((int64_t)e->shg.nbricks / std::max(1, a.ngroups)) *
                              std::max(1, e->shg.brick_nodes / 8 / e->shift_nw);
         s.lazy = e->cfg_shift_lazy >= 0 ? e->cfg_shift_lazy : (life >= qm::kShiftLazyGroups ? 1 : 0);
+        if (e->shift_nblk > 1 && !e->shift_direct) s.lazy = 0;    // (the register-staged form: eager only)
         e->shift_lazy_last = s.lazy;
         const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, e->shift_nw * qm::kWave,
                                                   qm::shift_lds_bytes(e->shift_nw));

@@ -667,9 +667,14 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
                 const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRec;
                 const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
                     (int)((k == 0 ? 1u : 0u) | (k == s.nblk - 1 ? 2u : 0u)));
-                shift_group_rows(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
-                                 (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes), g.nz,
-                                 g.ny * g.nz, a.z_scale, c);
+                if (s.lazy)
+                    shift_group_rows_lazy(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                                          (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes),
+                                          g.nz, g.ny * g.nz, a.z_scale, c);
+                else
+                    shift_group_rows(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                                     (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes), g.nz,
+                                     g.ny * g.nz, a.z_scale, c);
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wavefront's loads are in LDS
             __syncthreads();                                       // ... everyone's; the current half is free

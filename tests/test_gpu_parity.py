@@ -1688,7 +1688,8 @@ def test_shift_kernel_row_blocks_beyond_64_rows(lib, oracle, grid, rows, ns):
     want = oracle.detect(onsets, tt, case.fsmp, lsmp, case.available, threads=4)
     out = {}
     # (the register form is automatic from 97 rows on; shift=1 asks for it from 65)
-    for tag, extra, per_block in (("direct", {}, 34), ("registers", {"shift_rows_direct": 0, "shift": 1}, 64),
+    for tag, extra, per_block in (("direct", {"shift_lazy": 0}, 34), ("lazy", {"shift_lazy": 1}, 34),
+                                  ("registers", {"shift_rows_direct": 0, "shift": 1}, 64),
                                   ("round2", {"shift": 0}, 0)):
         eng = lib.Engine(0, **extra)
         eng.load_lut(tt)
@@ -1697,7 +1698,7 @@ def test_shift_kernel_row_blocks_beyond_64_rows(lib, oracle, grid, rows, ns):
             assert eng.get("last_kernel") == 3 and eng.get("shift_row_blocks") == -(-rows // per_block), \
                 (tag, eng.get("last_kernel"), eng.get("shift_row_blocks"))
         eng.close()
-    for tag in ("direct", "registers"):
+    for tag in ("direct", "lazy", "registers"):
         _assert_series(out[tag], want)
         assert np.array_equal(out[tag][2], out["round2"][2])
         assert np.array_equal(out[tag][0], out["round2"][0])            # same bits
