@@ -526,7 +526,8 @@ def main():
             (10, True, False, True, False, False, "shift_groups_volume8"),
             (8, False, False, True, False, True, "shift_group_rows8"),
             (8, False, False, False, False, True, "shift_group_rows"),
-            (8, False, False, False, True, True, "shift_group_rows_lazy")):
+            (8, False, False, False, True, True, "shift_group_rows_lazy"),
+            (10, True, False, False, False, True, "shift_group_rows_volume")):
         configure(lds_state, far, lazy, block)
         lines = body(degree, volume)
         # the stream pointer lives in a hard SGPR pair (the halves of an s[lo:hi] operand cannot be

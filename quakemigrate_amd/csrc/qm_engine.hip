@@ -621,7 +621,8 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         e->shift_lazy_last = s.lazy;
         const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, e->shift_nw * qm::kWave,
                                                   qm::shift_lds_bytes(e->shift_nw));
-        if (e->shift_nblk > 1 && e->shift_direct) QM_TABLE(qm::launch_shift_rows2(s, shape));
+        if (e->shift_nblk > 1 && e->shift_direct && volume) QM_TABLE(qm::launch_shift_rows2_volume(s, shape));
+        else if (e->shift_nblk > 1 && e->shift_direct) QM_TABLE(qm::launch_shift_rows2(s, shape));
         else if (e->shift_nblk > 1) QM_TABLE(qm::launch_shift_rows8(s, shape));
         else if (volume && e->shift_nw == qm::kShiftWaves8) QM_TABLE(qm::launch_shift_volume8(s, shape));
         else if (volume) QM_TABLE(qm::launch_shift_volume(s, shape));
@@ -710,8 +711,9 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
                               volume != nullptr, vol_stride);
     if (shift) {
         if (ensure_shift_tables(e)) return 1;
-        // (the 12-wave shape and the row-block kernel are built for the fused detect only)
-        shift = e->shift_ok && !(volume != nullptr && (e->shift_nw == qm::kShiftWaves3 || e->shift_nblk > 1));
+        // (the 12-wave shape and the register-staged row blocks are built for the fused detect only)
+        shift = e->shift_ok && !(volume != nullptr && (e->shift_nw == qm::kShiftWaves3 ||
+                                                       (e->shift_nblk > 1 && !e->shift_direct)));
     }
     if (shift) {
         jp = 0;

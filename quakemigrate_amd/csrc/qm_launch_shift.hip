@@ -21,7 +21,10 @@ hipError_t launch_shift_rows8(const ShiftArgs &a, const LaunchShape &s) {
     return launch_with_lds(&stack_shift_rows_kernel<kShiftWaves8>, a, s);
 }
 hipError_t launch_shift_rows2(const ShiftArgs &a, const LaunchShape &s) {
-    return launch_with_lds(&stack_shift_rows2_kernel<kShiftWaves8>, a, s);
+    return launch_with_lds(&stack_shift_rows2_kernel<false, kShiftWaves8>, a, s);
+}
+hipError_t launch_shift_rows2_volume(const ShiftArgs &a, const LaunchShape &s) {
+    return launch_with_lds(&stack_shift_rows2_kernel<true, kShiftWaves8>, a, s);
 }
 hipError_t launch_shift_detect3(const ShiftArgs &a, const LaunchShape &s) {
     return launch_with_lds(&stack_shift_kernel<false, kShiftWaves3>, a, s);

@@ -95,6 +95,7 @@ hipError_t launch_shift_detect8(const ShiftArgs &a, const LaunchShape &s);  // t
 hipError_t launch_shift_volume8(const ShiftArgs &a, const LaunchShape &s);
 hipError_t launch_shift_rows8(const ShiftArgs &a, const LaunchShape &s);    // row blocks (> 64 rows)
 hipError_t launch_shift_rows2(const ShiftArgs &a, const LaunchShape &s);    // ... double-buffered, LDS-direct
+hipError_t launch_shift_rows2_volume(const ShiftArgs &a, const LaunchShape &s);
 
 // valid 2x2x2 groups of a brick form a box [0,cx) x [0,cy) x [0,cz) in group coordinates
 __device__ __forceinline__ void shift_group_box(const GridDesc &g, int b, int &x0, int &y0, int &z0,
@@ -606,7 +607,7 @@ __device__ __forceinline__ void stage_shift_block_direct(const ShiftArgs &s, dou
     }
 }
 
-template <int NW>
+template <bool VOLUME, int NW>
 __global__ __attribute__((amdgpu_flat_work_group_size(NW * kWave, NW * kWave), amdgpu_waves_per_eu(6, 6)))
 void stack_shift_rows2_kernel(ShiftArgs s) {
     static_assert(NW == kShiftWaves8, "row blocks: the 8-wave workgroup");
@@ -623,6 +624,9 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
     const int t_first =
         ((tile + 1) * kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT) ? a.n_chunk - kShiftKT : tile * kShiftKT;
     const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 16u;
+    // volume: lanes of a pulled-back tile whose four samples its predecessor stores are masked off
+    const int seam = tile * kShiftKT - t_first;
+    const unsigned long long store_lanes = ~0ull << (seam / 4);
 
     double vmax[4], vsum[4];
     int vidx[4];
@@ -632,7 +636,7 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
         vsum[k] = 0.0;
         vidx[k] = INT32_MAX;
     }
-    constexpr int D = Exp2Degree<false>::value;
+    constexpr int D = Exp2Degree<VOLUME>::value;
     double c[D + 1];
 #pragma unroll
     for (int i = 0; i <= D; ++i) c[i] = exp2_coeff<D>(i);
@@ -667,7 +671,12 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
                 const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRec;
                 const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
                     (int)((k == 0 ? 1u : 0u) | (k == s.nblk - 1 ? 2u : 0u)));
-                if (s.lazy)
+                if constexpr (VOLUME)
+                    shift_group_rows_volume(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                                            (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes),
+                                            g.nz, g.ny * g.nz, a.z_scale, c, a.volume + t_first,
+                                            (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u, store_lanes);
+                else if (s.lazy)
                     shift_group_rows_lazy(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
                                           (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes),
                                           g.nz, g.ny * g.nz, a.z_scale, c);

@@ -1703,6 +1703,24 @@ def test_shift_kernel_row_blocks_beyond_64_rows(lib, oracle, grid, rows, ns):
         assert np.array_equal(out[tag][2], out["round2"][2])
         assert np.array_equal(out[tag][0], out["round2"][0])            # same bits
         np.testing.assert_allclose(out[tag][1], out["round2"][1], rtol=NORM)
+    if ns < 256:
+        return
+    # the volume-writing variant (locate on such a table): every element against the oracle's
+    # volume, the chunked kernel's bits, and the series that comes with it
+    ref = oracle.c_migrate(onsets, tt, case.fsmp, lsmp, case.available, threads=4)
+    vols = {}
+    for tag, extra in (("blocks", {}), ("round2", {"shift": 0})):
+        eng = lib.Engine(0, **extra)
+        eng.load_lut(tt)
+        vol = np.full((case.n_nodes_total, ns), np.nan)
+        series = (np.full(ns, np.nan), np.full(ns, np.nan), np.full(ns, -1, dtype=np.int64))
+        eng.migrate(lon, case.fsmp, lsmp, case.available, vol, scan_out=series)
+        assert (eng.get("last_kernel") == 3) == (tag == "blocks"), (tag, eng.get("last_kernel"))
+        _assert_series(series, want)
+        np.testing.assert_allclose(vol, ref.reshape(vol.shape), rtol=TIGHT)
+        vols[tag] = vol
+        eng.close()
+    assert np.array_equal(vols["blocks"], vols["round2"])
 
 
 @pytest.mark.parametrize("recipe,grid,rows,ns", [SHIFT_SHAPES[0], SHIFT_SHAPES[2], SHIFT_SHAPES[5]])

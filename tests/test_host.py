@@ -436,14 +436,15 @@ def test_headline_kernels_stay_in_registers(tmp_path):
                      "template __global__ void qm::stack_shift_kernel<true, 8>(qm::ShiftArgs);\n"
                      "template __global__ void qm::stack_shift_kernel<false, 12>(qm::ShiftArgs);\n"
                      "template __global__ void qm::stack_shift_rows_kernel<8>(qm::ShiftArgs);\n"
-                     "template __global__ void qm::stack_shift_rows2_kernel<8>(qm::ShiftArgs);\n")
+                     "template __global__ void qm::stack_shift_rows2_kernel<false, 8>(qm::ShiftArgs);\n"
+                     "template __global__ void qm::stack_shift_rows2_kernel<true, 8>(qm::ShiftArgs);\n")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17",
                            f"-I{ROOT / 'quakemigrate_amd' / 'csrc'}", "-c", str(shift), "-o",
                            str(tmp_path / "s.o"), "--save-temps"], cwd=tmp_path,
                           stderr=subprocess.DEVNULL)
     sasm = next(tmp_path.glob("s-hip-amdgcn-*.s")).read_text()
     found = re.findall(r"\.set (\S*stack_shift\w*_kernel\S*)\.num_vgpr, (\d+)", sasm)
-    assert len(found) == 7, found
+    assert len(found) == 8, found
     for name, vgprs in found:
         if "Li12E" in name:                                # the opt-in 12-wave shape: three per SIMD
             assert int(vgprs) <= 168, (name, vgprs)
@@ -457,7 +458,8 @@ def test_headline_kernels_stay_in_registers(tmp_path):
     first_hard = int(re.search(r"kShiftBlockVgprs = (\d+);",
                                (ROOT / "quakemigrate_amd" / "csrc" / "qm_shift_asm.inc").read_text()).group(1))
     for symbol in ("_ZN2qm23stack_shift_rows_kernelILi8EEEvNS_9ShiftArgsE:",
-                   "_ZN2qm24stack_shift_rows2_kernelILi8EEEvNS_9ShiftArgsE:"):
+                   "_ZN2qm24stack_shift_rows2_kernelILb0ELi8EEEvNS_9ShiftArgsE:",
+                   "_ZN2qm24stack_shift_rows2_kernelILb1ELi8EEEvNS_9ShiftArgsE:"):
         body = sasm[sasm.index(symbol):]
         body = body[:body.index("s_endpgm")]
         inside, checked = False, 0
@@ -473,7 +475,7 @@ def test_headline_kernels_stay_in_registers(tmp_path):
             assert all(r < first_hard for r in regs), (first_hard, line.strip())
             checked += bool(regs)
         assert checked > 100
-    assert sasm.count("global_load_lds_dwordx4") >= 6      # the second form stages straight into LDS
+    assert sasm.count("global_load_lds_dwordx4") >= 12     # the second form stages straight into LDS
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17",
                            f"-I{ROOT / 'quakemigrate_amd' / 'csrc'}", "-c", str(src), "-o",
                            str(tmp_path / "k.o"), "--save-temps"], cwd=tmp_path,
