@@ -182,6 +182,8 @@ def stack_kernel_name(eng, S, volume=False):
     """Name of the stacking kernel the engine's last launch used (as rocprofv3 prints it)."""
     kind, j = eng.get("last_kernel"), eng.get("last_kernel_j")
     v = "true" if volume else "false"
+    if kind == 3 and eng.get("shift_row_blocks") > 1:          # tables of more than 64 rows
+        return f"void qm::stack_shift_rows2_kernel<{v}, 8>"
     if kind == 3:
         return f"void qm::stack_shift_kernel<{v}, {eng.get('shift_waves')}>"
     if kind == 2:

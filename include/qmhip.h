@@ -111,7 +111,7 @@ int qm_engine_synchronize(qm_engine *e);
  * launches of whole 256-sample tiles run the shift-reuse kernel, qm_shift.hpp -- 2x2x2 node groups
  * stacked from register windows, 0.56 LDS operands per add at C3 -- where the table qualifies: up
  * to 64 rows, every group's delay spread within 20 samples for >= 99.5 % of the bricks, no grid
- * dimension of 1; fused detect of tables of more than 64 rows runs its row-block form -- 4x4x4
+ * dimension of 1; launches on tables of more than 64 rows run its row-block form -- 4x4x4
  * bricks, the accumulators in registers while the rows pass through a double-buffered LDS in blocks
  * of <= 34, staged by LDS-direct loads ("shift_rows_direct" = 0: blocks of <= 64 staged through
  * registers instead, from 97 rows on); 0 = never, i.e. the round-2 kernels; 1 = as -1, also on

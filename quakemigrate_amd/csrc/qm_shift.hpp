@@ -30,7 +30,9 @@ namespace qm {
 #endif
 #include QM_SHIFT_ASM_INC
 
-// Three workgroup shapes: two 4-wave workgroups per CU with 80 KB each (tables of up to ~32 rows;
+// Tables of more than 64 rows: the row-block kernels at the end of this file (one group per
+// wavefront, its accumulators in registers while the rows pass through LDS block by block).
+// Up to 64 rows, three workgroup shapes: two 4-wave workgroups per CU with 80 KB each (up to ~32 rows;
 // running state in registers, two wavefronts per SIMD); ONE 8-wave workgroup that owns all 160 KB
 // (33-64 rows: twice the rows' windows; plane B lies beyond a DS instruction's 16-bit offset and
 // gets its own address register); or ONE 12-wave workgroup per CU (opt-in: three per SIMD, the

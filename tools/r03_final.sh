@@ -37,4 +37,5 @@ bash tools/prof_counters.sh C3 '[{}]' $TAG/pmc_locate "--ns 401 --volume" > $OUT
 python tools/tune.py --config C3 --rows 60 --ns 401 --volume --reps 3 --sweep '[{}, {"shift": 0}]' > $OUT/locate_60rows.txt 2>&1; tail -4 $OUT/locate_60rows.txt
 # tables of more than 64 rows: row blocks (LDS-direct form, register-staged form) beside the chunked kernel (C3 grid, 1536 samples)
 for r in 66 128 200; do python tools/tune.py --config C3 --rows $r --ns 1536 --reps 2 --sweep '[{}, {"shift_rows_direct": 0, "shift": 1}, {"shift": 0}]' 2>&1 | grep cfg; done > $OUT/rows_66_128_200.txt; cat $OUT/rows_66_128_200.txt
+python tools/tune.py --config C3 --rows 128 --ns 401 --volume --reps 2 --sweep '[{}, {"shift": 0}]' 2>&1 | grep cfg >> $OUT/rows_66_128_200.txt
 python tools/widen_bench.py > $OUT/widen_rows.jsonl 2> $OUT/widen.err; cat $OUT/widen_rows.jsonl
