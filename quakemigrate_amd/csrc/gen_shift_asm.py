@@ -500,7 +500,25 @@ def body(degree, volume):
         e("s_sub_u32 %[ng], %[ng], 1")
         e("s_cmp_lg_u32 %[ng], 0")
         e(f"s_cbranch_scc1 {group}")
-    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    if BLOCK and not volume and PF_AHEAD:
+        # Loads return in order: the block staged before this call (LDS-direct loads) is in LDS once
+        # no more loads are outstanding than this call issued itself -- its stream prefetches, one
+        # per row, which nobody needs to wait for (a full vmcnt(0) here cost a round trip to HBM
+        # per block).  2 * npairs of them at least: wait down to the largest step below that.
+        end = e.label("wv")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_lshl_b32 s{SPAIRS}, %[npairs], 1")
+        for step in (32, 24, 16, 8):
+            nxt = e.label("ws")
+            e(f"s_cmp_ge_u32 s{SPAIRS}, {step}")
+            e(f"s_cbranch_scc0 {nxt}")
+            e(f"s_waitcnt vmcnt({step})")
+            e(f"s_branch {end}")
+            e(f"{nxt}:")
+        e("s_waitcnt vmcnt(0)")
+        e(f"{end}:")
+    else:
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     return e.lines
 
 

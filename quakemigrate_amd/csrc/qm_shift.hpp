@@ -577,8 +577,37 @@ __device__ __forceinline__ void stage_shift_block_direct(const ShiftArgs &s, dou
     const StackArgs &a = s.a;
     using lds_ptr = __attribute__((address_space(3))) void *;
     using glb_ptr = const __attribute__((address_space(1))) void *;
-    for (int r = wave; r < S; r += NW) {
-        const int4 m = s.smeta[(int64_t)vb * s.sb + r];
+    // (the rows' metadata first, all loads in flight at once: a wavefront stages up to five rows of
+    // a block, and five dependent round trips to L2 were as long as the block's adds -- PMC of the
+    // first version: VALU busy 44 %, profiles/r03_pmc_rows128_*)
+    // They come by SCALAR loads (their own counter: a vector load's wait would also wait for the
+    // stream prefetches the loop of the block before has left in flight).
+    constexpr int R = (34 + NW - 1) / NW;
+    static_assert(R == 5, "five metadata loads per wavefront and block");
+    using int4s = int __attribute__((ext_vector_type(4)));
+    int4s ms[R];
+    {
+        const int4 *base = s.smeta + (int64_t)vb * s.sb;
+        unsigned off[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int r = wave + j * NW;
+            off[j] = (unsigned)__builtin_amdgcn_readfirstlane((r < S ? r : 0) * 16);
+        }
+        asm volatile("s_load_dwordx4 %0, %5, %6\n\ts_load_dwordx4 %1, %5, %7\n\ts_load_dwordx4 %2, %5, %8\n\t"
+                     "s_load_dwordx4 %3, %5, %9\n\ts_load_dwordx4 %4, %5, %10\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(ms[0]), "=&s"(ms[1]), "=&s"(ms[2]), "=&s"(ms[3]), "=&s"(ms[4])
+                     : "s"(base), "s"(off[0]), "s"(off[1]), "s"(off[2]), "s"(off[3]), "s"(off[4])
+                     : "memory");
+    }
+    int4 meta[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) meta[j] = make_int4(ms[j].x, ms[j].y, ms[j].z, ms[j].w);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int r = wave + j * NW;
+        if (r >= S) break;
+        const int4 m = meta[j];
         const int first = m.x + a.fsmp + a.sample0 + t_first;      // index inside the row
         const int room = a.T - first;
         const double *src = a.onsets + (int64_t)(row0 + r) * a.T + first;
@@ -687,8 +716,11 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
                                      (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes), g.nz,
                                      g.ny * g.nz, a.z_scale, c);
             }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wavefront's loads are in LDS
-            __syncthreads();                                       // ... everyone's; the current half is free
+            // this wavefront's staging loads are in LDS (the loop has waited for them, leaving only
+            // its own stream prefetches in flight; a wavefront without a group waits here), then
+            // everyone's; the current half is free
+            if (!mine || VOLUME) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             cur ^= 1;
         }
         b = nb;
