@@ -1955,6 +1955,8 @@ def test_permuted_twins_near_ties_are_quantified(lib, oracle):
     rule = np.argmax(z, axis=0)
     ref_idx = g["max_coa_idx"]
     assert abs(float(g["reference_differs"]) - np.mean(ref_idx != g["idx_by_largest_sum"])) < 1e-12
+    # (both flavours of the shift-reuse loop: the lazy one keeps the maximum over the raw stacks and
+    # forms z only where a group is examined -- the rule must still be 'largest rounded z')
     for cfg in ({}, {"shift": 0}, {"screen": 1}):
         eng = lib.Engine(0, **cfg)
         eng.load_lut(tt)
@@ -1966,6 +1968,58 @@ def test_permuted_twins_near_ties_are_quantified(lib, oracle):
         differs = c != ref_idx
         assert 0.02 < differs.mean() < 0.3                     # the measured deviation, ~0.13
         assert np.array_equal(c[differs] // 2, ref_idx[differs] // 2)   # ... always the other twin
+
+
+def test_mirror_twins_near_ties_on_the_shift_kernel(lib, oracle):
+    """The fixture above is an incoherent table (the shift-reuse kernel does not take it).  A
+    COHERENT one with the same property: stations in pairs mirrored about the grid's mid-plane in x
+    and seen with the same onset function, so that a node and its mirror image stack the same
+    multiset of log-onsets in a different row order -- near-ties at every sample, on a table the
+    shift-reuse kernel qualifies for.  Both flavours of its loop (the lazy one keeps the maximum
+    over the raw stacks and forms z only where a group is examined) and the round-2 kernels pick
+    exactly 'largest rounded z, lowest index'; where the reference's compare of exponentiated
+    values (the oracle's) picks differently, it is the mirror twin, with the same value."""
+    rng = np.random.default_rng(4)
+    nx, ny, nz, pairs, ns, fsmp = 16, 12, 10, 7, 700, 9
+    S = 2 * pairs
+    ijk = np.stack(np.indices((nx, ny, nz)), axis=-1).astype(np.float64)
+    tt = np.empty((nx, ny, nz, S), dtype=np.int32)
+    for p in range(pairs):
+        src = rng.uniform([-3, -3, -3], [nx / 2, ny + 3, nz + 3])
+        mirror = np.array([nx - 1 - src[0], src[1], src[2]])
+        steep = rng.uniform(1.0, 4.0)
+        for r, pos in ((2 * p, src), (2 * p + 1, mirror)):
+            tt[..., r] = np.rint(np.sqrt(((ijk - pos) ** 2).sum(-1)) * steep).astype(np.int32)
+    lsmp = int(tt.max())
+    T = fsmp + ns + lsmp
+    rows = np.log(np.clip(rng.lognormal(0, 0.6, size=(pairs, T)), 0.01, None))
+    lon = np.ascontiguousarray(np.repeat(rows, 2, axis=0))        # a pair shares its onset function
+    avail = S
+    flat = tt.reshape(-1, S)
+    sums = np.zeros((flat.shape[0], ns))
+    for r in range(S):                                              # the reference's row order
+        sums += lon[r][fsmp + flat[:, r][:, None] + np.arange(ns)[None, :]]
+    z = sums * (1.4426950408889634074 / avail)
+    rule = np.argmax(z, axis=0)
+    top2 = np.sort(z, axis=0)[-2:]
+    assert np.mean(np.abs(top2[1] - top2[0]) <= 4 * np.spacing(top2[1])) > 0.5    # near-ties indeed
+    want = oracle.detect(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True)
+    mirror_of = np.ravel_multi_index(np.stack(np.unravel_index(np.arange(nx * ny * nz), (nx, ny, nz)))
+                                     * np.array([[-1], [1], [1]]) + np.array([[nx - 1], [0], [0]]),
+                                     (nx, ny, nz))
+    for cfg in ({"shift_lazy": 0}, {"shift_lazy": 1}, {"shift": 0}):
+        eng = lib.Engine(0, **cfg)
+        eng.load_lut(tt)
+        a, b, c = eng.detect(lon, fsmp, lsmp, avail)
+        if "shift_lazy" in cfg:
+            assert eng.get("last_kernel") == 3 and eng.get("shift_lazy") == cfg["shift_lazy"], cfg
+        eng.close()
+        assert np.array_equal(c, rule), cfg
+        np.testing.assert_allclose(a, want[0], rtol=TIGHT)
+        np.testing.assert_allclose(b, want[1], rtol=NORM)
+        differs = c != want[2]
+        assert np.array_equal(mirror_of[c[differs]], want[2][differs])      # ... always the mirror twin
+        assert differs.mean() < 0.5
 
 
 def test_spline_location_on_device_equals_scipy_rbf_on_map_windows(lib):
