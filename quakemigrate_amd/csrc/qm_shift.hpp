@@ -322,6 +322,34 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
     }
 }
 
+// What a workgroup of the shift-reuse kernels works on: XCD-aware (time tile, brick group) map as
+// stack_lds_kernel -- group g runs on XCD g mod 8 --, the grid is padded to a multiple of 8 groups;
+// the last tile of a scan that is not a multiple of the tile length is pulled back so that it ends
+// with the scan (it overlaps its predecessor: same arithmetic, same bits).
+struct ShiftWork {
+    int tile, group, t_first;
+    bool run;
+};
+__device__ __forceinline__ ShiftWork shift_work(const StackArgs &a) {
+    ShiftWork w;
+    const int slot = blockIdx.x >> 3;
+    w.tile = slot % a.ntiles;
+    w.group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    w.run = w.group < a.ngroups && !(a.run_if != nullptr && *a.run_if == 0);
+    w.t_first = ((w.tile + 1) * kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT) ? a.n_chunk - kShiftKT
+                                                                                : w.tile * kShiftKT;
+    return w;
+}
+// a wavefront's running (max z, sum of 2^z, first index) of its four samples per lane
+__device__ __forceinline__ void shift_reset(double (&vmax)[4], double (&vsum)[4], int (&vidx)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        vmax[k] = -__builtin_inf();
+        vsum[k] = 0.0;
+        vidx[k] = INT32_MAX;
+    }
+}
+
 // The workgroup's wavefronts hold (max, sum, index) of the tile's 256 samples, four per lane:
 // combine them through LDS (thread k owns sample k) and publish the workgroup's partial set.
 // Call after a barrier behind the last use of `win`.
@@ -374,16 +402,9 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
     const GridDesc &g = a.g;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-aware workgroup -> (time tile, brick group) map, as stack_lds_kernel
-    const int slot = blockIdx.x >> 3;
-    const int tile = slot % a.ntiles;
-    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
-    if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
-    if (a.run_if != nullptr && *a.run_if == 0) return;
-    // the last tile of a scan that is not a multiple of the tile length is pulled back so that it
-    // ends with the scan (it overlaps its predecessor: same arithmetic, same bits)
-    const int t_first =
-        ((tile + 1) * kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT) ? a.n_chunk - kShiftKT : tile * kShiftKT;
+    const ShiftWork work = shift_work(a);
+    if (!work.run) return;
+    const int tile = work.tile, group = work.group, t_first = work.t_first;
     const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 16u;
     // volume: lanes of a pulled-back tile whose four samples its predecessor stores are masked off
     // at the stores (a lane that straddles the seam stores its four: same bits)
@@ -392,12 +413,7 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
 
     double vmax[4], vsum[4];
     int vidx[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        vmax[k] = -__builtin_inf();
-        vsum[k] = 0.0;
-        vidx[k] = INT32_MAX;
-    }
+    shift_reset(vmax, vsum, vidx);
     // 12-wave shape: the running state lives in LDS behind the windows, 5 chunks of 64 lanes x 16
     // bytes per wavefront (maxima 0-1 / 2-3, sums 0-1 / 2-3, indices)
     double *state = win + (2 * shift_plane(NW) + wave * kShiftStateBytes) / 8 + 2 * lane;
@@ -503,23 +519,14 @@ void stack_shift_rows_kernel(ShiftArgs s) {
     const GridDesc &g = a.g;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = blockIdx.x >> 3;
-    const int tile = slot % a.ntiles;
-    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
-    if (group >= a.ngroups) return;
-    if (a.run_if != nullptr && *a.run_if == 0) return;
-    const int t_first =
-        ((tile + 1) * kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT) ? a.n_chunk - kShiftKT : tile * kShiftKT;
+    const ShiftWork work = shift_work(a);
+    if (!work.run) return;
+    const int tile = work.tile, group = work.group, t_first = work.t_first;
     const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 16u;
 
     double vmax[4], vsum[4];
     int vidx[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        vmax[k] = -__builtin_inf();
-        vsum[k] = 0.0;
-        vidx[k] = INT32_MAX;
-    }
+    shift_reset(vmax, vsum, vidx);
     constexpr int D = Exp2Degree<false>::value;
     double c[D + 1];
 #pragma unroll
@@ -647,13 +654,9 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
     const GridDesc &g = a.g;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = blockIdx.x >> 3;
-    const int tile = slot % a.ntiles;
-    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
-    if (group >= a.ngroups) return;
-    if (a.run_if != nullptr && *a.run_if == 0) return;
-    const int t_first =
-        ((tile + 1) * kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT) ? a.n_chunk - kShiftKT : tile * kShiftKT;
+    const ShiftWork work = shift_work(a);
+    if (!work.run) return;
+    const int tile = work.tile, group = work.group, t_first = work.t_first;
     const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 16u;
     // volume: lanes of a pulled-back tile whose four samples its predecessor stores are masked off
     const int seam = tile * kShiftKT - t_first;
@@ -661,12 +664,7 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
 
     double vmax[4], vsum[4];
     int vidx[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        vmax[k] = -__builtin_inf();
-        vsum[k] = 0.0;
-        vidx[k] = INT32_MAX;
-    }
+    shift_reset(vmax, vsum, vidx);
     constexpr int D = Exp2Degree<VOLUME>::value;
     double c[D + 1];
 #pragma unroll

@@ -461,7 +461,8 @@ def test_headline_kernels_stay_in_registers(tmp_path):
                    "_ZN2qm24stack_shift_rows2_kernelILb0ELi8EEEvNS_9ShiftArgsE:",
                    "_ZN2qm24stack_shift_rows2_kernelILb1ELi8EEEvNS_9ShiftArgsE:"):
         body = sasm[sasm.index(symbol):]
-        body = body[:body.index("s_endpgm")]
+        body = body[:body.index(".Lfunc_end")]                 # (the whole kernel, early exits included)
+        assert "s_endpgm" in body
         inside, checked = False, 0
         for line in body.splitlines():
             if ";;#ASMSTART" in line or ";;#ASMEND" in line:
