@@ -184,8 +184,8 @@ def stack_kernel_name(eng, S, volume=False):
     v = "true" if volume else "false"
     if kind == 3 and eng.get("shift_row_blocks") > 1:          # tables of more than 64 rows
         return f"void qm::stack_shift_rows2_kernel<{v}, 8>"
-    if kind == 3:
-        return f"void qm::stack_shift_kernel<{v}, {eng.get('shift_waves')}>"
+    if kind == 3:                                              # <mode: 0 detect, 1 volume, 2 marginal map; waves>
+        return f"void qm::stack_shift_kernel<{1 if volume else 0}, {eng.get('shift_waves')}>"
     if kind == 2:
         return f"qm::stack_pair_kernel<{j // 2}, {v}, {S}>"
     if kind == 1:

@@ -107,8 +107,8 @@ int qm_engine_synchronize(qm_engine *e);
  * is within 6.7e-7 relative of it by a deterministic bound whose preconditions are checked per
  * step on the device; a step that fails one is redone in float64), "screen_pairs" /
  * "screen_big" (sweep launch shape, 0 / -1 = automatic), "exact" (default 1: the
- * exact-row-count float64 kernel), "shift" (default -1: the fused detect and volume-writing
- * launches of whole 256-sample tiles run the shift-reuse kernel, qm_shift.hpp -- 2x2x2 node groups
+ * exact-row-count float64 kernel), "shift" (default -1: the fused detect, the volume-writing
+ * and the marginal-map launches run the shift-reuse kernel, qm_shift.hpp -- 2x2x2 node groups
  * stacked from register windows, 0.56 LDS operands per add at C3 -- where the table qualifies: up
  * to 64 rows, every group's delay spread within 20 samples for >= 99.5 % of the bricks, no grid
  * dimension of 1; launches on tables of more than 64 rows run its row-block form -- 4x4x4
@@ -120,7 +120,12 @@ int qm_engine_synchronize(qm_engine *e);
  * wavefronts' running state in LDS: same bits, measured no faster), "shift_lazy" (default -1: the
  * detect loop keeps only the group maximum per node and recovers the arg-max where a group
  * reaches the wavefront's running maximum, when a wavefront sees >= 160 groups per launch -- same
- * bits, -2 % at C3; 0 / 1 force the eager / lazy flavour; read back = what the last launch took),
+ * maximum, arg-max and max_coa bits, max_norm_coa within the rounding of the sum's terms (1e-15);
+ * -2 % at C3; 0 / 1 force the eager / lazy flavour; read back = what the last launch took),
+ * "shift_tail" (default 1: what a scan leaves beyond its whole 256-sample tiles -- up to 192
+ * samples -- runs as ONE tail tile of 64 / 128 / 192 samples with 1 / 2 / 3 samples per lane, so a
+ * 401-sample locate window costs 448 samples instead of 512 and scans shorter than a tile run here
+ * too; 0 = whole tiles only, the last one pulled back over its predecessor: same bits either way),
  * "pair" (default 1: the 16-byte-operand kernel for volume-writing launches the shift-reuse
  * kernel does not take; 2 = for every launch, 0 = off), "rounds" (grid size of the automatic
  * group count), "scan_waves" (find_max_coa of a volume: wavefronts per CU over the whole grid).
@@ -129,7 +134,8 @@ int qm_engine_synchronize(qm_engine *e);
  * a dynamic range outside the bound's preconditions), "last_candidates", and of the shift-reuse
  * layout once built: "shift_ok", "shift_brick_nodes", "shift_wide_bricks" (bricks left to the direct
  * kernel), "shift_row_blocks" (1, or the blocks a brick's rows are staged in),
- * "shift_operands_per_add_x1000"; "last_kernel" = 3 when the last launch used it. */
+ * "shift_operands_per_add_x1000", "shift_tail_spl" (samples per lane of the last launch's tail
+ * tile, 0 = none); "last_kernel" = 3 when the last launch used it. */
 int qm_engine_config(qm_engine *e, const char *key, int64_t value);
 int qm_engine_get(qm_engine *e, const char *key, int64_t *value);
 

@@ -28,6 +28,27 @@ trailing pad.  Record of row r:
 One s_load_dwordx16 per row, issued one row ahead; the window is read one row ahead into the other
 of two register windows (rows unrolled by two).
 
+Round 4 adds two things to the same loop.
+
+TAIL TILES (SPL = 1, 2, 3 samples per lane: time tiles of 64, 128, 192 samples): a scan that is not
+a multiple of 256 samples used to compute a whole 256-sample tile for its remainder (401 samples
+cost 512, 625 cost 768).  The remainder now runs as ONE tile of 64 * SPL samples with the same
+stream and the same register-index scheme: a lane owns SPL consecutive samples, node g's SPL adds
+take window registers [idx_g, idx_g + SPL).  Row windows of a tail tile are staged CONTIGUOUSLY
+(sample u at byte 8 u of the row's LDS region; the two-plane layout exists to make four samples
+per lane conflict-free) -- sample e0 of a row sits at twice the record's plane offset -- and read
+with ds_read_b64 (lane stride 8 / 24 bytes) or, for SPL = 2, aligned ds_read_b128 (lane stride 16
+bytes): 4 nq - 4 + SPL doubles per row.  A tail tile starts where the full tiles end (nothing is
+computed twice); lanes past the scan's end compute on zero-filled / following samples and are
+masked where results leave the wavefront (partial sets, per-sample EXEC masks at the volume
+stores, zero weights in the marginal sum).
+
+MARGINAL flavour (locate's marginalised map without the 4-D volume, signal/scan.py:720,
+io/event.py:421-439): the volume flavour's epilogue with the two stores replaced by
+m = sum_k w_k * 2^z_k (w = 1.0 inside the window [m0, m1), 0.0 outside: exact), a wavefront sum
+by DPP moves (quad_perm, row_half_mirror, row_mirror, row_bcast 15 / 31: the total lands in lane
+63) and one 8-byte store per (node, tile) from that lane.
+
 Usage: python gen_shift_asm.py > qm_shift_asm.inc   (committed; build() checks it is current).
 """
 
@@ -48,16 +69,21 @@ PLANE8 = 81856           # ... for the 8-wave workgroup that owns a CU's whole L
                          # address register ("far plane")
 STATE_CHUNK = 1024       # running state in LDS: 5 chunks of 64 lanes x 16 bytes per wavefront
 VB_BLOCK = 80            # first hard VGPR of the row-block flavour
+MARGINAL_DEGREE = 10     # 2^f of the marginalised map's terms (the stored values' polynomial)
 
 
-def configure(lds_state, far=False, lazy=False, block=False):
+def configure(lds_state, far=False, lazy=False, block=False, spl=4, contig=False, marginal=False):
     """Register plan.  far: plane B is addressed through a second register (see PLANE8).  lds_state = False: the wavefront's running (max, sum, index) are inline-asm
     operands (20 VGPRs the compiler places below VB).  True: they live in LDS and are read and
     written by the group merge, the per-node temporaries move into window 1 -- 167 VGPRs in all,
     three wavefronts per SIMD."""
     global LDS_STATE, FAR, PLANE, VB, ACC, WIN, VADDR, VADDRB, VNODE, VC, VPF, VZERO, VEND, VMAG
-    global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR, LAZY, BLOCK
+    global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR, LAZY, BLOCK, SPL, CONTIG, MARGINAL
     BLOCK = block            # one group per call, accumulators kept between calls (row blocks)
+    SPL = spl                # samples per lane (4: full tiles; 1..3: tail tiles)
+    CONTIG = contig          # row windows staged contiguously (tail tiles)
+    MARGINAL = marginal      # the marginalised map instead of the volume
+    assert 1 <= spl <= 4 and (contig or spl == 4) and not (contig and (far or lds_state or lazy or block))
     LDS_STATE = lds_state
     LAZY = lazy
     FAR = far
@@ -92,9 +118,9 @@ def configure(lds_state, far=False, lazy=False, block=False):
         VC = (VNODE + 2) & ~1    # (64-bit register tuples are even-aligned on gfx90a+)
         VPF = VC + 2
         assert KI + 1 <= WIN[1] + 2 * WMAX
-        MAXR = [f"%[max{k}]" for k in range(4)]
-        SUMR = [f"%[sum{k}]" for k in range(4)]
-        IDXR = [f"%[idx{k}]" for k in range(4)]
+        MAXR = [f"%[max{k}]" for k in range(SPL)]
+        SUMR = [f"%[sum{k}]" for k in range(SPL)]
+        IDXR = [f"%[idx{k}]" for k in range(SPL)]
     VZERO = VPF + 1
     VMAG = (VZERO + 2) & ~1      # 1.5 * 2^52 as a VGPR pair (lazy flavour: z is folded into FMAs)
     VEND = VMAG + 2 if lazy else VZERO + 1
@@ -144,7 +170,29 @@ def quad_reads(win, m):
             f"ds_read_b128 v[{win + 8 * m + 4}:{win + 8 * m + 7}], {plane_b}"]
 
 
+def contig_reads(win, m):
+    """tail tiles: the reads quad count m + 1 adds to quad count m (m < NQMIN: nothing, the first
+    NQMIN quads' worth -- 4 NQMIN - 4 + SPL doubles -- is fetched by contig_base_reads)"""
+    if SPL == 2:             # pairs of doubles, 16-byte aligned: 2 nq - 1 of them
+        return [f"ds_read_b128 v[{win + 4 * p}:{win + 4 * p + 3}], v{VADDR} offset:{16 * p}"
+                for p in range(2 * m - 1, 2 * m + 1)]
+    return [f"ds_read_b64 {v2(win + 2 * i)}, v{VADDR} offset:{8 * i}"
+            for i in range(4 * m - 4 + SPL, 4 * m + SPL)]
+
+
+def contig_base_reads(win):
+    if SPL == 2:
+        return [f"ds_read_b128 v[{win + 4 * p}:{win + 4 * p + 3}], v{VADDR} offset:{16 * p}"
+                for p in range(2 * NQMIN - 1)]
+    return [f"ds_read_b64 {v2(win + 2 * i)}, v{VADDR} offset:{8 * i}"
+            for i in range(4 * NQMIN - 4 + SPL)]
+
+
 def window_address(e, hdr):
+    if CONTIG:
+        # sample e0 of the row: byte 2 * (the record's plane offset) of the contiguous layout
+        e(f"v_lshl_add_u32 v{VADDR}, s{hdr}, 1, %[lane]")
+        return
     e(f"v_add_u32 v{VADDR}, s{hdr}, %[lane]")          # src0 scalar: untouched by SRC0-relative mode
     if FAR:
         e(f"v_add_u32 v{VADDRB}, s{hdr}, %[laneb]")
@@ -153,14 +201,18 @@ def window_address(e, hdr):
 def issue_window(e, q, hdr):
     """block form (prologue only): reads of the row whose header is s[hdr], s[hdr+1] into WIN[q]"""
     window_address(e, hdr)
-    for m in range(NQMIN):
-        for line in quad_reads(WIN[q], m):
+    if CONTIG:
+        for line in contig_base_reads(WIN[q]):
             e(line)
+    else:
+        for m in range(NQMIN):
+            for line in quad_reads(WIN[q], m):
+                e(line)
     done = e.label("rd")
     for m in range(NQMIN, NQMAX):
         e(f"s_cmp_le_u32 s{hdr + 1}, {m}")
         e(f"s_cbranch_scc1 {done}")
-        for line in quad_reads(WIN[q], m):
+        for line in (contig_reads(WIN[q], m) if CONTIG else quad_reads(WIN[q], m)):
             e(line)
     e(f"{done}:")
 
@@ -171,7 +223,7 @@ def node_adds(e, p, g, first):
         e("s_nop 0")
     else:
         e(f"s_set_gpr_idx_on s{BUF[p] + g}, 1")               # SRC0 relative, index = idx[g]
-    for k in range(4):
+    for k in range(SPL):
         a = v2(ACC + 8 * g + 2 * k)
         w = v2(WIN[p] + 2 * k)
         e(f"v_add_f64 {a}, {w}, {'0' if first else a}")
@@ -240,6 +292,31 @@ def node_index(e, g, to_vgpr=True):
         e(f"v_mov_b32 v{VNODE}, s{SNODE}")
 
 
+def node_tail(e, g, A, opens_group):
+    """the node's terms into the running sums and its arg-max (independent of what precedes)"""
+    if not (LDS_STATE and opens_group):
+        for k in range(SPL):
+            e(f"v_add_f64 {SUMR[k]}, {SUMR[k]}, {v2(P + 2 * k)}")
+    if LAZY:
+        if opens_group:
+            return                                             # node 1 takes max(z0, z1)
+        for k in range(SPL):
+            prev = v2(ACC + 2 * k) if opens_group is None else v2(GMAX + 2 * k)
+            e(f"v_max_f64 {v2(GMAX + 2 * k)}, {prev}, {v2(A[k])}")       # a NaN never wins
+        return
+    for k in range(SPL):
+        if opens_group:
+            # the group's first node against the (-inf, none) start, without materialising it
+            # (a NaN or -inf z leaves (-inf, none), exactly as the strict '>' below would)
+            e(f"v_cmp_gt_f64 vcc, {v2(A[k])}, {s2(SNEGINF)}")
+            e(f"v_cndmask_b32 v{GIDX + k}, v{KI}, v{VNODE}, vcc")   # v[KI] = "none"
+            e(f"v_max_f64 {v2(GMAX + 2 * k)}, {v2(A[k])}, {s2(SNEGINF)}")
+        else:
+            e(f"v_cmp_gt_f64 vcc, {v2(A[k])}, {v2(GMAX + 2 * k)}")
+            e(f"v_cndmask_b32 v{GIDX + k}, v{GIDX + k}, v{VNODE}, vcc")
+            e(f"v_max_f64 {v2(GMAX + 2 * k)}, {v2(GMAX + 2 * k)}, {v2(A[k])}")
+
+
 def epilogue_node(e, degree, volume, g, opens_group):
     """LAZY flavour: only the group's maximum is kept per node (v_max_f64); WHICH node holds it is
     recovered after the eight nodes, per sample slot, and only where the group's maximum reaches
@@ -250,38 +327,93 @@ def epilogue_node(e, degree, volume, g, opens_group):
     on."""
     if volume or not LAZY:
         node_index(e, g, not LAZY)
-    A = [ACC + 8 * g + 2 * k for k in range(4)]
+    A = [ACC + 8 * g + 2 * k for k in range(SPL)]
     if LAZY:
         # z = stack * scale is never formed per node-sample: t = fma(stack, scale, 1.5*2^52),
         # k = t - 1.5*2^52, f = fma(stack, scale, -k) (three instructions instead of four; the sum's
         # terms differ from the other kernels' in the last bits, the maximum is taken over the raw
         # stacks -- monotone in z -- and brought to z where a group is examined, epilogue)
-        for k in range(4):
+        for k in range(SPL):
             e(f"v_fma_f64 {v2(TT + 2 * k)}, {v2(A[k])}, %[scale], {v2(VMAG)}")
-        for k in range(4):
+        for k in range(SPL):
             e(f"v_add_f64 {v2(F + 2 * k)}, {v2(TT + 2 * k)}, -{s2(SMAGIC)}")
-        for k in range(4):
+        for k in range(SPL):
             e(f"v_fma_f64 {v2(F + 2 * k)}, {v2(A[k])}, %[scale], -{v2(F + 2 * k)}")
     else:
-        for k in range(4):                                      # z = stack * log2(e)/available
+        for k in range(SPL):                                      # z = stack * log2(e)/available
             e(f"v_mul_f64 {v2(A[k])}, {v2(A[k])}, %[scale]")
         # k = rint(z), f = z - k:  t = z + 1.5*2^52 holds k in its low dword (round half to even, as
         # v_rndne_f64), t - 1.5*2^52 is k as a double -- two adds instead of rndne + the slower cvt
-        for k in range(4):
+        for k in range(SPL):
             e(f"v_add_f64 {v2(TT + 2 * k)}, {v2(A[k])}, {s2(SMAGIC)}")
-        for k in range(4):
+        for k in range(SPL):
             e(f"v_add_f64 {v2(F + 2 * k)}, {v2(TT + 2 * k)}, -{s2(SMAGIC)}")
-        for k in range(4):                                      # f = z - k
+        for k in range(SPL):                                      # f = z - k
             e(f"v_add_f64 {v2(F + 2 * k)}, {v2(A[k])}, -{v2(F + 2 * k)}")
-    for k in range(4):
+    for k in range(SPL):
         e(f"v_fma_f64 {v2(P + 2 * k)}, {v2(VC)}, {v2(F + 2 * k)}, %[c{degree - 1}]")
     for i in range(degree - 2, -1, -1):
-        for k in range(4):
+        for k in range(SPL):
             e(f"v_fma_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, {v2(F + 2 * k)}, %[c{i}]")
-    for k in range(4):
+    for k in range(SPL):
         dst = SUMR[k] if (LDS_STATE and opens_group) else v2(P + 2 * k)   # the group's sum starts here
         e(f"v_ldexp_f64 {dst}, {v2(P + 2 * k)}, v{TT + 2 * k}")
-    if volume:
+    if volume and MARGINAL:
+        # the marginalised map: m = sum_k w_k * 2^z_k over the lane's samples (w = 1.0 inside the
+        # window and the tile's own samples, 0.0 elsewhere: products and the first sum are exact),
+        # summed over the wavefront with DPP moves in the order of an xor butterfly (as
+        # wave_sum_to_last_lane, qm_kernels.hpp: the total lands in lane 63), one 8-byte store per
+        # (node, tile).  A DPP read needs 2 wait states after the VALU write of its source: the
+        # node's remaining, independent instructions (its terms into the running sums, its
+        # arg-max) are dealt into those gaps, s_nop where they run out.
+        # F is dead after the Horner steps: m in F[0:1], the moved copy in F[2:3].
+        assert not LAZY and not LDS_STATE
+        pool = Emitter()
+        node_tail(pool, g, A, opens_group)
+        pool = pool.lines
+
+        def gap():
+            take, pool[:] = pool[:2], pool[2:]
+            # (a v_cmp and the v_cndmask that reads its vcc stay in order: nothing here writes vcc)
+            for line in take:
+                e(line)
+            if len(take) < 2:
+                e(f"s_nop {1 - len(take)}")
+        m, t = F, F + 2
+        e(f"v_mul_f64 {v2(m)}, {v2(P)}, %[w0]")
+        for k in range(1, SPL):
+            e(f"v_fma_f64 {v2(m)}, {v2(P + 2 * k)}, %[w{k}], {v2(m)}")
+        for ctrl in ("quad_perm:[1,0,3,2] row_mask:0xf", "quad_perm:[2,3,0,1] row_mask:0xf",
+                     "row_half_mirror row_mask:0xf", "row_mirror row_mask:0xf",
+                     "row_bcast:15 row_mask:0xa", "row_bcast:31 row_mask:0xc"):
+            gap()
+            e(f"v_mov_b32_dpp v{t}, v{m} {ctrl} bank_mask:0xf")
+            e(f"v_mov_b32_dpp v{t + 1}, v{m + 1} {ctrl} bank_mask:0xf")
+            e(f"v_add_f64 {v2(m)}, {v2(m)}, {v2(t)}")
+        e(f"s_lshl_b32 s{SVA}, s{SNODE}, 3")                  # byte offset of the node's element
+        e(f"s_lshr_b32 s{SVA + 1}, s{SNODE}, 29")
+        e(f"s_add_u32 s{SVA}, s{SVA}, %[vlo]")
+        e(f"s_addc_u32 s{SVA + 1}, s{SVA + 1}, %[vhi]")
+        e("s_mov_b32 exec_lo, 0")
+        e("s_mov_b32 exec_hi, 0x80000000")                     # lane 63
+        e(f"global_store_dwordx2 v{VZERO}, {v2(m)}, {s2(SVA)}")
+        e("s_mov_b64 exec, -1")
+        for line in pool:
+            e(line)
+        return
+    elif volume and CONTIG:
+        # tail tile: the lane's SPL values are 8 SPL contiguous bytes of the node's volume row;
+        # one 8-byte store per sample slot, each under the mask of the lanes whose sample k lies
+        # inside the scan (the tile may reach past its end)
+        e(f"s_mul_i32 s{SVA}, s{SNODE}, %[vstride]")
+        e(f"s_mul_hi_u32 s{SVA + 1}, s{SNODE}, %[vstride]")
+        e(f"s_add_u32 s{SVA}, s{SVA}, %[vlo]")
+        e(f"s_addc_u32 s{SVA + 1}, s{SVA + 1}, %[vhi]")
+        for k in range(SPL):
+            e(f"s_mov_b64 exec, %[m{k}]")
+            e(f"global_store_dwordx2 %[voff], {v2(P + 2 * k)}, {s2(SVA)} offset:{8 * k} nt")
+        e("s_mov_b64 exec, -1")
+    elif volume:
         # the node's four values per lane are 32 contiguous bytes of its volume row (the tile's
         # first sample is in the base): two 16-byte stores.  P is not written again before the
         # next node's first Horner step, a dozen instructions away (gfx940+: 2 wait states
@@ -306,27 +438,7 @@ def epilogue_node(e, degree, volume, g, opens_group):
                 e(f"global_store_dwordx4 %[voff], v[{P + 4}:{P + 7}], {s2(SVA)} offset:16{nt}")
             if "nomask" not in EXP:
                 e("s_mov_b64 exec, -1")
-    if not (LDS_STATE and opens_group):
-        for k in range(4):
-            e(f"v_add_f64 {SUMR[k]}, {SUMR[k]}, {v2(P + 2 * k)}")
-    if LAZY:
-        if opens_group:
-            return                                             # node 1 takes max(z0, z1)
-        for k in range(4):
-            prev = v2(ACC + 2 * k) if opens_group is None else v2(GMAX + 2 * k)
-            e(f"v_max_f64 {v2(GMAX + 2 * k)}, {prev}, {v2(A[k])}")       # a NaN never wins
-        return
-    for k in range(4):
-        if opens_group:
-            # the group's first node against the (-inf, none) start, without materialising it
-            # (a NaN or -inf z leaves (-inf, none), exactly as the strict '>' below would)
-            e(f"v_cmp_gt_f64 vcc, {v2(A[k])}, {s2(SNEGINF)}")
-            e(f"v_cndmask_b32 v{GIDX + k}, v{KI}, v{VNODE}, vcc")   # v[KI] = "none"
-            e(f"v_max_f64 {v2(GMAX + 2 * k)}, {v2(A[k])}, {s2(SNEGINF)}")
-        else:
-            e(f"v_cmp_gt_f64 vcc, {v2(A[k])}, {v2(GMAX + 2 * k)}")
-            e(f"v_cndmask_b32 v{GIDX + k}, v{GIDX + k}, v{VNODE}, vcc")
-            e(f"v_max_f64 {v2(GMAX + 2 * k)}, {v2(GMAX + 2 * k)}, {v2(A[k])}")
+    node_tail(e, g, A, opens_group)
 
 
 def epilogue(e, degree, volume):
@@ -348,7 +460,7 @@ def epilogue(e, degree, volume):
         epilogue_node(e, degree, volume, g, g == 0 if not LAZY else (True if g == 0 else None if g == 1 else False))
     e(f"s_branch {merge}")
     e(f"{partial}:")
-    for k in range(4):
+    for k in range(SPL):
         e(f"v_mov_b32 v{GMAX + 2 * k}, 0")
         e(f"v_mov_b32 v{GMAX + 2 * k + 1}, 0xfff00000")        # -inf
         if not LAZY:
@@ -363,7 +475,7 @@ def epilogue(e, degree, volume):
             # a node outside the grid: NaN, so that it never equals the group's maximum below
             inside = e.label("in")
             e(f"s_cbranch_scc1 {inside}")
-            for k in range(4):
+            for k in range(SPL):
                 e(f"v_mov_b32 v{ACC + 8 * g + 2 * k + 1}, 0x7ff80000")
             e(f"s_branch {skip}")
             e(f"{inside}:")
@@ -378,10 +490,10 @@ def epilogue(e, degree, volume):
         # ascending flat index, an equal value may have to hand over a lower index)
         # (the group maxima are raw stacks: z = stack * scale, the rounded product every kernel
         # compares, once per group and sample slot -- into the dead TT registers)
-        for k in range(4):
+        for k in range(SPL):
             e(f"v_mul_f64 {v2(TT + 2 * k)}, {v2(GMAX + 2 * k)}, %[scale]")
         e(f"v_cmp_ge_f64 {s2(ST)}, {v2(TT)}, {MAXR[0]}")
-        for k in range(1, 4):
+        for k in range(1, SPL):
             e(f"v_cmp_ge_f64 vcc, {v2(TT + 2 * k)}, {MAXR[k]}")
             e(f"s_or_b64 {s2(ST)}, {s2(ST)}, vcc")
         e(f"s_cmp_eq_u64 {s2(ST)}, 0")
@@ -395,7 +507,7 @@ def epilogue(e, degree, volume):
         for g in range(8):
             node_index(e, g, False)
             e(f"v_mov_b32 v{F + g}, s{SNODE}")
-        for k in range(4):
+        for k in range(SPL):
             nxt = e.label("nk")
             g_ = v2(TT + 2 * k)
             e(f"v_cmp_ge_f64 vcc, {g_}, {MAXR[k]}")
@@ -424,7 +536,7 @@ def epilogue(e, degree, volume):
         for c, reg in enumerate((F, F + 4, P, P + 4, TT)):
             e(f"ds_read_b128 v[{reg}:{reg + 3}], %[state] offset:{c * STATE_CHUNK}")
         e("s_waitcnt lgkmcnt(0)")
-    for k in range(4):
+    for k in range(SPL):
         g_ = v2(GMAX + 2 * k)
         e(f"v_cmp_gt_f64 {s2(ST)}, {g_}, {MAXR[k]}")
         e(f"v_cmp_eq_f64 {s2(ST + 2)}, {g_}, {MAXR[k]}")
@@ -434,7 +546,7 @@ def epilogue(e, degree, volume):
         e(f"v_cndmask_b32 {IDXR[k]}, {IDXR[k]}, v{GIDX + k}, vcc")
         e(f"v_max_f64 {MAXR[k]}, {MAXR[k]}, {g_}")
     if LDS_STATE:
-        for k in range(4):
+        for k in range(SPL):
             e(f"v_add_f64 {v2(P + 2 * k)}, {v2(P + 2 * k)}, {SUMR[k]}")
         for c, reg in enumerate((F, F + 4, P, P + 4, TT)):
             e(f"ds_write_b128 %[state], v[{reg}:{reg + 3}] offset:{c * STATE_CHUNK}")
@@ -522,6 +634,82 @@ def body(degree, volume):
     return e.lines
 
 
+def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False, marginal=False):
+    configure(lds_state, far, lazy, block, spl, contig, marginal)
+    lines = body(degree, volume)
+    # the stream pointer lives in a hard SGPR pair (the halves of an s[lo:hi] operand cannot be
+    # named in inline asm): it is handed over as two 32-bit scalars
+    text = "\\n\\t".join(lines)
+    ragged = volume and contig and not marginal
+    print()
+    print(f"// degree-{degree} 2^f{', marginalised map' if marginal else ', values stored' if volume else ''}"
+          f"{', running state in LDS' if lds_state else ''}{', far plane' if far else ''}"
+          f"{', arg-max recovered lazily' if lazy else ''}"
+          f"{', ONE group, one block of its rows per call (flags: 1 = first block, 2 = last)' if block else ''}"
+          f"{f', TAIL tile of {spl} sample(s) per lane, contiguous row windows' if contig else ''}; "
+          f"window of up to {WMAX} doubles; "
+          f"hard VGPRs v{VB}..v{VEND - 1}, SGPRs s{SB}..s{SEND - 1}")
+    print(f"__device__ __forceinline__ void {name}("
+          + ("" if lds_state else f"double (&vmax)[{spl}], double (&vsum)[{spl}], int (&vidx)[{spl}],"))
+    print("        const void *stream, " + ("unsigned flags, const void *next_run, unsigned next_off, "
+                                            if block else "int ngroups, ") + "int npairs, unsigned lane_addr, "
+          + ("unsigned state_addr, " if lds_state else "")
+          + ("unsigned lane_addr_b, " if far else "") + "int nz, "
+          f"int nynz, double scale, const double (&c)[{degree + 1}]"
+          + (f", double *marg_tile, const double (&w)[{spl}]" if marginal else
+             f", double *vol_tile, unsigned vol_stride_bytes, unsigned lane_bytes, "
+             f"const unsigned long long (&store_lanes)[{spl}]" if ragged else
+             ", double *vol_tile, unsigned vol_stride_bytes, unsigned lane_bytes, "
+             "unsigned long long store_lanes" if volume else "")
+          + ") {")
+    print("    const unsigned long long sp = (unsigned long long)stream;")
+    print("    const unsigned tablo = (unsigned)sp, tabhi = (unsigned)(sp >> 32);")
+    print(f"    const unsigned long long cl = (unsigned long long)__double_as_longlong(c[{degree}]);")
+    print("    const unsigned clo = (unsigned)cl, chi = (unsigned)(cl >> 32);")
+    if marginal:
+        print("    const unsigned long long vp = (unsigned long long)marg_tile;")
+        print("    const unsigned vlo = (unsigned)vp, vhi = (unsigned)(vp >> 32);")
+    elif volume:
+        print("    const unsigned long long vp = (unsigned long long)vol_tile;")
+        print("    const unsigned vlo = (unsigned)vp, vhi = (unsigned)(vp >> 32);")
+        if not ragged:
+            print("    const unsigned mlo = (unsigned)store_lanes, mhi = (unsigned)(store_lanes >> 32);")
+    outs = []
+    if not lds_state:
+        outs += [f'[max{k}] "+v"(vmax[{k}])' for k in range(spl)]
+        outs += [f'[sum{k}] "+v"(vsum[{k}])' for k in range(spl)]
+        outs += [f'[idx{k}] "+v"(vidx[{k}])' for k in range(spl)]
+    if not block:
+        outs += ['[ng] "+s"(ngroups)']
+    ins = ['[tablo] "s"(tablo)', '[tabhi] "s"(tabhi)', '[lane] "v"(lane_addr)',
+           '[npairs] "s"(npairs)', '[nz] "s"(nz)', '[nynz] "s"(nynz)', '[scale] "s"(scale)',
+           '[clo] "s"(clo)', '[chi] "s"(chi)']
+    if lds_state:
+        ins += ['[state] "v"(state_addr)']
+    if far:
+        ins += ['[laneb] "v"(lane_addr_b)']
+    if block:
+        ins += ['[flags] "s"(flags)', '[nxrun] "s"(next_run)', '[nxoff] "v"(next_off)']
+    if marginal:
+        ins += ['[vlo] "s"(vlo)', '[vhi] "s"(vhi)']
+        ins += [f'[w{k}] "v"(w[{k}])' for k in range(spl)]
+    elif ragged:
+        ins += ['[vlo] "s"(vlo)', '[vhi] "s"(vhi)', '[vstride] "s"(vol_stride_bytes)',
+                '[voff] "v"(lane_bytes)']
+        ins += [f'[m{k}] "s"(store_lanes[{k}])' for k in range(spl)]
+    elif volume:
+        ins += ['[vlo] "s"(vlo)', '[vhi] "s"(vhi)', '[vstride] "s"(vol_stride_bytes)',
+                '[voff] "v"(lane_bytes)', '[mlo] "s"(mlo)', '[mhi] "s"(mhi)']
+    ins += [f'[c{i}] "s"(c[{i}])' for i in range(degree)]
+    clob = [f'"v{r}"' for r in range(VB, VEND)] + [f'"s{r}"' for r in range(SB, SEND)]
+    clob += ['"vcc"', '"scc"', '"m0"', '"memory"']
+    print(f'    asm volatile("{text}"')
+    print(f'                 : {", ".join(outs)}')
+    print(f'                 : {", ".join(ins)}')
+    print(f'                 : {", ".join(clob)});')
+    print("}")
+
+
 def main():
     print("// GENERATED by gen_shift_asm.py -- do not edit.  See that file for the schedule and the")
     print("// stream format.")
@@ -546,63 +734,15 @@ def main():
             (8, False, False, False, False, True, "shift_group_rows"),
             (8, False, False, False, True, True, "shift_group_rows_lazy"),
             (10, True, False, False, False, True, "shift_group_rows_volume")):
-        configure(lds_state, far, lazy, block)
-        lines = body(degree, volume)
-        # the stream pointer lives in a hard SGPR pair (the halves of an s[lo:hi] operand cannot be
-        # named in inline asm): it is handed over as two 32-bit scalars
-        text = "\\n\\t".join(lines)
-        print()
-        print(f"// degree-{degree} 2^f{', values stored' if volume else ''}"
-              f"{', running state in LDS' if lds_state else ''}{', far plane' if far else ''}"
-              f"{', arg-max recovered lazily' if lazy else ''}"
-              f"{', ONE group, one block of its rows per call (flags: 1 = first block, 2 = last)' if block else ''}; "
-              f"window of up to {WMAX} doubles; "
-              f"hard VGPRs v{VB}..v{VEND - 1}, SGPRs s{SB}..s{SEND - 1}")
-        print(f"__device__ __forceinline__ void {name}("
-              + ("" if lds_state else "double (&vmax)[4], double (&vsum)[4], int (&vidx)[4],"))
-        print("        const void *stream, " + ("unsigned flags, const void *next_run, unsigned next_off, "
-                                                if block else "int ngroups, ") + "int npairs, unsigned lane_addr, "
-              + ("unsigned state_addr, " if lds_state else "")
-              + ("unsigned lane_addr_b, " if far else "") + "int nz, "
-              f"int nynz, double scale, const double (&c)[{degree + 1}]"
-              + (", double *vol_tile, unsigned vol_stride_bytes, unsigned lane_bytes, "
-                 "unsigned long long store_lanes" if volume else "")
-              + ") {")
-        print("    const unsigned long long sp = (unsigned long long)stream;")
-        print("    const unsigned tablo = (unsigned)sp, tabhi = (unsigned)(sp >> 32);")
-        print(f"    const unsigned long long cl = (unsigned long long)__double_as_longlong(c[{degree}]);")
-        print("    const unsigned clo = (unsigned)cl, chi = (unsigned)(cl >> 32);")
-        if volume:
-            print("    const unsigned long long vp = (unsigned long long)vol_tile;")
-            print("    const unsigned vlo = (unsigned)vp, vhi = (unsigned)(vp >> 32);")
-            print("    const unsigned mlo = (unsigned)store_lanes, mhi = (unsigned)(store_lanes >> 32);")
-        outs = []
-        if not lds_state:
-            outs += [f'[max{k}] "+v"(vmax[{k}])' for k in range(4)]
-            outs += [f'[sum{k}] "+v"(vsum[{k}])' for k in range(4)]
-            outs += [f'[idx{k}] "+v"(vidx[{k}])' for k in range(4)]
-        if not block:
-            outs += ['[ng] "+s"(ngroups)']
-        ins = ['[tablo] "s"(tablo)', '[tabhi] "s"(tabhi)', '[lane] "v"(lane_addr)',
-               '[npairs] "s"(npairs)', '[nz] "s"(nz)', '[nynz] "s"(nynz)', '[scale] "s"(scale)',
-               '[clo] "s"(clo)', '[chi] "s"(chi)']
-        if lds_state:
-            ins += ['[state] "v"(state_addr)']
-        if far:
-            ins += ['[laneb] "v"(lane_addr_b)']
-        if block:
-            ins += ['[flags] "s"(flags)', '[nxrun] "s"(next_run)', '[nxoff] "v"(next_off)']
-        if volume:
-            ins += ['[vlo] "s"(vlo)', '[vhi] "s"(vhi)', '[vstride] "s"(vol_stride_bytes)',
-                    '[voff] "v"(lane_bytes)', '[mlo] "s"(mlo)', '[mhi] "s"(mhi)']
-        ins += [f'[c{i}] "s"(c[{i}])' for i in range(degree)]
-        clob = [f'"v{r}"' for r in range(VB, VEND)] + [f'"s{r}"' for r in range(SB, SEND)]
-        clob += ['"vcc"', '"scc"', '"m0"', '"memory"']
-        print(f'    asm volatile("{text}"')
-        print(f'                 : {", ".join(outs)}')
-        print(f'                 : {", ".join(ins)}')
-        print(f'                 : {", ".join(clob)});')
-        print("}")
+        emit(degree, volume, lds_state, far, lazy, block, name)
+    # round 4: the marginalised map on full tiles (both workgroup shapes) ...
+    emit(MARGINAL_DEGREE, True, False, False, False, False, "shift_groups_marginal", marginal=True)
+    emit(MARGINAL_DEGREE, True, False, True, False, False, "shift_groups_marginal8", marginal=True)
+    # ... and the tail tiles: 1, 2, 3 samples per lane, contiguous row windows (either shape)
+    for spl in (1, 2, 3):
+        emit(8, False, False, False, False, False, f"shift_tail{spl}_detect", spl, True)
+        emit(10, True, False, False, False, False, f"shift_tail{spl}_volume", spl, True)
+        emit(MARGINAL_DEGREE, True, False, False, False, False, f"shift_tail{spl}_marginal", spl, True, True)
 
 
 if __name__ == "__main__":

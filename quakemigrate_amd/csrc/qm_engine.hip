@@ -147,7 +147,10 @@ struct qm_engine {
     int cfg_shift = -1;                     // -1: where the table qualifies, 0: never, 1: as -1 (explicit)
     int cfg_shift_waves = 0;                // workgroup shape: 4 (two per CU), 12 (one per CU), 0 = automatic
     int cfg_shift_lazy = -1;                // detect loop flavour: -1 automatic, 0 eager, 1 lazy arg-max
+    int cfg_shift_tail = 1;                 // 1: a scan's remainder of <= 192 samples runs as one tail tile of
+                                            // 64 / 128 / 192 samples; 0: whole tiles only (round 3)
     int shift_lazy_last = 0;                // ... the last launch took
+    int shift_tail_last = 0;                // samples per lane of the last launch's tail tile (0: none)
     int shift_nw = 0;                       // ... the tables were built for
     qm::GridDesc shg{};
     DevBuf<int32_t> d_shraw, d_shmeta, d_shtotal, d_shfit, d_shwide;
@@ -170,6 +173,7 @@ struct qm_engine {
 
     // scratch
     DevBuf<double> d_onsets, d_pmax, d_psum, d_out_a, d_out_b, d_chunk, d_marg, d_marg_out;
+    int marg_tiles = 0;             // time tiles of the last marginal-map launch (rows of d_marg)
     DevBuf<int64_t> d_pidx, d_out_i;
     // locate fits: three map-sized work buffers, reduction partials, device-side scalars
     DevBuf<double> d_fit_a, d_fit_b, d_fit_c, d_fit_part, d_fit_val, d_fit_win;
@@ -456,10 +460,34 @@ bool pair_built(int S) { return S >= 1 && S <= qm::kPairMaxRows; }
 // Own brick grid (e->shg, even brick dimensions: the kernel walks 2x2x2 node groups): the largest
 // shape whose de-interleaved row windows fit 80 KB and whose groups' delay spread fits the
 // register window for (almost) every brick; per-(brick, row) slot records and the record stream.
+int build_shift_tables(qm_engine *e);
+
+void release_shift_tables(qm_engine *e) {
+    e->d_shraw.release(); e->d_shmeta.release(); e->d_shtotal.release(); e->d_shfit.release();
+    e->d_shwide.release(); e->d_shstream.release();
+}
+
+// Outcome per resident table: the layout is built (shift_ok), or the table does not qualify, or the
+// tables could not be built -- most likely no memory for the record stream (8 S bytes per node, twice
+// the table): that, too, is "does not qualify": the buffers are released, the error is dropped and
+// the same step runs on the other kernels.
 int ensure_shift_tables(qm_engine *e) {
     if (e->shift_built) return 0;
-    e->shift_built = true;
     e->shift_ok = false;
+    const int rc = build_shift_tables(e);
+    if (rc != 0 || !e->shift_ok) {
+        e->shift_ok = false;
+        release_shift_tables(e);
+        if (rc != 0) {
+            (void)hipGetLastError();                    // (an allocation failure is not sticky)
+            g_error.clear();
+        }
+    }
+    e->shift_built = true;
+    return 0;
+}
+
+int build_shift_tables(qm_engine *e) {
     const int S = e->g.n_rows;
     // More rows than a CU's LDS holds windows for: row blocks (stack_shift_rows_kernel) -- bricks of
     // 4x4x4 nodes = one 2x2x2 group per wavefront of the 8-wave workgroup, whose accumulators stay
@@ -585,19 +613,29 @@ int ensure_shift_tables(qm_engine *e) {
     return 0;
 }
 
-// does this launch take the shift-reuse kernel?  (fused detect over whole 256-sample tiles' worth of
-// scan; short scans run on shorter tiles, run_j)
+// does this launch take the shift-reuse kernel?  Whole 256-sample tiles plus, for what a scan leaves
+// beyond them, one tail tile of 64 / 128 / 192 samples (qm_shift.hpp: shift_work); the kernels
+// without tail flavours (row blocks, the 12-wave shape) and remainders of more than 192 samples pull a
+// last whole tile back over its predecessor, which needs a scan of at least one tile.
 bool shift_wanted(const qm_engine *e, int n_chunk, bool plain, bool volume, int64_t vol_stride) {
     if (!plain || e->cfg_shift == 0 || e->cfg_generic || e->cfg_force_direct ||
         e->user_waves || e->user_lds || e->cfg_j > 0 || e->cfg_pair == 2)
         return false;
-    // volume-writing launches store whole tiles; the row stride goes into a 32-bit byte count
-    if (volume) return n_chunk >= qm::kShiftKT && vol_stride * 8 < ((int64_t)1 << 32);
-    return n_chunk >= 192;
+    // volume-writing launches: the row stride goes into a 32-bit byte count
+    if (volume && vol_stride * 8 >= ((int64_t)1 << 32)) return false;
+    return n_chunk >= 1;
+}
+
+// samples per lane of the scan's tail tile (0: none -- whole tiles only, the last one pulled back)
+int shift_tail_spl(const qm_engine *e, int n_chunk) {
+    const int rem = n_chunk % qm::kShiftKT;
+    if (rem == 0 || rem > 192 || !e->cfg_shift_tail) return 0;
+    return (rem + qm::kWave - 1) / qm::kWave;
 }
 
 int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_direct,
-                      bool use_lds, bool use_direct, bool volume) {
+                      bool use_lds, bool use_direct, int mode) {
+    const bool volume = mode != qm::kShiftDetect;        // (the direct kernel's VOLUME covers the map too)
     if (use_lds) {
         a.ngroups = groups_lds;
         a.brick_list = nullptr;
@@ -619,15 +657,19 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         s.lazy = e->cfg_shift_lazy >= 0 ? e->cfg_shift_lazy : (life >= qm::kShiftLazyGroups ? 1 : 0);
         if (e->shift_nblk > 1 && !e->shift_direct) s.lazy = 0;    // (the register-staged form: eager only)
         e->shift_lazy_last = s.lazy;
+        e->shift_tail_last = a.tail_spl;
         const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, e->shift_nw * qm::kWave,
                                                   qm::shift_lds_bytes(e->shift_nw));
-        if (e->shift_nblk > 1 && e->shift_direct && volume) QM_TABLE(qm::launch_shift_rows2_volume(s, shape));
-        else if (e->shift_nblk > 1 && e->shift_direct) QM_TABLE(qm::launch_shift_rows2(s, shape));
-        else if (e->shift_nblk > 1) QM_TABLE(qm::launch_shift_rows8(s, shape));
-        else if (volume && e->shift_nw == qm::kShiftWaves8) QM_TABLE(qm::launch_shift_volume8(s, shape));
-        else if (volume) QM_TABLE(qm::launch_shift_volume(s, shape));
+        const bool rows = e->shift_nblk > 1, big = e->shift_nw == qm::kShiftWaves8;
+        if (rows && e->shift_direct && mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_rows2_volume(s, shape));
+        else if (rows && e->shift_direct) QM_TABLE(qm::launch_shift_rows2(s, shape));
+        else if (rows) QM_TABLE(qm::launch_shift_rows8(s, shape));
+        else if (mode == qm::kShiftMarginal && big) QM_TABLE(qm::launch_shift_marginal8(s, shape));
+        else if (mode == qm::kShiftMarginal) QM_TABLE(qm::launch_shift_marginal(s, shape));
+        else if (mode == qm::kShiftVolume && big) QM_TABLE(qm::launch_shift_volume8(s, shape));
+        else if (mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_volume(s, shape));
         else if (e->shift_nw == qm::kShiftWaves3) QM_TABLE(qm::launch_shift_detect3(s, shape));
-        else if (e->shift_nw == qm::kShiftWaves8) QM_TABLE(qm::launch_shift_detect8(s, shape));
+        else if (big) QM_TABLE(qm::launch_shift_detect8(s, shape));
         else QM_TABLE(qm::launch_shift_detect(s, shape));
         e->last_kernel = 3;
         e->last_j = 4;
@@ -639,6 +681,7 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         a.ngroups = groups_direct;
         a.brick_list = e->d_shwide.p;
         a.n_list = e->n_shwide;
+        a.tail_spl = 0;                                // (its own whole tiles of 256 samples, clamped)
         if (launch_direct(e, a, 4, volume, groups_direct, threads, publish_bytes)) return 1;
         a.set0 += groups_direct;
     }
@@ -667,8 +710,10 @@ int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu) {
 // e->d_pmax/d_pidx/d_psum as [*n_sets][n_chunk].
 int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_samples,
               int available, int sample0, int n_chunk, double *volume, int64_t vol_stride,
-              int accumulate, bool want_scan, int *n_sets, double *marginal = nullptr,
+              int accumulate, bool want_scan, int *n_sets, bool marginal = false,
               int m0 = 0, int m1 = 0, const int32_t *run_if = nullptr) {
+    // marginal: per-tile sums over the samples [m0, m1) land in e->d_marg as [*n_tiles][n_nodes]
+    // (e->marg_tiles: the kernels differ in their tile length)
     const int J = run_j(e, n_chunk);
     if (plan_wide(e, J)) return 1;
     const int KT = qm::kWave * J;
@@ -693,36 +738,47 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     a.accumulate = accumulate;
     a.want_scan = want_scan ? 1 : 0;
     a.set0 = 0;
-    a.marginal = marginal;
+    a.marginal = nullptr;
     a.m0 = m0;
     a.m1 = m1;
     a.n_nodes = e->n_nodes;
     a.run_if = run_if;
 
-    // ---- the paired (16-byte operand) kernel where it applies: own brick grid and tables
-    int jp = (accumulate || marginal) ? 0 : pair_jp(e, n_chunk, volume != nullptr);
-    if (jp > 0) {
-        if (!pair_built(e->g.n_rows)) jp = 0;
-        else if (ensure_pair_tables(e, jp) != 0) return 1;   // a HIP failure while building the tables
-        else if (!e->pair_ok) jp = 0;                         // the layout does not fit this table
-    }
     // ---- the shift-reuse kernel (qm_shift.hpp): the fused detect's default where the table fits
-    bool shift = shift_wanted(e, n_chunk, !marginal && !accumulate && (volume || want_scan),
+    bool shift = shift_wanted(e, n_chunk, !accumulate && (volume || marginal || want_scan),
                               volume != nullptr, vol_stride);
+    const int shift_mode = marginal ? qm::kShiftMarginal : volume ? qm::kShiftVolume : qm::kShiftDetect;
     if (shift) {
         if (ensure_shift_tables(e)) return 1;
-        // (the 12-wave shape and the register-staged row blocks are built for the fused detect only)
-        shift = e->shift_ok && !(volume != nullptr && (e->shift_nw == qm::kShiftWaves3 ||
-                                                       (e->shift_nblk > 1 && !e->shift_direct)));
+        // the 12-wave shape and the register-staged row blocks are built for the fused detect only,
+        // row blocks have no marginal-map flavour; none of the three has tail tiles
+        const bool plain = e->shift_nblk == 1 && e->shift_nw != qm::kShiftWaves3;
+        shift = e->shift_ok && (plain || (shift_mode == qm::kShiftDetect) ||
+                                (shift_mode == qm::kShiftVolume && e->shift_nblk > 1 && e->shift_direct));
+        a.tail_spl = (shift && plain) ? shift_tail_spl(e, n_chunk) : 0;
+        // a last tile that is pulled back needs a whole tile of scan (and the detect flavours of the
+        // kernels without tail tiles keep their former lower bound)
+        if (shift && a.tail_spl == 0 && n_chunk % qm::kShiftKT != 0 &&
+            (shift_mode == qm::kShiftDetect ? n_chunk < 192 : n_chunk < qm::kShiftKT))
+            shift = false;
     }
     if (shift) {
-        jp = 0;
         a.g = e->shg;
         a.rel = nullptr;
         a.brick_meta = nullptr;
         a.brick_total = nullptr;
         a.ntiles = (n_chunk + qm::kShiftKT - 1) / qm::kShiftKT;
         a.cap_doubles = qm::kShiftLdsBytes / 8;
+    } else {
+        a.tail_spl = 0;
+    }
+    // ---- the paired (16-byte operand) kernel where it applies and the shift-reuse kernel does not
+    // take the launch: own brick grid and tables (built only then)
+    int jp = (shift || accumulate || marginal) ? 0 : pair_jp(e, n_chunk, volume != nullptr);
+    if (jp > 0) {
+        if (!pair_built(e->g.n_rows)) jp = 0;
+        else if (ensure_pair_tables(e, jp) != 0) return 1;   // a HIP failure while building the tables
+        else if (!e->pair_ok) jp = 0;                         // the layout does not fit this table
     }
     if (jp > 0) {
         const int PKT = 128 * jp;
@@ -732,6 +788,11 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         a.brick_total = e->d_ptotal.p;
         a.ntiles = (n_chunk + PKT - 1) / PKT;
         a.cap_doubles = kPairLdsBytes / 8;
+    }
+    if (marginal) {
+        if (e->d_marg.ensure((size_t)a.ntiles * e->n_nodes)) return 1;
+        a.marginal = e->d_marg.p;
+        e->marg_tiles = a.ntiles;
     }
     const int n_wide_now = shift ? e->n_shwide : jp > 0 ? e->n_pwide : e->n_wide;
     const int nbricks_now = shift ? e->shg.nbricks : jp > 0 ? e->pg.nbricks : e->g.nbricks;
@@ -783,7 +844,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
              ? launch_stack_j<JJ, true>(e, a, groups_lds, groups_direct, use_lds, use_direct)  \
                 : launch_stack_j<JJ, false>(e, a, groups_lds, groups_direct, use_lds, use_direct)
     if (shift)
-        rc = launch_shift_path(e, a, groups_lds, groups_direct, use_lds, use_direct, volume != nullptr);
+        rc = launch_shift_path(e, a, groups_lds, groups_direct, use_lds, use_direct, shift_mode);
     else if (jp == 2)
         rc = volume ? launch_pair_path<2, true>(e, a, groups_lds, groups_direct, use_lds, use_direct)
                     : launch_pair_path<2, false>(e, a, groups_lds, groups_direct, use_lds, use_direct);
@@ -1158,7 +1219,7 @@ int detect_core(qm_engine *e, const double *d_on, int T, int fsmp, int ns, int a
             return 1;
         run_if = e->d_flags.p;
     }
-    if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, &sets, nullptr, 0, 0,
+    if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, &sets, false, 0, 0,
                   run_if))
         return 1;
     return combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, mode, e->node_offset,
@@ -1351,6 +1412,8 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
     } else if (k == "shift_rows_direct") {
         e->cfg_shift_rows_direct = v ? 1 : 0;
         e->shift_built = false;
+    } else if (k == "shift_tail") {
+        e->cfg_shift_tail = v ? 1 : 0;
     } else if (k == "shift_lazy") {
         if (v < -1 || v > 1) return fail("shift_lazy must be -1 (automatic), 0 or 1");
         e->cfg_shift_lazy = (int)v;
@@ -1407,6 +1470,8 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "shift_ok") *v = e->shift_built && e->shift_ok ? 1 : 0;
     else if (k == "shift_waves") *v = e->shift_ok ? e->shift_nw : e->cfg_shift_waves;
     else if (k == "shift_lazy") *v = e->shift_lazy_last;
+    else if (k == "shift_tail") *v = e->cfg_shift_tail;
+    else if (k == "shift_tail_spl") *v = e->shift_tail_last;
     else if (k == "shift_row_blocks") *v = e->shift_ok ? e->shift_nblk : 0;
     else if (k == "shift_brick_nodes") *v = e->shift_ok ? e->shg.brick_nodes : 0;
     else if (k == "shift_wide_bricks") *v = e->shift_ok ? e->n_shwide : 0;
@@ -1776,19 +1841,16 @@ int qm_engine_marginal(qm_engine *e, const double *log_onsets, int onsets_on_dev
     OutStage st{nullptr, nullptr, nullptr};
     if (want_scan && stage_out(e, ns, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st))
         return 1;
-    const int KT = qm::kWave * run_j(e, ns);            // the tile length run_stack will use
-    const int ntiles = (ns + KT - 1) / KT;
-    if (e->d_marg.ensure((size_t)ntiles * e->n_nodes)) return 1;
     double *d_map = coa_map;
     if (!map_on_device) {
         if (e->d_marg_out.ensure((size_t)e->n_nodes)) return 1;
         d_map = e->d_marg_out.p;
     }
-    if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, want_scan, &sets,
-                  e->d_marg.p, first_sample, end_sample))
+    if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, want_scan, &sets, true,
+                  first_sample, end_sample))
         return 1;
     hipLaunchKernelGGL(qm::marginal_reduce_kernel, dim3((unsigned)((e->n_nodes + 255) / 256)),
-                       dim3(256), 0, e->stream, e->d_marg.p, ntiles, e->n_nodes, d_map);
+                       dim3(256), 0, e->stream, e->d_marg.p, e->marg_tiles, e->n_nodes, d_map);
     QM_HIP(hipGetLastError());
     if (want_scan && combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, 1,
                              e->node_offset, n_nodes_total, st.a, st.b, st.i))

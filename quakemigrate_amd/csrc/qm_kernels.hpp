@@ -50,6 +50,8 @@ struct StackArgs {
     int sample0;                   // first scanned sample handled by this launch (chunking)
     int n_chunk;                   // samples handled by this launch
     int ntiles, ngroups;
+    int tail_spl;                  // shift-reuse kernels: samples per lane of the scan's tail tile (1..3;
+                                   // 0: whole 256-sample tiles only, the last one pulled back)
     int cap_doubles;               // LDS window capacity in doubles
     double z_scale;                // log2(e) / available: z = stack * z_scale, coa = 2^z
     double *volume;                // [N][vol_stride] or nullptr

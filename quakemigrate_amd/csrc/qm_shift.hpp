@@ -89,9 +89,19 @@ struct ShiftArgs {
 // maximum takes the lazy flavour (gen_shift_asm.py, epilogue_node)
 constexpr int kShiftLazyGroups = 160;
 
+// What a launch produces besides the partial sets of the scan
+constexpr int kShiftDetect = 0;     // nothing: the fused detect
+constexpr int kShiftVolume = 1;     // the 4-D volume (whole tiles: two 16-byte stores per node and lane, a
+                                    // pulled-back last tile masks the lanes its predecessor stores; tail
+                                    // tiles: one masked 8-byte store per sample slot)
+constexpr int kShiftMarginal = 2;   // the marginalised map: per (tile, node) the sum over the tile's own
+                                    // samples inside [m0, m1) -> a.marginal[tile][node]
+
 struct LaunchShape;
 hipError_t launch_shift_detect(const ShiftArgs &a, const LaunchShape &s);   // qm_launch_shift.hip
 hipError_t launch_shift_volume(const ShiftArgs &a, const LaunchShape &s);
+hipError_t launch_shift_marginal(const ShiftArgs &a, const LaunchShape &s);
+hipError_t launch_shift_marginal8(const ShiftArgs &a, const LaunchShape &s);
 hipError_t launch_shift_detect3(const ShiftArgs &a, const LaunchShape &s);  // the 12-wave shape
 hipError_t launch_shift_detect8(const ShiftArgs &a, const LaunchShape &s);  // the 8-wave shape
 hipError_t launch_shift_volume8(const ShiftArgs &a, const LaunchShape &s);
@@ -266,7 +276,9 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
 // to plane (u & 2) / 2, slot first_r + u / 4, half u & 1.  Every slot of the row is written (zero
 // past the data the brick can touch and past the rows' end): a lane may fetch whole quads.
 // Row blocks: vb = (brick, block), the block's S rows start at table row row0, metadata sb rows apart.
-template <int NW, int RB = (NW == 12 ? 3 : 8), int U = 6>
+// CONTIG (tail tiles of KT = 64, 128 or 192 samples, gen_shift_asm.py): one plane, window sample u of
+// row r at byte 8 u of the row's region (which starts at twice the two-plane layout's slot offset).
+template <int NW, int RB = (NW == 12 ? 3 : 8), int U = 6, bool CONTIG = false, int KT = kShiftKT>
 __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *win, int vb, int row0,
                                                     int S, int sb, int wave, int lane, int t_first) {
     const StackArgs &a = s.a;
@@ -276,6 +288,11 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
     // half rate: a wavefront alone issues one float64 instruction per 8 cycles).
     // (RB rows per wavefront and pass, U 64-sample chunks per row and pass)
     constexpr int kPlane = shift_plane(NW);
+    // LDS position (in doubles) of window sample u of a row whose first slot is z
+    auto where = [&](int z, int u) {
+        if constexpr (CONTIG) return 4 * z + u;
+        else return ((u & 2) ? kPlane / 8 : 0) + 2 * (z + (u >> 2)) + (u & 1);
+    };
     for (int r0 = wave; r0 < S; r0 += NW * RB) {
         double v[RB][U];
         int4 m[RB];
@@ -283,7 +300,7 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
         for (int k = 0; k < RB; ++k) {
             const int r = r0 + k * NW;
             m[k] = r < S ? s.smeta[(int64_t)vb * sb + r] : make_int4(0, 0, 0, 0);
-            const int len = m[k].y + kShiftKT;                     // samples the brick can touch
+            const int len = m[k].y + KT;                           // samples the brick can touch
             const int first = m[k].x + a.fsmp + a.sample0 + t_first;   // index inside the row
             const int room = a.T - first;
             const double *src = a.onsets + (int64_t)(r < S ? row0 + r : 0) * a.T + first;
@@ -299,35 +316,35 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 const int u = kWave * i + lane;
-                if (u < total)
-                    win[((u & 2) ? kPlane / 8 : 0) + 2 * (m[k].z + (u >> 2)) + (u & 1)] = v[k][i];
+                if (u < total) win[where(m[k].z, u)] = v[k][i];
             }
             // (a row window longer than U x 64 samples: the rest, one load at a time)
             if (total > kWave * U) {
                 const int r = r0 + k * NW;
-                const int len = m[k].y + kShiftKT;
+                const int len = m[k].y + KT;
                 const int first = m[k].x + a.fsmp + a.sample0 + t_first;
                 const int room = a.T - first;
                 const double *src = a.onsets + (int64_t)(row0 + r) * a.T + first;
                 for (int u = kWave * U + lane; u < total; u += kWave)
-                    win[((u & 2) ? kPlane / 8 : 0) + 2 * (m[k].z + (u >> 2)) + (u & 1)] =
-                        (u < len && u < room) ? src[u] : 0.0;
+                    win[where(m[k].z, u)] = (u < len && u < room) ? src[u] : 0.0;
             }
         }
     }
     if ((S & 1) && wave == 0) {                                    // the padding row's zero window
         const int z = s.stotal[vb];
-        for (int u = lane; u < 4 * (64 + kShiftNqMin); u += kWave)
-            win[((u & 2) ? kPlane / 8 : 0) + 2 * (z + (u >> 2)) + (u & 1)] = 0.0;
+        for (int u = lane; u < 4 * (64 + kShiftNqMin); u += kWave) win[where(z, u)] = 0.0;
     }
 }
 
 // What a workgroup of the shift-reuse kernels works on: XCD-aware (time tile, brick group) map as
-// stack_lds_kernel -- group g runs on XCD g mod 8 --, the grid is padded to a multiple of 8 groups;
-// the last tile of a scan that is not a multiple of the tile length is pulled back so that it ends
-// with the scan (it overlaps its predecessor: same arithmetic, same bits).
+// stack_lds_kernel -- group g runs on XCD g mod 8 --, the grid is padded to a multiple of 8 groups.
+// Tiles are 256 samples; what a scan leaves beyond its whole tiles is either (a.tail_spl = 1, 2, 3)
+// ONE tail tile of 64 / 128 / 192 samples starting where they end -- `spl` samples per lane, its own
+// loop flavour (gen_shift_asm.py) -- or (a.tail_spl = 0: a remainder of more than 192 samples, and the
+// kernels without tail flavours) a last whole tile pulled back so that it ends with the scan (it
+// overlaps its predecessor: same arithmetic, same bits).
 struct ShiftWork {
-    int tile, group, t_first;
+    int tile, group, t_first, spl;
     bool run;
 };
 __device__ __forceinline__ ShiftWork shift_work(const StackArgs &a) {
@@ -336,45 +353,48 @@ __device__ __forceinline__ ShiftWork shift_work(const StackArgs &a) {
     w.tile = slot % a.ntiles;
     w.group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
     w.run = w.group < a.ngroups && !(a.run_if != nullptr && *a.run_if == 0);
-    w.t_first = ((w.tile + 1) * kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT) ? a.n_chunk - kShiftKT
-                                                                                : w.tile * kShiftKT;
+    w.spl = (a.tail_spl > 0 && w.tile == a.ntiles - 1) ? a.tail_spl : 4;
+    w.t_first = (w.spl == 4 && (w.tile + 1) * kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT)
+                    ? a.n_chunk - kShiftKT : w.tile * kShiftKT;
     return w;
 }
-// a wavefront's running (max z, sum of 2^z, first index) of its four samples per lane
-__device__ __forceinline__ void shift_reset(double (&vmax)[4], double (&vsum)[4], int (&vidx)[4]) {
+// a wavefront's running (max z, sum of 2^z, first index) of its J samples per lane
+template <int J>
+__device__ __forceinline__ void shift_reset(double (&vmax)[J], double (&vsum)[J], int (&vidx)[J]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < J; ++k) {
         vmax[k] = -__builtin_inf();
         vsum[k] = 0.0;
         vidx[k] = INT32_MAX;
     }
 }
 
-// The workgroup's wavefronts hold (max, sum, index) of the tile's 256 samples, four per lane:
+// The workgroup's wavefronts hold (max, sum, index) of the tile's 64 J samples, J per lane:
 // combine them through LDS (thread k owns sample k) and publish the workgroup's partial set.
 // Call after a barrier behind the last use of `win`.
-template <int NW>
-__device__ __forceinline__ void shift_publish(const StackArgs &a, double *win, const double (&vmax)[4],
-                                              const double (&vsum)[4], const int (&vidx)[4], int wave,
+template <int NW, int J = 4>
+__device__ __forceinline__ void shift_publish(const StackArgs &a, double *win, const double (&vmax)[J],
+                                              const double (&vsum)[J], const int (&vidx)[J], int wave,
                                               int lane, int group, int t_first) {
-    double *smax = win, *ssum = win + NW * kShiftKT;
-    int *sidx = reinterpret_cast<int *>(win + 2 * NW * kShiftKT);
+    constexpr int KT = kWave * J;
+    double *smax = win, *ssum = win + NW * KT;
+    int *sidx = reinterpret_cast<int *>(win + 2 * NW * KT);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int o = wave * kShiftKT + 4 * lane + k;
+    for (int k = 0; k < J; ++k) {
+        const int o = wave * KT + J * lane + k;
         smax[o] = vmax[k];
         ssum[o] = vsum[k];
         sidx[o] = vidx[k];
     }
     __syncthreads();
     const int k = threadIdx.x;
-    if (k >= kShiftKT) return;                        // (8- and 12-wave workgroups have more threads than samples)
+    if (k >= KT) return;                              // (more threads than samples: 8 / 12 waves, tail tiles)
     double best = smax[k], total = ssum[k];
     int bi = sidx[k];
     for (int w = 1; w < NW; ++w) {
-        const double v = smax[w * kShiftKT + k];
-        const int i = sidx[w * kShiftKT + k];
-        total += ssum[w * kShiftKT + k];
+        const double v = smax[w * KT + k];
+        const int i = sidx[w * KT + k];
+        total += ssum[w * KT + k];
         if (better(v, i, best, bi)) {
             best = v;
             bi = i;
@@ -389,31 +409,39 @@ __device__ __forceinline__ void shift_publish(const StackArgs &a, double *win, c
     }
 }
 
-// VOLUME: the 4-D volume is written too (whole 256-sample tiles only: a scan that is not a multiple
-// of the tile pulls its last tile back; the lanes whose samples its predecessor stores are masked
-// off at the stores; scans shorter than a tile stay with the other kernels)
-template <bool VOLUME, int NW>
-__global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_shift_kernel(ShiftArgs s) {
-    static_assert(NW == kShiftWaves || NW == kShiftWaves8 || (NW == kShiftWaves3 && !VOLUME),
-                  "workgroup shapes: 4 or 8 waves, or 12 (detect only)");
+// One (time tile, brick group) of a launch: J samples per lane (4: a whole tile on the two-plane
+// layout; 1..3: the scan's tail tile on the contiguous layout).
+template <int MODE, int NW, int J>
+__device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, const ShiftWork &work,
+                                           int lane, int wave) {
     constexpr bool kLdsState = NW == kShiftWaves3;
-    extern __shared__ __attribute__((aligned(16))) double win[];
+    constexpr bool kTail = J < 4;
+    static_assert(!(kTail && kLdsState), "the 12-wave shape has no tail flavours");
     const StackArgs &a = s.a;
     const GridDesc &g = a.g;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const ShiftWork work = shift_work(a);
-    if (!work.run) return;
     const int tile = work.tile, group = work.group, t_first = work.t_first;
-    const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 16u;
-    // volume: lanes of a pulled-back tile whose four samples its predecessor stores are masked off
-    // at the stores (a lane that straddles the seam stores its four: same bits)
+    const unsigned lds_base = (unsigned)(uintptr_t)((lds_f64 *)win);
+    const unsigned lane_addr = lds_base + (unsigned)lane * (kTail ? 8u * J : 16u);
+    // volume, whole tiles: lanes of a pulled-back tile whose four samples its predecessor stores are
+    // masked off at the stores (a lane that straddles the seam stores its four: same bits)
     const int seam = tile * kShiftKT - t_first;                    // samples of overlap, 0 .. 255
     const unsigned long long store_lanes = ~0ull << (seam / 4);
+    // volume, tail tiles: per sample slot the lanes whose sample lies inside the scan
+    unsigned long long slot_lanes[J];
+    // marginal: 1.0 for the lane's samples that are the tile's own (not its predecessor's) and lie
+    // inside the window, 0.0 for the others
+    double weight[J];
+#pragma unroll
+    for (int k = 0; k < J; ++k) {
+        const int t = t_first + J * lane + k;
+        slot_lanes[k] = __builtin_amdgcn_ballot_w64(t < a.n_chunk);
+        weight[k] = (t >= tile * kShiftKT && t >= a.m0 && t < a.m1 && t < a.n_chunk) ? 1.0 : 0.0;
+    }
+    (void)store_lanes; (void)slot_lanes; (void)weight;
 
-    double vmax[4], vsum[4];
-    int vidx[4];
-    shift_reset(vmax, vsum, vidx);
+    double vmax[J], vsum[J];
+    int vidx[J];
+    shift_reset<J>(vmax, vsum, vidx);
     // 12-wave shape: the running state lives in LDS behind the windows, 5 chunks of 64 lanes x 16
     // bytes per wavefront (maxima 0-1 / 2-3, sums 0-1 / 2-3, indices)
     double *state = win + (2 * shift_plane(NW) + wave * kShiftStateBytes) / 8 + 2 * lane;
@@ -426,12 +454,18 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
             reinterpret_cast<int *>(state + 4 * (kShiftStateChunk / 8))[k] = vidx[k];
         }
     }
-    constexpr int D = Exp2Degree<VOLUME>::value;
+    (void)state_addr;
+    constexpr int D = MODE == kShiftDetect ? Exp2Degree<false>::value : Exp2Degree<true>::value;
     double c[D + 1];
 #pragma unroll
     for (int i = 0; i <= D; ++i) c[i] = exp2_coeff<D>(i);
 
     const int64_t rpw = shift_recs_per_wave(g, s.rows2, NW);
+    const int npairs = s.rows2 / 2, nz = g.nz, nynz = g.ny * g.nz;
+    double *const marg_tile = a.marginal + (int64_t)tile * a.n_nodes;
+    double *const vol_tile = a.volume + t_first;
+    const unsigned vol_stride_bytes = (unsigned)(a.vol_stride * 8);
+    (void)marg_tile; (void)vol_tile; (void)vol_stride_bytes;
     for (int b = group; b < g.nbricks; b += a.ngroups) {
         if (!s.sfit[b]) continue;                     // direct kernel's job
 #ifdef QM_SHIFT_EXP_NOSTAGE                            // timing experiment (wrong results): the first
@@ -442,44 +476,59 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
         }
 #else
         __syncthreads();                              // previous brick fully consumed
-        stage_shift_windows<NW>(s, win, b, 0, g.n_rows, g.n_rows, wave, lane, t_first);
+        stage_shift_windows<NW, (NW == 12 ? 3 : 8), 6, kTail, kWave * J>(s, win, b, 0, g.n_rows, g.n_rows, wave,
+                                                                         lane, t_first);
         __syncthreads();
 #endif
         int x0, y0, z0, vx, vy, vz, cx, cy, cz;
         shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
         const int nvg = cx * cy * cz;
         const int mine = (nvg - wave + NW - 1) / NW;                       // groups of this wave
-        if (mine > 0) {
-            const char *run = s.stream + shift_run_record(b, wave, 0, NW, 1, rpw) * kShiftRec;
-            if constexpr (kLdsState)
-                shift_groups_detect3(run, mine, s.rows2 / 2, lane_addr, state_addr, g.nz,
-                                     g.ny * g.nz, a.z_scale, c);
-            else if constexpr (NW == kShiftWaves8 && VOLUME)
-                shift_groups_volume8(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr,
-                                     lane_addr + (unsigned)kShiftPlane8, g.nz, g.ny * g.nz,
-                                     a.z_scale, c, a.volume + t_first,
-                                     (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u, store_lanes);
-            else if constexpr (NW == kShiftWaves8) {
-                if (s.lazy)
-                    shift_groups_detect8_lazy(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr,
-                                              lane_addr + (unsigned)kShiftPlane8, g.nz, g.ny * g.nz,
-                                              a.z_scale, c);
-                else
-                    shift_groups_detect8(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr,
-                                         lane_addr + (unsigned)kShiftPlane8, g.nz, g.ny * g.nz,
-                                         a.z_scale, c);
-            }
-            else if constexpr (VOLUME)
-                shift_groups_volume(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr, g.nz,
-                                    g.ny * g.nz, a.z_scale, c, a.volume + t_first,
-                                    (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u, store_lanes);
-            else if (s.lazy)
-                shift_groups_detect_lazy(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr, g.nz,
-                                         g.ny * g.nz, a.z_scale, c);
+        if (mine <= 0) continue;
+        const char *run = s.stream + shift_run_record(b, wave, 0, NW, 1, rpw) * kShiftRec;
+        const unsigned lane_addr_b = lane_addr + (unsigned)kShiftPlane8;   // (8-wave shape: plane B)
+        (void)lane_addr_b;
+#define QM_TAIL_CALL(JJ)                                                                              \
+        if constexpr (MODE == kShiftMarginal)                                                         \
+            shift_tail##JJ##_marginal(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz,       \
+                                      a.z_scale, c, marg_tile, weight);                               \
+        else if constexpr (MODE == kShiftVolume)                                                      \
+            shift_tail##JJ##_volume(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz,         \
+                                    a.z_scale, c, vol_tile, vol_stride_bytes, (unsigned)lane * (8u * JJ), \
+                                    slot_lanes);                                                      \
+        else                                                                                          \
+            shift_tail##JJ##_detect(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz,         \
+                                    a.z_scale, c)
+        if constexpr (J == 1) { QM_TAIL_CALL(1); }
+        else if constexpr (J == 2) { QM_TAIL_CALL(2); }
+        else if constexpr (J == 3) { QM_TAIL_CALL(3); }
+#undef QM_TAIL_CALL
+        else if constexpr (kLdsState)
+            shift_groups_detect3(run, mine, npairs, lane_addr, state_addr, nz, nynz, a.z_scale, c);
+        else if constexpr (NW == kShiftWaves8 && MODE == kShiftMarginal)
+            shift_groups_marginal8(vmax, vsum, vidx, run, mine, npairs, lane_addr, lane_addr_b, nz, nynz,
+                                   a.z_scale, c, marg_tile, weight);
+        else if constexpr (MODE == kShiftMarginal)
+            shift_groups_marginal(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz, a.z_scale, c,
+                                  marg_tile, weight);
+        else if constexpr (NW == kShiftWaves8 && MODE == kShiftVolume)
+            shift_groups_volume8(vmax, vsum, vidx, run, mine, npairs, lane_addr, lane_addr_b, nz, nynz,
+                                 a.z_scale, c, vol_tile, vol_stride_bytes, (unsigned)lane * 32u, store_lanes);
+        else if constexpr (NW == kShiftWaves8) {
+            if (s.lazy)
+                shift_groups_detect8_lazy(vmax, vsum, vidx, run, mine, npairs, lane_addr, lane_addr_b, nz,
+                                          nynz, a.z_scale, c);
             else
-                shift_groups_detect(vmax, vsum, vidx, run, mine, s.rows2 / 2, lane_addr, g.nz,
-                                    g.ny * g.nz, a.z_scale, c);
+                shift_groups_detect8(vmax, vsum, vidx, run, mine, npairs, lane_addr, lane_addr_b, nz, nynz,
+                                     a.z_scale, c);
         }
+        else if constexpr (MODE == kShiftVolume)
+            shift_groups_volume(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz, a.z_scale, c,
+                                vol_tile, vol_stride_bytes, (unsigned)lane * 32u, store_lanes);
+        else if (s.lazy)
+            shift_groups_detect_lazy(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz, a.z_scale, c);
+        else
+            shift_groups_detect(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz, a.z_scale, c);
     }
     if (!a.want_scan) return;
     if constexpr (kLdsState) {
@@ -492,7 +541,24 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
     }
     // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
     __syncthreads();
-    shift_publish<NW>(a, win, vmax, vsum, vidx, wave, lane, group, t_first);
+    shift_publish<NW, J>(a, win, vmax, vsum, vidx, wave, lane, group, t_first);
+}
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_shift_kernel(ShiftArgs s) {
+    static_assert(NW == kShiftWaves || NW == kShiftWaves8 || (NW == kShiftWaves3 && MODE == kShiftDetect),
+                  "workgroup shapes: 4 or 8 waves, or 12 (detect only)");
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const ShiftWork work = shift_work(s.a);
+    if (!work.run) return;
+    if constexpr (NW != kShiftWaves3) {
+        if (work.spl == 3) return shift_tile<MODE, NW, 3>(s, win, work, lane, wave);
+        if (work.spl == 2) return shift_tile<MODE, NW, 2>(s, win, work, lane, wave);
+        if (work.spl == 1) return shift_tile<MODE, NW, 1>(s, win, work, lane, wave);
+    }
+    shift_tile<MODE, NW, 4>(s, win, work, lane, wave);
 }
 
 // Tables of more rows than a CU's LDS holds windows for (> 64): ROW BLOCKS.  A brick is as many

@@ -2110,3 +2110,152 @@ def test_reference_signature_table_caching_and_grid_hint(lib, oracle, monkeypatc
     monkeypatch.setenv("QM_HIP_GRID", "3,3,3")
     so.migrate(lon, tt, shaped, fsmp, lsmp, ns, tt.shape[-1], avail, n_nodes, 1)
     assert so.qm_compat_status() != 0 and np.isnan(shaped).all()
+
+
+# ---- round 4: tail tiles and the marginal-map flavour of the shift-reuse kernel -------------------
+TAIL_SHAPES = [  # recipe, grid, rows, scanned samples, samples per lane of the tail tile
+    ("C3", (18, 17, 12), 30, 60, 1),     # shorter than every tile: one 64-sample tile, 4 lanes idle
+    ("C3", (18, 17, 12), 30, 64, 1),     # exactly one 64-sample tile
+    ("C3", (18, 17, 12), 29, 100, 2),    # one 128-sample tile; odd row count (padding row)
+    ("C3", (19, 17, 13), 30, 401, 3),    # the locate window: 256 + a 192-sample tile (145 used)
+    ("C3", (18, 17, 12), 30, 448, 3),    # ... filled to its last lane
+    ("C1", (23, 20, 19), 24, 625, 2),    # the Icequake timestep: 2 x 256 + a 128-sample tile (113 used)
+    ("C1", (23, 20, 19), 24, 320, 1),    # 256 + 64
+    ("C3", (9, 10, 33), 1, 129, 3),      # one row; 192-sample tile barely past 128
+    ("C4", (20, 21, 14), 47, 401, 3),    # the 8-wave shape (33-64 rows)
+    ("C4", (20, 21, 14), 64, 130, 3),
+    ("C4", (21, 20, 15), 36, 290, 1),
+    ("C4", (20, 21, 14), 60, 370, 2),
+]
+
+
+@pytest.mark.parametrize("recipe,grid,rows,ns,spl", TAIL_SHAPES)
+def test_shift_tail_tiles_detect_volume_and_marginal(lib, oracle, recipe, grid, rows, ns, spl):
+    """What a scan leaves beyond its whole 256-sample tiles runs as one tail tile of 64 / 128 / 192
+    samples (1 / 2 / 3 samples per lane, contiguous row windows): fused detect, volume and
+    marginalised map against the oracle, and bit for bit against the same engine with whole tiles
+    only (where that form can run the scan) and against the round-2 kernels."""
+    case = synth.make_case(recipe, step=3, grid=grid, rows=rows, n_samples=ns)
+    lon = oracle.log_onsets(case.onsets)
+    ref = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
+                           threads=4)
+    want = oracle.c_find_max_coa(ref, threads=2)
+    flat = ref.reshape(case.n_nodes_total, ns)
+    windows = [(0, ns), (ns // 4, ns - ns // 4), (ns - 1, ns), (0, 1)]
+    if ns > 256:
+        windows += [(255, 257), (256, ns), (200, 256)]
+    got = {}
+    for tag, cfg in (("tail", {}), ("whole", {"shift_tail": 0}), ("round2", {"shift": 0})):
+        eng = lib.Engine(0, **cfg)
+        eng.load_lut(case.traveltimes)
+        det = eng.detect(lon, case.fsmp, case.lsmp, case.available,
+                         out=(np.full(ns, np.nan), np.full(ns, np.nan), np.full(ns, -1, dtype=np.int64)))
+        if tag == "tail":
+            assert eng.get("last_kernel") == 3 and eng.get("shift_tail_spl") == spl, \
+                (eng.get("last_kernel"), eng.get("shift_tail_spl"))
+            assert eng.get("shift_waves") == (4 if rows <= 32 else 8)
+        _assert_series(det, want)
+        vol = np.full((case.n_nodes_total, ns), np.nan)
+        series = (np.full(ns, np.nan), np.full(ns, np.nan), np.full(ns, -1, dtype=np.int64))
+        eng.migrate(lon, case.fsmp, case.lsmp, case.available, vol, scan_out=series)
+        if tag == "tail":
+            assert eng.get("last_kernel") == 3 and eng.get("shift_tail_spl") == spl
+        _assert_series(series, want)
+        np.testing.assert_allclose(vol, flat, rtol=TIGHT)
+        maps = []
+        for i0, i1 in windows:
+            s2 = (np.full(ns, np.nan), np.full(ns, np.nan), np.full(ns, -1, dtype=np.int64))
+            m = eng.marginal_map(lon, case.fsmp, case.lsmp, case.available, i0, i1, scan_out=s2)
+            if tag == "tail":
+                assert eng.get("last_kernel") == 3 and eng.get("shift_tail_spl") == spl
+            np.testing.assert_allclose(m.reshape(-1), flat[:, i0:i1].sum(axis=-1), rtol=1e-12)
+            # ... and much closer to the time sum of the engine's own volume (same terms)
+            np.testing.assert_allclose(m.reshape(-1), vol[:, i0:i1].sum(axis=-1), rtol=1e-14)
+            _assert_series(s2, want)
+            maps.append(m)
+        got[tag] = (det, vol, series, maps)
+        eng.close()
+    for other in ("whole", "round2"):
+        assert np.array_equal(got["tail"][1], got[other][1]), other           # every stored value
+        for k in (0, 2):
+            assert np.array_equal(got["tail"][0][k], got[other][0][k]), (other, k)
+            assert np.array_equal(got["tail"][2][k], got[other][2][k]), (other, k)
+
+
+@pytest.mark.parametrize("recipe,grid,rows,ns", [
+    ("C3", (19, 17, 13), 30, 512),       # whole tiles only, two 4-wave workgroups per CU
+    ("C3", (19, 17, 13), 31, 450),       # a remainder of 194 samples: the last whole tile pulled back
+    ("C4", (20, 21, 14), 47, 768),       # the 8-wave shape
+    ("C4", (20, 21, 14), 64, 500),       # ... pulled back
+])
+def test_shift_marginal_map_on_whole_tiles(lib, oracle, recipe, grid, rows, ns):
+    """The marginal-map flavour on whole tiles (both workgroup shapes), including a last tile that is
+    pulled back over its predecessor: the overlap belongs to the predecessor (zero weights)."""
+    case = synth.make_case(recipe, step=5, grid=grid, rows=rows, n_samples=ns)
+    lon = oracle.log_onsets(case.onsets)
+    ref = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
+                           threads=4)
+    want = oracle.c_find_max_coa(ref, threads=2)
+    flat = ref.reshape(case.n_nodes_total, ns)
+    eng = lib.Engine(0)
+    eng.load_lut(case.traveltimes)
+    old = lib.Engine(0, shift=0)
+    old.load_lut(case.traveltimes)
+    for i0, i1 in [(0, ns), (100, 301), (255, 257), (ns - 200, ns), (ns - 1, ns), (256, 257)]:
+        s2 = (np.full(ns, np.nan), np.full(ns, np.nan), np.full(ns, -1, dtype=np.int64))
+        m = eng.marginal_map(lon, case.fsmp, case.lsmp, case.available, i0, i1, scan_out=s2)
+        assert eng.get("last_kernel") == 3 and eng.get("shift_tail_spl") == 0
+        np.testing.assert_allclose(m.reshape(-1), flat[:, i0:i1].sum(axis=-1), rtol=1e-12)
+        _assert_series(s2, want)
+        m_old = old.marginal_map(lon, case.fsmp, case.lsmp, case.available, i0, i1)
+        assert old.get("last_kernel") != 3
+        np.testing.assert_allclose(m, m_old, rtol=1e-14)
+        # without the scan outputs
+        m2 = eng.marginal_map(lon, case.fsmp, case.lsmp, case.available, i0, i1)
+        assert np.array_equal(m2, m)
+    eng.close()
+    old.close()
+
+
+def test_shift_tail_tiles_beside_the_direct_kernel_and_in_shards(lib, oracle):
+    """Tail tiles where some bricks go to the direct kernel (its own whole tiles) and with a node
+    offset: partial sets of both launches combine to the oracle's series, the marginalised map takes
+    every node from exactly one of the two."""
+    case = synth.make_case("C3", step=2, grid=(24, 20, 18), rows=12, n_samples=401)
+    tt = case.traveltimes.copy()
+    rng = np.random.default_rng(404)
+    tt[:6, :5, :7] = rng.integers(0, case.lsmp, size=tt[:6, :5, :7].shape)     # an incoherent corner
+    lon = oracle.log_onsets(case.onsets)
+    ref = oracle.c_migrate(case.onsets, tt, case.fsmp, case.lsmp, case.available, threads=4)
+    want = oracle.c_find_max_coa(ref, threads=2)
+    ns = 401
+    flat = ref.reshape(-1, ns)
+    eng = lib.Engine(0, brick_x=4, brick_y=4, brick_z=4)
+    eng.load_lut(tt)
+    got = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+    assert eng.get("last_kernel") == 3 and eng.get("shift_wide_bricks") >= 1
+    assert eng.get("shift_tail_spl") == 3
+    _assert_series(got, want)
+    s2 = (np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64))
+    m = eng.marginal_map(lon, case.fsmp, case.lsmp, case.available, 100, 301, scan_out=s2)
+    assert eng.get("last_kernel") == 3
+    np.testing.assert_allclose(m.reshape(-1), flat[:, 100:301].sum(axis=-1), rtol=1e-12)
+    _assert_series(s2, want)
+    vol = np.full((flat.shape[0], ns), np.nan)
+    eng.migrate(lon, case.fsmp, case.lsmp, case.available, vol)
+    assert eng.get("last_kernel") == 3
+    np.testing.assert_allclose(vol, flat, rtol=TIGHT)
+    eng.close()
+    # two shards (x-planes 0..11 / 12..23), each with its node offset
+    halves = []
+    for x0, x1 in ((0, 12), (12, 24)):
+        e2 = lib.Engine(0)
+        e2.load_lut(np.ascontiguousarray(case.traveltimes[x0:x1]), node_offset=x0 * 20 * 18)
+        halves.append(e2.detect(lon, case.fsmp, case.lsmp, case.available,
+                                n_nodes_total=case.n_nodes_total))
+        assert e2.get("last_kernel") == 3 and e2.get("shift_tail_spl") == 3
+        e2.close()
+    whole = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available, threads=4)
+    best = np.where(halves[0][0] >= halves[1][0], halves[0][2], halves[1][2])
+    assert np.array_equal(best, whole[2])
+    np.testing.assert_allclose(np.maximum(halves[0][0], halves[1][0]), whole[0], rtol=TIGHT)
