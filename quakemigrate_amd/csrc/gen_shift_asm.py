@@ -69,7 +69,8 @@ PLANE8 = 81856           # ... for the 8-wave workgroup that owns a CU's whole L
                          # address register ("far plane")
 STATE_CHUNK = 1024       # running state in LDS: 5 chunks of 64 lanes x 16 bytes per wavefront
 VB_BLOCK = 80            # first hard VGPR of the row-block flavour
-MARGINAL_DEGREE = 10     # 2^f of the marginalised map's terms (the stored values' polynomial)
+MARGINAL_DEGREE = 8      # 2^f of the marginalised map's terms: the polynomial of the running sums (7.8e-13), every
+                         # term positive -- the map inherits at most that (tests: 1e-12)
 
 
 def configure(lds_state, far=False, lazy=False, block=False, spl=4, contig=False, marginal=False):
@@ -722,6 +723,7 @@ def main():
     print(f"constexpr int kShiftStateChunk = {STATE_CHUNK};   // LDS running state: 5 chunks per wavefront")
     print(f"constexpr int kShiftRec = {REC};            // bytes per stream record")
     print(f"constexpr int kShiftBlockVgprs = {VB_BLOCK};   // row-block flavour: the compiler's own code stays below")
+    print(f"constexpr int kShiftMarginalDegree = {MARGINAL_DEGREE};   // 2^f polynomial of the marginal-map flavours")
     for degree, volume, lds_state, far, lazy, block, name in (
             (8, False, False, False, False, False, "shift_groups_detect"),
             (8, False, False, False, True, False, "shift_groups_detect_lazy"),

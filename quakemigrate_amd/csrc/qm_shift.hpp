@@ -455,7 +455,10 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
         }
     }
     (void)state_addr;
-    constexpr int D = MODE == kShiftDetect ? Exp2Degree<false>::value : Exp2Degree<true>::value;
+    // 2^f: the stored values' polynomial where values are stored; the running sums' for the fused
+    // detect and for the marginalised map (sums of positive terms: they inherit its 7.8e-13)
+    constexpr int D = MODE == kShiftVolume ? Exp2Degree<true>::value
+                      : MODE == kShiftMarginal ? kShiftMarginalDegree : Exp2Degree<false>::value;
     double c[D + 1];
 #pragma unroll
     for (int i = 0; i <= D; ++i) c[i] = exp2_coeff<D>(i);

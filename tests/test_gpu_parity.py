@@ -1966,7 +1966,11 @@ def test_permuted_twins_near_ties_are_quantified(lib, oracle):
         np.testing.assert_allclose(a, g["max_coa"], rtol=TIGHT)
         np.testing.assert_allclose(b, g["max_norm_coa"], rtol=NORM if not cfg.get("screen") else SCREEN_NORM)
         differs = c != ref_idx
-        assert 0.02 < differs.mean() < 0.3                     # the measured deviation, ~0.13
+        # the measured deviation: 12.7 % against the reference's -Ofast build (libmvec's 2-lane exp;
+        # the fixture), within two points either way -- for scale, that build and the same two C
+        # files compiled with -fno-tree-vectorize (glibc's scalar exp) disagree with EACH OTHER on
+        # 8.2 % of these samples (tools/near_tie_study.py, profiles/r04_near_tie_study.txt)
+        assert abs(differs.mean() - 0.127) < 0.02, differs.mean()
         assert np.array_equal(c[differs] // 2, ref_idx[differs] // 2)   # ... always the other twin
 
 
@@ -2019,7 +2023,7 @@ def test_mirror_twins_near_ties_on_the_shift_kernel(lib, oracle):
         np.testing.assert_allclose(b, want[1], rtol=NORM)
         differs = c != want[2]
         assert np.array_equal(mirror_of[c[differs]], want[2][differs])      # ... always the mirror twin
-        assert differs.mean() < 0.5
+        assert abs(differs.mean() - 0.09) < 0.02, differs.mean()       # measured: 9.0 %
 
 
 def test_spline_location_on_device_equals_scipy_rbf_on_map_windows(lib):
@@ -2169,8 +2173,8 @@ def test_shift_tail_tiles_detect_volume_and_marginal(lib, oracle, recipe, grid, 
             if tag == "tail":
                 assert eng.get("last_kernel") == 3 and eng.get("shift_tail_spl") == spl
             np.testing.assert_allclose(m.reshape(-1), flat[:, i0:i1].sum(axis=-1), rtol=1e-12)
-            # ... and much closer to the time sum of the engine's own volume (same terms)
-            np.testing.assert_allclose(m.reshape(-1), vol[:, i0:i1].sum(axis=-1), rtol=1e-14)
+            # (the map's terms use the running sums' 2^f polynomial, 7.8e-13; stored values 2.8e-16)
+            np.testing.assert_allclose(m.reshape(-1), vol[:, i0:i1].sum(axis=-1), rtol=1e-12)
             _assert_series(s2, want)
             maps.append(m)
         got[tag] = (det, vol, series, maps)
@@ -2209,7 +2213,7 @@ def test_shift_marginal_map_on_whole_tiles(lib, oracle, recipe, grid, rows, ns):
         _assert_series(s2, want)
         m_old = old.marginal_map(lon, case.fsmp, case.lsmp, case.available, i0, i1)
         assert old.get("last_kernel") != 3
-        np.testing.assert_allclose(m, m_old, rtol=1e-14)
+        np.testing.assert_allclose(m, m_old, rtol=1e-12)
         # without the scan outputs
         m2 = eng.marginal_map(lon, case.fsmp, case.lsmp, case.available, i0, i1)
         assert np.array_equal(m2, m)
