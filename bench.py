@@ -72,7 +72,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3",
-                    help="C3 (default), C2, C1, C4 (401x401x201 x 60 rows x 12000 samples): the "
+                    help="C3 (default), C2, C1, C4 (401x401x201 x 60 rows x 12000 samples), E1 / E2 (the "
+                         "sizes the reference's Volcanotectonic / Askja examples run detect at): the "
                          "grid is partitioned over the N GPUs by x-plane slabs; C5 = C3 as a "
                          "continuous stream of --steps timesteps with copies overlapped on HIP "
                          "streams inside the timed region")
@@ -91,11 +92,17 @@ def parse():
                     help="skip the PCIe-inclusive leg (step_with_copies)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-materialised", action="store_true")
+    ap.add_argument("--no-table-switch", action="store_true",
+                    help="skip the availability-change leg (table_switch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--engine", default="{}", help="json dict of engine tunables")
     ap.add_argument("--materialise-full", action="store_true",
                     help="also run configs[2] literally: the whole n_samples volume (196 GB at "
                          "C3) written to HBM with the scan outputs (needs the memory)")
+    ap.add_argument("--steps-per-launch", type=int, default=1,
+                    help="timesteps stacked by ONE launch (Engine.detect_batch; N = 1 and the C5 "
+                         "stream): what fills the GPU on the reference's example-sized grids "
+                         "(C1, E1, E2); --steps is rounded up to a multiple of it")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single process: build and time the slab rank --emulate-rank of an "
                          "N-GPU partition would hold (no exchange); for measuring C4 on 1 GPU")
@@ -329,8 +336,23 @@ def main():
         sharded = (qd.ShardedDetector(eng, n_total, ns, dev, exchange=args.exchange)
                    if use_dist and not time_sharded else None)
 
+    spl = max(1, args.steps_per_launch) if (sharded is None and world == 1) else 1
+    if spl > 1:
+        args.steps = -(-args.steps // spl) * spl
+        if not streaming:
+            # the launch's K onset arrays, resident like the single step's: [K][rows][T]
+            batch_dev = [torch.stack([onsets_dev[(b + j) % n_pool] for j in range(spl)]).contiguous()
+                         for b in range(n_pool)]
+            out_batch = (torch.empty((spl, ns), dtype=torch.float64, device=dev),
+                         torch.empty((spl, ns), dtype=torch.float64, device=dev),
+                         torch.empty((spl, ns), dtype=torch.int64, device=dev))
+
     def step(i):
         on = onsets_dev[i % n_pool]
+        if spl > 1 and not streaming:                   # steps i .. i + spl - 1 in one launch
+            eng.detect_batch(batch_dev[i % n_pool], case.fsmp, case.lsmp, case.available,
+                             n_nodes_total=n_total, out=out_batch)
+            return tuple(t[-1] for t in out_batch)
         if sharded is None:
             eng.detect(on, case.fsmp, case.lsmp, case.available, n_nodes_total=n_total,
                        out=out)
@@ -353,7 +375,7 @@ def main():
         from quakemigrate_amd.stream import StreamingDetector
 
         sd = StreamingDetector(eng, S, t_samples, case.fsmp, case.lsmp, case.available,
-                               n_nodes_total=n_total, depth=3, device=dev)
+                               n_nodes_total=n_total, depth=3, device=dev, steps_per_launch=spl)
     fence()
     eng.config("log_timing", 1)
     t0 = time.perf_counter()
@@ -364,7 +386,7 @@ def main():
         res = tuple(torch.from_numpy(a) for a in got[-1])
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
     else:
-        for i in range(args.steps):
+        for i in range(0, args.steps, spl):
             res = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
@@ -380,6 +402,8 @@ def main():
 
     # ---- in-bench sanity: injected events are found where they were put ------------
     last = (args.warmup + args.steps - 1) % n_pool
+    if spl > 1 and not streaming:                       # the last launch's last step
+        last = (args.warmup + args.steps - spl + spl - 1) % n_pool
     if time_sharded:
         last = (args.warmup + rank + world * (args.steps - 1)) % n_pool
     idx = res[2].cpu().numpy()
@@ -413,6 +437,9 @@ def main():
         work_step *= world                              # every rank scanned its own timesteps
     value = work_step * args.steps / elapsed
     kern_s = kern_ms / 1e3 / max(kern_calls, 1)         # avg stacking-kernel time, this rank
+    steps_per_launch = eng.get("steps_per_launch") if spl > 1 else 1
+    kern_launch_s = kern_s
+    kern_s /= steps_per_launch                          # ... per timestep
     # (column partition: the kernel line describes the engine holding the whole planes)
     n_kernel = ((boxes[0][1] - boxes[0][0]) * (boxes[0][3] - boxes[0][2]) * nz
                 if by_columns and boxes else n_local)
@@ -445,6 +472,7 @@ def main():
                                + (f"; {x_range[1] - x_range[0]} x-planes of it on rank {part_rank}"
                                   if part_world > 1 else ""),
                    "n_nodes_per_gpu": n_local, "n_rows": S, "n_samples": ns,
+                   "steps_per_launch": steps_per_launch,
                    "sharding": ("timesteps round-robin over the ranks, whole grid on every rank"
                                 if time_sharded else
                                 "flat-index ranges at (x, y)-column granularity (up to 3 boxes per "
@@ -463,7 +491,8 @@ def main():
                                   samples_per_lane=eng.get("samples_per_lane"),
                                   waves=eng.get("waves"))},
         "kernel": {"name": (f"qm::screen_lds_kernel<{eng.get('screen_pairs')}, {(S + 7) // 8}>"
-                            if screened else stack_kernel_name(eng, S)), "avg_ms": kern_s * 1e3,
+                            if screened else stack_kernel_name(eng, S)), "avg_ms": kern_launch_s * 1e3,
+                   "avg_ms_per_step": kern_s * 1e3, "steps_per_launch": steps_per_launch,
                    "launches": kern_calls, "timing": "HIP events on the launch stream"},
         "roofline": {"bound": bind, "achieved": chip[bind]["achieved"], "peak": chip[bind]["peak"],
                      "unit": chip[bind]["unit"], "frac": chip[bind]["frac"],
@@ -490,8 +519,8 @@ def main():
         from quakemigrate_amd.stream import StreamingDetector
 
         sd = StreamingDetector(eng, S, t_samples, case.fsmp, case.lsmp, case.available,
-                               n_nodes_total=n_norm, depth=3, device=dev)
-        sd.run(host_onsets[i % n_pool] for i in range(2))           # set-up + warm
+                               n_nodes_total=n_norm, depth=3, device=dev, steps_per_launch=spl)
+        sd.run(host_onsets[i % n_pool] for i in range(2 * spl))     # set-up + warm
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         got = sd.run(host_onsets[(args.warmup + i) % n_pool] for i in range(args.steps))
@@ -607,6 +636,61 @@ def main():
             "unit": "GB/s", "frac": 8.0 * n_local * ns_loc / sec / HBM_PEAK, "avg_ms": sec * 1e3,
             "workload": "find_max_coa of the resident locate volume (scan + combine kernels)"}
         del vol
+
+    # ---- a change of station availability: another table takes over (lut.py:529-537) --------------
+    if not args.no_table_switch and world == 1 and cfg_name == "C3" and not streaming and spl == 1:
+        torch.cuda.synchronize()
+        keep = [r for r in range(S) if r not in (3, S - 2)]        # a P and an S row drop out
+        tt_b = torch.from_numpy(np.ascontiguousarray(case.traveltimes[..., keep])).to(dev)
+        tt_a = torch.from_numpy(case.traveltimes).to(dev)
+        on_b = onsets_dev[0][keep].contiguous()
+        out_b = tuple(torch.empty_like(o) for o in out)
+
+        def run(which):
+            if which == "A":
+                eng.detect(onsets_dev[0], case.fsmp, case.lsmp, S, n_nodes_total=n_norm, out=out)
+            else:
+                eng.detect(on_b, case.fsmp, case.lsmp, S - 2, n_nodes_total=n_norm, out=out_b)
+
+        def timed(fn):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3
+
+        sw = lib.Engine(local_rank, **tunables)
+        sw.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng_saved, eng = eng, sw
+        # first sight of each table: upload from HBM + brick tables + the kernel's layouts + one step
+        first_a = timed(lambda: (sw.select_table("A"), sw.load_lut(tt_a), run("A")))
+        first_b = timed(lambda: (sw.select_table("B"), sw.load_lut(tt_b), run("B")))
+        assert sw.select_table("A")
+        run("A")
+        steady_a = min(timed(lambda: run("A")) for _ in range(3))
+        # alternating between the two parked tables, one step each
+        alt = []
+        for i in range(6):
+            which = "B" if i % 2 == 0 else "A"
+            alt.append(timed(lambda: (sw.select_table(which), run(which))))
+        assert sw.get("table_misses") == 2
+        same = bool(torch.equal(out[2], res[2])) if last == 0 else None
+        result["table_switch"] = {
+            "what": "station availability changes: table A = the 30 rows, table B = 28 of them; first "
+                    "sight of a table = load from HBM + derived layouts + one step; afterwards "
+                    "Engine.select_table swaps the parked device state in (no device work) and the "
+                    "step runs at its usual time",
+            "first_step_with_new_table_ms": {"A": first_a, "B": first_b},
+            "steady_step_ms": steady_a,
+            "alternating_step_ms": alt,
+            "table_switch_ms": max(0.0, float(np.mean(alt[2:])) - steady_a),
+            "rebuild_ms": first_b - steady_a,
+            "device_bytes_per_table": sw.get("table_bytes"),
+            "parked_bytes": sw.get("tables_parked_bytes"),
+            "result_unchanged": same}
+        eng = eng_saved
+        sw.close()
+        del tt_a, tt_b
 
     if args.materialise_full and world == 1 and not streaming:
         vol = torch.empty((n_local, ns), dtype=torch.float64, device=dev)

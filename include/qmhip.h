@@ -147,6 +147,20 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *value);
 int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device,
                        int32_t nx, int32_t ny, int32_t nz, int32_t n_rows,
                        int64_t node_offset);
+/* Several resident tables.  The reference serves a table per timestep from the stations available
+ * in it (LUT.serve_traveltimes, quakemigrate/lut/lut.py:502-538; QuakeScan._compute,
+ * signal/scan.py:619-634): when a station drops out and comes back, the same few tables alternate.
+ * qm_engine_table_select(key) declares which table the following calls work on: the state of the
+ * current one (table, brick records, window offsets, the kernels' derived layouts -- about 4x the
+ * table's size) is parked under its key, at most `capacity` of them, least recently used evicted,
+ * and the state parked under `key` is brought back -- a swap of pointers, no device work.
+ * *resident = 1: the table is there, go on; 0: nothing is resident now, load it (qm_engine_load_lut
+ * / qm_engine_serve), it is then known under `key`.  The float64 grids of the serving path and all
+ * per-step scratch are shared by every table.  capacity = 0 parks nothing (one resident table, as
+ * without this call).  qm_engine_get: "table_hits", "table_misses", "table_evictions",
+ * "tables_parked", "table_bytes", "tables_parked_bytes". */
+int qm_engine_table_select(qm_engine *e, uint64_t key, int32_t capacity, int32_t *resident);
+
 /* On-device table serving -- replaces LUT.serve_traveltimes (quakemigrate/lut/lut.py:502-538)
  * and Grid3D.decimate (lut.py:102-140) on the host.  Upload the float64 travel-time grids (seconds,
  * [nx][ny][nz] each, one per station/phase) once; qm_engine_serve then builds and makes
@@ -173,6 +187,20 @@ int qm_engine_detect(qm_engine *e, const double *log_onsets, int onsets_on_devic
                      int32_t available, int64_t n_nodes_total, double *max_coa,
                      double *max_norm_coa, int64_t *max_coa_idx,
                      int out_on_device);
+
+/* n_steps consecutive timesteps of the detect sweep in ONE launch: log_onsets f64
+ * [n_steps][n_rows][t_samples] (every step with the same table, pads and `available`), outputs
+ * [n_steps][n_samples].  What QuakeScan._continuous_compute (quakemigrate/signal/scan.py:407-470)
+ * does one timestep at a time; timesteps are independent given their onsets, so a launch can hold
+ * several -- which is what fills the GPU on the grids the reference's examples use (1e4-3e5 nodes:
+ * one timestep is a fraction of a millisecond of work and a few workgroup rounds).  Every step's
+ * result is the bits qm_engine_detect gives for it.  Launches that cannot carry a step axis (the
+ * screened detect, tables of more than 64 rows on row blocks) run step by step inside the call;
+ * qm_engine_get "steps_per_launch" reports what the last call did. */
+int qm_engine_detect_batch(qm_engine *e, const double *log_onsets, int onsets_on_device,
+                           int32_t n_steps, int32_t t_samples, int32_t fsmp, int32_t lsmp,
+                           int32_t available, int64_t n_nodes_total, double *max_coa,
+                           double *max_norm_coa, int64_t *max_coa_idx, int out_on_device);
 
 /* Same step, but stop before the final normalisation: this engine's partial
  * (log2-domain maximum, global node index, sum of coalescence) per sample, on

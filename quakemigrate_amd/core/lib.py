@@ -69,6 +69,7 @@ qmlib.qm_engine_config.argtypes = [_vp, ctypes.c_char_p, c_int64]
 qmlib.qm_engine_get.argtypes = [_vp, ctypes.c_char_p, ctypes.POINTER(c_int64)]
 qmlib.qm_engine_load_lut.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32,
                                      c_int32, c_int32, c_int64]
+qmlib.qm_engine_table_select.argtypes = [_vp, ctypes.c_uint64, c_int32, ctypes.POINTER(c_int32)]
 qmlib.qm_engine_lut_max.argtypes = [_vp, ctypes.POINTER(c_int32)]
 qmlib.qm_engine_grids_begin.argtypes = [_vp, c_int32, c_int32, c_int32, c_int32]
 qmlib.qm_engine_grids_set.argtypes = [_vp, c_int32, _vp, ctypes.c_int]
@@ -78,6 +79,9 @@ qmlib.qm_engine_lut_download.argtypes = [_vp, c_i32Pt]
 qmlib.qm_engine_detect.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32,
                                    c_int32, c_int32, c_int64, _vp, _vp, _vp,
                                    ctypes.c_int]
+qmlib.qm_engine_detect_batch.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32, c_int32,
+                                         c_int32, c_int32, c_int64, _vp, _vp, _vp,
+                                         ctypes.c_int]
 qmlib.qm_engine_detect_partial.argtypes = [_vp, _vp, ctypes.c_int, c_int32,
                                            c_int32, c_int32, c_int32, _vp, _vp,
                                            _vp]
@@ -143,6 +147,9 @@ class Engine:
         self.n_rows = None
         self.node_offset = 0
         self.table_generation = 0       # bumped whenever the resident table is replaced
+        self._current_key = None        # key of the resident table (select_table), if it has one
+        self.grids_generation = 0       # bumped by set_traveltime_grids (the grids are shared by
+                                        # every MigrationScan on this engine)
         for k, v in config.items():
             self.config(k, v)
 
@@ -250,6 +257,32 @@ class Engine:
         self.node_offset = int(node_offset)
         self.table_generation += 1
 
+    def select_table(self, key, capacity=4):
+        """
+        Work on the table known under ``key`` (any hashable): parks the current table's device
+        state -- up to ``capacity`` tables, least recently used evicted -- and brings the one parked
+        under ``key`` back (a pointer swap).  Returns True if that table is resident now; False if
+        the caller has to load it (``load_lut`` / ``serve``: it is then known under ``key``).
+        For the alternating station availabilities of a continuous run (lut.py:529-537).
+        """
+        import hashlib
+
+        digest = hashlib.blake2b(repr(key).encode(), digest_size=8).digest()
+        k64 = int.from_bytes(digest, "little")
+        if not hasattr(self, "_tables"):
+            self._tables = {}
+        if self._current_key is not None:
+            self._tables[self._current_key] = (self.grid, self.n_rows, self.node_offset)
+        resident = c_int32()
+        _check(qmlib.qm_engine_table_select(self._h, k64, int(capacity), ctypes.byref(resident)))
+        self._current_key = k64
+        if resident.value and k64 in self._tables:
+            self.grid, self.n_rows, self.node_offset = self._tables[k64]
+        elif not resident.value:
+            self.grid, self.n_rows = None, None
+        self.table_generation += 1
+        return bool(resident.value)
+
     # -- on-device serving (lut.py:502-538 / :102-140 moved to the GPU) ----------
     def set_traveltime_grids(self, grids):
         """
@@ -258,6 +291,7 @@ class Engine:
         """
         grids = list(grids)
         nx, ny, nz = (int(v) for v in grids[0].shape)
+        self.grids_generation += 1
         _check(qmlib.qm_engine_grids_begin(self._h, nx, ny, nz, len(grids)))
         for i, g in enumerate(grids):
             if tuple(g.shape) != (nx, ny, nz):
@@ -312,6 +346,25 @@ class Engine:
         _check(qmlib.qm_engine_detect(self._h, po, dev_on, t_samples, int(fsmp),
                                       int(lsmp), int(available), total, pa, pb,
                                       pc, da))
+        return out
+
+    def detect_batch(self, log_onsets, fsmp, lsmp, available, n_nodes_total=None, out=None):
+        """
+        ``K`` consecutive timesteps of the detect sweep in one launch: ``log_onsets`` (K, rows, T),
+        already ``log(clip(.))``; returns / fills three (K, n_samples) series.  Every step's result
+        is what :meth:`detect` gives for it (``get("steps_per_launch")`` tells whether the kernels
+        took the K steps in one launch or the call went step by step).
+        """
+        steps, rows, t_samples = (int(v) for v in log_onsets.shape)
+        self._check_rows(rows)
+        n = max(t_samples - int(fsmp) - int(lsmp), 0)
+        if out is None:
+            out = (np.zeros((steps, n)), np.zeros((steps, n)), np.zeros((steps, n), dtype=np.int64))
+        po, dev_on = self._ptr(log_onsets, np.float64)
+        pa, pb, pc, da = self._series(out, steps * n)
+        total = self.n_nodes if n_nodes_total is None else int(n_nodes_total)
+        _check(qmlib.qm_engine_detect_batch(self._h, po, dev_on, steps, t_samples, int(fsmp),
+                                            int(lsmp), int(available), total, pa, pb, pc, da))
         return out
 
     def detect_partial(self, log_onsets, fsmp, lsmp, available, part):

@@ -72,7 +72,77 @@ struct DevBuf {
 
 }  // namespace
 
-struct qm_engine {
+// Everything that is derived from ONE travel-time table: the table itself, its brick records and
+// window offsets, the layouts of the paired / screened / shift-reuse kernels built from it on first
+// use, and the launch shape the table's layout search picked.  The engine works on the state it
+// inherits; qm_engine_table_select parks it in a slot and brings another one in (a swap of pointers:
+// no device work), so that a change of station availability -- a different served table,
+// lut.py:529-537 -- costs a rebuild only the first time that table is seen.
+struct TableState {
+    bool have_lut = false;
+    qm::GridDesc g{};
+    int64_t n_nodes = 0;
+    int64_t node_offset = 0;
+    int32_t lut_max = 0;
+    int n_rows_hint = 0;            // row count the automatic choice is based on
+    int auto_j = 0;                 // samples per lane picked by the table's layout search (> 64 rows)
+    int tab_waves = 0, tab_lds_bytes = 0;   // workgroup shape the layout search picked (0: none yet)
+    DevBuf<int32_t> d_lut, d_bmeta, d_btotal, d_wide;
+    DevBuf<uint16_t> d_rel;
+    std::vector<int32_t> h_btotal;
+    int n_wide = 0;
+    int plan_j = -1, plan_cap = -1;
+
+    // float32 screening (qm_screen.hpp): staggered-copy offset table
+    DevBuf<int32_t> d_smeta, d_smeta_raw, d_stotal, d_swide;
+    qm::GridDesc sg{};                      // the sweep's own brick grid
+    DevBuf<uint16_t> d_srel;
+    int n_swide = 0;
+    int screen_kt = 0, screen_wb = 0;       // what the screening table was built for
+
+    // paired (16-byte operand) layout of the float64 kernel (qm_pair.hpp): own brick grid
+    qm::GridDesc pg{};
+    DevBuf<int32_t> d_pmeta, d_pmeta_raw, d_ptotal, d_pwide;
+    DevBuf<uint16_t> d_prel;
+    int n_pwide = 0;
+    int pair_kt = 0;                        // tile length the paired tables were built for
+    bool pair_ok = false;                   // ... and whether (almost) every brick fits
+
+    // shift-reuse layout of the fused float64 detect (qm_shift.hpp): own brick grid, row-window
+    // slots, record stream
+    int shift_nw = 0;                       // workgroup shape the tables were built for
+    qm::GridDesc shg{};
+    DevBuf<int32_t> d_shraw, d_shmeta, d_shtotal, d_shfit, d_shwide;
+    DevBuf<uint32_t> d_shstream;
+    int n_shwide = 0, shift_rows2 = 0;
+    int shift_nblk = 1, shift_sb = 0;       // row blocks (tables of more than 64 rows): blocks, rows per block
+    bool shift_direct = false;              // ... staged by LDS-direct loads (stack_shift_rows2_kernel)
+    bool shift_built = false, shift_ok = false;
+    int64_t shift_quads = 0, shift_group_rows = 0;   // register-window quads fetched / (group, row)s
+
+    void release_all() {
+        d_lut.release(); d_bmeta.release(); d_btotal.release(); d_wide.release(); d_rel.release();
+        d_smeta.release(); d_smeta_raw.release(); d_stotal.release(); d_swide.release(); d_srel.release();
+        d_pmeta.release(); d_pmeta_raw.release(); d_ptotal.release(); d_pwide.release(); d_prel.release();
+        d_shraw.release(); d_shmeta.release(); d_shtotal.release(); d_shfit.release();
+        d_shwide.release(); d_shstream.release();
+    }
+    size_t device_bytes() const {
+        return (d_lut.n + d_bmeta.n + d_btotal.n + d_wide.n + d_smeta.n + d_smeta_raw.n + d_stotal.n +
+                d_swide.n + d_pmeta.n + d_pmeta_raw.n + d_ptotal.n + d_pwide.n + d_shraw.n + d_shmeta.n +
+                d_shtotal.n + d_shfit.n + d_shwide.n + d_shstream.n) * 4 +
+               (d_rel.n + d_srel.n + d_prel.n) * 2;
+    }
+};
+
+struct TableSlot {
+    TableState state;
+    uint64_t key = 0;
+    uint64_t stamp = 0;             // last use (the engine's table clock): the oldest slot is evicted
+    bool used = false;
+};
+
+struct qm_engine : TableState {
     int device = 0;
     int n_cu = 256;
     hipStream_t own_stream = nullptr;
@@ -84,11 +154,15 @@ struct qm_engine {
     std::vector<hipEvent_t> ev_log;     // 2 events per recorded call
     size_t ev_used = 0;
 
+    // parked tables (qm_engine_table_select) and the key of the one being worked on
+    std::vector<TableSlot> slots;
+    uint64_t cur_key = 0, table_clock = 0;
+    bool cur_keyed = false;
+    int64_t table_hits = 0, table_misses = 0, table_evictions = 0;
+
     // tunables
     int cfg_bx = 0, cfg_by = 0, cfg_bz = 0;      // 0 = choose the brick shape per table
     int cfg_j = 0;                  // samples per lane (time tile = 64*J); 0 = by table width
-    int n_rows_hint = 0;            // row count the automatic choice is based on
-    int auto_j = 0;                 // samples per lane picked by the table's layout search (> 64 rows)
     int cfg_waves = 8;
     bool user_waves = false, user_lds = false;   // set explicitly: no automatic layout
     int cfg_groups = 0;
@@ -106,61 +180,26 @@ struct qm_engine {
     int cfg_screen_pairs = 0;       // pairs of samples per lane in the sweep (0 = automatic)
     int cfg_screen_brick16 = 0;     // also try 16x8x8 bricks for the sweep
     int cfg_screen_big = -1;        // 1: one 16-wave workgroup per CU with 160 KB of LDS; -1 = automatic
-
-    // resident table
-    bool have_lut = false;
-    qm::GridDesc g{};
-    int64_t n_nodes = 0;
-    int64_t node_offset = 0;
-    int32_t lut_max = 0;
-    DevBuf<int32_t> d_lut, d_bmeta, d_btotal, d_wide, d_scalar;
-    DevBuf<uint16_t> d_rel;
-    std::vector<int32_t> h_btotal;
-    int n_wide = 0;
-    int plan_j = -1, plan_cap = -1;
-
-    // float32 screening (qm_screen.hpp): staggered-copy offset table and per-step scratch
-    DevBuf<int32_t> d_smeta, d_smeta_raw, d_stotal, d_swide, d_counts, d_cells, d_work, d_flags;
-    qm::GridDesc sg{};                      // the sweep's own brick grid
-    DevBuf<uint16_t> d_srel;
-    DevBuf<int32_t> d_onq, d_cell, d_gmax, d_pm, d_sparams;
-    DevBuf<double> d_rowmax, d_ssum, d_cand_z;
-    DevBuf<int64_t> d_cand_idx;
-    int n_swide = 0;
-    int screen_kt = 0, screen_wb = 0;       // what the screening table was built for
-    int64_t screened_steps = 0, fallback_steps = 0, last_candidates = 0;
-    int last_plan_jp = 0, last_plan_big = 0;
-    int last_kernel = 0, last_j = 0;        // stacking kernel of the last launch: 0 chunked, 1 exact-row-count, 2 paired
-    int32_t *h_flags = nullptr;             // pinned ring of per-step (flags, candidates) pairs
-    int flags_pending = 0, flags_head = 0;  // not yet folded into the counters
-
-    // paired (16-byte operand) layout of the float64 kernel (qm_pair.hpp): own brick grid
-    qm::GridDesc pg{};
-    DevBuf<int32_t> d_pmeta, d_pmeta_raw, d_ptotal, d_pwide;
-    DevBuf<uint16_t> d_prel;
-    int n_pwide = 0;
-    int pair_kt = 0;                        // tile length the paired tables were built for
-    bool pair_ok = false;                   // ... and whether (almost) every brick fits
-
-    // shift-reuse layout of the fused float64 detect (qm_shift.hpp): own brick grid, row-window
-    // slots, record stream
     int cfg_shift = -1;                     // -1: where the table qualifies, 0: never, 1: as -1 (explicit)
     int cfg_shift_waves = 0;                // workgroup shape: 4 (two per CU), 12 (one per CU), 0 = automatic
     int cfg_shift_lazy = -1;                // detect loop flavour: -1 automatic, 0 eager, 1 lazy arg-max
     int cfg_shift_tail = 1;                 // 1: a scan's remainder of <= 192 samples runs as one tail tile of
                                             // 64 / 128 / 192 samples; 0: whole tiles only (round 3)
-    int shift_lazy_last = 0;                // ... the last launch took
-    int shift_tail_last = 0;                // samples per lane of the last launch's tail tile (0: none)
-    int shift_nw = 0;                       // ... the tables were built for
-    qm::GridDesc shg{};
-    DevBuf<int32_t> d_shraw, d_shmeta, d_shtotal, d_shfit, d_shwide;
-    DevBuf<uint32_t> d_shstream;
-    int n_shwide = 0, shift_rows2 = 0;
-    int shift_nblk = 1, shift_sb = 0;       // row blocks (tables of more than 64 rows): blocks, rows per block
-    bool shift_direct = false;              // ... staged by LDS-direct loads (stack_shift_rows2_kernel)
     int cfg_shift_rows_direct = 1;
-    bool shift_built = false, shift_ok = false;
-    int64_t shift_quads = 0, shift_group_rows = 0;   // register-window quads fetched / (group, row)s
+
+    // per-step scratch of the screened detect (qm_screen.hpp) and its statistics
+    DevBuf<int32_t> d_scalar, d_counts, d_cells, d_work, d_flags;
+    DevBuf<int32_t> d_onq, d_cell, d_gmax, d_pm, d_sparams;
+    DevBuf<double> d_rowmax, d_ssum, d_cand_z;
+    DevBuf<int64_t> d_cand_idx;
+    int64_t screened_steps = 0, fallback_steps = 0, last_candidates = 0;
+    int last_plan_jp = 0, last_plan_big = 0;
+    int last_kernel = 0, last_j = 0;        // stacking kernel of the last launch: 0 chunked, 1 exact-row-count, 2 paired
+    int32_t *h_flags = nullptr;             // pinned ring of per-step (flags, candidates) pairs
+    int flags_pending = 0, flags_head = 0;  // not yet folded into the counters
+    int shift_lazy_last = 0;                // loop flavour the last shift-reuse launch took
+    int shift_tail_last = 0;                // samples per lane of the last launch's tail tile (0: none)
+    int last_batched = 1;                   // timesteps the last detect_batch put into one launch
 
     // float64 travel-time grids in seconds (optional; on-device table serving)
     DevBuf<double> d_grids;
@@ -261,7 +300,9 @@ int plan_wide(qm_engine *e, int J) {
 qm::LaunchShape stack_shape(const qm_engine *e, const qm::StackArgs &a, int groups, int threads,
                             size_t lds) {
     // the grid is padded to a multiple of 8 groups (XCD-aware workgroup -> (tile, group) map)
-    return {(unsigned)(a.ntiles * ((groups + 7) / 8 * 8)), threads, lds, e->stream};
+    // (several timesteps per launch: the tile axis runs over (step, tile))
+    const int steps = a.n_steps > 1 ? a.n_steps : 1;
+    return {(unsigned)(steps * a.ntiles * ((groups + 7) / 8 * 8)), threads, lds, e->stream};
 }
 
 int launch_direct(qm_engine *e, const qm::StackArgs &a, int J, bool volume, int groups,
@@ -711,7 +752,11 @@ int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu) {
 int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_samples,
               int available, int sample0, int n_chunk, double *volume, int64_t vol_stride,
               int accumulate, bool want_scan, int *n_sets, bool marginal = false,
-              int m0 = 0, int m1 = 0, const int32_t *run_if = nullptr) {
+              int m0 = 0, int m1 = 0, const int32_t *run_if = nullptr, int n_steps = 1,
+              int64_t step_stride = 0, bool *batched = nullptr) {
+    // n_steps > 1: that many timesteps in ONE launch (fused detect only) -- onset arrays step_stride
+    // doubles apart, partial sets [*n_sets][n_steps * n_chunk].  Not every kernel can (row blocks, the
+    // 12-wave shape): *batched = false then, nothing is launched and the caller goes step by step.
     // marginal: per-tile sums over the samples [m0, m1) land in e->d_marg as [*n_tiles][n_nodes]
     // (e->marg_tiles: the kernels differ in their tile length)
     const int J = run_j(e, n_chunk);
@@ -789,6 +834,16 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         a.ntiles = (n_chunk + PKT - 1) / PKT;
         a.cap_doubles = kPairLdsBytes / 8;
     }
+    if (n_steps > 1) {
+        const bool ok = !volume && !marginal && !accumulate && run_if == nullptr && want_scan &&
+                        (!shift || (e->shift_nblk == 1 && e->shift_nw != qm::kShiftWaves3));
+        if (batched) *batched = ok;
+        if (!ok) return batched ? 0 : fail("run_stack: this launch cannot hold several timesteps");
+        a.n_steps = n_steps;
+        a.step_stride = step_stride;
+    }
+    const int steps = a.n_steps > 1 ? a.n_steps : 1;
+    a.part_stride = (int64_t)steps * n_chunk;
     if (marginal) {
         if (e->d_marg.ensure((size_t)a.ntiles * e->n_nodes)) return 1;
         a.marginal = e->d_marg.p;
@@ -805,15 +860,15 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     int groups_lds = 0, groups_direct = 0;
     if (use_lds)
         groups_lds = e->cfg_groups > 0 ? std::min(e->cfg_groups, nbricks_now)
-                                       : auto_groups(e, a.ntiles, nbricks_now, lds_blocks_per_cu);
+                                       : auto_groups(e, steps * a.ntiles, nbricks_now, lds_blocks_per_cu);
     if (use_direct) {
         const int units = e->cfg_force_direct ? nbricks_now : n_wide_now;
         groups_direct = e->cfg_groups > 0 ? std::min(e->cfg_groups, units)
-                                          : auto_groups(e, a.ntiles, units, 2048 / threads);
+                                          : auto_groups(e, steps * a.ntiles, units, 2048 / threads);
     }
     const int sets = groups_lds + groups_direct;
     if (want_scan) {
-        const size_t need = (size_t)sets * n_chunk;
+        const size_t need = (size_t)sets * steps * n_chunk;
         if (e->d_pmax.ensure(need) || e->d_psum.ensure(need) || e->d_pidx.ensure(need)) return 1;
     }
     a.part_max = e->d_pmax.p;
@@ -1316,23 +1371,19 @@ void qm_engine_destroy(qm_engine *e) {
     if (!e) return;
     DeviceGuard guard(e->device);
     (void)hipStreamSynchronize(e->stream);
+    e->release_all();
+    for (TableSlot &slot : e->slots) slot.state.release_all();
     e->d_grids.release(); e->d_rows.release(); e->d_served.release();
     e->d_sig.release(); e->d_sta.release(); e->d_lta.release(); e->d_raw.release();
-    e->d_onset_meta.release();
-    e->d_shraw.release(); e->d_shmeta.release(); e->d_shtotal.release(); e->d_shfit.release();
-    e->d_shwide.release(); e->d_shstream.release();
-    e->d_lut.release(); e->d_bmeta.release();
-    e->d_btotal.release(); e->d_wide.release(); e->d_scalar.release(); e->d_rel.release();
+    e->d_onset_meta.release(); e->d_scalar.release();
     e->d_onsets.release(); e->d_pmax.release(); e->d_psum.release(); e->d_out_a.release();
     e->d_out_b.release(); e->d_chunk.release(); e->d_marg.release(); e->d_marg_out.release(); e->d_pidx.release(); e->d_out_i.release();
     e->d_fit_a.release(); e->d_fit_b.release(); e->d_fit_c.release(); e->d_fit_part.release();
     e->d_fit_val.release(); e->d_fit_win.release(); e->d_fit_pidx.release();
-    e->d_smeta.release(); e->d_smeta_raw.release(); e->d_stotal.release(); e->d_swide.release(); e->d_counts.release();
-    e->d_cells.release(); e->d_work.release(); e->d_flags.release(); e->d_srel.release(); e->d_onq.release(); e->d_sparams.release();
+    e->d_counts.release(); e->d_cells.release(); e->d_work.release(); e->d_flags.release();
+    e->d_onq.release(); e->d_sparams.release();
     e->d_cell.release(); e->d_gmax.release(); e->d_pm.release(); e->d_rowmax.release(); e->d_ssum.release();
     e->d_cand_z.release(); e->d_cand_idx.release();
-    e->d_pmeta.release(); e->d_pmeta_raw.release(); e->d_ptotal.release(); e->d_pwide.release();
-    e->d_prel.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
     for (hipEvent_t ev : e->ev_log) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -1472,6 +1523,19 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "shift_lazy") *v = e->shift_lazy_last;
     else if (k == "shift_tail") *v = e->cfg_shift_tail;
     else if (k == "shift_tail_spl") *v = e->shift_tail_last;
+    else if (k == "steps_per_launch") *v = e->last_batched;
+    else if (k == "table_hits") *v = e->table_hits;
+    else if (k == "table_misses") *v = e->table_misses;
+    else if (k == "table_evictions") *v = e->table_evictions;
+    else if (k == "tables_parked") {
+        *v = 0;
+        for (const TableSlot &sl : e->slots) *v += sl.used ? 1 : 0;
+    } else if (k == "table_bytes") {                     // device bytes of the resident table's state
+        *v = (int64_t)e->device_bytes();
+    } else if (k == "tables_parked_bytes") {
+        *v = 0;
+        for (const TableSlot &sl : e->slots) *v += sl.used ? (int64_t)sl.state.device_bytes() : 0;
+    }
     else if (k == "shift_row_blocks") *v = e->shift_ok ? e->shift_nblk : 0;
     else if (k == "shift_brick_nodes") *v = e->shift_ok ? e->shg.brick_nodes : 0;
     else if (k == "shift_wide_bricks") *v = e->shift_ok ? e->n_shwide : 0;
@@ -1620,6 +1684,8 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     e->g = g;
     e->n_nodes = n_nodes;
     e->node_offset = node_offset;
+    e->tab_waves = e->cfg_waves;                        // (what the layout search left in the tunables)
+    e->tab_lds_bytes = e->cfg_lds_bytes;
     e->plan_j = -1;
     e->screen_kt = 0;
     e->pair_kt = 0;
@@ -1627,6 +1693,66 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     e->shift_ok = false;
     e->have_lut = true;
     return plan_wide(e, eff_j(e));
+}
+
+int qm_engine_table_select(qm_engine *e, uint64_t key, int32_t capacity, int32_t *resident) {
+    if (!e || !resident) return fail("qm_engine_table_select: NULL argument");
+    if (capacity < 0 || capacity > 64) return fail("qm_engine_table_select: capacity must be in 0..64");
+    *resident = 0;
+    if (e->cur_keyed && e->cur_key == key && e->have_lut) {
+        *resident = 1;
+        ++e->table_hits;
+        return 0;
+    }
+    DeviceGuard guard(e->device);
+    TableState &cur = *e;
+    // park the table being worked on (if it has a key: one loaded without a key is simply replaced)
+    if (e->have_lut && e->cur_keyed && capacity > 0) {
+        TableSlot *slot = nullptr;
+        for (TableSlot &sl : e->slots)
+            if (!sl.used) { slot = &sl; break; }
+        if (!slot && (int)e->slots.size() < capacity) {
+            e->slots.emplace_back();
+            slot = &e->slots.back();
+        }
+        if (!slot) {                                    // evict the least recently used
+            slot = &e->slots[0];
+            for (TableSlot &sl : e->slots)
+                if (sl.stamp < slot->stamp) slot = &sl;
+            // (frees device memory: hipFree waits for work that may still read it)
+            slot->state.release_all();
+            slot->state = TableState{};
+            ++e->table_evictions;
+        }
+        std::swap(cur, slot->state);                    // the engine now holds the slot's empty state
+        slot->key = e->cur_key;
+        slot->stamp = ++e->table_clock;
+        slot->used = true;
+    } else if (e->have_lut) {
+        // nothing may be parked: keep the buffers for the next table (load_lut reuses allocations)
+        e->have_lut = false;
+        e->shift_built = e->shift_ok = false;
+        e->pair_kt = 0;
+        e->screen_kt = 0;
+        e->plan_j = -1;
+    }
+    e->cur_key = key;
+    e->cur_keyed = true;
+    for (TableSlot &sl : e->slots) {
+        if (sl.used && sl.key == key) {
+            std::swap(cur, sl.state);                   // (the slot keeps the empty state)
+            sl.state.release_all();
+            sl.state = TableState{};
+            sl.used = false;
+            if (!e->user_waves && e->tab_waves) e->cfg_waves = e->tab_waves;
+            if (!e->user_lds && e->tab_lds_bytes) e->cfg_lds_bytes = e->tab_lds_bytes;
+            *resident = 1;
+            ++e->table_hits;
+            return 0;
+        }
+    }
+    ++e->table_misses;
+    return 0;
 }
 
 int qm_engine_grids_begin(qm_engine *e, int32_t nx, int32_t ny, int32_t nz, int32_t n_grids) {
@@ -1763,6 +1889,48 @@ int qm_engine_detect(qm_engine *e, const double *log_onsets, int onsets_on_devic
     if (stage_out(e, ns, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st)) return 1;
     if (detect_core(e, d_on, T, fsmp, ns, available, 1, n_nodes_total, st.a, st.b, st.i)) return 1;
     return fetch_out(e, ns, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
+}
+
+int qm_engine_detect_batch(qm_engine *e, const double *log_onsets, int onsets_on_device,
+                           int32_t n_steps, int32_t T, int32_t fsmp, int32_t lsmp, int32_t available,
+                           int64_t n_nodes_total, double *max_coa, double *max_norm_coa,
+                           int64_t *max_coa_idx, int out_on_device) {
+    if (!e || !log_onsets || !max_coa || !max_norm_coa || !max_coa_idx)
+        return fail("qm_engine_detect_batch: NULL argument");
+    if (n_steps < 1) return fail("qm_engine_detect_batch: n_steps must be >= 1 (got %d)", n_steps);
+    DeviceGuard guard(e->device);
+    int ns = 0;
+    if (check_step(e, T, fsmp, lsmp, available, &ns)) return 1;
+    if ((int64_t)n_steps * ns >= INT32_MAX) return fail("qm_engine_detect_batch: too many samples");
+    const size_t per_step = (size_t)e->g.n_rows * T;
+    const double *d_on = log_onsets;
+    if (!onsets_on_device) {
+        if (e->d_onsets.ensure(per_step * n_steps)) return 1;
+        QM_HIP(hipMemcpyAsync(e->d_onsets.p, log_onsets, per_step * n_steps * sizeof(double),
+                              hipMemcpyHostToDevice, e->stream));
+        d_on = e->d_onsets.p;
+    }
+    const int n_all = n_steps * ns;
+    OutStage st;
+    if (stage_out(e, n_all, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st)) return 1;
+    bool batched = false;
+    int sets = 0;
+    if (n_steps > 1 && !e->cfg_screen) {
+        if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, &sets, false, 0, 0,
+                      nullptr, n_steps, (int64_t)per_step, &batched))
+            return 1;
+        // partial sets [sets][n_steps * ns] -> the steps' series back to back
+        if (batched && combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, n_all, 1, e->node_offset,
+                               n_nodes_total, st.a, st.b, st.i))
+            return 1;
+    }
+    if (!batched)                                       // step by step (a single step, the screened
+        for (int k = 0; k < n_steps; ++k)               // detect, kernels without the step axis)
+            if (detect_core(e, d_on + (size_t)k * per_step, T, fsmp, ns, available, 1, n_nodes_total,
+                            st.a + (size_t)k * ns, st.b + (size_t)k * ns, st.i + (size_t)k * ns))
+                return 1;
+    e->last_batched = batched ? n_steps : 1;
+    return fetch_out(e, n_all, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
 }
 
 int qm_engine_migrate(qm_engine *e, const double *log_onsets, int onsets_on_device, int32_t T,

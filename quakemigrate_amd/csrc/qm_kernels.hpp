@@ -52,6 +52,12 @@ struct StackArgs {
     int ntiles, ngroups;
     int tail_spl;                  // shift-reuse kernels: samples per lane of the scan's tail tile (1..3;
                                    // 0: whole 256-sample tiles only, the last one pulled back)
+    // K timesteps in one launch (detect-type launches): step k scans onsets + k * step_stride with
+    // the same table and geometry and publishes its partial sets at column k * n_chunk of rows that
+    // are part_stride long.  The time-tile axis of the grid is n_steps * ntiles long.
+    int n_steps;                   // 0 or 1: a single step
+    int64_t step_stride;           // doubles between the onset arrays of consecutive steps
+    int64_t part_stride;           // elements per partial set (0: n_chunk)
     int cap_doubles;               // LDS window capacity in doubles
     double z_scale;                // log2(e) / available: z = stack * z_scale, coa = 2^z
     double *volume;                // [N][vol_stride] or nullptr
@@ -80,6 +86,30 @@ __device__ __forceinline__ double max_keep(double best, double x) {
 template <typename I>
 __device__ __forceinline__ bool better(double v, I i, double best, I bi) {
     return (v > best) || (v == best && i < bi);
+}
+
+// XCD-aware workgroup -> (time tile, brick group) map of the stacking kernels: workgroup b is observed
+// to run on XCD b % 8, each XCD has its own L2; all time tiles of one brick group read the same slice
+// of the offset table / record stream, so whole groups are dealt to XCDs (group = xcd + 8 * k) and a
+// slice is fetched into one L2 instead of eight.  The grid is padded to a multiple of 8 groups.
+// With several timesteps per launch the tile axis runs over (step, tile); `step_view` is the
+// launch's arguments as that step sees them (its onsets, its columns of the partial sets).
+__device__ __forceinline__ void stack_tile_group(const StackArgs &a, int &tile, int &group) {
+    const int slot = blockIdx.x >> 3;
+    const int all = a.ntiles * (a.n_steps > 1 ? a.n_steps : 1);
+    tile = (slot % all) % a.ntiles;
+    group = (int)(blockIdx.x & 7) + 8 * (slot / all);
+}
+__device__ __forceinline__ StackArgs step_view(StackArgs a) {
+    if (a.part_stride == 0) a.part_stride = a.n_chunk;
+    if (a.n_steps > 1) {
+        const int step = (int)((blockIdx.x >> 3) % (unsigned)(a.ntiles * a.n_steps)) / a.ntiles;
+        a.onsets += (int64_t)step * a.step_stride;
+        a.part_max += (int64_t)step * a.n_chunk;
+        a.part_idx += (int64_t)step * a.n_chunk;
+        a.part_sum += (int64_t)step * a.n_chunk;
+    }
+    return a;
 }
 
 // a brick fits the LDS-tiled kernel iff its byte offsets fit uint16 and its windows fit LDS
@@ -639,7 +669,7 @@ __device__ __forceinline__ void publish(const StackArgs &a, Running<J> &run, dou
         }
         const int t = t_first + k;
         if (t < a.n_chunk) {
-            const int64_t o = (int64_t)set * a.n_chunk + t;
+            const int64_t o = (int64_t)set * (a.part_stride ? a.part_stride : a.n_chunk) + t;
             a.part_max[o] = best;
             a.part_idx[o] = bi;
             a.part_sum[o] = total;
@@ -868,8 +898,9 @@ __device__ __forceinline__ void stack_full_chunks(double (&acc)[J], uint4 (&q)[N
 // node is prefetched into registers while the current one is stacked, and the chunk loop is
 // unrolled.  NCH == 0: any row count, one-chunk-ahead prefetch (slower, always valid).
 template <int J, bool VOLUME, int NCH>
-__global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
+__global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a_launch) {
     extern __shared__ __attribute__((aligned(16))) double win[];
+    const StackArgs a = step_view(a_launch);
     constexpr int KT = kWave * J;
     const GridDesc &g = a.g;
     const int lane = threadIdx.x & (kWave - 1);
@@ -879,9 +910,8 @@ __global__ __launch_bounds__(1024) void stack_lds_kernel(StackArgs a) {
     // b % 8, each XCD has its own L2; all time tiles of one brick group read the same slice of the
     // offset table, so whole groups are dealt to XCDs (group = xcd + 8 * k) and a slice is fetched
     // into one L2 instead of eight.  Purely a placement hint: any mapping gives the same result.
-    const int slot = blockIdx.x >> 3;
-    const int tile = slot % a.ntiles;
-    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    int tile, group;
+    stack_tile_group(a, tile, group);
     if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
     if (a.run_if != nullptr && *a.run_if == 0) return;
     const int t_first = tile * KT;                    // relative to sample0
@@ -1246,9 +1276,8 @@ __device__ __forceinline__ void stack_exact_body(const StackArgs &a, double *win
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     // XCD-aware workgroup -> (time tile, brick group) map, as stack_lds_kernel
-    const int slot = blockIdx.x >> 3;
-    const int tile = slot % a.ntiles;
-    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    int tile, group;
+    stack_tile_group(a, tile, group);
     // TAIL 1: the last tile of a scan that is not a multiple of the tile length is pulled back so
     // that it ends with the scan (it overlaps its predecessor; both compute the overlap with the
     // same arithmetic and write the same bits to the partial sets): no lane is past the end
@@ -1331,19 +1360,20 @@ __device__ __forceinline__ void stack_exact_body(const StackArgs &a, double *win
 template <int J, int S>
 __global__ __launch_bounds__(1024) void stack_exact_marginal_kernel(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) double win[];
-    const int group = (int)(blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / a.ntiles);
+    int tile, group;
+    stack_tile_group(a, tile, group);
     if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
     if (a.run_if != nullptr && *a.run_if == 0) return;
     stack_exact_body<J, true, 3, S>(a, win);
 }
 
 template <int J, bool VOLUME, int S>
-__global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a) {
+__global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a_launch) {
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int KT = kWave * J;
-    const int slot = blockIdx.x >> 3;
-    const int tile = slot % a.ntiles;
-    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    const StackArgs a = step_view(a_launch);
+    int tile, group;
+    stack_tile_group(a, tile, group);
     if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
     if (a.run_if != nullptr && *a.run_if == 0) return;
     // only the volume-writing variant cares where its tile lies in the scan
@@ -1358,8 +1388,9 @@ __global__ __launch_bounds__(1024) void stack_exact_kernel(StackArgs a) {
 // fit the LDS budget (arbitrary tables stay correct), and serves as an on-device cross-check.
 // ---------------------------------------------------------------------------------------
 template <int J, bool VOLUME>
-__global__ __launch_bounds__(1024) void stack_direct_kernel(StackArgs a) {
+__global__ __launch_bounds__(1024) void stack_direct_kernel(StackArgs a_launch) {
     extern __shared__ __attribute__((aligned(16))) double win[];
+    const StackArgs a = step_view(a_launch);
     constexpr int KT = kWave * J;
     const GridDesc &g = a.g;
     const int lane = threadIdx.x & (kWave - 1);
@@ -1369,9 +1400,8 @@ __global__ __launch_bounds__(1024) void stack_direct_kernel(StackArgs a) {
     // b % 8, each XCD has its own L2; all time tiles of one brick group read the same slice of the
     // offset table, so whole groups are dealt to XCDs (group = xcd + 8 * k) and a slice is fetched
     // into one L2 instead of eight.  Purely a placement hint: any mapping gives the same result.
-    const int slot = blockIdx.x >> 3;
-    const int tile = slot % a.ntiles;
-    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    int tile, group;
+    stack_tile_group(a, tile, group);
     if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
     if (a.run_if != nullptr && *a.run_if == 0) return;
     const int t_first = tile * KT;

@@ -270,9 +270,8 @@ __device__ __forceinline__ void stack_pair_body(const StackArgs &a, double *win)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     // XCD-aware workgroup -> (time tile, brick group) map, as stack_lds_kernel
-    const int slot = blockIdx.x >> 3;
-    const int tile = slot % a.ntiles;
-    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    int tile, group;
+    stack_tile_group(a, tile, group);
     // The last tile of a scan that is not a multiple of the tile length is pulled back so that it
     // ends with the scan: it then overlaps its predecessor, both compute the overlap with the same
     // arithmetic and write the same bits to the partial sets -- no lane is ever past the end.  Only
@@ -388,7 +387,7 @@ __device__ __forceinline__ void stack_pair_body(const StackArgs &a, double *win)
             for (int w = 0; w < nwaves; ++w) total += ssum[w * KT + k];
             const int t = t_first + k;
             if (t < a.n_chunk) {
-                const int64_t o = (int64_t)(a.set0 + group) * a.n_chunk + t;
+                const int64_t o = (int64_t)(a.set0 + group) * (a.part_stride ? a.part_stride : a.n_chunk) + t;
                 a.part_max[o] = tmax;
                 a.part_idx[o] = tidx == INT32_MAX ? kNoIndex : (int64_t)tidx;
                 a.part_sum[o] = total;
@@ -401,13 +400,12 @@ template <int JP, bool VOLUME, int S>
 __global__ __launch_bounds__(1024) void stack_pair_kernel(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int KT = 128 * JP;
-    const int slot = blockIdx.x >> 3;
-    const int group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    int tile, group;
+    stack_tile_group(a, tile, group);
     if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups
     if (a.run_if != nullptr && *a.run_if == 0) return;
     // only the volume-writing variant cares where its tile lies in the scan (see t_first in the
     // body and the store step of pepi_step)
-    const int tile = slot % a.ntiles;
     if (VOLUME && a.n_chunk < KT) stack_pair_body<JP, VOLUME, 2, S>(a, win);
     else if (VOLUME && (tile + 1) * KT > a.n_chunk) stack_pair_body<JP, VOLUME, 1, S>(a, win);
     else stack_pair_body<JP, VOLUME, 0, S>(a, win);

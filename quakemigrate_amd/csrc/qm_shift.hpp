@@ -349,9 +349,7 @@ struct ShiftWork {
 };
 __device__ __forceinline__ ShiftWork shift_work(const StackArgs &a) {
     ShiftWork w;
-    const int slot = blockIdx.x >> 3;
-    w.tile = slot % a.ntiles;
-    w.group = (int)(blockIdx.x & 7) + 8 * (slot / a.ntiles);
+    stack_tile_group(a, w.tile, w.group);
     w.run = w.group < a.ngroups && !(a.run_if != nullptr && *a.run_if == 0);
     w.spl = (a.tail_spl > 0 && w.tile == a.ntiles - 1) ? a.tail_spl : 4;
     w.t_first = (w.spl == 4 && (w.tile + 1) * kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT)
@@ -402,7 +400,7 @@ __device__ __forceinline__ void shift_publish(const StackArgs &a, double *win, c
     }
     const int t = t_first + k;
     if (t < a.n_chunk) {
-        const int64_t o = (int64_t)(a.set0 + group) * a.n_chunk + t;
+        const int64_t o = (int64_t)(a.set0 + group) * (a.part_stride ? a.part_stride : a.n_chunk) + t;
         a.part_max[o] = best;
         a.part_idx[o] = bi == INT32_MAX ? kNoIndex : (int64_t)bi;
         a.part_sum[o] = total;
@@ -554,6 +552,7 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
     extern __shared__ __attribute__((aligned(16))) double win[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (MODE == kShiftDetect) s.a = step_view(s.a);   // (several timesteps per launch: this workgroup's)
     const ShiftWork work = shift_work(s.a);
     if (!work.run) return;
     if constexpr (NW != kShiftWaves3) {

