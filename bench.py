@@ -29,7 +29,9 @@ One JSON line on stdout (rank 0).  Besides the contract's keys it carries
                   ALGORITHMIC bytes (table + onsets + outputs) -- by construction far below
                   1 %: the kernel is LDS-gather / VALU bound, not HBM bound (SURVEY.md
                   section 8d) -- plus ``lds_frac`` / ``fp64_valu_frac``, the ceilings that do
-                  bind it; ``traffic`` is null (PMC passes are separate runs: profiles/);
+                  bind it, and ``adds_only_frac`` (the reference's S adds alone); ``traffic`` =
+                  HBM bytes per launch from the newest stored PMC passes over this kernel and
+                  workload (profiles/rNN_pmc_traffic.json; null if none matches);
   step_with_copies : the same steps fed from pinned host memory -- H2D of the onsets and D2H
                   of the three series inside the timed region, overlapped on HIP streams
                   (SURVEY.md section 8d's PCIe-inclusive step; never ``value``);
@@ -183,6 +185,38 @@ def onchip(screened, local_ns, S, kern_s, operands_per_add=1.0, exp_ops=EXP_FP64
                           "unit": "TFLOP/s (FP64 VALU instruction-lanes, one operation per instruction)",
                           "frac": local_ns * (S + exp_ops) / kern_s / FP64_PEAK,
                           "ops_per_node_sample": S + exp_ops}}
+
+
+def stored_traffic(label, kernel_name, algorithmic_bytes):
+    """
+    HBM bytes per launch of the dominant kernel from the newest stored PMC passes
+    (profiles/rNN_pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE /
+    WRITE_SIZE rocprofv3 runs of this workload): PMC cannot be collected inside an un-profiled
+    bench run.  Returned only when the stored kernel is the one this run launched.
+    """
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        rec = json.load(open(files[-1])).get(label)
+    except (OSError, ValueError):
+        return None, None
+    if not rec or rec.get("kernel") != kernel_name:
+        return None, None
+    total = rec["fetch_bytes"] + rec["write_bytes"]
+    detail = {"fetch_bytes": rec["fetch_bytes"], "write_bytes": rec["write_bytes"],
+              "fetch_bytes_if_128B_requests_tallied_at_64B": rec["fetch_bytes_upper"],
+              "algorithmic_bytes": algorithmic_bytes,
+              "ratio_to_algorithmic": total / algorithmic_bytes,
+              "ratio_to_algorithmic_upper": (rec["fetch_bytes_upper"] + rec["write_bytes"]) / algorithmic_bytes,
+              "source": "profiles/" + os.path.basename(files[-1]) + " <- " + ", ".join(rec["source"]),
+              "note": "separate rocprofv3 --pmc passes over one launch of this kernel on this workload "
+                      "(FETCH_SIZE, WRITE_SIZE: KB); on gfx950 FETCH_SIZE counts the 128-byte requests "
+                      "of wide reads at 64 bytes (MI355X_MICROARCH.md), hence the upper figure; beyond "
+                      "the table the kernel reads its record stream (8 S bytes per node) once per step"}
+    return total, detail
 
 
 def stack_kernel_name(eng, S, volume=False):
@@ -455,8 +489,18 @@ def main():
     # the ceiling that binds: whichever on-chip unit is busier (the fused detect cannot be HBM
     # bound: SURVEY.md section 8d); the HBM-compulsory figure is kept under its own key
     bind = "lds" if chip["lds"]["frac"] >= chip[valu_key]["frac"] else valu_key
+    kname = (f"qm::screen_lds_kernel<{eng.get('screen_pairs')}, {(S + 7) // 8}>"
+             if screened else stack_kernel_name(eng, S))
+    traffic, traffic_detail = (stored_traffic(f"{args.config}:detect", kname, b_fused)
+                               if world == 1 and part_world == 1 and spl == 1 else (None, None))
     result = {
         "metric": "grid-nodes x time-samples stacked /sec (detect sweep)",
+        "metric_definition": "value = n_nodes x n_samples x steps / wall time of the timed region, the "
+                             "travel-time table AND the log-onsets already resident in HBM when the "
+                             "clock starts, the three output series left in HBM (the bench contract's "
+                             "definition).  SURVEY.md section 8d defines the same metric with the "
+                             "per-step H2D of the onsets and D2H of the series inside the timed region: "
+                             "that is `step_with_copies.value` (copies overlapped on HIP streams).",
         "value": value, "unit": "node-samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
@@ -490,14 +534,19 @@ def main():
                                                    eng.get("brick_z")],
                                   samples_per_lane=eng.get("samples_per_lane"),
                                   waves=eng.get("waves"))},
-        "kernel": {"name": (f"qm::screen_lds_kernel<{eng.get('screen_pairs')}, {(S + 7) // 8}>"
-                            if screened else stack_kernel_name(eng, S)), "avg_ms": kern_launch_s * 1e3,
+        "kernel": {"name": kname, "avg_ms": kern_launch_s * 1e3,
                    "avg_ms_per_step": kern_s * 1e3, "steps_per_launch": steps_per_launch,
                    "launches": kern_calls, "timing": "HIP events on the launch stream"},
         "roofline": {"bound": bind, "achieved": chip[bind]["achieved"], "peak": chip[bind]["peak"],
                      "unit": chip[bind]["unit"], "frac": chip[bind]["frac"],
-                     "traffic": None,       # PMC passes are separate runs (profiles/, README there)
+                     # HBM bytes per launch (fetch + write) from the stored PMC passes over this
+                     # kernel and workload -- null when none is stored for what this run launched
+                     "traffic": traffic, "traffic_detail": traffic_detail,
                      "lds_frac": chip["lds"]["frac"], "valu_frac": chip[valu_key]["frac"],
+                     # the reference's own arithmetic alone (S float64 adds per node-sample; the
+                     # engine's 2^z / sum / arg-max epilogue left out) against the same VALU peak
+                     "adds_only_frac": (None if screened else
+                                        local_ns * S / kern_s / FP64_PEAK),
                      "hbm_compulsory": {"bound": "hbm", "achieved": b_fused / kern_s / 1e9,
                                         "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                         "frac": b_fused / kern_s / HBM_PEAK,
@@ -599,8 +648,9 @@ def main():
         sec = ms / 1e3 / calls
         b_mat = 8.0 * n_local * ns_loc + 4.0 * n_local * S + \
             8.0 * S * on.shape[1] + 24.0 * ns_loc      # SURVEY 8d figure 1
+        mt, mt_detail = stored_traffic("C3L:volume", stack_kernel_name(eng, S, volume=True), b_mat)
         result["roofline_materialised"] = {
-            "kernel": stack_kernel_name(eng, S, volume=True),
+            "kernel": stack_kernel_name(eng, S, volume=True), "traffic": mt, "traffic_detail": mt_detail,
             "bound": "hbm", "achieved": b_mat / sec / 1e9, "peak": HBM_PEAK / 1e9,
             "unit": "GB/s", "frac": b_mat / sec / HBM_PEAK, "avg_ms": sec * 1e3,
             "node_samples_per_s": n_local * ns_loc / sec,

@@ -406,6 +406,33 @@ def main():
          served_50=served, decimate=np.array([2, 3, 4]), served_dec_250=served_dec,
          dec_node_count=np.array(dec.node_count))
 
+    # 9b. the same class on grids that hold what a real LUT can: NaN (nodes a ray tracer could not
+    #     reach), infinities, travel times beyond the int32 range at the sampling rate, negative
+    #     values.  lut.py:538 is `np.rint(tt * sr).astype(np.int32)`: on x86-64 the float64 -> int32
+    #     cast of NaN and of anything outside [-2^31, 2^31) gives INT32_MIN ("integer indefinite"),
+    #     which migrate clamps to a delay of 0 (migratelib.c:55) -- recorded here, not assumed.
+    shape_b = (6, 5, 4)
+    special = [np.nan, np.inf, -np.inf, 1e12, -1e12, (2.0 ** 31) / 50, (2.0 ** 31 - 1) / 50,
+               (2.0 ** 31 - 0.5) / 50, -(2.0 ** 31) / 50, -(2.0 ** 31 + 1) / 50, -0.3, -0.0,
+               0.5 / 50, 1.5 / 50, 2.5 / 50, 4.3e7]
+    lut_b = lutmod.LUT.__new__(lutmod.LUT)
+    lut_b.node_count = np.array(shape_b, dtype=float)
+    lut_b.node_spacing = np.array([0.5, 0.5, 0.5])
+    lut_b.phases = ["P"]
+    lut_b.traveltimes = {}
+    grids_b = {}
+    for k, st in enumerate(["AAA", "BBB", "CCC"]):
+        g = rng9.uniform(0.0, 3.0, size=shape_b)
+        flat = g.reshape(-1)
+        flat[rng9.permutation(flat.size)[:len(special)]] = np.roll(special, k)
+        lut_b.traveltimes.setdefault(st, {})["P"] = g
+        grids_b[f"{st}_P"] = g
+    avail_b = {k: 1 for k in grids_b}
+    with np.errstate(invalid="ignore"):
+        served_b = lut_b.serve_traveltimes(50, avail_b)
+    save("serve_nonfinite", keys=np.array(list(grids_b.keys())), grids=np.stack(list(grids_b.values())),
+         served_50=served_b, machine=np.array(platform.machine()))
+
     # 10. onset stage: the reference's OWN STALTAOnset._onset / _trim_taper_pad
     #     (signal/onsets/stalta.py:491-583, calling the reference C STA/LTA through the
     #     reference binding) on lists of trace-like objects, then lib.migrate's clip + log

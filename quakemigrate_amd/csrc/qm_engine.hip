@@ -859,12 +859,15 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
                : std::max(1, std::min(160 * 1024 / std::max(1, e->cfg_lds_bytes), 2048 / threads));
     int groups_lds = 0, groups_direct = 0;
     if (use_lds)
+        // (several timesteps per launch: the group count is the single step's -- the groups are the
+        // order in which a sample's coalescence is summed over the nodes, and a step's result must
+        // not depend on how many steps share its launch; the extra steps only make the grid longer)
         groups_lds = e->cfg_groups > 0 ? std::min(e->cfg_groups, nbricks_now)
-                                       : auto_groups(e, steps * a.ntiles, nbricks_now, lds_blocks_per_cu);
+                                       : auto_groups(e, a.ntiles, nbricks_now, lds_blocks_per_cu);
     if (use_direct) {
         const int units = e->cfg_force_direct ? nbricks_now : n_wide_now;
         groups_direct = e->cfg_groups > 0 ? std::min(e->cfg_groups, units)
-                                          : auto_groups(e, steps * a.ntiles, units, 2048 / threads);
+                                          : auto_groups(e, a.ntiles, units, 2048 / threads);
     }
     const int sets = groups_lds + groups_direct;
     if (want_scan) {
@@ -1589,46 +1592,63 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     e->n_rows_hint = n_rows;
     e->auto_j = 0;
     qm::GridDesc g{};
-    // largest candidate shape whose windows fit for tile length 64 * J (result in g, e->d_bmeta,
-    // e->d_btotal, e->h_btotal)
+    // Per candidate shape ONE pass over the table (min / span per (brick, row), the bricks' totals,
+    // the table's largest delay); whether a shape's windows fit depends on the tile length and the
+    // LDS budget and is decided on the host from the cached totals -- the layout search below asks
+    // for up to seven (tile length, budget) pairs, which used to cost as many passes and host
+    // round trips per load.  `on_device`: the shape whose records d_bmeta / d_btotal hold.
+    std::vector<std::vector<int32_t>> totals(n_shapes);
+    std::vector<qm::GridDesc> shapes(n_shapes);
+    int on_device = -1;
+    auto measure = [&](int s) -> int {
+        qm::GridDesc &gs = shapes[s];
+        gs = qm::GridDesc{};
+        gs.nx = nx; gs.ny = ny; gs.nz = nz;
+        gs.bx = std::min(e->cfg_bx > 0 ? e->cfg_bx : kShapes[s][0], (int)nx);
+        gs.by = std::min(e->cfg_bx > 0 ? e->cfg_by : kShapes[s][1], (int)ny);
+        gs.bz = std::min(e->cfg_bx > 0 ? e->cfg_bz : kShapes[s][2], (int)nz);
+        gs.nbx = (nx + gs.bx - 1) / gs.bx;
+        gs.nby = (ny + gs.by - 1) / gs.by;
+        gs.nbz = (nz + gs.bz - 1) / gs.bz;
+        const int64_t nbricks = (int64_t)gs.nbx * gs.nby * gs.nbz;
+        if (nbricks >= INT32_MAX) return fail("too many bricks");
+        gs.nbricks = (int)nbricks;
+        gs.brick_nodes = gs.bx * gs.by * gs.bz;
+        gs.n_rows = n_rows;
+        gs.row_pad = (n_rows + 7) / 8 * 8;
+        const size_t br = (size_t)nbricks * n_rows;
+        if (e->d_bmeta.ensure(4 * br) || e->d_btotal.ensure(nbricks)) return 1;
+        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
+        hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(gs.nbricks), dim3(64), 0, e->stream, gs,
+                           e->d_lut.p, reinterpret_cast<int4 *>(e->d_bmeta.p), e->d_scalar.p);
+        QM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(qm::brick_prefix_kernel, dim3((gs.nbricks + 255) / 256), dim3(256),
+                           0, e->stream, gs, reinterpret_cast<int4 *>(e->d_bmeta.p),
+                           e->d_btotal.p);
+        QM_HIP(hipGetLastError());
+        totals[s].resize(nbricks);
+        QM_HIP(hipMemcpyAsync(totals[s].data(), e->d_btotal.p, nbricks * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, e->stream));
+        QM_HIP(hipMemcpyAsync(&e->lut_max, e->d_scalar.p, sizeof(int32_t),
+                              hipMemcpyDeviceToHost, e->stream));
+        QM_HIP(hipStreamSynchronize(e->stream));
+        on_device = s;
+        return 0;
+    };
+    // largest candidate shape whose windows fit for tile length 64 * J under the current budget
+    // (result: g and e->h_btotal; `chosen` = its index)
+    int chosen = 0;
     auto search = [&](int J) -> int {
         const int KT = qm::kWave * J;
         for (int s = 0; s < n_shapes; ++s) {
-            g = qm::GridDesc{};
-            g.nx = nx; g.ny = ny; g.nz = nz;
-            g.bx = std::min(e->cfg_bx > 0 ? e->cfg_bx : kShapes[s][0], (int)nx);
-            g.by = std::min(e->cfg_bx > 0 ? e->cfg_by : kShapes[s][1], (int)ny);
-            g.bz = std::min(e->cfg_bx > 0 ? e->cfg_bz : kShapes[s][2], (int)nz);
-            g.nbx = (nx + g.bx - 1) / g.bx;
-            g.nby = (ny + g.by - 1) / g.by;
-            g.nbz = (nz + g.bz - 1) / g.bz;
-            const int64_t nbricks = (int64_t)g.nbx * g.nby * g.nbz;
-            if (nbricks >= INT32_MAX) return fail("too many bricks");
-            g.nbricks = (int)nbricks;
-            g.brick_nodes = g.bx * g.by * g.bz;
-            g.n_rows = n_rows;
-            g.row_pad = (n_rows + 7) / 8 * 8;
-            const size_t br = (size_t)nbricks * n_rows;
-            if (e->d_bmeta.ensure(4 * br) || e->d_btotal.ensure(nbricks)) return 1;
-            QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
-            hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
-                               e->d_lut.p, reinterpret_cast<int4 *>(e->d_bmeta.p), e->d_scalar.p);
-            QM_HIP(hipGetLastError());
-            hipLaunchKernelGGL(qm::brick_prefix_kernel, dim3((g.nbricks + 255) / 256), dim3(256),
-                               0, e->stream, g, reinterpret_cast<int4 *>(e->d_bmeta.p),
-                               e->d_btotal.p);
-            QM_HIP(hipGetLastError());
-            e->h_btotal.resize(nbricks);
-            QM_HIP(hipMemcpyAsync(e->h_btotal.data(), e->d_btotal.p, nbricks * sizeof(int32_t),
-                                  hipMemcpyDeviceToHost, e->stream));
-            QM_HIP(hipMemcpyAsync(&e->lut_max, e->d_scalar.p, sizeof(int32_t),
-                                  hipMemcpyDeviceToHost, e->stream));
-            QM_HIP(hipStreamSynchronize(e->stream));
+            if (totals[s].empty() && measure(s)) return 1;
+            chosen = s;
             int64_t wide = 0;
-            for (int64_t b = 0; b < nbricks; ++b)
-                if (!qm::brick_fits(e->h_btotal[b], n_rows, KT, lds_cap_doubles(e))) ++wide;
-            if (wide * 200 <= nbricks) break;          // <= 0.5 % of the bricks on the slow path
+            for (int32_t t : totals[s])
+                if (!qm::brick_fits(t, n_rows, KT, lds_cap_doubles(e))) ++wide;
+            if (wide * 200 <= (int64_t)totals[s].size()) break;   // <= 0.5 % of the bricks on the slow path
         }
+        g = shapes[chosen];
         return 0;
     };
     if (e->cfg_j == 0 && e->cfg_bx == 0 && !e->user_waves && !e->user_lds) {
@@ -1675,6 +1695,9 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
         e->cfg_lds_bytes = big ? 160 * 1024 : 80 * 1024;
     }
     if (search(eff_j(e))) return 1;
+    if (on_device != chosen && measure(chosen)) return 1;   // the chosen shape's records on the device
+    g = shapes[chosen];
+    e->h_btotal = totals[chosen];
     if (e->d_rel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;
     hipLaunchKernelGGL(qm::brick_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
                        e->d_lut.p, reinterpret_cast<const int4 *>(e->d_bmeta.p), e->d_btotal.p,

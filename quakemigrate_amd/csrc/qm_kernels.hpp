@@ -425,8 +425,13 @@ __global__ __launch_bounds__(256) void serve_table_kernel(ServeArgs a) {
     for (int s = wave; s < a.S; s += 4) {
         int32_t v = 0;
         if (n < n_out) {
-            const double t = a.grids[(int64_t)a.rows[s] * n_full + src] * a.rate;
-            v = (int32_t)__builtin_rint(t);
+            // np.rint(tt * sr).astype(np.int32), lut.py:538.  What the cast gives outside int32 is
+            // the host's: on x86-64 (cvttsd2si) NaN, the infinities and everything beyond
+            // [-2^31, 2^31) become INT32_MIN -- a negative delay, which migrate clamps to 0
+            // (migratelib.c:55).  The GPU's own conversion would saturate (NaN -> 0, +huge ->
+            // INT32_MAX): reproduce the host (fixture serve_nonfinite.npz, from the reference's class).
+            const double r = __builtin_rint(a.grids[(int64_t)a.rows[s] * n_full + src] * a.rate);
+            v = (r >= -2147483648.0 && r <= 2147483647.0) ? (int32_t)r : INT32_MIN;
         }
         tile[lane * (a.S + 1) + s] = v;
     }

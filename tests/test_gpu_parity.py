@@ -905,6 +905,16 @@ def test_on_device_table_serving_matches_reference_lut_class(lib, oracle):
     assert np.array_equal(eng.download_lut(), g["served_dec_250"])
     # half-to-even: 2.5 samples -> 2 (the fixture plants tt = 2.5/50 s in every grid)
     assert (g["served_50"] == 2).any()
+    # NaN, infinities, travel times beyond int32 at the sampling rate, negative values: what the
+    # reference's `np.rint(tt * sr).astype(np.int32)` gave for them on the host that recorded the
+    # fixture (lut.py:538: INT32_MIN for everything the cast cannot represent), bit for bit
+    nf = load_golden("serve_nonfinite")
+    eng.set_traveltime_grids(list(nf["grids"]))
+    eng.serve(50, [0, 1, 2])
+    got = eng.download_lut()
+    assert (nf["served_50"] == np.iinfo(np.int32).min).sum() >= 30 and np.isnan(nf["grids"]).sum() == 3
+    assert np.array_equal(got, nf["served_50"])
+    eng.set_traveltime_grids(list(g["grids"]))
 
     # MigrationScan with device serving == with the host-served table
     keys = [str(k) for k in g["keys"]]

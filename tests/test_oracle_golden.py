@@ -145,6 +145,13 @@ def test_table_serving_restatement_matches_reference_lut_class(oracle):
     dec = [oracle.np_decimate(p, g["decimate"]) for p in picked]
     assert dec[0].shape == tuple(int(v) for v in g["dec_node_count"])
     assert np.array_equal(oracle.np_serve_traveltimes(dec, 250), g["served_dec_250"])
+    # NaN / infinities / beyond-int32 travel times: the recorded cast results of the reference's
+    # class (INT32_MIN for what int32 cannot hold; x86-64 semantics, the fixture names its machine)
+    nf = load_golden("serve_nonfinite")
+    if str(nf["machine"]) == __import__("platform").machine():
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(oracle.np_serve_traveltimes(list(nf["grids"]), 50), nf["served_50"])
+    assert (nf["served_50"][np.isnan(nf["grids"]).transpose(1, 2, 3, 0)] == np.iinfo(np.int32).min).all()
 
 
 def _onset_stage_inputs(g, tf):
