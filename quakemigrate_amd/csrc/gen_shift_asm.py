@@ -69,6 +69,8 @@ PLANE8 = 81856           # ... for the 8-wave workgroup that owns a CU's whole L
                          # address register ("far plane")
 STATE_CHUNK = 1024       # running state in LDS: 5 chunks of 64 lanes x 16 bytes per wavefront
 VB_BLOCK = 80            # first hard VGPR of the row-block flavour
+BUTTERFLY = os.environ.get("QM_SHIFT_BUTTERFLY", "1") == "1"   # marginal map: the eight nodes of a whole group
+                                                              # summed over the wavefront together
 MARGINAL_DEGREE = 8      # 2^f of the marginalised map's terms: the polynomial of the running sums (7.8e-13), every
                          # term positive -- the map inherits at most that (tests: 1e-12)
 
@@ -318,7 +320,7 @@ def node_tail(e, g, A, opens_group):
             e(f"v_max_f64 {v2(GMAX + 2 * k)}, {v2(GMAX + 2 * k)}, {v2(A[k])}")
 
 
-def epilogue_node(e, degree, volume, g, opens_group):
+def epilogue_node(e, degree, volume, g, opens_group, defer=False):
     """LAZY flavour: only the group's maximum is kept per node (v_max_f64); WHICH node holds it is
     recovered after the eight nodes, per sample slot, and only where the group's maximum reaches
     the wavefront's running one (epilogue) -- one instead of three instructions per node-sample
@@ -359,7 +361,18 @@ def epilogue_node(e, degree, volume, g, opens_group):
     for k in range(SPL):
         dst = SUMR[k] if (LDS_STATE and opens_group) else v2(P + 2 * k)   # the group's sum starts here
         e(f"v_ldexp_f64 {dst}, {v2(P + 2 * k)}, v{TT + 2 * k}")
+    if volume and MARGINAL and defer:
+        # whole groups: the lane's share m_g = sum_k w_k * 2^z_k of node g goes into the node's first
+        # accumulator pair (dead once its z has been compared); the eight are summed over the
+        # wavefront together after the last node (marginal_butterfly)
+        node_tail(e, g, A, opens_group)
+        dst = v2(ACC + 8 * g)
+        e(f"v_mul_f64 {dst if SPL == 1 else v2(F)}, {v2(P)}, %[w0]")
+        for k in range(1, SPL):
+            e(f"v_fma_f64 {dst if k == SPL - 1 else v2(F)}, {v2(P + 2 * k)}, %[w{k}], {v2(F)}")
+        return
     if volume and MARGINAL:
+        # (groups cut by the grid's edge: node by node)
         # the marginalised map: m = sum_k w_k * 2^z_k over the lane's samples (w = 1.0 inside the
         # window and the tile's own samples, 0.0 elsewhere: products and the first sum are exact),
         # summed over the wavefront with DPP moves in the order of an xor butterfly (as
@@ -442,6 +455,65 @@ def epilogue_node(e, degree, volume, g, opens_group):
     node_tail(e, g, A, opens_group)
 
 
+def marginal_butterfly(e):
+    """Wavefront sums of the eight nodes' shares M_g = v[ACC + 8 g : +1] at once: three exchange levels
+    in which a lane keeps half of its values and hands the other half to its partner (row_half_mirror,
+    then the two quad permutations; the partner keeps the complementary half), so that 8 -> 4 -> 2 -> 1
+    values per lane remain, each the sum over 2 -> 4 -> 8 lanes; then the eight-lane sums are added
+    across the wavefront (row_ror:8, two ds_bpermute for the rows 16 and 32 lanes away).  Lane l ends
+    with the total of node 4 b2 + 2 b0 + b1 of its lane index; lanes 0..7 store.  49 + 5 VALU
+    instructions per group instead of 8 x 18 for eight separate sums.  Temporaries: F, P, TT (dead
+    after the last node)."""
+    def pair_sel(dst, mask, a_if0, a_if1):              # dst = mask ? a_if1 : a_if0 (64-bit)
+        for h in range(2):
+            e(f"v_cndmask_b32 v{dst + h}, v{a_if0 + h}, v{a_if1 + h}, {mask}")
+
+    def pair_dpp(dst, src, ctrl):
+        for h in range(2):
+            e(f"v_mov_b32_dpp v{dst + h}, v{src + h} {ctrl} row_mask:0xf bank_mask:0xf")
+
+    Mg = [ACC + 8 * g for g in range(8)]
+    # level 1: partner 7 - i within 8 lanes; lanes with bit 2 keep nodes 4..7
+    for j in range(4):
+        pair_sel(P + 2 * j, "%[mb2]", Mg[4 + j], Mg[j])            # send: b2 ? M_j : M_{4+j}
+    for j in range(4):
+        pair_sel(F + 2 * j, "%[mb2]", Mg[j], Mg[4 + j])            # keep: b2 ? M_{4+j} : M_j
+    for j in range(4):
+        pair_dpp(TT + 2 * j, P + 2 * j, "row_half_mirror")
+    for j in range(4):
+        e(f"v_add_f64 {v2(F + 2 * j)}, {v2(F + 2 * j)}, {v2(TT + 2 * j)}")     # X_j
+    # level 2: partner i ^ 1; lanes with bit 0 keep X_2, X_3
+    for j in range(2):
+        pair_sel(P + 2 * j, "%[mb0]", F + 4 + 2 * j, F + 2 * j)    # send: b0 ? X_j : X_{2+j}
+    for j in range(2):
+        pair_sel(P + 4 + 2 * j, "%[mb0]", F + 2 * j, F + 4 + 2 * j)   # keep: b0 ? X_{2+j} : X_j
+    for j in range(2):
+        pair_dpp(TT + 2 * j, P + 2 * j, "quad_perm:[1,0,3,2]")
+    for j in range(2):
+        e(f"v_add_f64 {v2(P + 2 * j)}, {v2(P + 4 + 2 * j)}, {v2(TT + 2 * j)}")  # Y_j
+    # level 3: partner i ^ 2; lanes with bit 1 keep Y_1
+    pair_sel(F + 2, "%[mb1]", P + 2, P)                             # send: b1 ? Y_0 : Y_1
+    pair_sel(F, "%[mb1]", P, P + 2)                                 # keep: b1 ? Y_1 : Y_0
+    pair_dpp(TT, F + 2, "quad_perm:[2,3,0,1]")
+    e(f"v_add_f64 {v2(F)}, {v2(F)}, {v2(TT)}")                       # the node's sum over 8 lanes
+    # across the wavefront: the other 8 lanes of the row, then the rows 16 and 32 lanes away
+    e("s_nop 1")
+    pair_dpp(TT, F, "row_ror:8")
+    e(f"v_add_f64 {v2(F)}, {v2(F)}, {v2(TT)}")
+    for addr in ("%[x16]", "%[x32]"):
+        e(f"ds_bpermute_b32 v{TT}, {addr}, v{F}")
+        e(f"ds_bpermute_b32 v{TT + 1}, {addr}, v{F + 1}")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"v_add_f64 {v2(F)}, {v2(F)}, {v2(TT)}")
+    e(f"s_lshl_b32 s{SVA}, s{SBASE}, 3")                   # the group's first node: byte offset
+    e(f"s_lshr_b32 s{SVA + 1}, s{SBASE}, 29")
+    e(f"s_add_u32 s{SVA}, s{SVA}, %[vlo]")
+    e(f"s_addc_u32 s{SVA + 1}, s{SVA + 1}, %[vhi]")
+    e("s_mov_b64 exec, 0xff")                              # lanes 0..7: one node each
+    e(f"global_store_dwordx2 %[mvoff], {v2(F)}, {s2(SVA)}")
+    e("s_mov_b64 exec, -1")
+
+
 def epilogue(e, degree, volume):
     e("s_set_gpr_idx_off")
     # Group-level running maximum (nodes of a group are visited in ascending flat index: strict >).
@@ -457,8 +529,12 @@ def epilogue(e, degree, volume):
     e(f"s_cbranch_scc1 {partial}")
     if not LAZY:
         e(f"v_mov_b32 v{KI}, 0x7fffffff")                      # "no index" (a literal and vcc cannot
+    butterfly = volume and MARGINAL and BUTTERFLY
     for g in range(8):                                         # feed one instruction)
-        epilogue_node(e, degree, volume, g, g == 0 if not LAZY else (True if g == 0 else None if g == 1 else False))
+        epilogue_node(e, degree, volume, g, g == 0 if not LAZY else (True if g == 0 else None if g == 1 else False),
+                      defer=butterfly)
+    if butterfly:
+        marginal_butterfly(e)
     e(f"s_branch {merge}")
     e(f"{partial}:")
     for k in range(SPL):
@@ -657,7 +733,8 @@ def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False,
           + ("unsigned state_addr, " if lds_state else "")
           + ("unsigned lane_addr_b, " if far else "") + "int nz, "
           f"int nynz, double scale, const double (&c)[{degree + 1}]"
-          + (f", double *marg_tile, const double (&w)[{spl}]" if marginal else
+          + (f", double *marg_tile, const double (&w)[{spl}], unsigned node_off, unsigned lane_x16, "
+             f"unsigned lane_x32" if marginal else
              f", double *vol_tile, unsigned vol_stride_bytes, unsigned lane_bytes, "
              f"const unsigned long long (&store_lanes)[{spl}]" if ragged else
              ", double *vol_tile, unsigned vol_stride_bytes, unsigned lane_bytes, "
@@ -694,6 +771,10 @@ def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False,
     if marginal:
         ins += ['[vlo] "s"(vlo)', '[vhi] "s"(vhi)']
         ins += [f'[w{k}] "v"(w[{k}])' for k in range(spl)]
+        if BUTTERFLY:
+            ins += ['[mb0] "s"(0xaaaaaaaaaaaaaaaaull)', '[mb1] "s"(0xccccccccccccccccull)',
+                    '[mb2] "s"(0xf0f0f0f0f0f0f0f0ull)', '[mvoff] "v"(node_off)', '[x16] "v"(lane_x16)',
+                    '[x32] "v"(lane_x32)']
     elif ragged:
         ins += ['[vlo] "s"(vlo)', '[vhi] "s"(vhi)', '[vstride] "s"(vol_stride_bytes)',
                 '[voff] "v"(lane_bytes)']

@@ -89,6 +89,7 @@ struct TableState {
     int tab_waves = 0, tab_lds_bytes = 0;   // workgroup shape the layout search picked (0: none yet)
     DevBuf<int32_t> d_lut, d_bmeta, d_btotal, d_wide;
     DevBuf<uint16_t> d_rel;
+    bool rel_built = false;         // d_rel holds this table's offsets (built on first use)
     std::vector<int32_t> h_btotal;
     int n_wide = 0;
     int plan_j = -1, plan_cap = -1;
@@ -233,6 +234,19 @@ struct DeviceGuard {
 };
 
 int lds_cap_doubles(const qm_engine *e) { return e->cfg_lds_bytes / 8; }
+
+// 16-bit window offsets of the round-2 stacking kernels (brick_rel_kernel), on first use per table
+int ensure_rel(qm_engine *e) {
+    if (e->rel_built) return 0;
+    const qm::GridDesc &g = e->g;
+    if (e->d_rel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;
+    hipLaunchKernelGGL(qm::brick_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
+                       e->d_lut.p, reinterpret_cast<const int4 *>(e->d_bmeta.p), e->d_btotal.p,
+                       e->d_rel.p);
+    QM_HIP(hipGetLastError());
+    e->rel_built = true;
+    return 0;
+}
 
 // Samples per lane: explicit, the table's layout search's choice (load_lut), or the largest J
 // whose S row windows leave >= 20 % of the LDS budget for the delay spans (J = 4 up to 64 rows:
@@ -662,8 +676,10 @@ bool shift_wanted(const qm_engine *e, int n_chunk, bool plain, bool volume, int6
     if (!plain || e->cfg_shift == 0 || e->cfg_generic || e->cfg_force_direct ||
         e->user_waves || e->user_lds || e->cfg_j > 0 || e->cfg_pair == 2)
         return false;
-    // volume-writing launches: the row stride goes into a 32-bit byte count
+    // volume-writing launches: the row stride goes into a 32-bit byte count (as do, for the marginal
+    // map, the offsets of a group's nodes: an x-plane of fewer than 2^29 nodes)
     if (volume && vol_stride * 8 >= ((int64_t)1 << 32)) return false;
+    if ((int64_t)e->g.ny * e->g.nz * 8 >= ((int64_t)1 << 32)) return false;
     return n_chunk >= 1;
 }
 
@@ -844,6 +860,10 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     }
     const int steps = a.n_steps > 1 ? a.n_steps : 1;
     a.part_stride = (int64_t)steps * n_chunk;
+    if (!shift && jp == 0) {                            // the round-2 kernels' own offsets
+        if (ensure_rel(e)) return 1;
+        a.rel = e->d_rel.p;
+    }
     if (marginal) {
         if (e->d_marg.ensure((size_t)a.ntiles * e->n_nodes)) return 1;
         a.marginal = e->d_marg.p;
@@ -1698,11 +1718,10 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     if (on_device != chosen && measure(chosen)) return 1;   // the chosen shape's records on the device
     g = shapes[chosen];
     e->h_btotal = totals[chosen];
-    if (e->d_rel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;
-    hipLaunchKernelGGL(qm::brick_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
-                       e->d_lut.p, reinterpret_cast<const int4 *>(e->d_bmeta.p), e->d_btotal.p,
-                       e->d_rel.p);
-    QM_HIP(hipGetLastError());
+    // (the window-offset table of the round-2 kernels -- 2 bytes per table entry padded to 8 rows --
+    // is built when one of them first runs: ensure_rel; tables the shift-reuse kernel takes never
+    // need it)
+    e->rel_built = false;
     QM_HIP(hipStreamSynchronize(e->stream));
     e->g = g;
     e->n_nodes = n_nodes;
@@ -1825,10 +1844,18 @@ int qm_engine_serve(qm_engine *e, double sampling_rate, const int32_t *rows, int
     a.grids = e->d_grids.p;
     a.rows = e->d_rows.p;
     a.out = e->d_served.p;
-    const size_t lds = (size_t)64 * (n_rows + 1) * sizeof(int32_t);
+    // 256 nodes per workgroup while their rows fit 64 KB of LDS (up to 63 rows), else 64
+    const int pitch = (n_rows + 1) | 1;
+    const bool wide = (size_t)256 * pitch * sizeof(int32_t) <= 64 * 1024;
+    const int npb = wide ? 256 : 64;
+    const size_t lds = (size_t)npb * pitch * sizeof(int32_t);
     if (lds > 64 * 1024) return fail("too many rows (%d) for the serving kernel", n_rows);
-    hipLaunchKernelGGL(qm::serve_table_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(256), lds,
-                       e->stream, a);
+    if (wide)
+        hipLaunchKernelGGL(qm::serve_table_kernel<256>, dim3((unsigned)((n_out + 255) / 256)), dim3(256),
+                           lds, e->stream, a);
+    else
+        hipLaunchKernelGGL(qm::serve_table_kernel<64>, dim3((unsigned)((n_out + 63) / 64)), dim3(256), lds,
+                           e->stream, a);
     QM_HIP(hipGetLastError());
     return qm_engine_load_lut(e, e->d_served.p, 1, a.nx, a.ny, a.nz, n_rows, node_offset);
 }

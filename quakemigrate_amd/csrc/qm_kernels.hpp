@@ -409,37 +409,50 @@ struct ServeArgs {
 };
 
 #ifdef QM_ENGINE_TU
+// NPB nodes x all rows per workgroup of 256 threads: thread t reads the grids of node t, t + 256, ...
+// of the workgroup row by row (coalesced along the nodes, eight loads in flight), the rounded
+// delays are transposed through LDS, and the workgroup's NPB x S block of the table -- contiguous
+// in memory -- is written coalesced.  One pass: 8 bytes read and 4 written per table entry.
+template <int NPB>
 __global__ __launch_bounds__(256) void serve_table_kernel(ServeArgs a) {
-    extern __shared__ int32_t tile[];                   // [64][S + 1]
+    extern __shared__ int32_t tile[];                   // [NPB][pitch]
     const int64_t n_out = (int64_t)a.nx * a.ny * a.nz;
     const int64_t n_full = (int64_t)a.nxf * a.nyf * a.nzf;
-    const int64_t n0 = (int64_t)blockIdx.x * 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t n = n0 + lane;
-    int64_t src = 0;
-    if (n < n_out) {
+    const int64_t n0 = (int64_t)blockIdx.x * NPB;
+    const int S = a.S, pitch = (S + 1) | 1;            // (odd: the row-wise stores spread over the banks)
+    for (int m = threadIdx.x; m < NPB; m += blockDim.x) {
+        const int64_t n = n0 + m;
+        if (n >= n_out) break;
         const int iz = (int)(n % a.nz), iy = (int)((n / a.nz) % a.ny), ix = (int)(n / ((int64_t)a.nz * a.ny));
-        src = ((int64_t)(a.c1x + ix * a.dfx) * a.nyf + (a.c1y + iy * a.dfy)) * a.nzf +
-              (a.c1z + iz * a.dfz);
-    }
-    for (int s = wave; s < a.S; s += 4) {
-        int32_t v = 0;
-        if (n < n_out) {
-            // np.rint(tt * sr).astype(np.int32), lut.py:538.  What the cast gives outside int32 is
-            // the host's: on x86-64 (cvttsd2si) NaN, the infinities and everything beyond
-            // [-2^31, 2^31) become INT32_MIN -- a negative delay, which migrate clamps to 0
-            // (migratelib.c:55).  The GPU's own conversion would saturate (NaN -> 0, +huge ->
-            // INT32_MAX): reproduce the host (fixture serve_nonfinite.npz, from the reference's class).
-            const double r = __builtin_rint(a.grids[(int64_t)a.rows[s] * n_full + src] * a.rate);
-            v = (r >= -2147483648.0 && r <= 2147483647.0) ? (int32_t)r : INT32_MIN;
+        const int64_t src = ((int64_t)(a.c1x + ix * a.dfx) * a.nyf + (a.c1y + iy * a.dfy)) * a.nzf +
+                            (a.c1z + iz * a.dfz);
+        constexpr int U = 8;
+        for (int s0 = 0; s0 < S; s0 += U) {
+            double t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = s0 + u < S ? s0 + u : S - 1;
+                t[u] = __builtin_nontemporal_load(a.grids + (int64_t)a.rows[s] * n_full + src);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (s0 + u >= S) break;
+                // np.rint(tt * sr).astype(np.int32), lut.py:538.  What the cast gives outside int32
+                // is the host's: on x86-64 (cvttsd2si) NaN, the infinities and everything beyond
+                // [-2^31, 2^31) become INT32_MIN -- a negative delay, which migrate clamps to 0
+                // (migratelib.c:55).  The GPU's own conversion would saturate (NaN -> 0, +huge ->
+                // INT32_MAX): reproduce the host (fixture serve_nonfinite.npz, from the reference's
+                // own class).
+                const double r = __builtin_rint(t[u] * a.rate);
+                tile[m * pitch + s0 + u] = (r >= -2147483648.0 && r <= 2147483647.0) ? (int32_t)r : INT32_MIN;
+            }
         }
-        tile[lane * (a.S + 1) + s] = v;
     }
     __syncthreads();
-    const int64_t count = (n_out - n0 < 64 ? n_out - n0 : 64) * a.S;
+    const int64_t count = (n_out - n0 < NPB ? n_out - n0 : NPB) * S;
     for (int64_t i = threadIdx.x; i < count; i += blockDim.x) {
-        const int node = (int)(i / a.S), s = (int)(i % a.S);
-        a.out[n0 * a.S + i] = tile[node * (a.S + 1) + s];
+        const int node = (int)(i / S), s = (int)(i % S);
+        a.out[n0 * S + i] = tile[node * pitch + s];
     }
 }
 #endif  // QM_ENGINE_TU

@@ -435,7 +435,15 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
         slot_lanes[k] = __builtin_amdgcn_ballot_w64(t < a.n_chunk);
         weight[k] = (t >= tile * kShiftKT && t >= a.m0 && t < a.m1 && t < a.n_chunk) ? 1.0 : 0.0;
     }
-    (void)store_lanes; (void)slot_lanes; (void)weight;
+    // marginal map, whole groups: the eight nodes' shares are summed over the wavefront together
+    // (gen_shift_asm.py, marginal_butterfly); lane l ends with the total of node 4 b2 + 2 b0 + b1 of
+    // its index -- its element's byte offset from the group's first node -- and fetches from the
+    // lanes 16 and 32 away on the way
+    const int lane_node = 4 * ((lane >> 2) & 1) + 2 * (lane & 1) + ((lane >> 1) & 1);
+    const unsigned node_off = 8u * (unsigned)((lane_node & 4 ? g.ny * g.nz : 0) + (lane_node & 2 ? g.nz : 0) +
+                                             (lane_node & 1));
+    const unsigned lane_x16 = 4u * (unsigned)(lane ^ 16), lane_x32 = 4u * (unsigned)(lane ^ 32);
+    (void)store_lanes; (void)slot_lanes; (void)weight; (void)node_off; (void)lane_x16; (void)lane_x32;
 
     double vmax[J], vsum[J];
     int vidx[J];
@@ -492,7 +500,7 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
 #define QM_TAIL_CALL(JJ)                                                                              \
         if constexpr (MODE == kShiftMarginal)                                                         \
             shift_tail##JJ##_marginal(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz,       \
-                                      a.z_scale, c, marg_tile, weight);                               \
+                                      a.z_scale, c, marg_tile, weight, node_off, lane_x16, lane_x32); \
         else if constexpr (MODE == kShiftVolume)                                                      \
             shift_tail##JJ##_volume(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz,         \
                                     a.z_scale, c, vol_tile, vol_stride_bytes, (unsigned)lane * (8u * JJ), \
@@ -508,10 +516,10 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
             shift_groups_detect3(run, mine, npairs, lane_addr, state_addr, nz, nynz, a.z_scale, c);
         else if constexpr (NW == kShiftWaves8 && MODE == kShiftMarginal)
             shift_groups_marginal8(vmax, vsum, vidx, run, mine, npairs, lane_addr, lane_addr_b, nz, nynz,
-                                   a.z_scale, c, marg_tile, weight);
+                                   a.z_scale, c, marg_tile, weight, node_off, lane_x16, lane_x32);
         else if constexpr (MODE == kShiftMarginal)
             shift_groups_marginal(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz, a.z_scale, c,
-                                  marg_tile, weight);
+                                  marg_tile, weight, node_off, lane_x16, lane_x32);
         else if constexpr (NW == kShiftWaves8 && MODE == kShiftVolume)
             shift_groups_volume8(vmax, vsum, vidx, run, mine, npairs, lane_addr, lane_addr_b, nz, nynz,
                                  a.z_scale, c, vol_tile, vol_stride_bytes, (unsigned)lane * 32u, store_lanes);
