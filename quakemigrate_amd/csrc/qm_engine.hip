@@ -168,6 +168,7 @@ struct qm_engine : TableState {
     bool user_waves = false, user_lds = false;   // set explicitly: no automatic layout
     int cfg_groups = 0;
     int cfg_rounds = 12;            // automatic group count: grid = this many rounds over the slots
+    bool user_rounds = false;       // ... set explicitly
     int cfg_lds_bytes = 80 * 1024;
     int cfg_force_direct = 0;
     int cfg_generic = 0;            // 1 = always the generic (any row count) LDS kernel
@@ -745,14 +746,14 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
     return 0;
 }
 
-int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu) {
+int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu, int rounds = 0) {
     // Workgroups all do the same amount of work, so the grid should be a whole number of
     // "rounds" over the resident slots (n_cu * blocks_per_cu): ntiles * groups <= rounds * slots,
     // as close from below as possible.  12 rounds measured best on C2/C3 (finer load balance
     // than 4; flat beyond); the partial sets stay a few tens of MB.  Never more groups than
     // there are bricks.
     const int64_t slots = (int64_t)e->n_cu * blocks_per_cu;
-    int64_t want = ((int64_t)e->cfg_rounds * slots) / ntiles;
+    int64_t want = ((int64_t)(rounds > 0 ? rounds : e->cfg_rounds) * slots) / ntiles;
     if (want < 1) want = std::max<int64_t>(1, slots / ntiles);
     want = std::max<int64_t>(1, std::min<int64_t>(want, units));
     // Group g runs on XCD g % 8 (the XCD-aware workgroup map of the stacking kernels), so a
@@ -878,12 +879,17 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         shift ? (e->shift_nw == qm::kShiftWaves ? 2 : 1) : jp > 0 ? 1
                : std::max(1, std::min(160 * 1024 / std::max(1, e->cfg_lds_bytes), 2048 / threads));
     int groups_lds = 0, groups_direct = 0;
-    if (use_lds)
+    if (use_lds) {
         // (several timesteps per launch: the group count is the single step's -- the groups are the
         // order in which a sample's coalescence is summed over the nodes, and a step's result must
         // not depend on how many steps share its launch; the extra steps only make the grid longer)
+        // (bricks of <= 64 nodes -- coarse grids with wide tables, 4 nodes per wavefront and brick: a
+        // workgroup's fixed costs weigh more than the grid's tail, three rounds instead of twelve:
+        // E2 0.418 -> 0.394 ms, profiles/r04_rounds_sweep.txt)
+        const int rounds = (!shift && jp == 0 && !e->user_rounds && e->g.brick_nodes <= 64) ? 3 : 0;
         groups_lds = e->cfg_groups > 0 ? std::min(e->cfg_groups, nbricks_now)
-                                       : auto_groups(e, a.ntiles, nbricks_now, lds_blocks_per_cu);
+                                       : auto_groups(e, a.ntiles, nbricks_now, lds_blocks_per_cu, rounds);
+    }
     if (use_direct) {
         const int units = e->cfg_force_direct ? nbricks_now : n_wide_now;
         groups_direct = e->cfg_groups > 0 ? std::min(e->cfg_groups, units)
@@ -1458,6 +1464,7 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
     } else if (k == "rounds") {
         if (v < 1 || v > 1024) return fail("rounds must be in 1..1024");
         e->cfg_rounds = (int)v;
+        e->user_rounds = true;
     } else if (k == "lds_bytes") {
         if (v < 1024 || v > 160 * 1024) return fail("lds_bytes must be in 1 KiB..160 KiB");
         e->cfg_lds_bytes = (int)(v / 16 * 16);
