@@ -21,7 +21,9 @@ import sys
 
 ROW_BLOCK_KERNELS = ("_ZN2qm23stack_shift_rows_kernelILi8EEEvNS_9ShiftArgsE",
                      "_ZN2qm24stack_shift_rows2_kernelILb0ELi8EEEvNS_9ShiftArgsE",
-                     "_ZN2qm24stack_shift_rows2_kernelILb1ELi8EEEvNS_9ShiftArgsE")
+                     "_ZN2qm24stack_shift_rows2_kernelILb1ELi8EEEvNS_9ShiftArgsE",
+                     "_ZN2qm24stack_shift_rows4_kernelILb0EEEvNS_9ShiftArgsE",
+                     "_ZN2qm24stack_shift_rows4_kernelILb1EEEvNS_9ShiftArgsE")
 
 
 def first_hard_register(inc_text):

@@ -118,6 +118,7 @@ struct TableState {
     int n_shwide = 0, shift_rows2 = 0;
     int shift_nblk = 1, shift_sb = 0;       // row blocks (tables of more than 64 rows): blocks, rows per block
     bool shift_direct = false;              // ... staged by LDS-direct loads (stack_shift_rows2_kernel)
+    bool shift_quad = false;                // ... by two 4-wave workgroups per CU (stack_shift_rows4_kernel)
     bool shift_built = false, shift_ok = false;
     int64_t shift_quads = 0, shift_group_rows = 0;   // register-window quads fetched / (group, row)s
 
@@ -553,12 +554,18 @@ int build_shift_tables(qm_engine *e) {
     // a double-buffered LDS (default), or blocks of <= 64 staged through registers between two barriers
     // (that one only from 97 rows on: at 65-96 two blocks of <= 48 rows stage as often as they
     // compute and the chunked kernel with its 8x8x8 bricks is 4-5 % faster, profiles/r03_ab_runs.txt)
-    const bool direct = e->cfg_shift_rows_direct != 0;
+    // (round 4, form 2: the LDS-direct staging with TWO 4-wave workgroups per CU on bricks of 4x4x2
+    // nodes, single-buffered -- stack_shift_rows4_kernel)
+    const int form = e->cfg_shift_rows_direct;          // 0 registers, 1 double-buffered 8 waves, 2 two x 4 waves
+    const bool direct = form != 0;
+    const bool quad = form == 2;
     if (blocks && !direct && S <= 96 && e->cfg_shift != 1) return 0;
     const int block_rows = direct ? 34 : qm::kShiftMaxRows;
     const int nblk = blocks ? (S + block_rows - 1) / block_rows : 1;
     const int sb = blocks ? ((S + nblk - 1) / nblk + 1) / 2 * 2 : S;
-    if (S > 1024 || (blocks && e->cfg_shift_waves != 0 && e->cfg_shift_waves != qm::kShiftWaves8)) return 0;
+    if (S > 1024 || (blocks && e->cfg_shift_waves != 0 &&
+                     e->cfg_shift_waves != (quad ? qm::kShiftWaves : qm::kShiftWaves8)))
+        return 0;
     // a grid one node thick has half-empty 2x2x2 groups everywhere (e.g. the flat 1 x 1 x N view
     // of the reference-signature migrate): leave it to the other kernels unless asked explicitly
     if (e->cfg_shift < 0 && (e->g.nx < 2 || e->g.ny < 2 || e->g.nz < 2)) return 0;
@@ -573,6 +580,9 @@ int build_shift_tables(qm_engine *e) {
     if (e->cfg_shift_waves != 0) {
         candidates[0] = e->cfg_shift_waves;
         n_candidates = 1;
+    } else if (blocks && quad) {
+        candidates[0] = qm::kShiftWaves;
+        n_candidates = 1;
     } else if (S > 40) {                               // (80 KB cannot hold that many row windows)
         candidates[0] = qm::kShiftWaves8;
         n_candidates = 1;
@@ -580,6 +590,7 @@ int build_shift_tables(qm_engine *e) {
     const bool fixed = e->cfg_bx > 0 && !blocks;
     const int n_shapes = fixed || blocks ? 1 : 5;
     static const int kShapesBlocks[][3] = {{4, 4, 4}};
+    static const int kShapesBlocks4[][3] = {{4, 4, 2}};
     int nw = candidates[0];
     qm::GridDesc g = e->g;
     std::vector<int32_t> fit, wide;
@@ -587,7 +598,7 @@ int build_shift_tables(qm_engine *e) {
     auto even_up = [](int v) { return v + (v & 1); };
     for (int cand = 0; cand < n_candidates && !ok; ++cand) {
     nw = candidates[cand];
-    const int (*kShapes)[3] = blocks ? kShapesBlocks : nw == qm::kShiftWaves3 ? kShapes12
+    const int (*kShapes)[3] = blocks ? (quad ? kShapesBlocks4 : kShapesBlocks) : nw == qm::kShiftWaves3 ? kShapes12
                               : nw == qm::kShiftWaves8 ? kShapes8 : kShapes4;
     for (int s = 0; s < n_shapes; ++s) {
         g = e->g;
@@ -665,6 +676,7 @@ int build_shift_tables(qm_engine *e) {
     e->shift_nblk = nblk;
     e->shift_sb = sb;
     e->shift_direct = blocks && direct;
+    e->shift_quad = blocks && quad;
     e->shift_ok = true;
     return 0;
 }
@@ -719,7 +731,9 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, e->shift_nw * qm::kWave,
                                                   qm::shift_lds_bytes(e->shift_nw));
         const bool rows = e->shift_nblk > 1, big = e->shift_nw == qm::kShiftWaves8;
-        if (rows && e->shift_direct && mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_rows2_volume(s, shape));
+        if (rows && e->shift_quad && mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_rows4_volume(s, shape));
+        else if (rows && e->shift_quad) QM_TABLE(qm::launch_shift_rows4(s, shape));
+        else if (rows && e->shift_direct && mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_rows2_volume(s, shape));
         else if (rows && e->shift_direct) QM_TABLE(qm::launch_shift_rows2(s, shape));
         else if (rows) QM_TABLE(qm::launch_shift_rows8(s, shape));
         else if (mode == qm::kShiftMarginal && big) QM_TABLE(qm::launch_shift_marginal8(s, shape));
@@ -1491,7 +1505,8 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
         e->cfg_shift_waves = (int)v;
         e->shift_built = false;
     } else if (k == "shift_rows_direct") {
-        e->cfg_shift_rows_direct = v ? 1 : 0;
+        if (v < 0 || v > 2) return fail("shift_rows_direct must be 0, 1 or 2");
+        e->cfg_shift_rows_direct = (int)v;
         e->shift_built = false;
     } else if (k == "shift_tail") {
         e->cfg_shift_tail = v ? 1 : 0;

@@ -32,6 +32,12 @@ hipError_t launch_shift_rows2(const ShiftArgs &a, const LaunchShape &s) {
 hipError_t launch_shift_rows2_volume(const ShiftArgs &a, const LaunchShape &s) {
     return launch_with_lds(&stack_shift_rows2_kernel<true, kShiftWaves8>, a, s);
 }
+hipError_t launch_shift_rows4(const ShiftArgs &a, const LaunchShape &s) {
+    return launch_with_lds(&stack_shift_rows4_kernel<false>, a, s);
+}
+hipError_t launch_shift_rows4_volume(const ShiftArgs &a, const LaunchShape &s) {
+    return launch_with_lds(&stack_shift_rows4_kernel<true>, a, s);
+}
 hipError_t launch_shift_detect3(const ShiftArgs &a, const LaunchShape &s) {
     return launch_with_lds(&stack_shift_kernel<kShiftDetect, kShiftWaves3>, a, s);
 }

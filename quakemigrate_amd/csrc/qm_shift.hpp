@@ -108,6 +108,8 @@ hipError_t launch_shift_volume8(const ShiftArgs &a, const LaunchShape &s);
 hipError_t launch_shift_rows8(const ShiftArgs &a, const LaunchShape &s);    // row blocks (> 64 rows)
 hipError_t launch_shift_rows2(const ShiftArgs &a, const LaunchShape &s);    // ... double-buffered, LDS-direct
 hipError_t launch_shift_rows2_volume(const ShiftArgs &a, const LaunchShape &s);
+hipError_t launch_shift_rows4(const ShiftArgs &a, const LaunchShape &s);    // ... two 4-wave workgroups per CU
+hipError_t launch_shift_rows4_volume(const ShiftArgs &a, const LaunchShape &s);
 
 // valid 2x2x2 groups of a brick form a box [0,cx) x [0,cy) x [0,cz) in group coordinates
 __device__ __forceinline__ void shift_group_box(const GridDesc &g, int b, int &x0, int &y0, int &z0,
@@ -666,10 +668,10 @@ __device__ __forceinline__ void stage_shift_block_direct(const ShiftArgs &s, dou
     // They come by SCALAR loads (their own counter: a vector load's wait would also wait for the
     // stream prefetches the loop of the block before has left in flight).
     constexpr int R = (34 + NW - 1) / NW;
-    static_assert(R == 5, "five metadata loads per wavefront and block");
     using int4s = int __attribute__((ext_vector_type(4)));
     int4s ms[R];
-    {
+    if constexpr (NW == kShiftWaves8) {
+        static_assert(R == 5, "five metadata loads per wavefront and block");
         const int4 *base = s.smeta + (int64_t)vb * s.sb;
         unsigned off[R];
 #pragma unroll
@@ -682,6 +684,14 @@ __device__ __forceinline__ void stage_shift_block_direct(const ShiftArgs &s, dou
                      : "=&s"(ms[0]), "=&s"(ms[1]), "=&s"(ms[2]), "=&s"(ms[3]), "=&s"(ms[4])
                      : "s"(base), "s"(off[0]), "s"(off[1]), "s"(off[2]), "s"(off[3]), "s"(off[4])
                      : "memory");
+    } else {
+        // (the 4-wave form: nine rows per wavefront; the wave-uniform index makes these scalar loads)
+        const int4s *base = reinterpret_cast<const int4s *>(s.smeta + (int64_t)vb * s.sb);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int r = wave + j * NW;
+            ms[j] = base[__builtin_amdgcn_readfirstlane(r < S ? r : 0)];
+        }
     }
     int4 meta[R];
 #pragma unroll
@@ -801,6 +811,85 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
     }
     if (!a.want_scan) return;
     // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
+    shift_publish<NW>(a, win, vmax, vsum, vidx, wave, lane, group, t_first);
+}
+// Row blocks, third form (round 4): TWO 4-wave workgroups per CU, 80 KB each -- the shape of the
+// tables of up to ~32 rows, for the same reason: the two wavefronts of a SIMD then belong to
+// different workgroups and are in different phases, so one's block boundary (the barrier, the
+// generated loop's lead-in: two records and the first window from L2) is covered by the other's adds.
+// In the 8-wave forms above both wavefronts of every SIMD enter every block together and the
+// lead-in is exposed on all SIMDs at once (PMC: VALU busy 48 %).  A brick is 4x4x2 nodes = one
+// 2x2x2 group per wavefront; a block of <= 34 rows is staged by LDS-direct loads into the
+// workgroup's single buffer between two barriers (no double buffering: the other workgroup is what
+// runs meanwhile).  Same generated loop, same accumulators in its hard registers across the calls,
+// same bits.
+template <bool VOLUME>
+__global__ __attribute__((amdgpu_flat_work_group_size(kShiftWaves * kWave, kShiftWaves * kWave),
+                          amdgpu_waves_per_eu(6, 6)))
+void stack_shift_rows4_kernel(ShiftArgs s) {
+    constexpr int NW = kShiftWaves;
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    const StackArgs &a = s.a;
+    const GridDesc &g = a.g;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const ShiftWork work = shift_work(a);
+    if (!work.run) return;
+    const int tile = work.tile, group = work.group, t_first = work.t_first;
+    const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * 16u;
+    // volume: lanes of a pulled-back tile whose four samples its predecessor stores are masked off
+    const int seam = tile * kShiftKT - t_first;
+    const unsigned long long store_lanes = ~0ull << (seam / 4);
+    (void)store_lanes;
+
+    double vmax[4], vsum[4];
+    int vidx[4];
+    shift_reset(vmax, vsum, vidx);
+    constexpr int D = Exp2Degree<VOLUME>::value;
+    double c[D + 1];
+#pragma unroll
+    for (int i = 0; i <= D; ++i) c[i] = exp2_coeff<D>(i);
+
+    const int rows2max = s.sb + (s.sb & 1);
+    const int64_t rpw = shift_recs_per_wave(g, rows2max, NW);
+    auto rows_of = [&](int k) { return g.n_rows - k * s.sb < s.sb ? g.n_rows - k * s.sb : s.sb; };
+    int b = group;
+    while (b < g.nbricks && !s.sfit[b]) b += a.ngroups;            // (others: the direct kernel's job)
+    while (b < g.nbricks) {
+        int nb = b + a.ngroups;
+        while (nb < g.nbricks && !s.sfit[nb]) nb += a.ngroups;
+        int x0, y0, z0, vx, vy, vz, cx, cy, cz;
+        shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
+        const bool mine = wave < cx * cy * cz;                     // one group per wavefront
+        const char *next_run =
+            s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, s.nblk, rpw) * kShiftRec;
+        for (int k = 0; k < s.nblk; ++k) {
+            // everyone is done with the block in LDS; this block's rows in, by LDS-direct loads
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            stage_shift_block_direct<NW>(s, win, b * s.nblk + k, k * s.sb, rows_of(k), wave, lane, t_first);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (mine) {
+                const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRec;
+                const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
+                    (int)((k == 0 ? 1u : 0u) | (k == s.nblk - 1 ? 2u : 0u)));
+                if constexpr (VOLUME)
+                    shift_group_rows_volume(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                                            (rows_of(k) + 1) / 2, lane_addr, g.nz, g.ny * g.nz, a.z_scale, c,
+                                            a.volume + t_first, (unsigned)(a.vol_stride * 8),
+                                            (unsigned)lane * 32u, store_lanes);
+                else if (s.lazy)
+                    shift_group_rows_lazy(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                                          (rows_of(k) + 1) / 2, lane_addr, g.nz, g.ny * g.nz, a.z_scale, c);
+                else
+                    shift_group_rows(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                                     (rows_of(k) + 1) / 2, lane_addr, g.nz, g.ny * g.nz, a.z_scale, c);
+            }
+        }
+        b = nb;
+    }
+    if (!a.want_scan) return;
+    // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     shift_publish<NW>(a, win, vmax, vsum, vidx, wave, lane, group, t_first);
 }
 #endif  // QM_SHIFT_TU

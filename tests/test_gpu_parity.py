@@ -1698,7 +1698,11 @@ def test_shift_kernel_row_blocks_beyond_64_rows(lib, oracle, grid, rows, ns):
     want = oracle.detect(onsets, tt, case.fsmp, lsmp, case.available, threads=4)
     out = {}
     # (the register form is automatic from 97 rows on; shift=1 asks for it from 65)
-    for tag, extra, per_block in (("direct", {"shift_lazy": 0}, 34), ("lazy", {"shift_lazy": 1}, 34),
+    # (round 4: the LDS-direct staging also as two 4-wave workgroups per CU on 4x4x2 bricks)
+    for tag, extra, per_block in (("direct", {"shift_lazy": 0, "shift_rows_direct": 1}, 34),
+                                  ("lazy", {"shift_lazy": 1, "shift_rows_direct": 1}, 34),
+                                  ("quad", {"shift_lazy": 0, "shift_rows_direct": 2}, 34),
+                                  ("quad_lazy", {"shift_lazy": 1, "shift_rows_direct": 2}, 34),
                                   ("registers", {"shift_rows_direct": 0, "shift": 1}, 64),
                                   ("round2", {"shift": 0}, 0)):
         eng = lib.Engine(0, **extra)
@@ -1707,8 +1711,10 @@ def test_shift_kernel_row_blocks_beyond_64_rows(lib, oracle, grid, rows, ns):
         if per_block:
             assert eng.get("last_kernel") == 3 and eng.get("shift_row_blocks") == -(-rows // per_block), \
                 (tag, eng.get("last_kernel"), eng.get("shift_row_blocks"))
+            assert eng.get("shift_waves") == (4 if tag.startswith("quad") else 8)
+            assert eng.get("shift_brick_nodes") == (32 if tag.startswith("quad") else 64) or min(grid) < 4
         eng.close()
-    for tag in ("direct", "lazy", "registers"):
+    for tag in ("direct", "lazy", "quad", "quad_lazy", "registers"):
         _assert_series(out[tag], want)
         assert np.array_equal(out[tag][2], out["round2"][2])
         assert np.array_equal(out[tag][0], out["round2"][0])            # same bits
@@ -1719,18 +1725,20 @@ def test_shift_kernel_row_blocks_beyond_64_rows(lib, oracle, grid, rows, ns):
     # volume, the chunked kernel's bits, and the series that comes with it
     ref = oracle.c_migrate(onsets, tt, case.fsmp, lsmp, case.available, threads=4)
     vols = {}
-    for tag, extra in (("blocks", {}), ("round2", {"shift": 0})):
+    for tag, extra in (("blocks", {"shift_rows_direct": 1}), ("quad", {"shift_rows_direct": 2}),
+                       ("round2", {"shift": 0})):
         eng = lib.Engine(0, **extra)
         eng.load_lut(tt)
         vol = np.full((case.n_nodes_total, ns), np.nan)
         series = (np.full(ns, np.nan), np.full(ns, np.nan), np.full(ns, -1, dtype=np.int64))
         eng.migrate(lon, case.fsmp, lsmp, case.available, vol, scan_out=series)
-        assert (eng.get("last_kernel") == 3) == (tag == "blocks"), (tag, eng.get("last_kernel"))
+        assert (eng.get("last_kernel") == 3) == (tag != "round2"), (tag, eng.get("last_kernel"))
         _assert_series(series, want)
         np.testing.assert_allclose(vol, ref.reshape(vol.shape), rtol=TIGHT)
         vols[tag] = vol
         eng.close()
     assert np.array_equal(vols["blocks"], vols["round2"])
+    assert np.array_equal(vols["quad"], vols["round2"])
 
 
 @pytest.mark.parametrize("recipe,grid,rows,ns", [SHIFT_SHAPES[0], SHIFT_SHAPES[2], SHIFT_SHAPES[5]])
