@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Randomised differential campaign for the shift-reuse kernel (development aid).
 
-Random grids (every dimension >= 2), 1-64 rows (both workgroup shapes; a fifth of the trials 65-200 rows: row blocks), 192-900 scanned samples, coherent tables of random
+Random grids (every dimension >= 2), 1-64 rows (both workgroup shapes; a fifth of the trials 65-200 rows: row blocks
+in any of their three forms), 1-900 scanned samples (round 4: every tail-tile length, with and without tail tiles), coherent tables of random
 steepness (in 30 % of the trials with a few steep rows: bricks on the direct kernel, or a table that
 does not qualify at all), quantised onsets in half of the trials (exact ties), negative delays, random `available` and
 group counts: the automatic engine against Engine(shift=0) (maxima bit for bit, indices) and the
-oracle; every fourth trial also the volume-writing variant against the oracle's volume.
+oracle; every fourth trial also the volume-writing variant against the oracle's volume, every third
+the marginalised map of a random window against the time sum of that volume, every fifth a batch of
+two or three timesteps in one launch against the steps one by one.
 usage: fuzz_shift.py [trials] [seed]"""
 import os
 import sys
@@ -24,7 +27,7 @@ for trial in range(trials):
     if np.prod(grid) > 12000:
         grid = (grid[0], grid[1], max(2, 12000 // (grid[0] * grid[1])))
     S = int(rng.integers(1, 65)) if rng.random() < 0.8 else int(rng.integers(65, 201))   # (row blocks)
-    ns = int(rng.integers(192, 900))
+    ns = int(rng.integers(1, 900)) if rng.random() < 0.7 else int(rng.integers(192, 900))
     fsmp, lsmp = int(rng.integers(0, 30)), int(rng.integers(30, 160))
     # coherent table: distance-like delays from random "stations", steepness up to ~7 samples per node, a fifth of the rows up to 30
     ijk = np.stack(np.indices(grid), axis=-1).astype(np.float64)
@@ -44,7 +47,8 @@ for trial in range(trials):
         lon = np.log(np.clip(rng.lognormal(0, 0.6, size=(S, T)), 0.01, None))
     avail = int(2 ** rng.integers(0, 5)) if trial % 2 else int(rng.integers(1, S + 1))
     cfg = dict(groups=int(rng.choice([0, 1, 3, 9])), shift_lazy=int(rng.integers(-1, 2)),
-               shift=1 if 64 < S <= 96 else -1, shift_rows_direct=int(rng.integers(0, 2)))
+               shift=1 if 64 < S <= 96 else -1, shift_rows_direct=int(rng.integers(0, 3)),
+               shift_tail=int(rng.integers(0, 2)))
     if os.environ.get("QM_FUZZ_ONLY") and trial != int(os.environ["QM_FUZZ_ONLY"]):
         continue                                                    # (replay one trial of a seed)
     want = qm_oracle.detect(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True)
@@ -65,15 +69,34 @@ for trial in range(trials):
         eng = lib.Engine(0, **{**cfg, **extra})
         eng.load_lut(tt)
         res[tag] = eng.detect(lon, fsmp, lsmp, avail)
+        res_first = res[tag]
         if tag == "shift":
             kern, nwide = eng.get("last_kernel"), eng.get("shift_wide_bricks")
+            ref = None
+            if trial % 4 == 0 or trial % 3 == 0:
+                ref = qm_oracle.c_migrate(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True)
             if trial % 4 == 0:
                 vol = np.zeros(grid + (ns,))
                 series = (np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64))
                 eng.migrate(lon, fsmp, lsmp, avail, vol, scan_out=series)
-                ref = qm_oracle.c_migrate(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True)
                 np.testing.assert_allclose(vol, ref, rtol=1e-13, err_msg=str((trial, grid, S, ns)))
                 assert np.array_equal(series[2], want[2]), (trial, "volume scan idx")
+            if trial % 3 == 0:
+                i0 = int(rng.integers(0, ns))
+                i1 = int(rng.integers(i0 + 1, ns + 1))
+                series = (np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64))
+                m = eng.marginal_map(lon, fsmp, lsmp, avail, i0, i1, scan_out=series)
+                np.testing.assert_allclose(m, ref[..., i0:i1].sum(axis=-1), rtol=2e-12,
+                                           err_msg=str((trial, grid, S, ns, i0, i1, cfg)))
+                assert np.array_equal(series[2], want[2]) and np.array_equal(series[0], res_first[0]), \
+                    (trial, "marginal scan", cfg)
+            if trial % 5 == 0:
+                k = int(rng.integers(2, 4))
+                lons = np.stack([lon] + [np.roll(lon, 7 * (j + 1), axis=1) for j in range(k - 1)])
+                both = eng.detect_batch(lons, fsmp, lsmp, avail)
+                for j in range(k):
+                    one = eng.detect(lons[j], fsmp, lsmp, avail)
+                    assert all(np.array_equal(both[i][j], one[i]) for i in range(3)), (trial, "batch", j, cfg)
         eng.close()
     used += kern == 3
     blocks += kern == 3 and S > 64
