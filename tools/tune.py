@@ -23,10 +23,19 @@ def main():
     ap.add_argument("--ns", type=int, default=0, help="override n_samples")
     ap.add_argument("--rows", type=int, default=0, help="override the number of table rows")
     ap.add_argument("--volume", action="store_true", help="materialising path (device volume)")
+    ap.add_argument("--marginal", action="store_true",
+                    help="the marginalised map of the central half of the scan instead of the volume")
     args = ap.parse_args()
     t0 = time.time()
     case = synth.make_case(args.config, n_samples=args.ns or None, rows=args.rows or None)
     vol = None
+    cmap = None
+    if args.marginal:
+        import torch
+        cmap = torch.empty(case.n_nodes_total, dtype=torch.float64, device="cuda")
+        scan = tuple(torch.empty(case.n_samples, dtype=d, device="cuda")
+                     for d in (torch.float64, torch.float64, torch.int64))
+        lon_dev = torch.from_numpy(np.ascontiguousarray(np.log(np.clip(case.onsets, 0.01, np.inf)))).cuda()
     if args.volume:
         import torch
         vol = torch.empty((case.n_nodes_total, case.n_samples), dtype=torch.float64, device="cuda")
@@ -53,7 +62,12 @@ def main():
             wide = eng.get("n_wide_bricks")
             best = 1e9
             for _ in range(args.reps):
-                if vol is None:
+                if cmap is not None:
+                    ns = case.n_samples
+                    eng.marginal_map(lon_dev, case.fsmp, case.lsmp, case.available, ns // 4, ns - ns // 4,
+                                     out=cmap, scan_out=scan)
+                    out = tuple(t.cpu().numpy() for t in scan)
+                elif vol is None:
                     out = eng.detect(lon, case.fsmp, case.lsmp, case.available)
                 else:
                     eng.migrate(lon, case.fsmp, case.lsmp, case.available, vol, scan_out=scan)
