@@ -43,11 +43,14 @@ CONFIGS = {
     # (examples/Askja_Iceland_VT-DLP/askja_lut.py:42-44, askja_detect.py:44,66)
     "E2": dict(grid=(36, 31, 21), spacing=2.0, rows=46, n_samples=3000,
                rate=50.0, vp=5.0, vs=2.9, fsmp=580, paired=True),
+    # ... and the same LUT NOT decimated (1 km nodes, askja_lut.py:42-44): what one would feed a GPU
+    "E2F": dict(grid=(72, 62, 41), spacing=1.0, rows=46, n_samples=3000,
+                rate=50.0, vp=5.0, vs=2.9, fsmp=580, paired=True),
     # locate-style window on the C3 grid: 4 * marginal_window(2 s) * 50 Hz + 1
     "C3L": dict(grid=(201, 201, 101), spacing=0.5, rows=30, n_samples=401,
                 rate=50.0, vp=5.0, vs=2.9, fsmp=580, paired=False),
 }
-CONFIG_IDS = {"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C3L": 3, "E1": 11, "E2": 12}
+CONFIG_IDS = {"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C3L": 3, "E1": 11, "E2": 12, "E2F": 12}
 BASE_SEED = 20260927
 
 
