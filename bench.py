@@ -614,7 +614,7 @@ def main():
                     "sample) cell that can hold the maximum re-evaluated in float64 -- max_coa / "
                     "max_coa_idx are the float64 engine's bits; max_norm_coa within 6.7e-7 of it "
                     "by a deterministic bound whose preconditions are checked per step on the "
-                    "device (DESIGN.md section 3.2, qm_screen.hpp)",
+                    "device (DESIGN_HISTORY.md section 3.2, qm_screen.hpp)",
             "dtype": "i32 fixed-point sweep + f64 refinement",
             "max_norm_coa_bound": 6.7e-7,
             "ms_per_step": dt * 1e3, "value": work_step / dt, "unit": "node-samples/s",

@@ -1752,7 +1752,7 @@ def test_shift_kernel_row_blocks_beyond_64_rows(lib, oracle, grid, rows, ns):
 def test_shift_kernel_twelve_wave_shape_gives_the_same_bits(lib, oracle, recipe, grid, rows, ns):
     """Engine(shift_waves=12): one 12-wave workgroup per CU, three wavefronts per SIMD, the
     wavefronts' running (max, sum, index) in LDS, bricks of 8x8x12 -- an opt-in shape (measured no
-    faster than two 4-wave workgroups) that must give the same series."""
+    faster than two 4-wave workgroups, DESIGN_HISTORY.md section 3.4) that must give the same series."""
     case = synth.make_case(recipe, step=1, grid=grid, rows=rows, n_samples=ns)
     lon = oracle.log_onsets(case.onsets)
     r = _detect_both(lib, lon, case.traveltimes, case.fsmp, case.lsmp, case.available, shift_waves=12)
