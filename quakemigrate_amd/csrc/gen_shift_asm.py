@@ -58,7 +58,17 @@ EXP = set(filter(None, os.environ.get("QM_SHIFT_EXP", "").split(",")))   # timin
 NQMAX = int(os.environ.get("QM_SHIFT_NQMAX", "6"))    # window = 4 * NQMAX doubles
 NQMIN = int(os.environ.get("QM_SHIFT_NQMIN", "4"))    # quads fetched unconditionally
 WMAX = 4 * NQMAX
-REC = 64                 # bytes per stream record
+# Record size.  64 bytes: the eight register indices as dwords.  32 bytes ("packed"): as bytes of two
+# dwords -- six more SALU shifts per row, half the stream and half the scalar-load bytes.  Measured
+# (profiles/r04_ab_runs.txt): the loops that process all groups of a brick per call lose 1 % with
+# packed records (C3 detect 45.8 -> 46.3 ms), the row-block loops -- one group per call, the lead-in
+# loads exposed -- gain 5 % (128 rows 59.3 -> 56.5 ms): each takes the form that suits it.
+PACKED_GROUPS = os.environ.get("QM_SHIFT_PACKED", "0") == "1"
+PACKED_BLOCKS = os.environ.get("QM_SHIFT_PACKED_BLOCKS", "1") == "1"
+
+
+def rec_bytes(packed):
+    return 32 if packed else 64
 PF_AHEAD = int(os.environ.get("QM_SHIFT_PF", "16"))   # records ahead (0: no prefetch)
 PLANE2 = 40896           # plane A -> plane B, bytes (two 4-wave workgroups per CU, 80 KB each): 128 q + 64
                          # keeps the staging stores conflict-free
@@ -83,6 +93,7 @@ def configure(lds_state, far=False, lazy=False, block=False, spl=4, contig=False
     global LDS_STATE, FAR, PLANE, VB, ACC, WIN, VADDR, VADDRB, VNODE, VC, VPF, VZERO, VEND, VMAG
     global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR, LAZY, BLOCK, SPL, CONTIG, MARGINAL
     BLOCK = block            # one group per call, accumulators kept between calls (row blocks)
+    configure_scalars(PACKED_BLOCKS if block else PACKED_GROUPS)
     SPL = spl                # samples per lane (4: full tiles; 1..3: tail tiles)
     CONTIG = contig          # row windows staged contiguously (tail tiles)
     MARGINAL = marginal      # the marginalised map instead of the volume
@@ -129,21 +140,32 @@ def configure(lds_state, far=False, lazy=False, block=False, spl=4, contig=False
     VEND = VMAG + 2 if lazy else VZERO + 1
 
 
-SB = 48                  # first hard SGPR (s_load_dwordx16 destinations)
-BUF = [SB, SB + 16]
-ST = SB + 32             # [ST:ST+1], [ST+2:ST+3] compare masks
-SBASE = ST + 4
-SMASK = ST + 5
-SPAIRS = ST + 6
-SNODE = ST + 7
-STAB = ST + 8            # stream base (pair, even)
-SOFF = ST + 10           # byte offset of the record loaded last
-SPF = ST + 12            # prefetch address (pair)
-SVA = ST + 14            # volume row address of the node in the epilogue (pair)
-SNEGINF = ST + 16        # -inf (pair)
-SMAGIC = ST + 18         # 1.5 * 2^52 (pair): z + magic has rint(z) in its low dword
-SEND = ST + 20
-assert STAB % 2 == 0 and SB % 4 == 0 and SVA % 2 == 0 and SPF % 2 == 0 and SNEGINF % 2 == 0 and SEND <= 102
+SB = 48                  # first hard SGPR (s_load_dwordx16 / x8 destinations)
+
+
+def configure_scalars(packed):
+    """hard SGPR plan; the record buffers shrink with packed records"""
+    global PACKED, REC, NBUF, BUF, R_HDR, R_BASE, ST, SBASE, SMASK, SPAIRS, SNODE, STAB, SOFF, SPF, SVA
+    global SNEGINF, SMAGIC, SEND
+    PACKED = packed
+    REC = rec_bytes(packed)  # bytes per stream record
+    NBUF = REC // 4          # dwords of a record
+    BUF = [SB, SB + NBUF]
+    R_HDR = 2 if packed else 8     # dwords of the next row's header inside a record (LDS offset, quad count)
+    R_BASE = 4 if packed else 10   # ... of the group's first node and valid-node mask (row 0 of a group)
+    ST = SB + 2 * NBUF       # [ST:ST+1], [ST+2:ST+3] compare masks
+    SBASE = ST + 4
+    SMASK = ST + 5
+    SPAIRS = ST + 6
+    SNODE = ST + 7
+    STAB = ST + 8            # stream base (pair, even)
+    SOFF = ST + 10           # byte offset of the record loaded last
+    SPF = ST + 12            # prefetch address (pair)
+    SVA = ST + 14            # volume row address of the node in the epilogue (pair)
+    SNEGINF = ST + 16        # -inf (pair)
+    SMAGIC = ST + 18         # 1.5 * 2^52 (pair): z + magic has rint(z) in its low dword
+    SEND = ST + 20
+    assert STAB % 2 == 0 and SB % 4 == 0 and SVA % 2 == 0 and SPF % 2 == 0 and SNEGINF % 2 == 0 and SEND <= 102
 
 
 def v2(r):
@@ -225,7 +247,15 @@ def node_adds(e, p, g, first):
     if "noidx" in EXP:
         e("s_nop 0")
     else:
-        e(f"s_set_gpr_idx_on s{BUF[p] + g}, 1")               # SRC0 relative, index = idx[g]
+        if PACKED:
+            # the record packs the eight indices as bytes of two dwords; the instruction takes bits
+            # [7:0] of its operand, so nodes 0 and 4 use the dword as it is and the others shift it
+            reg = BUF[p] + g // 4
+            if g % 4:
+                e(f"s_lshr_b32 s{reg}, s{reg}, 8")
+            e(f"s_set_gpr_idx_on s{reg}, 1")
+        else:
+            e(f"s_set_gpr_idx_on s{BUF[p] + g}, 1")           # SRC0 relative, index = idx[g]
     for k in range(SPL):
         a = v2(ACC + 8 * g + 2 * k)
         w = v2(WIN[p] + 2 * k)
@@ -237,15 +267,15 @@ def row_iter(e, p, first):
     requested before this row's adds (a block of reads at the row's start: spread between the adds,
     the late ones land after the next row's wait -- measured slower, tools/micro results r03a)."""
     q = 1 - p
-    hdr = BUF[p] + 8
+    hdr = BUF[p] + R_HDR
     if "nowait" not in EXP:
         e("s_waitcnt lgkmcnt(0)")                              # both have landed
     if first:
-        e(f"s_mov_b32 s{SBASE}, s{BUF[p] + 10}")
-        e(f"s_mov_b32 s{SMASK}, s{BUF[p] + 11}")
+        e(f"s_mov_b32 s{SBASE}, s{BUF[p] + R_BASE}")
+        e(f"s_mov_b32 s{SMASK}, s{BUF[p] + R_BASE + 1}")
     if "nosmem" not in EXP:
         e(f"s_add_u32 s{SOFF}, s{SOFF}, {REC}")
-        e(f"s_load_dwordx16 s[{BUF[q]}:{BUF[q] + 15}], {s2(STAB)}, s{SOFF}")
+        e(f"s_load_dwordx{NBUF} s[{BUF[q]}:{BUF[q] + NBUF - 1}], {s2(STAB)}, s{SOFF}")
     if "interleave" in EXP:
         # experiment: one body per quad count, the next row's reads dealt two per node behind the
         # first nodes' adds (all issued by the row's middle)
@@ -639,8 +669,8 @@ def body(degree, volume):
     e(f"s_mov_b32 s{STAB}, %[tablo]")
     e(f"s_mov_b32 s{STAB + 1}, %[tabhi]")
     # prologue: lead-in record (header of row 0) and row 0's record; window of row 0
-    e(f"s_load_dwordx16 s[{BUF[1]}:{BUF[1] + 15}], {s2(STAB)}, 0")
-    e(f"s_load_dwordx16 s[{BUF[0]}:{BUF[0] + 15}], {s2(STAB)}, {REC}")
+    e(f"s_load_dwordx{NBUF} s[{BUF[1]}:{BUF[1] + NBUF - 1}], {s2(STAB)}, 0")
+    e(f"s_load_dwordx{NBUF} s[{BUF[0]}:{BUF[0] + NBUF - 1}], {s2(STAB)}, {REC}")
     e(f"s_mov_b32 s{SOFF}, {REC}")
     e(f"s_mov_b32 s{SNEGINF}, 0")
     e(f"s_mov_b32 s{SNEGINF + 1}, 0xfff00000")
@@ -653,7 +683,7 @@ def body(degree, volume):
     e(f"s_add_u32 s{SPF}, s{STAB}, {PF_AHEAD * REC}")
     e(f"s_addc_u32 s{SPF + 1}, s{STAB + 1}, 0")
     e("s_waitcnt lgkmcnt(0)")
-    issue_window(e, 0, BUF[1] + 8)
+    issue_window(e, 0, BUF[1] + R_HDR)
     group = e.label("grp")
     pair = e.label("pair")
     nopair = e.label("np")
@@ -802,7 +832,8 @@ def main():
     print(f"constexpr int kShiftPlane3 = {PLANE3};       // ... of the 12-wave workgroup")
     print(f"constexpr int kShiftPlane8 = {PLANE8};       // ... of the 8-wave workgroup (33-64 rows)")
     print(f"constexpr int kShiftStateChunk = {STATE_CHUNK};   // LDS running state: 5 chunks per wavefront")
-    print(f"constexpr int kShiftRec = {REC};            // bytes per stream record")
+    print(f"constexpr bool kShiftPackedGroups = {'true' if PACKED_GROUPS else 'false'};   // 32-byte records (register indices as bytes)")
+    print(f"constexpr bool kShiftPackedBlocks = {'true' if PACKED_BLOCKS else 'false'};   // ... of the row-block loops")
     print(f"constexpr int kShiftBlockVgprs = {VB_BLOCK};   // row-block flavour: the compiler's own code stays below")
     print(f"constexpr int kShiftMarginalDegree = {MARGINAL_DEGREE};   // 2^f polynomial of the marginal-map flavours")
     for degree, volume, lds_state, far, lazy, block, name in (

@@ -647,7 +647,7 @@ int build_shift_tables(qm_engine *e) {
     if (!ok) return 0;                                   // an incoherent table: the other kernels
     const int rows2 = sb + (sb & 1);
     const int64_t words = (int64_t)g.nbricks * nw * nblk * qm::shift_recs_per_wave(g, rows2, nw) *
-                          (qm::kShiftRec / 4);
+                          (qm::shift_rec_bytes(blocks) / 4);
     if (blocks)                                          // per-brick verdicts for the kernels
         QM_HIP(hipMemcpyAsync(e->d_shfit.p, fit.data(), (size_t)g.nbricks * sizeof(int32_t),
                               hipMemcpyHostToDevice, e->stream));
@@ -660,7 +660,7 @@ int build_shift_tables(qm_engine *e) {
     hipLaunchKernelGGL(qm::shift_stream_kernel, dim3((unsigned)((size_t)g.nbricks * nblk)), dim3(256),
                        hdr_bytes, e->stream, g, e->d_lut.p,
                        reinterpret_cast<const int4 *>(e->d_shmeta.p), e->d_shtotal.p, e->d_shfit.p,
-                       rows2, nw, nblk, sb, e->d_shstream.p);
+                       rows2, nw, nblk, sb, qm::shift_packed(blocks) ? 1 : 0, e->d_shstream.p);
     QM_HIP(hipGetLastError());
     e->n_shwide = (int)wide.size();
     if (e->n_shwide) {

@@ -57,6 +57,17 @@ constexpr int kShiftMaxRows = 64;                       // table rows the stream
 static_assert(QM_EXP2_DEGREE_SUM == 8 && QM_EXP2_DEGREE_VOLUME == 10,
               "the generated loops carry the degree-8 (detect) and degree-10 (stored values) 2^f");
 
+// Record geometry: 64 bytes with the eight register indices as dwords, or 32 bytes with them as bytes
+// of two dwords ("packed": gen_shift_asm.py says which loops take which).  Row blocks and the other
+// loops may differ; a table's stream is built in the format of the kernels that will read it.
+__host__ __device__ constexpr bool shift_packed(bool blocks) { return blocks ? kShiftPackedBlocks : kShiftPackedGroups; }
+__host__ __device__ constexpr int shift_rec_bytes(bool blocks) { return shift_packed(blocks) ? 32 : 64; }
+constexpr int kShiftRec = shift_rec_bytes(false);       // ... of the loops that take all groups of a brick per call
+constexpr int kShiftRecBlocks = shift_rec_bytes(true);  // ... of the row-block loops
+// dwords of the next row's header (LDS offset, quad count) / of the group's first node and valid mask
+__host__ __device__ constexpr int shift_rec_hdr(bool packed) { return packed ? 2 : 8; }
+__host__ __device__ constexpr int shift_rec_base(bool packed) { return packed ? 4 : 10; }
+
 // records per (brick, wave): lead-in + groups * rows2 + trailing pad; every (brick, wave) owns a
 // fixed-size run (a brick at the grid's edge uses a prefix of it)
 __host__ __device__ __forceinline__ int shift_groups_per_brick(const GridDesc &g) {
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
                                                            const int4 *__restrict__ smeta,
                                                            const int32_t *__restrict__ stotal,
                                                            const int32_t *__restrict__ sfit, int rows2max,
-                                                           int nw, int nblk, int sb,
+                                                           int nw, int nblk, int sb, int packed,
                                                            uint32_t *__restrict__ stream) {
     extern __shared__ uint2 hdr[];                      // [group j][row] (LDS address, quads)
     // (row blocks: workgroup vb = (brick, block); sfit is per brick -- all of its blocks fit)
@@ -225,14 +236,14 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
     const int nvg = cx * cy * cz;
     const int64_t rpw = shift_recs_per_wave(g, rows2max, nw);
     auto record = [&](int w, int64_t i) {
-        return stream + (shift_run_record(b, w, k, nw, nblk, rpw) + i) * (kShiftRec / 4);
+        return stream + (shift_run_record(b, w, k, nw, nblk, rpw) + i) * (packed ? 8 : 16);
     };
     for (int i = threadIdx.x; i < nvg * rows2; i += blockDim.x) {
         const int j = i / rows2, r = i % rows2;
         const int w = j % nw, pos = j / nw;
         uint32_t *rec = record(w, 1 + (int64_t)pos * rows2 + r);
         if (r >= S) {                                   // padding row of an odd S: adds 0.0
-            for (int n = 0; n < 8; ++n) rec[n] = 0;
+            for (int n = 0; n < (packed ? 2 : 8); ++n) rec[n] = 0;
             hdr[j * rows2 + r] = make_uint2(16u * (unsigned)stotal[vb], 2u);
             continue;
         }
@@ -241,11 +252,21 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
         int d[8], e0, nq;
         const unsigned mask = shift_group_delays(g, lut, x0, y0, z0, vx, vy, vz, gx, gy, gz, r0 + r, m.x, d);
         shift_window(d, e0, nq);
-        for (int n = 0; n < 8; ++n) rec[n] = 2u * (unsigned)(d[n] - e0);
+        if (packed) {                                   // the eight register indices (< 48) as bytes
+            uint32_t lo = 0, hi = 0;
+            for (int n = 0; n < 4; ++n) {
+                lo |= (2u * (unsigned)(d[n] - e0)) << (8 * n);
+                hi |= (2u * (unsigned)(d[4 + n] - e0)) << (8 * n);
+            }
+            rec[0] = lo;
+            rec[1] = hi;
+        } else {
+            for (int n = 0; n < 8; ++n) rec[n] = 2u * (unsigned)(d[n] - e0);
+        }
         hdr[j * rows2 + r] = make_uint2(16u * (unsigned)(m.z + e0 / 4), (unsigned)nq);
         if (r == 0) {
-            rec[10] = (uint32_t)(((int64_t)(x0 + 2 * gx) * g.ny + (y0 + 2 * gy)) * g.nz + (z0 + 2 * gz));
-            rec[11] = mask;
+            rec[shift_rec_base(packed)] = (uint32_t)(((int64_t)(x0 + 2 * gx) * g.ny + (y0 + 2 * gy)) * g.nz + (z0 + 2 * gz));
+            rec[shift_rec_base(packed) + 1] = mask;
         }
     }
     __syncthreads();
@@ -256,8 +277,8 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
             if (w < nvg) {
                 const uint2 h = hdr[w * rows2];
                 uint32_t *rec = record(w, 0);
-                rec[8] = h.x;
-                rec[9] = h.y;
+                rec[shift_rec_hdr(packed)] = h.x;
+                rec[shift_rec_hdr(packed) + 1] = h.y;
             }
             continue;
         }
@@ -267,8 +288,8 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
         uint2 h = make_uint2(0u, 2u);                    // after the wave's last row: harmless
         if (r + 1 < rows2) h = hdr[j * rows2 + r + 1];
         else if (j + nw < nvg) h = hdr[(j + nw) * rows2];
-        rec[8] = h.x;
-        rec[9] = h.y;
+        rec[shift_rec_hdr(packed)] = h.x;
+        rec[shift_rec_hdr(packed) + 1] = h.y;
     }
 }
 #endif  // QM_ENGINE_TU
@@ -620,7 +641,7 @@ void stack_shift_rows_kernel(ShiftArgs s) {
         // this wavefront's next run: the first block of its next brick
         int nb = b + a.ngroups;
         while (nb < g.nbricks && !s.sfit[nb]) nb += a.ngroups;
-        const char *next_run = s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, s.nblk, rpw) * kShiftRec;
+        const char *next_run = s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, s.nblk, rpw) * kShiftRecBlocks;
         for (int k = 0; k < s.nblk; ++k) {
             const int row0 = k * s.sb;
             const int rows = g.n_rows - row0 < s.sb ? g.n_rows - row0 : s.sb;
@@ -629,7 +650,7 @@ void stack_shift_rows_kernel(ShiftArgs s) {
                                                            lane, t_first);
             __syncthreads();
             if (mine) {
-                const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRec;
+                const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRecBlocks;
                 const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
                     (int)((k == 0 ? 1u : 0u) | (k == s.nblk - 1 ? 2u : 0u)));
                 shift_group_rows8(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
@@ -773,7 +794,7 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
         shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
         const bool mine = wave < cx * cy * cz;                     // one group per wavefront
         const char *next_run =
-            s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, s.nblk, rpw) * kShiftRec;
+            s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, s.nblk, rpw) * kShiftRecBlocks;
         for (int k = 0; k < s.nblk; ++k) {
             // the next block (of this brick, or the first of the next) into the idle half
             double *idle = win + (cur ^ 1) * (kShiftHalfBytes / 8);
@@ -783,7 +804,7 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
             else if (nb < g.nbricks)
                 stage_shift_block_direct<NW>(s, idle, nb * s.nblk, 0, rows_of(0), wave, lane, t_first);
             if (mine) {
-                const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRec;
+                const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRecBlocks;
                 const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
                     (int)((k == 0 ? 1u : 0u) | (k == s.nblk - 1 ? 2u : 0u)));
                 if constexpr (VOLUME)
@@ -862,14 +883,14 @@ void stack_shift_rows4_kernel(ShiftArgs s) {
         shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
         const bool mine = wave < cx * cy * cz;                     // one group per wavefront
         const char *next_run =
-            s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, s.nblk, rpw) * kShiftRec;
+            s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, s.nblk, rpw) * kShiftRecBlocks;
         for (int k = 0; k < s.nblk; ++k) {
             // everyone is done with the block in LDS; this block's rows in, by LDS-direct loads
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             stage_shift_block_direct<NW>(s, win, b * s.nblk + k, k * s.sb, rows_of(k), wave, lane, t_first);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (mine) {
-                const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRec;
+                const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRecBlocks;
                 const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
                     (int)((k == 0 ? 1u : 0u) | (k == s.nblk - 1 ? 2u : 0u)));
                 if constexpr (VOLUME)

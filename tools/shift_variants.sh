@@ -13,6 +13,12 @@ for spec in "$@"; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DQM_SHIFT_ASM_INC="\"$inc\"" $defs -c $C/qm_launch_shift.hip \
       -o build_variants/qm_launch_shift_$name.o 2>&1 | grep -E "error|Spill" 
   objs=$(ls $C/build/*.o | grep -v qm_launch_shift)
+  if [ "${QM_VARIANT_ENGINE:-0}" = "1" ]; then
+    # knobs that change the record stream's format also change its builder (qm_engine.hip includes the loop's constants)
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DQM_SHIFT_ASM_INC="\"$inc\"" -c $C/qm_engine.hip \
+        -o build_variants/qm_engine_$name.o 2>&1 | grep -E "error"
+    objs=$(echo "$objs" | grep -v qm_engine.hip.o)" build_variants/qm_engine_$name.o"
+  fi
   hipcc --offload-arch=gfx950 -shared -fPIC -o build_variants/libqmhip_$name.so $objs build_variants/qm_launch_shift_$name.o || exit 1
 done
 ls -la build_variants/libqmhip_*.so | awk '{print $5, $9}'
