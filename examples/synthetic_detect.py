@@ -27,7 +27,9 @@ from quakemigrate_amd.core import lib  # noqa: E402
 
 
 def run(out_dir, grid=(24, 20, 12), spacing=0.5, n_stations=6, rate=50, timestep=6.0,
-        n_steps=4, seed=3):
+        n_steps=4, seed=3, steps_per_launch=1):
+    """``steps_per_launch`` > 1: the onset rows of that many timesteps are stacked by ONE launch
+    (``Engine.detect_batch``) -- what fills the GPU on grids of this size; same series."""
     import torch
 
     rng = np.random.default_rng(seed)
@@ -63,18 +65,24 @@ def run(out_dir, grid=(24, 20, 12), spacing=0.5, n_stations=6, rate=50, timestep
         for row in range(n_rows):
             arrival = t0 + int(np.rint(grids[row][node] * rate))
             wave[2 * row:2 * row + 2, arrival:arrival + nsta] *= 9.0
-    d_log = torch.empty((n_rows, T), dtype=torch.float64, device="cuda")
-    out = tuple(torch.empty(ns, dtype=d, device="cuda")
+    K = max(1, int(steps_per_launch))
+    d_log = torch.empty((K, n_rows, T), dtype=torch.float64, device="cuda")
+    out = tuple(torch.empty((K, ns), dtype=d, device="cuda")
                 for d in (torch.float64, torch.float64, torch.int64))
     series = {k: [] for k in ("coa", "coa_n", "idx")}
-    for k in range(n_steps):
-        window = np.ascontiguousarray(wave[:, k * ns: k * ns + T])
-        eng.onsets(window, trace_row, [nsta] * n_rows, [nlta] * n_rows, transform="energy",
-                   position="classic", taper_pad=-1, min_onset_value=0.4, log_out=d_log)
-        eng.detect(d_log, fsmp, lsmp, n_rows, out=out)
-        series["coa"].append(out[0].cpu().numpy())
-        series["coa_n"].append(out[1].cpu().numpy())
-        series["idx"].append(out[2].cpu().numpy())
+    for k0 in range(0, n_steps, K):
+        n = min(K, n_steps - k0)
+        for j in range(n):                                  # the onset stage, timestep by timestep
+            window = np.ascontiguousarray(wave[:, (k0 + j) * ns: (k0 + j) * ns + T])
+            eng.onsets(window, trace_row, [nsta] * n_rows, [nlta] * n_rows, transform="energy",
+                       position="classic", taper_pad=-1, min_onset_value=0.4, log_out=d_log[j])
+        if K == 1:
+            eng.detect(d_log[0], fsmp, lsmp, n_rows, out=tuple(o[0] for o in out))
+        else:                                               # ... the migration of n timesteps at once
+            eng.detect_batch(d_log[:n], fsmp, lsmp, n_rows, out=tuple(o[:n] for o in out))
+        series["coa"].append(out[0][:n].reshape(-1).cpu().numpy())
+        series["coa_n"].append(out[1][:n].reshape(-1).cpu().numpy())
+        series["idx"].append(out[2][:n].reshape(-1).cpu().numpy())
     coa, coa_n, idx = (np.concatenate(series[k]) for k in ("coa", "coa_n", "idx"))
     coord = np.stack(np.unravel_index(idx, grid), axis=-1) * spacing    # index2coord, no pyproj
     # ---- write what detect() writes ------------------------------------------------------------

@@ -1243,6 +1243,11 @@ def test_end_to_end_synthetic_detect_example(lib, tmp_path):
     assert rate == 50.0 and len(cols["COA"]) == len(res["coa"])
     np.testing.assert_allclose(cols["COA"], np.minimum(res["coa"], 21474.0), atol=5.1e-6)
     np.testing.assert_allclose(cols["X"], res["coord"][:, 0], atol=5.1e-7)
+    # the same run with three timesteps per launch (4 = 3 + 1): the same series and the same file
+    res3 = mod.run(tmp_path / "k3", steps_per_launch=3)
+    for k in ("coa", "coa_n", "idx"):
+        assert np.array_equal(res3[k], res[k]), k
+    assert res3["path"].read_bytes() == res["path"].read_bytes()
 
 
 @pytest.mark.parametrize("screen", [False, True], ids=["float64", "screened"])
