@@ -2482,6 +2482,21 @@ def test_changing_availability_alternates_between_parked_tables(lib, oracle, dev
             _assert_series((a, b, idx), want[step])
         assert eng.get("table_misses") == misses, (cache, eng.get("table_misses"))
         assert eng.get("table_hits") == len(sequence) - misses
+        if cache == 4:
+            # a table that has been parked and brought back serves every kind of launch: the volume
+            # and the marginalised map (their derived layouts travel with the table's state)
+            state["avail"] = patterns[1]
+            s._compute(Data())
+            rows = [i for i, k in enumerate(keys) if patterns[1][k] == 1]
+            lon1 = oracle.log_onsets(case.onsets[rows])
+            ref1 = oracle.c_migrate(case.onsets[rows], np.ascontiguousarray(case.traveltimes[..., rows]),
+                                    case.fsmp, case.lsmp, len(rows), threads=4)
+            vol = np.full((case.n_nodes_total, case.n_samples), np.nan)
+            eng.migrate(lon1, case.fsmp, case.lsmp, len(rows), vol)
+            np.testing.assert_allclose(vol, ref1.reshape(vol.shape), rtol=TIGHT)
+            m = eng.marginal_map(lon1, case.fsmp, case.lsmp, len(rows), 50, 250)
+            np.testing.assert_allclose(m, ref1[..., 50:250].sum(axis=-1), rtol=1e-12)
+            assert eng.get("tables_parked") == 3 and eng.get("tables_parked_bytes") > 0
         if not device_serving:
             assert state["served"] == misses
         if cache == 1:
