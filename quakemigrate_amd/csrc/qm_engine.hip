@@ -50,6 +50,83 @@ int fail(const char *fmt, ...) {
                         __LINE__);                                                           \
     } while (0)
 
+// Two habits that come from one observation (round 4; DESIGN.md section 6, profiles/r04_host_copy_*).
+// With 16 processes sharing the GPU and an engine made per call, about one call in 1e4 returned
+// host outputs that still held zeros in part: results handed to hipMemcpyAsync as a pageable host
+// pointer went missing (the round-2 kernels and the shift kernels alike; a wait in front of the copy
+// changed nothing; one process alone: never seen).  Through a pinned bounce buffer: 0 of 57 600
+// trials where the two batches before had 5 each.  Independently, a program of two trivial kernels, a
+// copy and hipStreamSynchronize that creates a stream per call reads stale data about once per 4e4
+// calls under the same sharing, and never on a long-lived stream (tools/micro/d2h_order.hip).  So:
+// an engine's own stream comes from a per-device pool and goes back to it (pooled streams are never
+// destroyed), and results travel to host memory through pinned memory.
+std::mutex g_stream_mutex;
+std::vector<std::pair<int, hipStream_t>> g_idle_streams;
+hipError_t acquire_stream(int device, hipStream_t *out) {
+    {
+        std::lock_guard<std::mutex> lock(g_stream_mutex);
+        for (size_t i = 0; i < g_idle_streams.size(); ++i)
+            if (g_idle_streams[i].first == device) {
+                *out = g_idle_streams[i].second;
+                g_idle_streams.erase(g_idle_streams.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+void park_stream(int device, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    g_idle_streams.emplace_back(device, s);
+}
+
+// Results travel back to the host through a pinned bounce buffer (one per process, 32 MB, never
+// freed) and a CPU memcpy.  Both calls return when the data is in place.  (The statistics-only flag
+// ring of the screened sweep is pinned memory of its own and stays asynchronous.)
+std::mutex g_bounce_mutex;
+char *g_bounce = nullptr;
+constexpr size_t kBounceBytes = 32u << 20;
+hipError_t copy_back(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_bounce_mutex);
+    hipError_t r = hipSuccess;
+    if (!g_bounce && (r = hipHostMalloc(reinterpret_cast<void **>(&g_bounce), kBounceBytes)) != hipSuccess)
+        return r;
+    for (size_t at = 0; at < bytes; at += kBounceBytes) {
+        const size_t n = std::min(kBounceBytes, bytes - at);
+        r = hipMemcpyAsync(g_bounce, static_cast<const char *>(src) + at, n, hipMemcpyDeviceToHost, s);
+        if (r == hipSuccess) r = hipStreamSynchronize(s);
+        if (r != hipSuccess) return r;
+        std::memcpy(static_cast<char *>(dst) + at, g_bounce, n);
+    }
+    return hipSuccess;
+}
+hipError_t copy_back_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width,
+                        size_t height, hipStream_t s) {
+    if (width == dpitch && width == spitch) return copy_back(dst, src, width * height, s);
+    if (width > kBounceBytes) {                     // (rows longer than the buffer: one by one)
+        for (size_t row = 0; row < height; ++row) {
+            const hipError_t r = copy_back(static_cast<char *>(dst) + row * dpitch,
+                                           static_cast<const char *>(src) + row * spitch, width, s);
+            if (r != hipSuccess) return r;
+        }
+        return hipSuccess;
+    }
+    std::lock_guard<std::mutex> lock(g_bounce_mutex);
+    hipError_t r = hipSuccess;
+    if (!g_bounce && (r = hipHostMalloc(reinterpret_cast<void **>(&g_bounce), kBounceBytes)) != hipSuccess)
+        return r;
+    const size_t rows_at_once = kBounceBytes / width;
+    for (size_t row = 0; row < height; row += rows_at_once) {
+        const size_t n = std::min(rows_at_once, height - row);
+        r = hipMemcpy2DAsync(g_bounce, width, static_cast<const char *>(src) + row * spitch, spitch,
+                             width, n, hipMemcpyDeviceToHost, s);
+        if (r == hipSuccess) r = hipStreamSynchronize(s);
+        if (r != hipSuccess) return r;
+        for (size_t i = 0; i < n; ++i)
+            std::memcpy(static_cast<char *>(dst) + (row + i) * dpitch, g_bounce + i * width, width);
+    }
+    return hipSuccess;
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -448,8 +525,7 @@ int ensure_pair_tables(qm_engine *e, int jp) {
                            reinterpret_cast<int4 *>(e->d_pmeta.p), e->d_ptotal.p);
         QM_HIP(hipGetLastError());
         total.resize(g.nbricks);
-        QM_HIP(hipMemcpyAsync(total.data(), e->d_ptotal.p, (size_t)g.nbricks * sizeof(int32_t),
-                              hipMemcpyDeviceToHost, e->stream));
+        QM_HIP(copy_back(total.data(), e->d_ptotal.p, (size_t)g.nbricks * sizeof(int32_t), e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
         wide.clear();
         for (int b = 0; b < g.nbricks; ++b)
@@ -626,10 +702,8 @@ int build_shift_tables(qm_engine *e) {
         QM_HIP(hipGetLastError());
         fit.resize(nvb);
         unsigned long long tally[2] = {0, 0};
-        QM_HIP(hipMemcpyAsync(fit.data(), e->d_shfit.p, nvb * sizeof(int32_t),
-                              hipMemcpyDeviceToHost, e->stream));
-        QM_HIP(hipMemcpyAsync(tally, e->d_scalar.p + 4, sizeof(tally), hipMemcpyDeviceToHost,
-                              e->stream));
+        QM_HIP(copy_back(fit.data(), e->d_shfit.p, nvb * sizeof(int32_t), e->stream));
+        QM_HIP(copy_back(tally, e->d_scalar.p + 4, sizeof(tally), e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
         e->shift_quads = (int64_t)tally[0];
         e->shift_group_rows = (int64_t)tally[1];
@@ -1070,8 +1144,7 @@ int ensure_screen_tables(qm_engine *e, const ScreenPlan &plan) {
                            reinterpret_cast<int4 *>(e->d_smeta.p), e->d_stotal.p);
         QM_HIP(hipGetLastError());
         total.resize(g.nbricks);
-        QM_HIP(hipMemcpyAsync(total.data(), e->d_stotal.p, (size_t)g.nbricks * sizeof(int32_t),
-                              hipMemcpyDeviceToHost, e->stream));
+        QM_HIP(copy_back(total.data(), e->d_stotal.p, (size_t)g.nbricks * sizeof(int32_t), e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
         wide.clear();
         for (int b = 0; b < g.nbricks; ++b)
@@ -1370,9 +1443,9 @@ int stage_out(qm_engine *e, int n, int out_on_device, double *max_coa, double *m
 int fetch_out(qm_engine *e, int n, int out_on_device, const OutStage &st, double *max_coa,
               double *max_norm, int64_t *idx) {
     if (out_on_device) return 0;
-    QM_HIP(hipMemcpyAsync(max_coa, st.a, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    QM_HIP(hipMemcpyAsync(max_norm, st.b, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    QM_HIP(hipMemcpyAsync(idx, st.i, n * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
+    QM_HIP(copy_back(max_coa, st.a, n * sizeof(double), e->stream));
+    QM_HIP(copy_back(max_norm, st.b, n * sizeof(double), e->stream));
+    QM_HIP(copy_back(idx, st.i, n * sizeof(int64_t), e->stream));
     QM_HIP(hipStreamSynchronize(e->stream));
     return 0;
 }
@@ -1402,7 +1475,7 @@ int qm_engine_create(int device_id, qm_engine **out) {
     hipDeviceProp_t prop;
     QM_HIP(hipGetDeviceProperties(&prop, device_id));
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    QM_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    QM_HIP(acquire_stream(device_id, &e->own_stream));
     e->stream = e->own_stream;
     QM_HIP(hipEventCreate(&e->ev0));
     QM_HIP(hipEventCreate(&e->ev1));
@@ -1431,7 +1504,10 @@ void qm_engine_destroy(qm_engine *e) {
     for (hipEvent_t ev : e->ev_log) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
-    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    if (e->own_stream) {
+        (void)hipStreamSynchronize(e->own_stream);
+        park_stream(e->device, e->own_stream);
+    }
     delete e;
 }
 
@@ -1669,10 +1745,8 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
                            e->d_btotal.p);
         QM_HIP(hipGetLastError());
         totals[s].resize(nbricks);
-        QM_HIP(hipMemcpyAsync(totals[s].data(), e->d_btotal.p, nbricks * sizeof(int32_t),
-                              hipMemcpyDeviceToHost, e->stream));
-        QM_HIP(hipMemcpyAsync(&e->lut_max, e->d_scalar.p, sizeof(int32_t),
-                              hipMemcpyDeviceToHost, e->stream));
+        QM_HIP(copy_back(totals[s].data(), e->d_btotal.p, nbricks * sizeof(int32_t), e->stream));
+        QM_HIP(copy_back(&e->lut_max, e->d_scalar.p, sizeof(int32_t), e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
         on_device = s;
         return 0;
@@ -1886,8 +1960,7 @@ int qm_engine_lut_download(qm_engine *e, int32_t *out) {
     if (!e || !out) return fail("NULL argument");
     if (!e->have_lut) return fail("no travel-time table resident");
     DeviceGuard guard(e->device);
-    QM_HIP(hipMemcpyAsync(out, e->d_lut.p, (size_t)e->n_nodes * e->g.n_rows * sizeof(int32_t),
-                          hipMemcpyDeviceToHost, e->stream));
+    QM_HIP(copy_back(out, e->d_lut.p, (size_t)e->n_nodes * e->g.n_rows * sizeof(int32_t), e->stream));
     QM_HIP(hipStreamSynchronize(e->stream));
     return 0;
 }
@@ -2050,9 +2123,8 @@ int qm_engine_migrate(qm_engine *e, const double *log_onsets, int onsets_on_devi
                                      e->node_offset, n_nodes_total, st.a + k0, st.b + k0,
                                      st.i + k0))
                 return 1;
-            QM_HIP(hipMemcpy2DAsync(map4d + k0, (size_t)ns * sizeof(double), e->d_chunk.p,
-                                    nk * sizeof(double), nk * sizeof(double), e->n_nodes,
-                                    hipMemcpyDeviceToHost, e->stream));
+            QM_HIP(copy_back_2d(map4d + k0, (size_t)ns * sizeof(double), e->d_chunk.p,
+                                    nk * sizeof(double), nk * sizeof(double), e->n_nodes, e->stream));
             QM_HIP(hipStreamSynchronize(e->stream));
         }
     }
@@ -2096,8 +2168,7 @@ int qm_engine_marginal(qm_engine *e, const double *log_onsets, int onsets_on_dev
                              e->node_offset, n_nodes_total, st.a, st.b, st.i))
         return 1;
     if (!map_on_device) {
-        QM_HIP(hipMemcpyAsync(coa_map, d_map, (size_t)e->n_nodes * sizeof(double),
-                              hipMemcpyDeviceToHost, e->stream));
+        QM_HIP(copy_back(coa_map, d_map, (size_t)e->n_nodes * sizeof(double), e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
     }
     if (want_scan) return fetch_out(e, ns, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
@@ -2176,11 +2247,9 @@ int qm_engine_onsets(qm_engine *e, const double *signals, int signals_on_device,
                        e->stream, a);
     QM_HIP(hipGetLastError());
     if (!out_on_device) {
-        QM_HIP(hipMemcpyAsync(log_onsets, d_log, out * sizeof(double), hipMemcpyDeviceToHost,
-                              e->stream));
+        QM_HIP(copy_back(log_onsets, d_log, out * sizeof(double), e->stream));
         if (raw_onsets)
-            QM_HIP(hipMemcpyAsync(raw_onsets, d_raw, out * sizeof(double), hipMemcpyDeviceToHost,
-                                  e->stream));
+            QM_HIP(copy_back(raw_onsets, d_raw, out * sizeof(double), e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
     }
     return 0;
@@ -2385,14 +2454,12 @@ int qm_engine_locate_fits(qm_engine *e, const double *coa_map, int map_on_device
     QM_HIP(hipGetLastError());
 
     double h[32], w[343 + 125];
-    QM_HIP(hipMemcpyAsync(h, val, sizeof(h), hipMemcpyDeviceToHost, s));
-    QM_HIP(hipMemcpyAsync(w, e->d_fit_win.p, sizeof(w), hipMemcpyDeviceToHost, s));
+    QM_HIP(copy_back(h, val, sizeof(h), s));
+    QM_HIP(copy_back(w, e->d_fit_win.p, sizeof(w), s));
     if (norm_map && !out_on_device)
-        QM_HIP(hipMemcpyAsync(norm_map, d_norm, (size_t)n * sizeof(double),
-                              hipMemcpyDeviceToHost, s));
+        QM_HIP(copy_back(norm_map, d_norm, (size_t)n * sizeof(double), s));
     if (smoothed_map && !out_on_device)
-        QM_HIP(hipMemcpyAsync(smoothed_map, d_smooth, (size_t)n * sizeof(double),
-                              hipMemcpyDeviceToHost, s));
+        QM_HIP(copy_back(smoothed_map, d_smooth, (size_t)n * sizeof(double), s));
     QM_HIP(hipStreamSynchronize(s));
     if (h[1] < 0) return fail("qm_engine_locate_fits: the map holds no finite value");
     summary[0] = h[0];                      // nanmax of the input map
@@ -2434,7 +2501,7 @@ int qm_engine_rbf_peak(qm_engine *e, const double *weights, int32_t n, int32_t u
                        e->d_fit_pidx.p, NB, e->d_fit_val.p, e->d_fit_val.p + 1);
     QM_HIP(hipGetLastError());
     double h[2];
-    QM_HIP(hipMemcpyAsync(h, e->d_fit_val.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    QM_HIP(copy_back(h, e->d_fit_val.p, sizeof(h), s));
     QM_HIP(hipStreamSynchronize(s));
     if (h[1] < 0) return fail("qm_engine_rbf_peak: the interpolant holds no finite value");
     *peak_value = h[0];
@@ -2453,8 +2520,7 @@ int qm_exp2f_max_error(qm_engine *e, float lo, float hi, double *max_rel_error) 
                        e->d_fit_part.p);
     QM_HIP(hipGetLastError());
     std::vector<double> h(kBlocks);
-    QM_HIP(hipMemcpyAsync(h.data(), e->d_fit_part.p, kBlocks * sizeof(double),
-                          hipMemcpyDeviceToHost, e->stream));
+    QM_HIP(copy_back(h.data(), e->d_fit_part.p, kBlocks * sizeof(double), e->stream));
     QM_HIP(hipStreamSynchronize(e->stream));
     *max_rel_error = *std::max_element(h.begin(), h.end());
     return 0;

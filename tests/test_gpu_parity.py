@@ -2502,3 +2502,32 @@ def test_changing_availability_alternates_between_parked_tables(lib, oracle, dev
         if cache == 1:
             assert eng.get("table_evictions") >= 3 and eng.get("tables_parked") == 1
         eng.close()
+
+
+def test_host_volume_larger_than_the_bounce_buffer(lib, oracle):
+    """Results reach host memory through a 32 MB pinned bounce buffer (qm_engine.hip copy_back):
+    a 200 MB volume whole (one linear copy in seven pieces) and in time chunks (strided rows, several
+    row groups per chunk) is the device-resident volume; pre-filled with NaN."""
+    import torch
+
+    case = synth.make_case("C2", step=5, grid=(40, 40, 30), rows=12, n_samples=520)
+    lon = oracle.log_onsets(case.onsets)
+    n, ns = case.n_nodes_total, case.n_samples
+    assert n * ns * 8 > 2 * (32 << 20)
+    eng = lib.Engine(0)
+    eng.load_lut(case.traveltimes)
+    d_vol = torch.full((n, ns), float("nan"), dtype=torch.float64, device="cuda")
+    eng.migrate(torch.from_numpy(lon).cuda(), case.fsmp, case.lsmp, case.available, d_vol)
+    eng.synchronize()
+    want = d_vol.cpu().numpy()
+    assert not np.isnan(want).any()
+    series_want = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+    for chunk_bytes in (1 << 30, 24 << 20):
+        eng.config("chunk_bytes", chunk_bytes)
+        vol = np.full((n, ns), np.nan)
+        series = (np.full(ns, np.nan), np.full(ns, np.nan), np.full(ns, -1, dtype=np.int64))
+        eng.migrate(lon, case.fsmp, case.lsmp, case.available, vol, scan_out=series)
+        np.testing.assert_allclose(vol, want, rtol=1e-13, atol=0, err_msg=str(chunk_bytes))
+        assert all(np.array_equal(series[i], series_want[i]) for i in (0, 2))
+        np.testing.assert_allclose(series[1], series_want[1], rtol=1e-12)
+    eng.close()

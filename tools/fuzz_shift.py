@@ -22,6 +22,7 @@ from quakemigrate_amd.core import lib  # noqa: E402
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 used = wide = blocks = 0
+repeat = int(os.environ.get("QM_FUZZ_REPEAT", "1"))    # (with QM_FUZZ_ONLY: the trial's engine sequence this many times)
 for trial in range(trials):
     grid = tuple(int(v) for v in rng.integers(2, 34, size=3))
     if np.prod(grid) > 12000:
@@ -50,7 +51,14 @@ for trial in range(trials):
                shift=1 if 64 < S <= 96 else -1, shift_rows_direct=int(rng.integers(0, 3)),
                shift_tail=int(rng.integers(0, 2)))
     if os.environ.get("QM_FUZZ_ONLY") and trial != int(os.environ["QM_FUZZ_ONLY"]):
-        continue                                                    # (replay one trial of a seed)
+        # (replay one trial of a seed: the random stream has to advance as in the full run, including
+        # the draws the skipped checks would have made)
+        if trial % 3 == 0:
+            i0 = int(rng.integers(0, ns))
+            int(rng.integers(i0 + 1, ns + 1))
+        if trial % 5 == 0:
+            int(rng.integers(2, 4))
+        continue
     want = qm_oracle.detect(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True)
     if os.environ.get("QM_FUZZ_ONLY"):                              # ... with a diagnosis
         print("trial", trial, "grid", grid, "S", S, "ns", ns, "fsmp", fsmp, "lsmp", lsmp, "avail", avail, cfg)
@@ -64,48 +72,81 @@ for trial in range(trials):
                   "got idx", got[2][bad[:6]], "want idx", want[2][bad[:6]],
                   "got", got[0][bad[:4]], "want", want[0][bad[:4]])
             eng.close()
-    res = {}
-    for tag, extra in (("shift", {}), ("round2", {"shift": 0, "shift_lazy": -1})):
-        eng = lib.Engine(0, **{**cfg, **extra})
-        eng.load_lut(tt)
-        res[tag] = eng.detect(lon, fsmp, lsmp, avail)
-        res_first = res[tag]
-        if tag == "shift":
-            kern, nwide = eng.get("last_kernel"), eng.get("shift_wide_bricks")
-            ref = None
-            if trial % 4 == 0 or trial % 3 == 0:
-                ref = qm_oracle.c_migrate(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True)
-            if trial % 4 == 0:
-                vol = np.zeros(grid + (ns,))
-                series = (np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64))
-                eng.migrate(lon, fsmp, lsmp, avail, vol, scan_out=series)
-                np.testing.assert_allclose(vol, ref, rtol=1e-13, err_msg=str((trial, grid, S, ns)))
-                assert np.array_equal(series[2], want[2]), (trial, "volume scan idx")
-            if trial % 3 == 0:
-                i0 = int(rng.integers(0, ns))
-                i1 = int(rng.integers(i0 + 1, ns + 1))
-                series = (np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64))
-                m = eng.marginal_map(lon, fsmp, lsmp, avail, i0, i1, scan_out=series)
-                np.testing.assert_allclose(m, ref[..., i0:i1].sum(axis=-1), rtol=2e-12,
-                                           err_msg=str((trial, grid, S, ns, i0, i1, cfg)))
-                assert np.array_equal(series[2], want[2]) and np.array_equal(series[0], res_first[0]), \
-                    (trial, "marginal scan", cfg)
-            if trial % 5 == 0:
-                k = int(rng.integers(2, 4))
-                lons = np.stack([lon] + [np.roll(lon, 7 * (j + 1), axis=1) for j in range(k - 1)])
-                both = eng.detect_batch(lons, fsmp, lsmp, avail)
-                for j in range(k):
-                    one = eng.detect(lons[j], fsmp, lsmp, avail)
-                    assert all(np.array_equal(both[i][j], one[i]) for i in range(3)), (trial, "batch", j, cfg)
-        eng.close()
-    used += kern == 3
-    blocks += kern == 3 and S > 64
-    wide += kern == 3 and nwide > 0
-    a, b, c = res["shift"]
-    assert np.array_equal(c, want[2]), (trial, grid, S, ns, cfg, kern)
-    assert np.array_equal(c, res["round2"][2]) and np.array_equal(a, res["round2"][0]), (trial, grid, S, ns)
-    np.testing.assert_allclose(a, want[0], rtol=1e-13)
-    np.testing.assert_allclose(b, want[1], rtol=2e-12)   # degree-8 2^f: truncation 7.8e-13 + rounding
-    np.testing.assert_allclose(b, res["round2"][1], rtol=2e-12)
+    if trial % 3 == 0:                                              # (the draws of the checks below, in their order)
+        i0 = int(rng.integers(0, ns))
+        i1 = int(rng.integers(i0 + 1, ns + 1))
+    if trial % 5 == 0:
+        k = int(rng.integers(2, 4))
+    ref = None
+    if trial % 4 == 0 or trial % 3 == 0:
+        ref = qm_oracle.c_migrate(lon, tt, fsmp, lsmp, avail, threads=4, prelogged=True)
+    for rep in range(repeat if os.environ.get("QM_FUZZ_ONLY") else 1):
+        res = {}
+        for tag, extra in (("shift", {}), ("round2", {"shift": 0, "shift_lazy": -1})):
+            eng = lib.Engine(0, **{**cfg, **extra})
+            eng.load_lut(tt)
+            res[tag] = eng.detect(lon, fsmp, lsmp, avail)
+            res_first = res[tag]
+            if tag == "shift":
+                kern, nwide = eng.get("last_kernel"), eng.get("shift_wide_bricks")
+                if trial % 4 == 0:
+                    vol = np.zeros(grid + (ns,))
+                    series = (np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64))
+                    eng.migrate(lon, fsmp, lsmp, avail, vol, scan_out=series)
+                    if not np.allclose(vol, ref, rtol=1e-13, atol=0):
+                        bad = ~np.isclose(vol, ref, rtol=1e-13, atol=0)
+                        fv, fb = vol.reshape(-1, ns), bad.reshape(-1, ns)
+                        nodes = np.flatnonzero(fb.any(axis=1))
+                        cols = np.flatnonzero(fb.any(axis=0))
+                        print("VOLUME MISMATCH", trial, grid, S, ns, cfg, "kernel", eng.get("last_kernel"), "tail",
+                              eng.get("shift_tail_spl"), "waves", eng.get("shift_waves"), "blocks", eng.get("shift_row_blocks"),
+                              "wide", eng.get("shift_wide_bricks"), "\n nodes", len(nodes), nodes[:40], "\n samples", len(cols),
+                              cols[:8], "..", cols[-8:], "\n got", fv[nodes[0], cols[:6]], "want", ref.reshape(-1, ns)[nodes[0], cols[:6]],
+                              "\n node coords", [tuple(int(v) for v in np.unravel_index(n, grid)) for n in nodes[:24]], flush=True)
+                        flat = np.flatnonzero(bad.ravel())
+                        vol2 = np.zeros(grid + (ns,))
+                        eng.migrate(lon, fsmp, lsmp, avail, vol2)
+                        print("  flat elements", flat[0], "..", flat[-1], "count", flat.size, "byte offset of the first", flat[0] * 8,
+                              "base address mod 4096", vol.ctypes.data % 4096, "runs", 1 + int((np.diff(flat) > 1).sum()),
+                              "\n  a second migrate on the same engine matches the oracle:",
+                              bool(np.allclose(vol2, ref, rtol=1e-13, atol=0)), flush=True)
+                    np.testing.assert_allclose(vol, ref, rtol=1e-13, err_msg=str((trial, grid, S, ns)))
+                    assert np.array_equal(series[2], want[2]), (trial, "volume scan idx")
+                if trial % 3 == 0:
+                    series = (np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64))
+                    m = eng.marginal_map(lon, fsmp, lsmp, avail, i0, i1, scan_out=series)
+                    np.testing.assert_allclose(m, ref[..., i0:i1].sum(axis=-1), rtol=2e-12,
+                                               err_msg=str((trial, grid, S, ns, i0, i1, cfg)))
+                    assert np.array_equal(series[2], want[2]) and np.array_equal(series[0], res_first[0]), \
+                        (trial, "marginal scan", cfg)
+                if trial % 5 == 0:
+                    lons = np.stack([lon] + [np.roll(lon, 7 * (j + 1), axis=1) for j in range(k - 1)])
+                    both = eng.detect_batch(lons, fsmp, lsmp, avail)
+                    for j in range(k):
+                        one = eng.detect(lons[j], fsmp, lsmp, avail)
+                        assert all(np.array_equal(both[i][j], one[i]) for i in range(3)), (trial, "batch", j, cfg)
+            eng.close()
+        used += kern == 3
+        blocks += kern == 3 and S > 64
+        wide += kern == 3 and nwide > 0
+        a, b, c = res["shift"]
+        if not (np.array_equal(c, want[2]) and np.array_equal(c, res["round2"][2]) and np.array_equal(a, res["round2"][0])):
+            badt = np.flatnonzero((c != want[2]) | (a != res["round2"][0]) | (c != res["round2"][2]))
+            print("DETECT MISMATCH", trial, grid, S, ns, cfg, "kernel", kern, "bad samples", len(badt), badt[:16], "..", badt[-8:],
+                  "\n got idx", c[badt[:8]], "want", want[2][badt[:8]], "\n got max", a[badt[:4]], "round2", res["round2"][0][badt[:4]],
+                  "want", want[0][badt[:4]], "\n round2 idx", res["round2"][2][badt[:8]],
+                  "round2 vs oracle: idx", np.array_equal(res["round2"][2], want[2]), "max", np.allclose(res["round2"][0], want[0], rtol=1e-13),
+                  "shift vs oracle: max", np.allclose(a, want[0], rtol=1e-13), flush=True)
+            for tag, extra in (("shift", {}), ("round2", {"shift": 0, "shift_lazy": -1})):     # which one moves on a second run?
+                eng = lib.Engine(0, **{**cfg, **extra})
+                eng.load_lut(tt)
+                again = eng.detect(lon, fsmp, lsmp, avail)
+                print("  again", tag, "same as before:", [bool(np.array_equal(again[i], res[tag][i])) for i in range(3)], flush=True)
+                eng.close()
+        assert np.array_equal(c, want[2]), (trial, grid, S, ns, cfg, kern)
+        assert np.array_equal(c, res["round2"][2]) and np.array_equal(a, res["round2"][0]), (trial, grid, S, ns)
+        np.testing.assert_allclose(a, want[0], rtol=1e-13)
+        np.testing.assert_allclose(b, want[1], rtol=2e-12)   # degree-8 2^f: truncation 7.8e-13 + rounding
+        np.testing.assert_allclose(b, res["round2"][1], rtol=2e-12)
 print(f"{trials} trials ok; shift kernel used in {used} ({blocks} of them on row blocks), of which {wide} with "
       f"bricks on the direct kernel")
