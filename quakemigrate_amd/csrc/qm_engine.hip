@@ -85,11 +85,15 @@ void park_stream(int device, hipStream_t s) {
 std::mutex g_bounce_mutex;
 char *g_bounce = nullptr;
 constexpr size_t kBounceBytes = 32u << 20;
+hipError_t ensure_bounce() {                        // (caller holds g_bounce_mutex)
+    return g_bounce ? hipSuccess
+                    : hipHostMalloc(reinterpret_cast<void **>(&g_bounce), kBounceBytes,
+                                    hipHostMallocPortable);
+}
 hipError_t copy_back(void *dst, const void *src, size_t bytes, hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_bounce_mutex);
-    hipError_t r = hipSuccess;
-    if (!g_bounce && (r = hipHostMalloc(reinterpret_cast<void **>(&g_bounce), kBounceBytes)) != hipSuccess)
-        return r;
+    hipError_t r = ensure_bounce();
+    if (r != hipSuccess) return r;
     for (size_t at = 0; at < bytes; at += kBounceBytes) {
         const size_t n = std::min(kBounceBytes, bytes - at);
         r = hipMemcpyAsync(g_bounce, static_cast<const char *>(src) + at, n, hipMemcpyDeviceToHost, s);
@@ -111,9 +115,8 @@ hipError_t copy_back_2d(void *dst, size_t dpitch, const void *src, size_t spitch
         return hipSuccess;
     }
     std::lock_guard<std::mutex> lock(g_bounce_mutex);
-    hipError_t r = hipSuccess;
-    if (!g_bounce && (r = hipHostMalloc(reinterpret_cast<void **>(&g_bounce), kBounceBytes)) != hipSuccess)
-        return r;
+    hipError_t r = ensure_bounce();
+    if (r != hipSuccess) return r;
     const size_t rows_at_once = kBounceBytes / width;
     for (size_t row = 0; row < height; row += rows_at_once) {
         const size_t n = std::min(rows_at_once, height - row);
