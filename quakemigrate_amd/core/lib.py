@@ -272,7 +272,10 @@ class Engine:
         if not hasattr(self, "_tables"):
             self._tables = {}
         if self._current_key is not None:
+            self._tables.pop(self._current_key, None)           # (most recent last)
             self._tables[self._current_key] = (self.grid, self.n_rows, self.node_offset)
+            while len(self._tables) > 256:                      # shapes of long-evicted tables
+                self._tables.pop(next(iter(self._tables)))
         resident = c_int32()
         _check(qmlib.qm_engine_table_select(self._h, k64, int(capacity), ctypes.byref(resident)))
         self._current_key = k64

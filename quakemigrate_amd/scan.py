@@ -29,11 +29,29 @@ obspy / pyproj are not needed here: whatever ``data.starttime`` and
 
 from __future__ import annotations
 
+import itertools
 import logging
 
 import numpy as np
 
 from quakemigrate_amd.core import lib
+
+
+_LUT_TOKENS = itertools.count(1)
+
+
+def _lut_token(lut):
+    """A process-unique name for ``lut`` in the keys of parked tables (``id()`` would be reused by a
+    later object at the same address and bring a dead LUT's table back): kept on the object where
+    it takes attributes, else the caller gets a fresh one (no sharing between scans)."""
+    token = getattr(lut, "_qm_hip_token", None)
+    if token is None:
+        token = next(_LUT_TOKENS)
+        try:
+            lut._qm_hip_token = token
+        except (AttributeError, TypeError):
+            pass
+    return token
 
 
 class LUTPhasesException(Exception):
@@ -86,6 +104,7 @@ class MigrationScan:
         # the setting is applied around each call and the engine's own restored afterwards (the
         # default engine is shared by every MigrationScan and by lib.migrate_and_find_max)
         self.screen = None if screen is None else bool(screen)
+        self._lut_token = _lut_token(lut)
         self._resident_key = None
         self._resident_generation = -1
         self._grids_generation = -1
@@ -112,7 +131,7 @@ class MigrationScan:
         # its table generation moves whenever anybody replaces or switches the table)
         if key == self._resident_key and eng.table_generation == self._resident_generation:
             return eng
-        if eng.select_table((id(self.lut), key), capacity=self.table_cache):
+        if eng.select_table((self._lut_token, key), capacity=self.table_cache):
             self._resident_key, self._resident_generation = key, eng.table_generation
             return eng
         if self.device_serving:

@@ -178,6 +178,20 @@ def test_scan_glue_shapes_and_errors(built):
     with pytest.raises(scan.LUTPhasesException, match="phases"):
         s._compute(object())
 
+    # parked tables are keyed by a process-unique name of the LUT object, not id() (a later object
+    # at a dead LUT's address must not bring its table back): one per object, shared by the scans
+    # over the same object; an object that takes no attributes gets a fresh one per scan
+    lut_a, lut_b = Lut(), Lut()
+    ta = scan.MigrationScan(lut_a, Onset(), 1.0, 2.0, engine=NoEngine())._lut_token
+    assert scan.MigrationScan(lut_a, Onset(), 1.0, 2.0, engine=NoEngine())._lut_token == ta
+    assert scan.MigrationScan(lut_b, Onset(), 1.0, 2.0, engine=NoEngine())._lut_token != ta
+
+    class Slotted:
+        __slots__ = ()
+    frozen = Slotted()
+    assert (scan.MigrationScan(frozen, Onset(), 1.0, 2.0, engine=NoEngine())._lut_token
+            != scan.MigrationScan(frozen, Onset(), 1.0, 2.0, engine=NoEngine())._lut_token)
+
 
 # ---------------------------------------------------------------------------------
 # world_size-2 exchange on CPU (gloo): per-shard partials come from the oracle (the
