@@ -87,6 +87,10 @@ typedef struct qm_engine qm_engine;
 const char *qm_last_error(void);
 /* number of HIP devices visible, or -1 */
 int qm_device_count(void);
+/* Device memory released by engines (destroyed engines, replaced tables) is parked in the process
+ * and reused by the next request of its size (up to 8 GB stay parked); this returns all of it to
+ * the driver.  Always 0. */
+int qm_release_cached_memory(void);
 
 int qm_engine_create(int device_id, qm_engine **out);
 void qm_engine_destroy(qm_engine *e);

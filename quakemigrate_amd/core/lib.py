@@ -61,6 +61,8 @@ qmlib.qm_table_hash.restype = None
 qmlib.qm_table_hash.argtypes = [ctypes.c_void_p, c_int64, ctypes.POINTER(ctypes.c_uint64),
                                 ctypes.POINTER(ctypes.c_uint64)]
 qmlib.qm_engine_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
+qmlib.qm_release_cached_memory.argtypes = []
+qmlib.qm_release_cached_memory.restype = ctypes.c_int
 qmlib.qm_engine_destroy.argtypes = [_vp]
 qmlib.qm_engine_destroy.restype = None
 qmlib.qm_engine_set_stream.argtypes = [_vp, _vp, ctypes.c_int]
@@ -606,6 +608,12 @@ def timeit(*args_, **kwargs_):
 # quakemigrate_amd.scan.MigrationScan) and never pay for the hash either.
 # --------------------------------------------------------------------------
 _default = {"engine": None, "table_key": None}
+
+
+def release_cached_memory():
+    """Return the device memory that destroyed engines / replaced tables left parked in the process
+    (``qm_release_cached_memory``) to the driver."""
+    qmlib.qm_release_cached_memory()
 
 
 def default_engine():

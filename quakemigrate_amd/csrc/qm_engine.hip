@@ -130,21 +130,151 @@ hipError_t copy_back_2d(void *dst, size_t dpitch, const void *src, size_t spitch
     return hipSuccess;
 }
 
+// ... and inputs the same way in the other direction: the caller's buffer is copied into the pinned
+// buffer by the CPU before the call returns (so it may be a temporary), the device copy is waited for.
+hipError_t copy_in(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_bounce_mutex);
+    hipError_t r = ensure_bounce();
+    if (r != hipSuccess) return r;
+    for (size_t at = 0; at < bytes; at += kBounceBytes) {
+        const size_t n = std::min(kBounceBytes, bytes - at);
+        std::memcpy(g_bounce, static_cast<const char *>(src) + at, n);
+        r = hipMemcpyAsync(static_cast<char *>(dst) + at, g_bounce, n, hipMemcpyHostToDevice, s);
+        if (r == hipSuccess) r = hipStreamSynchronize(s);
+        if (r != hipSuccess) return r;
+    }
+    return hipSuccess;
+}
+hipError_t copy_in_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width,
+                      size_t height, hipStream_t s) {
+    if (width == dpitch && width == spitch) return copy_in(dst, src, width * height, s);
+    if (width > kBounceBytes) {                     // (rows longer than the buffer: one by one)
+        for (size_t row = 0; row < height; ++row) {
+            const hipError_t r = copy_in(static_cast<char *>(dst) + row * dpitch,
+                                         static_cast<const char *>(src) + row * spitch, width, s);
+            if (r != hipSuccess) return r;
+        }
+        return hipSuccess;
+    }
+    std::lock_guard<std::mutex> lock(g_bounce_mutex);
+    hipError_t r = ensure_bounce();
+    if (r != hipSuccess) return r;
+    const size_t rows_at_once = kBounceBytes / width;
+    for (size_t row = 0; row < height; row += rows_at_once) {
+        const size_t n = std::min(rows_at_once, height - row);
+        for (size_t i = 0; i < n; ++i)
+            std::memcpy(g_bounce + i * width, static_cast<const char *>(src) + (row + i) * spitch, width);
+        r = hipMemcpy2DAsync(static_cast<char *>(dst) + row * dpitch, dpitch, g_bounce, width, width, n,
+                             hipMemcpyHostToDevice, s);
+        if (r == hipSuccess) r = hipStreamSynchronize(s);
+        if (r != hipSuccess) return r;
+    }
+    return hipSuccess;
+}
+
+// Device memory is recycled inside the process: a released block is parked and handed to the next
+// request of (about) its size instead of going back to the driver -- what every long-running GPU
+// runtime does, here for a reason found the hard way (round 4, profiles/r04_host_copy_study.txt):
+// with 16 processes sharing the GPU, an engine made, used once and destroyed in a loop returned wrong
+// maxima on 10-100 % of the samples about once per 1e4 engines (two in 21 000, the round-2 kernels on
+// a fresh engine; none in 220 000 steps of ONE engine under the same sharing) -- results of kernels
+// that read buffers another kernel had just written into freshly mapped memory.  With recycled
+// blocks the address space of a process stops changing after its first engines.  The blocks of a
+// destroyed engine stay parked up to kPoolKeepBytes (beyond it the largest go back to the driver);
+// qm_release_cached_memory() returns them all.
+struct PoolBlock {
+    int device;
+    size_t bytes;
+    void *p;
+};
+std::mutex g_pool_mutex;
+std::vector<PoolBlock> g_pool_idle, g_pool_live;
+size_t g_pool_idle_bytes = 0;
+constexpr size_t kPoolKeepBytes = (size_t)8 << 30;
+
+void pool_trim_locked(size_t keep) {
+    while (g_pool_idle_bytes > keep && !g_pool_idle.empty()) {
+        size_t big = 0;
+        for (size_t i = 1; i < g_pool_idle.size(); ++i)
+            if (g_pool_idle[i].bytes > g_pool_idle[big].bytes) big = i;
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        if (prev != g_pool_idle[big].device) (void)hipSetDevice(g_pool_idle[big].device);
+        (void)hipFree(g_pool_idle[big].p);
+        if (prev >= 0 && prev != g_pool_idle[big].device) (void)hipSetDevice(prev);
+        g_pool_idle_bytes -= g_pool_idle[big].bytes;
+        g_pool_idle.erase(g_pool_idle.begin() + (long)big);
+    }
+}
+
+// (the caller has made the engine's device current)
+hipError_t pool_alloc(void **out, size_t bytes) {
+    const size_t unit = bytes < ((size_t)1 << 20) ? 256 : (size_t)2 << 20;
+    const size_t want = (std::max<size_t>(bytes, 1) + unit - 1) / unit * unit;
+    int device = 0;
+    hipError_t r = hipGetDevice(&device);
+    if (r != hipSuccess) return r;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        size_t best = g_pool_idle.size();
+        for (size_t i = 0; i < g_pool_idle.size(); ++i) {
+            const PoolBlock &b = g_pool_idle[i];
+            if (b.device != device || b.bytes < want || b.bytes > want + want / 4) continue;
+            if (best == g_pool_idle.size() || b.bytes < g_pool_idle[best].bytes) best = i;
+        }
+        if (best != g_pool_idle.size()) {
+            *out = g_pool_idle[best].p;
+            g_pool_idle_bytes -= g_pool_idle[best].bytes;
+            g_pool_live.push_back(g_pool_idle[best]);
+            g_pool_idle.erase(g_pool_idle.begin() + (long)best);
+            return hipSuccess;
+        }
+    }
+    r = hipMalloc(out, want);
+    if (r != hipSuccess) {                              // make room: everything parked goes back
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lock(g_pool_mutex);
+            pool_trim_locked(0);
+        }
+        r = hipMalloc(out, want);
+        if (r != hipSuccess) return r;
+    }
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pool_live.push_back(PoolBlock{device, want, *out});
+    return hipSuccess;
+}
+
+void pool_free(void *p) {
+    // as hipFree: nothing that was enqueued before may still be using the block when somebody else gets it
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (size_t i = 0; i < g_pool_live.size(); ++i) {
+        if (g_pool_live[i].p != p) continue;
+        g_pool_idle.push_back(g_pool_live[i]);
+        g_pool_idle_bytes += g_pool_live[i].bytes;
+        g_pool_live.erase(g_pool_live.begin() + (long)i);
+        pool_trim_locked(kPoolKeepBytes);
+        return;
+    }
+    (void)hipFree(p);                                   // (not one of ours: cannot happen)
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
     int ensure(size_t count) {
         if (count <= n) return 0;
-        if (p) (void)hipFree(p);
+        if (p) pool_free(p);
         p = nullptr;
         n = 0;
-        QM_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+        QM_HIP(pool_alloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
         n = count;
         return 0;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) pool_free(p);
         p = nullptr;
         n = 0;
     }
@@ -375,8 +505,7 @@ int plan_wide(qm_engine *e, int J) {
     e->n_wide = (int)wide.size();
     if (e->n_wide) {
         if (e->d_wide.ensure(wide.size())) return 1;
-        QM_HIP(hipMemcpyAsync(e->d_wide.p, wide.data(), wide.size() * sizeof(int32_t),
-                              hipMemcpyHostToDevice, e->stream));
+        QM_HIP(copy_in(e->d_wide.p, wide.data(), wide.size() * sizeof(int32_t), e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
     }
     e->plan_j = J;
@@ -542,8 +671,7 @@ int ensure_pair_tables(qm_engine *e, int jp) {
     e->pair_ok = fixed ? (int)wide.size() < g.nbricks : (int64_t)wide.size() * 200 <= g.nbricks;
     if (e->n_pwide) {
         if (e->d_pwide.ensure(wide.size())) return 1;
-        QM_HIP(hipMemcpyAsync(e->d_pwide.p, wide.data(), wide.size() * sizeof(int32_t),
-                              hipMemcpyHostToDevice, e->stream));
+        QM_HIP(copy_in(e->d_pwide.p, wide.data(), wide.size() * sizeof(int32_t), e->stream));
     }
     if (e->pair_ok) {
         if (e->d_prel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;
@@ -726,8 +854,7 @@ int build_shift_tables(qm_engine *e) {
     const int64_t words = (int64_t)g.nbricks * nw * nblk * qm::shift_recs_per_wave(g, rows2, nw) *
                           (qm::shift_rec_bytes(blocks) / 4);
     if (blocks)                                          // per-brick verdicts for the kernels
-        QM_HIP(hipMemcpyAsync(e->d_shfit.p, fit.data(), (size_t)g.nbricks * sizeof(int32_t),
-                              hipMemcpyHostToDevice, e->stream));
+        QM_HIP(copy_in(e->d_shfit.p, fit.data(), (size_t)g.nbricks * sizeof(int32_t), e->stream));
     // (+ slack: the loop loads one record past a wavefront's run and touches the line 16 records
     // ahead with its L2 prefetch -- after the last run of the last brick that is past the stream)
     if (e->d_shstream.ensure((size_t)words + 4096)) return 1;
@@ -742,8 +869,7 @@ int build_shift_tables(qm_engine *e) {
     e->n_shwide = (int)wide.size();
     if (e->n_shwide) {
         if (e->d_shwide.ensure(wide.size())) return 1;
-        QM_HIP(hipMemcpyAsync(e->d_shwide.p, wide.data(), wide.size() * sizeof(int32_t),
-                              hipMemcpyHostToDevice, e->stream));
+        QM_HIP(copy_in(e->d_shwide.p, wide.data(), wide.size() * sizeof(int32_t), e->stream));
     }
     QM_HIP(hipStreamSynchronize(e->stream));           // `wide` is a stack-lifetime buffer
     e->d_shraw.release();
@@ -1157,8 +1283,7 @@ int ensure_screen_tables(qm_engine *e, const ScreenPlan &plan) {
     e->n_swide = (int)wide.size();
     if (e->n_swide) {
         if (e->d_swide.ensure(wide.size())) return 1;
-        QM_HIP(hipMemcpyAsync(e->d_swide.p, wide.data(), wide.size() * sizeof(int32_t),
-                              hipMemcpyHostToDevice, e->stream));
+        QM_HIP(copy_in(e->d_swide.p, wide.data(), wide.size() * sizeof(int32_t), e->stream));
     }
     if (e->d_srel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;
     hipLaunchKernelGGL(qm::screen_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
@@ -1422,8 +1547,7 @@ int stage_onsets(qm_engine *e, const double *onsets, int on_device, int T, const
     }
     const size_t n = (size_t)e->g.n_rows * T;
     if (e->d_onsets.ensure(n)) return 1;
-    QM_HIP(hipMemcpyAsync(e->d_onsets.p, onsets, n * sizeof(double), hipMemcpyHostToDevice,
-                          e->stream));
+    QM_HIP(copy_in(e->d_onsets.p, onsets, n * sizeof(double), e->stream));
     *out = e->d_onsets.p;
     return 0;
 }
@@ -1459,6 +1583,12 @@ int fetch_out(qm_engine *e, int n, int out_on_device, const OutStage &st, double
 extern "C" {
 
 const char *qm_last_error(void) { return g_error.c_str(); }
+
+int qm_release_cached_memory(void) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    pool_trim_locked(0);
+    return 0;
+}
 
 int qm_device_count(void) {
     int n = 0;
@@ -1700,9 +1830,11 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     e->have_lut = false;
     const size_t lut_elems = (size_t)n_nodes * n_rows;
     if (e->d_lut.ensure(lut_elems) || e->d_scalar.ensure(4)) return 1;
-    QM_HIP(hipMemcpyAsync(e->d_lut.p, lut, lut_elems * sizeof(int32_t),
-                          lut_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                          e->stream));
+    if (lut_on_device)
+        QM_HIP(hipMemcpyAsync(e->d_lut.p, lut, lut_elems * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                              e->stream));
+    else
+        QM_HIP(copy_in(e->d_lut.p, lut, lut_elems * sizeof(int32_t), e->stream));
 
     // Brick shape: the configured one, or (brick_x == 0) the largest candidate whose windows fit
     // the LDS budget for (almost) every brick -- larger bricks amortise window staging, smaller
@@ -1910,10 +2042,11 @@ int qm_engine_grids_set(qm_engine *e, int32_t index, const double *grid, int on_
     if (index < 0 || index >= e->g_rows) return fail("grid index %d out of range", index);
     DeviceGuard guard(e->device);
     const size_t n = (size_t)e->gx * e->gy * e->gz;
-    QM_HIP(hipMemcpyAsync(e->d_grids.p + (size_t)index * n, grid, n * sizeof(double),
-                          on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                          e->stream));
-    if (!on_device) QM_HIP(hipStreamSynchronize(e->stream));
+    if (on_device)
+        QM_HIP(hipMemcpyAsync(e->d_grids.p + (size_t)index * n, grid, n * sizeof(double),
+                              hipMemcpyDeviceToDevice, e->stream));
+    else
+        QM_HIP(copy_in(e->d_grids.p + (size_t)index * n, grid, n * sizeof(double), e->stream));
     return 0;
 }
 
@@ -1938,8 +2071,7 @@ int qm_engine_serve(qm_engine *e, double sampling_rate, const int32_t *rows, int
     a.rate = sampling_rate;
     const int64_t n_out = (int64_t)a.nx * a.ny * a.nz;
     if (e->d_rows.ensure(n_rows) || e->d_served.ensure((size_t)n_out * n_rows)) return 1;
-    QM_HIP(hipMemcpyAsync(e->d_rows.p, rows, n_rows * sizeof(int32_t), hipMemcpyHostToDevice,
-                          e->stream));
+    QM_HIP(copy_in(e->d_rows.p, rows, n_rows * sizeof(int32_t), e->stream));
     a.grids = e->d_grids.p;
     a.rows = e->d_rows.p;
     a.out = e->d_served.p;
@@ -2054,8 +2186,7 @@ int qm_engine_detect_batch(qm_engine *e, const double *log_onsets, int onsets_on
     const double *d_on = log_onsets;
     if (!onsets_on_device) {
         if (e->d_onsets.ensure(per_step * n_steps)) return 1;
-        QM_HIP(hipMemcpyAsync(e->d_onsets.p, log_onsets, per_step * n_steps * sizeof(double),
-                              hipMemcpyHostToDevice, e->stream));
+        QM_HIP(copy_in(e->d_onsets.p, log_onsets, per_step * n_steps * sizeof(double), e->stream));
         d_on = e->d_onsets.p;
     }
     const int n_all = n_steps * ns;
@@ -2116,9 +2247,9 @@ int qm_engine_migrate(qm_engine *e, const double *log_onsets, int onsets_on_devi
         for (int k0 = 0; k0 < ns; k0 += (int)chunk) {
             const int nk = (int)std::min<int64_t>(chunk, ns - k0);
             if (accumulate)
-                QM_HIP(hipMemcpy2DAsync(e->d_chunk.p, nk * sizeof(double), map4d + k0,
+                QM_HIP(copy_in_2d(e->d_chunk.p, nk * sizeof(double), map4d + k0,
                                         (size_t)ns * sizeof(double), nk * sizeof(double),
-                                        e->n_nodes, hipMemcpyHostToDevice, e->stream));
+                                        e->n_nodes, e->stream));
             if (run_stack(e, d_on, T, fsmp, ns, available, k0, nk, e->d_chunk.p, nk, accumulate,
                           want_scan, &sets))
                 return 1;
@@ -2201,8 +2332,7 @@ int qm_engine_onsets(qm_engine *e, const double *signals, int signals_on_device,
     const double *d_sig = signals;
     if (!signals_on_device) {
         if (e->d_sig.ensure(sig)) return 1;
-        QM_HIP(hipMemcpyAsync(e->d_sig.p, signals, sig * sizeof(double), hipMemcpyHostToDevice,
-                              e->stream));
+        QM_HIP(copy_in(e->d_sig.p, signals, sig * sizeof(double), e->stream));
         d_sig = e->d_sig.p;
     }
     if (e->d_sta.ensure(sig) || e->d_lta.ensure(sig) ||
@@ -2211,8 +2341,7 @@ int qm_engine_onsets(qm_engine *e, const double *signals, int signals_on_device,
     std::vector<int32_t> meta(trace_row, trace_row + n_traces);
     meta.insert(meta.end(), nsta, nsta + n_rows);
     meta.insert(meta.end(), nlta, nlta + n_rows);
-    QM_HIP(hipMemcpyAsync(e->d_onset_meta.p, meta.data(), meta.size() * sizeof(int32_t),
-                          hipMemcpyHostToDevice, e->stream));
+    QM_HIP(copy_in(e->d_onset_meta.p, meta.data(), meta.size() * sizeof(int32_t), e->stream));
     QM_HIP(hipStreamSynchronize(e->stream));            // `meta` is a stack-lifetime buffer
     qm::OnsetArgs a{};
     a.signals = d_sig;
@@ -2296,9 +2425,9 @@ int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
         if (e->d_chunk.ensure((size_t)n_nodes * chunk)) return 1;
         for (int k0 = 0; k0 < n_samples; k0 += (int)chunk) {
             const int nk = (int)std::min<int64_t>(chunk, n_samples - k0);
-            QM_HIP(hipMemcpy2DAsync(e->d_chunk.p, nk * sizeof(double), map4d + k0,
+            QM_HIP(copy_in_2d(e->d_chunk.p, nk * sizeof(double), map4d + k0,
                                     (size_t)n_samples * sizeof(double), nk * sizeof(double),
-                                    n_nodes, hipMemcpyHostToDevice, e->stream));
+                                    n_nodes, e->stream));
             if (scan(e->d_chunk.p, nk, nk, k0)) return 1;
             QM_HIP(hipStreamSynchronize(e->stream));
         }
@@ -2362,8 +2491,7 @@ int qm_engine_locate_fits(qm_engine *e, const double *coa_map, int map_on_device
     hipStream_t s = e->stream;
     const double *d_in = coa_map;
     if (!map_on_device) {
-        QM_HIP(hipMemcpyAsync(e->d_fit_c.p, coa_map, (size_t)n * sizeof(double),
-                              hipMemcpyHostToDevice, s));
+        QM_HIP(copy_in(e->d_fit_c.p, coa_map, (size_t)n * sizeof(double), s));
         d_in = e->d_fit_c.p;
     }
     double *val = e->d_fit_val.p;
@@ -2493,8 +2621,7 @@ int qm_engine_rbf_peak(qm_engine *e, const double *weights, int32_t n, int32_t u
         e->d_fit_part.ensure((size_t)NB * 6) || e->d_fit_pidx.ensure(NB) || e->d_fit_val.ensure(32))
         return 1;
     hipStream_t s = e->stream;
-    QM_HIP(hipMemcpyAsync(e->d_fit_win.p, weights, (size_t)n * n * n * sizeof(double),
-                          hipMemcpyHostToDevice, s));
+    QM_HIP(copy_in(e->d_fit_win.p, weights, (size_t)n * n * n * sizeof(double), s));
     hipLaunchKernelGGL(qm::rbf_dense_kernel, dim3((unsigned)((fine + BS - 1) / BS)), dim3(BS), 0, s,
                        (const double *)e->d_fit_win.p, (int)n, m, (double)(n - 1) / (double)(m - 1),
                        e->d_fit_a.p);

@@ -2505,7 +2505,8 @@ def test_changing_availability_alternates_between_parked_tables(lib, oracle, dev
 
 
 def test_host_volume_larger_than_the_bounce_buffer(lib, oracle):
-    """Results reach host memory through a 32 MB pinned bounce buffer (qm_engine.hip copy_back):
+    """Results reach host memory -- and inputs the device -- through a 32 MB pinned bounce buffer
+    (qm_engine.hip copy_back / copy_in):
     a 200 MB volume whole (one linear copy in seven pieces) and in time chunks (strided rows, several
     row groups per chunk) is the device-resident volume; pre-filled with NaN."""
     import torch
@@ -2530,4 +2531,10 @@ def test_host_volume_larger_than_the_bounce_buffer(lib, oracle):
         np.testing.assert_allclose(vol, want, rtol=1e-13, atol=0, err_msg=str(chunk_bytes))
         assert all(np.array_equal(series[i], series_want[i]) for i in (0, 2))
         np.testing.assert_allclose(series[1], series_want[1], rtol=1e-12)
+        # ... and INTO the device the same way (the reference's `+=` on a volume that holds something,
+        # migratelib.c:57: the stack starts from the caller's values): exp((0.25 + sum) / available)
+        vol = np.full((n, ns), 0.25)
+        eng.migrate(lon, case.fsmp, case.lsmp, case.available, vol, accumulate=True)
+        np.testing.assert_allclose(vol, want * np.exp(0.25 / case.available), rtol=1e-12, atol=0,
+                                   err_msg=str(chunk_bytes))
     eng.close()
