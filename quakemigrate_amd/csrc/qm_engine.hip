@@ -50,16 +50,15 @@ int fail(const char *fmt, ...) {
                         __LINE__);                                                           \
     } while (0)
 
-// Two habits that come from one observation (round 4; DESIGN.md section 6, profiles/r04_host_copy_*).
-// With 16 processes sharing the GPU and an engine made per call, about one call in 1e4 returned
-// host outputs that still held zeros in part: results handed to hipMemcpyAsync as a pageable host
-// pointer went missing (the round-2 kernels and the shift kernels alike; a wait in front of the copy
-// changed nothing; one process alone: never seen).  Through a pinned bounce buffer: 0 of 57 600
-// trials where the two batches before had 5 each.  Independently, a program of two trivial kernels, a
-// copy and hipStreamSynchronize that creates a stream per call reads stale data about once per 4e4
-// calls under the same sharing, and never on a long-lived stream (tools/micro/d2h_order.hip).  So:
-// an engine's own stream comes from a per-device pool and goes back to it (pooled streams are never
-// destroyed), and results travel to host memory through pinned memory.
+// Three habits that come from one study (round 4; DESIGN.md section 6, profiles/r04_gpu_sharing_study.txt):
+// with 16 processes sharing the GPU and an engine made per call, about one call in 1e4 went wrong --
+// host outputs with holes (the runtime's copy into the caller's pageable memory), wrong values from
+// an engine's first step (freshly allocated device memory), and, in a program without this library,
+// stale data behind a stream created per call (tools/micro/d2h_order.hip).  One process alone, or
+// one long-lived engine under the same sharing: never.  So an engine's own stream comes from a
+// per-device pool and goes back to it (pooled streams are never destroyed), inputs and results
+// travel between host and device memory through pinned memory (below), and device memory is
+// recycled (pool_alloc).
 std::mutex g_stream_mutex;
 std::vector<std::pair<int, hipStream_t>> g_idle_streams;
 hipError_t acquire_stream(int device, hipStream_t *out) {
@@ -174,7 +173,7 @@ hipError_t copy_in_2d(void *dst, size_t dpitch, const void *src, size_t spitch, 
 
 // Device memory is recycled inside the process: a released block is parked and handed to the next
 // request of (about) its size instead of going back to the driver -- what every long-running GPU
-// runtime does, here for a reason found the hard way (round 4, profiles/r04_host_copy_study.txt):
+// runtime does, here for a reason found the hard way (round 4, profiles/r04_gpu_sharing_study.txt):
 // with 16 processes sharing the GPU, an engine made, used once and destroyed in a loop returned wrong
 // maxima on 10-100 % of the samples about once per 1e4 engines (two in 21 000, the round-2 kernels on
 // a fresh engine; none in 220 000 steps of ONE engine under the same sharing) -- results of kernels
