@@ -2538,3 +2538,23 @@ def test_host_volume_larger_than_the_bounce_buffer(lib, oracle):
         np.testing.assert_allclose(vol, want * np.exp(0.25 / case.available), rtol=1e-12, atol=0,
                                    err_msg=str(chunk_bytes))
     eng.close()
+
+
+def test_engines_made_and_destroyed_reuse_device_memory(lib, oracle):
+    """Device memory of destroyed engines is parked in the process and handed to the next engine
+    (qm_engine.hip pool_alloc): a run of engines over two tables of different
+    size -- each made, used once, destroyed -- returns the oracle's series every time, also right
+    after the parked blocks went back to the driver (``release_cached_memory``)."""
+    cases = [synth.make_case("C2", step=1, grid=(21, 17, 12), rows=9, n_samples=300),
+             synth.make_case("C2", step=2, grid=(12, 11, 9), rows=70, n_samples=130)]
+    lons = [oracle.log_onsets(c.onsets) for c in cases]
+    wants = [oracle.detect(c.onsets, c.traveltimes, c.fsmp, c.lsmp, c.available, threads=4) for c in cases]
+    for i in range(12):
+        k = i % 2
+        case = cases[k]
+        eng = lib.Engine(0, shift=0 if i % 3 == 0 else -1)
+        eng.load_lut(case.traveltimes)
+        _assert_series(eng.detect(lons[k], case.fsmp, case.lsmp, case.available), wants[k])
+        eng.close()
+        if i == 7:
+            lib.release_cached_memory()
