@@ -9,7 +9,9 @@ group counts: the automatic engine against Engine(shift=0) (maxima bit for bit, 
 oracle; every fourth trial also the volume-writing variant against the oracle's volume, every third
 the marginalised map of a random window against the time sum of that volume, every fifth a batch of
 two or three timesteps in one launch against the steps one by one.
-usage: fuzz_shift.py [trials] [seed]"""
+On a mismatch the trial's diagnosis is printed before the assertion (which kernel, which nodes and
+samples, whether a second run moves): the round-4 GPU-sharing study started from these lines.
+usage: fuzz_shift.py [trials] [seed]      (QM_FUZZ_ONLY=trial [QM_FUZZ_REPEAT=n]: that trial of the seed only)"""
 import os
 import sys
 
