@@ -18,10 +18,11 @@
  * failure; qm_last_error() returns a thread-local message.  `*_on_device`
  * flags say whether a pointer is host memory (synchronous, copied internally)
  * or device memory on the engine's GPU (asynchronous on the engine stream).
- * Host OUTPUTS may be any memory, pageable included: results are moved through a
- * pinned buffer of the library's own and copied with the CPU, the caller's
- * pointer is never handed to the HIP runtime.  An engine's
- * private stream comes from a per-device pool and returns to it.
+ * Host buffers may be any memory, pageable included: inputs and results are moved
+ * through a pinned buffer of the library's own and copied with the CPU, the
+ * caller's pointers are never handed to the HIP runtime.
+ * An engine's private stream and its device memory come from process-wide pools
+ * and return to them (qm_release_cached_memory()).
  * Layouts are the reference's: onsets f64 [n_rows][T] (already log(clip)),
  * travel-times i32 [nx][ny][nz][n_rows] (C order, flat node = (ix*ny+iy)*nz+iz,
  * quakemigrate/lut/lut.py:165-166), volume f64 [n_nodes][n_samples].
