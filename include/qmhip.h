@@ -329,6 +329,31 @@ int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
                            double *max_norm_coa, int64_t *max_coa_idx,
                            int out_on_device);
 
+/* ------------------------------------------------------------------ part 3 */
+/* The continuous detect sweep as a pipeline -- the hot-path part of the loop of
+ * QuakeScan._continuous_compute (quakemigrate/signal/scan.py:434-448: one timestep after the other:
+ * onsets -> migrate -> find_max_coa -> append), with host-resident onsets going in and the three
+ * series coming out per timestep.  A ring of `depth` slots of `steps_per_launch` timesteps each;
+ * qm_stream_push copies one timestep's log-onsets (host f64 [n_rows][t_samples], the resident table's
+ * row count) into pinned memory and, when a slot is full, enqueues its H2D copy (own stream), ONE
+ * fused-detect launch for its timesteps on the engine's stream (qm_engine_detect_batch: every
+ * timestep's bits are the single-step call's) and ONE D2H copy of the packed results (own stream);
+ * nothing waits.  qm_stream_pop hands out the results of the oldest timesteps in push order and is the
+ * only call that blocks (for the launch they belong to).
+ * qm_stream_push returns 0, or 2 when every slot holds results that have not been popped (pop, then
+ * push again), or 1 on error.  qm_stream_flush launches a partly filled slot (end of the data).
+ * The engine's table, stream and tunables must not change while a stream exists on it. */
+typedef struct qm_stream qm_stream;
+int qm_stream_create(qm_engine *e, int32_t t_samples, int32_t fsmp, int32_t lsmp, int32_t available,
+                     int64_t n_nodes_total, int32_t steps_per_launch, int32_t depth, qm_stream **out);
+void qm_stream_destroy(qm_stream *s);
+int qm_stream_push(qm_stream *s, const double *log_onsets);
+int qm_stream_flush(qm_stream *s);
+/* the next n_steps timesteps (<= launched and not yet popped): host f64 / f64 / i64 [n_steps][n_samples] */
+int qm_stream_pop(qm_stream *s, int32_t n_steps, double *max_coa, double *max_norm_coa,
+                  int64_t *max_coa_idx);
+int qm_stream_pending(qm_stream *s, int32_t *launched_not_popped, int32_t *pushed_not_launched);
+
 /* Duration (ms, HIP events on the engine stream) of the stacking kernel(s) of
  * the most recent detect / migrate call; negative if none.  Synchronises. */
 int qm_engine_last_kernel_ms(qm_engine *e, double *ms);

@@ -112,6 +112,14 @@ qmlib.qm_engine_find_max_coa.argtypes = [_vp, _vp, ctypes.c_int, c_int32,
                                          c_int64, _vp, _vp, _vp, ctypes.c_int]
 qmlib.qm_exp2f_max_error.argtypes = [_vp, ctypes.c_float, ctypes.c_float,
                                      ctypes.POINTER(ctypes.c_double)]
+qmlib.qm_stream_create.argtypes = [_vp, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32, c_int32,
+                                   ctypes.POINTER(_vp)]
+qmlib.qm_stream_destroy.argtypes = [_vp]
+qmlib.qm_stream_destroy.restype = None
+qmlib.qm_stream_push.argtypes = [_vp, _vp]
+qmlib.qm_stream_flush.argtypes = [_vp]
+qmlib.qm_stream_pop.argtypes = [_vp, c_int32, _vp, _vp, _vp]
+qmlib.qm_stream_pending.argtypes = [_vp, ctypes.POINTER(c_int32), ctypes.POINTER(c_int32)]
 qmlib.qm_engine_last_kernel_ms.argtypes = [_vp, ctypes.POINTER(ctypes.c_double)]
 qmlib.qm_engine_kernel_log.argtypes = [_vp, ctypes.POINTER(ctypes.c_double),
                                        ctypes.POINTER(c_int32)]
@@ -252,12 +260,19 @@ class Engine:
             raise ValueError("traveltimes must have shape (nx, ny, nz, n_rows)")
         p, dev = self._ptr(traveltimes, np.int32)
         nx, ny, nz, rows = (int(v) for v in shape)
+        self._foreign_load()
         _check(qmlib.qm_engine_load_lut(self._h, p, dev, nx, ny, nz, rows,
                                         int(node_offset)))
         self.grid = (nx, ny, nz)
         self.n_rows = rows
         self.node_offset = int(node_offset)
         self.table_generation += 1
+
+    def _foreign_load(self):
+        """A load on top of a resident table (no ``select_table`` miss in between) replaces it and
+        does not inherit its key -- the C side un-keys it the same way (qm_engine_load_lut)."""
+        if self.grid is not None:
+            self._current_key = None
 
     def select_table(self, key, capacity=4):
         """
@@ -313,6 +328,7 @@ class Engine:
         """
         rows = np.ascontiguousarray(rows, dtype=np.int32)
         dfx, dfy, dfz = (int(v) for v in decimate)
+        self._foreign_load()
         _check(qmlib.qm_engine_serve(self._h, float(sampling_rate), rows, len(rows), dfx, dfy,
                                      dfz, int(node_offset)))
         self.grid = (self.get("nx"), self.get("ny"), self.get("nz"))
@@ -601,7 +617,7 @@ def timeit(*args_, **kwargs_):
 # --------------------------------------------------------------------------
 # module-level engine for the reference-signature functions.  They receive the
 # table on every call (lib.py:53-60); like the C symbols beside them
-# (qm_engine.hip: migrate) they keep it resident and upload it again only when
+# (qm_compat.hip: migrate) they keep it resident and upload it again only when
 # its shape or content -- two independent 64-bit hashes of every word,
 # qm_table_hash -- changes (QM_HIP_COMPAT_REUPLOAD=1: on every call).  Callers
 # that keep a table across timesteps use an Engine (or

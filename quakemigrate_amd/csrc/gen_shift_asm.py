@@ -18,14 +18,16 @@ kShiftPlane bytes above A.  Lane l's window quad m (registers 4m .. 4m+3 = sampl
 e0 + 4l + 4m ..) is then ONE aligned ds_read_b128 per plane at slot e0/4 + l + m: conflict-free,
 consecutive registers, half the LDS instructions of 8-byte reads.
 
-Stream format (built once per table, qm_shift.hpp): per (brick, wave) a contiguous run of 64-byte
+Stream format (built once per table, qm_shift.hpp): per (brick, wave) a contiguous run of 32-byte
 records: a lead-in record, one record per (group, row) with rows padded to an even count, one
-trailing pad.  Record of row r:
-    dwords 0..7   idx[g] = 2 * (delay_g - e0_r)     register offset of node g's first operand
-    dwords 8, 9   header of row r + 1 (the lead-in carries row 0's; the last row's is harmless):
+trailing pad.  Record of row r (round 5: every loop reads this "packed" form; QM_SHIFT_PACKED=0
+generates the 64-byte form of rounds 3-4 with the eight indices as dwords 0..7, header 8-9, 10-11):
+    dwords 0, 1   idx[g] = 2 * (delay_g - e0_r), the register offset of node g's first operand, as
+                  byte g of the pair (nodes 0-3 in dword 0, nodes 4-7 in dword 1)
+    dwords 2, 3   header of row r + 1 (the lead-in carries row 0's; the last row's is harmless):
                   LDS byte offset of plane A's slot e0/4 of that row; its quad count (2 .. NQMAX)
-    dwords 10, 11 row 0 of a group only: flat index of the group's first node, valid-node mask
-One s_load_dwordx16 per row, issued one row ahead; the window is read one row ahead into the other
+    dwords 4, 5   row 0 of a group only: flat index of the group's first node, valid-node mask
+One s_load_dwordx8 per row, issued one row ahead; the window is read one row ahead into the other
 of two register windows (rows unrolled by two).
 
 Round 4 adds two things to the same loop.
@@ -59,12 +61,16 @@ NQMAX = int(os.environ.get("QM_SHIFT_NQMAX", "6"))    # window = 4 * NQMAX doubl
 NQMIN = int(os.environ.get("QM_SHIFT_NQMIN", "4"))    # quads fetched unconditionally
 WMAX = 4 * NQMAX
 # Record size.  64 bytes: the eight register indices as dwords.  32 bytes ("packed"): as bytes of two
-# dwords -- six more SALU shifts per row, half the stream and half the scalar-load bytes.  Measured
-# (profiles/r04_ab_runs.txt): the loops that process all groups of a brick per call lose 1 % with
-# packed records (C3 detect 45.8 -> 46.3 ms), the row-block loops -- one group per call, the lead-in
-# loads exposed -- gain 5 % (128 rows 59.3 -> 56.5 ms): each takes the form that suits it.
-PACKED_GROUPS = os.environ.get("QM_SHIFT_PACKED", "0") == "1"
+# dwords (nodes 0-3, nodes 4-7) -- half the stream, half the scalar-load bytes, 16 fewer hard SGPRs.
+# Round 4 shifted each dword on its own (six more SALU per row): the row-block loops gained 5 % (128
+# rows 59.3 -> 56.5 ms), the loops that take all groups of a brick per call lost 1 % (C3 detect 45.8 ->
+# 46.3 ms) and kept 64-byte records.  Round 5: the two dwords are ONE 64-bit scalar, shifted once per
+# node PAIR (nodes g and g + 4 are added back to back: three s_lshr_b64 per row) -- C3 detect 45.7 vs
+# 45.7 ms, the C3 locate volume 5.42 -> 5.26, the C4 slab 176.4 -> 175.0 (profiles/r05_ab_runs.txt):
+# every loop now reads 32-byte records, a table's stream is 4 S bytes per node -- the table's own size.
+PACKED_GROUPS = os.environ.get("QM_SHIFT_PACKED", "1") == "1"
 PACKED_BLOCKS = os.environ.get("QM_SHIFT_PACKED_BLOCKS", "1") == "1"
+PACKED_SHIFT64 = os.environ.get("QM_SHIFT_PACKED_SHIFT64", "1") == "1"   # round 5: see node_adds
 
 
 def rec_bytes(packed):
@@ -81,6 +87,7 @@ STATE_CHUNK = 1024       # running state in LDS: 5 chunks of 64 lanes x 16 bytes
 VB_BLOCK = 80            # first hard VGPR of the row-block flavour
 BUTTERFLY = os.environ.get("QM_SHIFT_BUTTERFLY", "1") == "1"   # marginal map: the eight nodes of a whole group
                                                               # summed over the wavefront together
+VOLUME_DEGREE = int(os.environ.get("QM_SHIFT_VOL_DEGREE", "10"))   # 2^f of stored values (qm_kernels.hpp: QM_EXP2_DEGREE_VOLUME)
 MARGINAL_DEGREE = 8      # 2^f of the marginalised map's terms: the polynomial of the running sums (7.8e-13), every
                          # term positive -- the map inherits at most that (tests: 1e-12)
 
@@ -242,16 +249,28 @@ def issue_window(e, q, hdr):
     e(f"{done}:")
 
 
+def node_order():
+    """order in which a row's eight nodes are added (each has its own accumulators: any order gives the
+    same sums).  Packed records: nodes g and g + 4 sit in the same byte of the record's two index
+    dwords, so they are taken together and ONE 64-bit shift moves both dwords to the next pair."""
+    return (0, 4, 1, 5, 2, 6, 3, 7) if PACKED and PACKED_SHIFT64 else tuple(range(8))
+
+
 def node_adds(e, p, g, first):
     first = first and not BLOCK          # (row blocks: the accumulators are zeroed, or carry on)
     if "noidx" in EXP:
         e("s_nop 0")
     else:
         if PACKED:
-            # the record packs the eight indices as bytes of two dwords; the instruction takes bits
-            # [7:0] of its operand, so nodes 0 and 4 use the dword as it is and the others shift it
+            # the record packs the eight indices as bytes of two dwords (nodes 0-3, nodes 4-7); the
+            # instruction takes bits [7:0] of its operand, so nodes 0 and 4 use the dwords as they
+            # are; round 5: the pair of dwords is shifted as ONE 64-bit scalar before nodes (1, 5),
+            # (2, 6), (3, 7) -- three SALU instructions per row instead of six
             reg = BUF[p] + g // 4
-            if g % 4:
+            if PACKED_SHIFT64:
+                if g in (1, 2, 3):
+                    e(f"s_lshr_b64 {s2(BUF[p])}, {s2(BUF[p])}, 8")
+            elif g % 4:
                 e(f"s_lshr_b32 s{reg}, s{reg}, 8")
             e(f"s_set_gpr_idx_on s{reg}, 1")
         else:
@@ -289,11 +308,11 @@ def row_iter(e, p, first):
             if nq > NQMIN:
                 e(f"{labels[nq]}:")
             pending = [r for m in range(nq) for r in quad_reads(WIN[q], m)]
-            for g in range(8):
+            for pos, g in enumerate(node_order()):
                 node_adds(e, p, g, first)
-                for r in pending[2 * g:2 * g + 2]:
+                for r in pending[2 * pos:2 * pos + 2]:
                     e(r)
-                if g == 6 and PF_AHEAD:
+                if pos == 6 and PF_AHEAD:
                     e(f"global_load_dword v{VPF}, v{VZERO}, {s2(SPF)}")
                     e(f"s_add_u32 s{SPF}, s{SPF}, {REC}")
                     e(f"s_addc_u32 s{SPF + 1}, s{SPF + 1}, 0")
@@ -302,9 +321,9 @@ def row_iter(e, p, first):
         e(f"{end}:")
         return
     issue_window(e, q, hdr)
-    for g in range(8):
+    for pos, g in enumerate(node_order()):
         node_adds(e, p, g, first)
-        if g == 3 and PF_AHEAD:
+        if pos == 3 and PF_AHEAD:
             # pull the record PF_AHEAD rows ahead into L2 with a vector load nobody waits for (its
             # own counter, vmcnt): the scalar load then finds it there instead of in HBM
             e(f"global_load_dword v{VPF}, v{VZERO}, {s2(SPF)}")
@@ -835,19 +854,20 @@ def main():
     print(f"constexpr bool kShiftPackedGroups = {'true' if PACKED_GROUPS else 'false'};   // 32-byte records (register indices as bytes)")
     print(f"constexpr bool kShiftPackedBlocks = {'true' if PACKED_BLOCKS else 'false'};   // ... of the row-block loops")
     print(f"constexpr int kShiftBlockVgprs = {VB_BLOCK};   // row-block flavour: the compiler's own code stays below")
+    print(f"constexpr int kShiftVolumeDegree = {VOLUME_DEGREE};   // 2^f polynomial of the volume-writing flavours")
     print(f"constexpr int kShiftMarginalDegree = {MARGINAL_DEGREE};   // 2^f polynomial of the marginal-map flavours")
     for degree, volume, lds_state, far, lazy, block, name in (
             (8, False, False, False, False, False, "shift_groups_detect"),
             (8, False, False, False, True, False, "shift_groups_detect_lazy"),
-            (10, True, False, False, False, False, "shift_groups_volume"),
+            (VOLUME_DEGREE, True, False, False, False, False, "shift_groups_volume"),
             (8, False, True, False, False, False, "shift_groups_detect3"),
             (8, False, False, True, False, False, "shift_groups_detect8"),
             (8, False, False, True, True, False, "shift_groups_detect8_lazy"),
-            (10, True, False, True, False, False, "shift_groups_volume8"),
+            (VOLUME_DEGREE, True, False, True, False, False, "shift_groups_volume8"),
             (8, False, False, True, False, True, "shift_group_rows8"),
             (8, False, False, False, False, True, "shift_group_rows"),
             (8, False, False, False, True, True, "shift_group_rows_lazy"),
-            (10, True, False, False, False, True, "shift_group_rows_volume")):
+            (VOLUME_DEGREE, True, False, False, False, True, "shift_group_rows_volume")):
         emit(degree, volume, lds_state, far, lazy, block, name)
     # round 4: the marginalised map on full tiles (both workgroup shapes) ...
     emit(MARGINAL_DEGREE, True, False, False, False, False, "shift_groups_marginal", marginal=True)
@@ -855,7 +875,7 @@ def main():
     # ... and the tail tiles: 1, 2, 3 samples per lane, contiguous row windows (either shape)
     for spl in (1, 2, 3):
         emit(8, False, False, False, False, False, f"shift_tail{spl}_detect", spl, True)
-        emit(10, True, False, False, False, False, f"shift_tail{spl}_volume", spl, True)
+        emit(VOLUME_DEGREE, True, False, False, False, False, f"shift_tail{spl}_volume", spl, True)
         emit(MARGINAL_DEGREE, True, False, False, False, False, f"shift_tail{spl}_marginal", spl, True, True)
 
 

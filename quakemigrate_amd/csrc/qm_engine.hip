@@ -1,525 +1,13 @@
-// qm_engine.hip -- host runtime + C ABI (include/qmhip.h) of the gfx950 migration engine.
+// qm_engine.hip -- the engine handle and the steps (C ABI part 2, include/qmhip.h).
 //
-// One engine = one GPU.  It keeps the travel-time table resident together with the per-brick
-// window tables derived from it, owns the scratch for partial reductions, and launches the
-// kernels of qm_kernels.hpp on a caller-supplied (e.g. torch) or private HIP stream.
-// Nothing here falls back to the CPU: if HIP fails, the call fails.
-#include "../../include/qmhip.h"
-
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
-
-#define QM_ENGINE_TU 1
-#include "qm_kernels.hpp"
-#include "qm_launch.hpp"
-#include "qm_locate.hpp"
-#include "qm_screen.hpp"
-#include "qm_pair.hpp"
-#include "qm_shift.hpp"
+// One engine = one GPU.  It keeps the travel-time table resident together with the tables derived
+// from it (qm_tables.hip), owns the scratch for partial reductions, and launches the stacking kernels
+// (qm_launch_*.hip) on a caller-supplied (e.g. torch) or private HIP stream.  Nothing here falls back
+// to the CPU: if HIP fails, the call fails.
+#define QM_TU_STEPS 1
+#include "qm_engine.hpp"
 
 namespace {
-
-thread_local std::string g_error;
-
-int fail(const char *fmt, ...) {
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    g_error = buf;
-    return 1;
-}
-
-#define QM_HIP(call)                                                                         \
-    do {                                                                                     \
-        hipError_t err__ = (call);                                                           \
-        if (err__ != hipSuccess)                                                             \
-            return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__,   \
-                        __LINE__);                                                           \
-    } while (0)
-
-// Three habits that come from one study (round 4; DESIGN.md section 6, profiles/r04_gpu_sharing_study.txt):
-// with 16 processes sharing the GPU and an engine made per call, about one call in 1e4 went wrong --
-// host outputs with holes (the runtime's copy into the caller's pageable memory), wrong values from
-// an engine's first step (freshly allocated device memory), and, in a program without this library,
-// stale data behind a stream created per call (tools/micro/d2h_order.hip).  One process alone, or
-// one long-lived engine under the same sharing: never.  So an engine's own stream comes from a
-// per-device pool and goes back to it (pooled streams are never destroyed), inputs and results
-// travel between host and device memory through pinned memory (below), and device memory is
-// recycled (pool_alloc).
-std::mutex g_stream_mutex;
-std::vector<std::pair<int, hipStream_t>> g_idle_streams;
-hipError_t acquire_stream(int device, hipStream_t *out) {
-    {
-        std::lock_guard<std::mutex> lock(g_stream_mutex);
-        for (size_t i = 0; i < g_idle_streams.size(); ++i)
-            if (g_idle_streams[i].first == device) {
-                *out = g_idle_streams[i].second;
-                g_idle_streams.erase(g_idle_streams.begin() + (long)i);
-                return hipSuccess;
-            }
-    }
-    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-}
-void park_stream(int device, hipStream_t s) {
-    std::lock_guard<std::mutex> lock(g_stream_mutex);
-    g_idle_streams.emplace_back(device, s);
-}
-
-// Results travel back to the host through a pinned bounce buffer (one per process, 32 MB, never
-// freed) and a CPU memcpy.  Both calls return when the data is in place.  (The statistics-only flag
-// ring of the screened sweep is pinned memory of its own and stays asynchronous.)
-std::mutex g_bounce_mutex;
-char *g_bounce = nullptr;
-constexpr size_t kBounceBytes = 32u << 20;
-hipError_t ensure_bounce() {                        // (caller holds g_bounce_mutex)
-    return g_bounce ? hipSuccess
-                    : hipHostMalloc(reinterpret_cast<void **>(&g_bounce), kBounceBytes,
-                                    hipHostMallocPortable);
-}
-hipError_t copy_back(void *dst, const void *src, size_t bytes, hipStream_t s) {
-    std::lock_guard<std::mutex> lock(g_bounce_mutex);
-    hipError_t r = ensure_bounce();
-    if (r != hipSuccess) return r;
-    for (size_t at = 0; at < bytes; at += kBounceBytes) {
-        const size_t n = std::min(kBounceBytes, bytes - at);
-        r = hipMemcpyAsync(g_bounce, static_cast<const char *>(src) + at, n, hipMemcpyDeviceToHost, s);
-        if (r == hipSuccess) r = hipStreamSynchronize(s);
-        if (r != hipSuccess) return r;
-        std::memcpy(static_cast<char *>(dst) + at, g_bounce, n);
-    }
-    return hipSuccess;
-}
-hipError_t copy_back_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width,
-                        size_t height, hipStream_t s) {
-    if (width == dpitch && width == spitch) return copy_back(dst, src, width * height, s);
-    if (width > kBounceBytes) {                     // (rows longer than the buffer: one by one)
-        for (size_t row = 0; row < height; ++row) {
-            const hipError_t r = copy_back(static_cast<char *>(dst) + row * dpitch,
-                                           static_cast<const char *>(src) + row * spitch, width, s);
-            if (r != hipSuccess) return r;
-        }
-        return hipSuccess;
-    }
-    std::lock_guard<std::mutex> lock(g_bounce_mutex);
-    hipError_t r = ensure_bounce();
-    if (r != hipSuccess) return r;
-    const size_t rows_at_once = kBounceBytes / width;
-    for (size_t row = 0; row < height; row += rows_at_once) {
-        const size_t n = std::min(rows_at_once, height - row);
-        r = hipMemcpy2DAsync(g_bounce, width, static_cast<const char *>(src) + row * spitch, spitch,
-                             width, n, hipMemcpyDeviceToHost, s);
-        if (r == hipSuccess) r = hipStreamSynchronize(s);
-        if (r != hipSuccess) return r;
-        for (size_t i = 0; i < n; ++i)
-            std::memcpy(static_cast<char *>(dst) + (row + i) * dpitch, g_bounce + i * width, width);
-    }
-    return hipSuccess;
-}
-
-// ... and inputs the same way in the other direction: the caller's buffer is copied into the pinned
-// buffer by the CPU before the call returns (so it may be a temporary), the device copy is waited for.
-hipError_t copy_in(void *dst, const void *src, size_t bytes, hipStream_t s) {
-    std::lock_guard<std::mutex> lock(g_bounce_mutex);
-    hipError_t r = ensure_bounce();
-    if (r != hipSuccess) return r;
-    for (size_t at = 0; at < bytes; at += kBounceBytes) {
-        const size_t n = std::min(kBounceBytes, bytes - at);
-        std::memcpy(g_bounce, static_cast<const char *>(src) + at, n);
-        r = hipMemcpyAsync(static_cast<char *>(dst) + at, g_bounce, n, hipMemcpyHostToDevice, s);
-        if (r == hipSuccess) r = hipStreamSynchronize(s);
-        if (r != hipSuccess) return r;
-    }
-    return hipSuccess;
-}
-hipError_t copy_in_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width,
-                      size_t height, hipStream_t s) {
-    if (width == dpitch && width == spitch) return copy_in(dst, src, width * height, s);
-    if (width > kBounceBytes) {                     // (rows longer than the buffer: one by one)
-        for (size_t row = 0; row < height; ++row) {
-            const hipError_t r = copy_in(static_cast<char *>(dst) + row * dpitch,
-                                         static_cast<const char *>(src) + row * spitch, width, s);
-            if (r != hipSuccess) return r;
-        }
-        return hipSuccess;
-    }
-    std::lock_guard<std::mutex> lock(g_bounce_mutex);
-    hipError_t r = ensure_bounce();
-    if (r != hipSuccess) return r;
-    const size_t rows_at_once = kBounceBytes / width;
-    for (size_t row = 0; row < height; row += rows_at_once) {
-        const size_t n = std::min(rows_at_once, height - row);
-        for (size_t i = 0; i < n; ++i)
-            std::memcpy(g_bounce + i * width, static_cast<const char *>(src) + (row + i) * spitch, width);
-        r = hipMemcpy2DAsync(static_cast<char *>(dst) + row * dpitch, dpitch, g_bounce, width, width, n,
-                             hipMemcpyHostToDevice, s);
-        if (r == hipSuccess) r = hipStreamSynchronize(s);
-        if (r != hipSuccess) return r;
-    }
-    return hipSuccess;
-}
-
-// Device memory is recycled inside the process: a released block is parked and handed to the next
-// request of (about) its size instead of going back to the driver -- what every long-running GPU
-// runtime does, here for a reason found the hard way (round 4, profiles/r04_gpu_sharing_study.txt):
-// with 16 processes sharing the GPU, an engine made, used once and destroyed in a loop returned wrong
-// maxima on 10-100 % of the samples about once per 1e4 engines (two in 21 000, the round-2 kernels on
-// a fresh engine; none in 220 000 steps of ONE engine under the same sharing) -- results of kernels
-// that read buffers another kernel had just written into freshly mapped memory.  With recycled
-// blocks the address space of a process stops changing after its first engines.  The blocks of a
-// destroyed engine stay parked up to kPoolKeepBytes (beyond it the largest go back to the driver);
-// qm_release_cached_memory() returns them all.
-struct PoolBlock {
-    int device;
-    size_t bytes;
-    void *p;
-};
-std::mutex g_pool_mutex;
-std::vector<PoolBlock> g_pool_idle, g_pool_live;
-size_t g_pool_idle_bytes = 0;
-constexpr size_t kPoolKeepBytes = (size_t)8 << 30;
-
-void pool_trim_locked(size_t keep) {
-    while (g_pool_idle_bytes > keep && !g_pool_idle.empty()) {
-        size_t big = 0;
-        for (size_t i = 1; i < g_pool_idle.size(); ++i)
-            if (g_pool_idle[i].bytes > g_pool_idle[big].bytes) big = i;
-        int prev = -1;
-        (void)hipGetDevice(&prev);
-        if (prev != g_pool_idle[big].device) (void)hipSetDevice(g_pool_idle[big].device);
-        (void)hipFree(g_pool_idle[big].p);
-        if (prev >= 0 && prev != g_pool_idle[big].device) (void)hipSetDevice(prev);
-        g_pool_idle_bytes -= g_pool_idle[big].bytes;
-        g_pool_idle.erase(g_pool_idle.begin() + (long)big);
-    }
-}
-
-// (the caller has made the engine's device current)
-hipError_t pool_alloc(void **out, size_t bytes) {
-    const size_t unit = bytes < ((size_t)1 << 20) ? 256 : (size_t)2 << 20;
-    const size_t want = (std::max<size_t>(bytes, 1) + unit - 1) / unit * unit;
-    int device = 0;
-    hipError_t r = hipGetDevice(&device);
-    if (r != hipSuccess) return r;
-    {
-        std::lock_guard<std::mutex> lock(g_pool_mutex);
-        size_t best = g_pool_idle.size();
-        for (size_t i = 0; i < g_pool_idle.size(); ++i) {
-            const PoolBlock &b = g_pool_idle[i];
-            if (b.device != device || b.bytes < want || b.bytes > want + want / 4) continue;
-            if (best == g_pool_idle.size() || b.bytes < g_pool_idle[best].bytes) best = i;
-        }
-        if (best != g_pool_idle.size()) {
-            *out = g_pool_idle[best].p;
-            g_pool_idle_bytes -= g_pool_idle[best].bytes;
-            g_pool_live.push_back(g_pool_idle[best]);
-            g_pool_idle.erase(g_pool_idle.begin() + (long)best);
-            return hipSuccess;
-        }
-    }
-    r = hipMalloc(out, want);
-    if (r != hipSuccess) {                              // make room: everything parked goes back
-        (void)hipGetLastError();
-        {
-            std::lock_guard<std::mutex> lock(g_pool_mutex);
-            pool_trim_locked(0);
-        }
-        r = hipMalloc(out, want);
-        if (r != hipSuccess) return r;
-    }
-    std::lock_guard<std::mutex> lock(g_pool_mutex);
-    g_pool_live.push_back(PoolBlock{device, want, *out});
-    return hipSuccess;
-}
-
-void pool_free(void *p) {
-    // as hipFree: nothing that was enqueued before may still be using the block when somebody else gets it
-    (void)hipDeviceSynchronize();
-    std::lock_guard<std::mutex> lock(g_pool_mutex);
-    for (size_t i = 0; i < g_pool_live.size(); ++i) {
-        if (g_pool_live[i].p != p) continue;
-        g_pool_idle.push_back(g_pool_live[i]);
-        g_pool_idle_bytes += g_pool_live[i].bytes;
-        g_pool_live.erase(g_pool_live.begin() + (long)i);
-        pool_trim_locked(kPoolKeepBytes);
-        return;
-    }
-    (void)hipFree(p);                                   // (not one of ours: cannot happen)
-}
-
-template <typename T>
-struct DevBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    int ensure(size_t count) {
-        if (count <= n) return 0;
-        if (p) pool_free(p);
-        p = nullptr;
-        n = 0;
-        QM_HIP(pool_alloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
-        n = count;
-        return 0;
-    }
-    void release() {
-        if (p) pool_free(p);
-        p = nullptr;
-        n = 0;
-    }
-};
-
-}  // namespace
-
-// Everything that is derived from ONE travel-time table: the table itself, its brick records and
-// window offsets, the layouts of the paired / screened / shift-reuse kernels built from it on first
-// use, and the launch shape the table's layout search picked.  The engine works on the state it
-// inherits; qm_engine_table_select parks it in a slot and brings another one in (a swap of pointers:
-// no device work), so that a change of station availability -- a different served table,
-// lut.py:529-537 -- costs a rebuild only the first time that table is seen.
-struct TableState {
-    bool have_lut = false;
-    qm::GridDesc g{};
-    int64_t n_nodes = 0;
-    int64_t node_offset = 0;
-    int32_t lut_max = 0;
-    int n_rows_hint = 0;            // row count the automatic choice is based on
-    int auto_j = 0;                 // samples per lane picked by the table's layout search (> 64 rows)
-    int tab_waves = 0, tab_lds_bytes = 0;   // workgroup shape the layout search picked (0: none yet)
-    DevBuf<int32_t> d_lut, d_bmeta, d_btotal, d_wide;
-    DevBuf<uint16_t> d_rel;
-    bool rel_built = false;         // d_rel holds this table's offsets (built on first use)
-    std::vector<int32_t> h_btotal;
-    int n_wide = 0;
-    int plan_j = -1, plan_cap = -1;
-
-    // float32 screening (qm_screen.hpp): staggered-copy offset table
-    DevBuf<int32_t> d_smeta, d_smeta_raw, d_stotal, d_swide;
-    qm::GridDesc sg{};                      // the sweep's own brick grid
-    DevBuf<uint16_t> d_srel;
-    int n_swide = 0;
-    int screen_kt = 0, screen_wb = 0;       // what the screening table was built for
-
-    // paired (16-byte operand) layout of the float64 kernel (qm_pair.hpp): own brick grid
-    qm::GridDesc pg{};
-    DevBuf<int32_t> d_pmeta, d_pmeta_raw, d_ptotal, d_pwide;
-    DevBuf<uint16_t> d_prel;
-    int n_pwide = 0;
-    int pair_kt = 0;                        // tile length the paired tables were built for
-    bool pair_ok = false;                   // ... and whether (almost) every brick fits
-
-    // shift-reuse layout of the fused float64 detect (qm_shift.hpp): own brick grid, row-window
-    // slots, record stream
-    int shift_nw = 0;                       // workgroup shape the tables were built for
-    qm::GridDesc shg{};
-    DevBuf<int32_t> d_shraw, d_shmeta, d_shtotal, d_shfit, d_shwide;
-    DevBuf<uint32_t> d_shstream;
-    int n_shwide = 0, shift_rows2 = 0;
-    int shift_nblk = 1, shift_sb = 0;       // row blocks (tables of more than 64 rows): blocks, rows per block
-    bool shift_direct = false;              // ... staged by LDS-direct loads (stack_shift_rows2_kernel)
-    bool shift_quad = false;                // ... by two 4-wave workgroups per CU (stack_shift_rows4_kernel)
-    bool shift_built = false, shift_ok = false;
-    int64_t shift_quads = 0, shift_group_rows = 0;   // register-window quads fetched / (group, row)s
-
-    void release_all() {
-        d_lut.release(); d_bmeta.release(); d_btotal.release(); d_wide.release(); d_rel.release();
-        d_smeta.release(); d_smeta_raw.release(); d_stotal.release(); d_swide.release(); d_srel.release();
-        d_pmeta.release(); d_pmeta_raw.release(); d_ptotal.release(); d_pwide.release(); d_prel.release();
-        d_shraw.release(); d_shmeta.release(); d_shtotal.release(); d_shfit.release();
-        d_shwide.release(); d_shstream.release();
-    }
-    size_t device_bytes() const {
-        return (d_lut.n + d_bmeta.n + d_btotal.n + d_wide.n + d_smeta.n + d_smeta_raw.n + d_stotal.n +
-                d_swide.n + d_pmeta.n + d_pmeta_raw.n + d_ptotal.n + d_pwide.n + d_shraw.n + d_shmeta.n +
-                d_shtotal.n + d_shfit.n + d_shwide.n + d_shstream.n) * 4 +
-               (d_rel.n + d_srel.n + d_prel.n) * 2;
-    }
-};
-
-struct TableSlot {
-    TableState state;
-    uint64_t key = 0;
-    uint64_t stamp = 0;             // last use (the engine's table clock): the oldest slot is evicted
-    bool used = false;
-};
-
-struct qm_engine : TableState {
-    int device = 0;
-    int n_cu = 256;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-    // optional per-call timing log (bench): pairs of events around every stacking launch
-    bool log_timing = false;
-    std::vector<hipEvent_t> ev_log;     // 2 events per recorded call
-    size_t ev_used = 0;
-
-    // parked tables (qm_engine_table_select) and the key of the one being worked on
-    std::vector<TableSlot> slots;
-    uint64_t cur_key = 0, table_clock = 0;
-    bool cur_keyed = false;
-    int64_t table_hits = 0, table_misses = 0, table_evictions = 0;
-
-    // tunables
-    int cfg_bx = 0, cfg_by = 0, cfg_bz = 0;      // 0 = choose the brick shape per table
-    int cfg_j = 0;                  // samples per lane (time tile = 64*J); 0 = by table width
-    int cfg_waves = 8;
-    bool user_waves = false, user_lds = false;   // set explicitly: no automatic layout
-    int cfg_groups = 0;
-    int cfg_rounds = 12;            // automatic group count: grid = this many rounds over the slots
-    bool user_rounds = false;       // ... set explicitly
-    int cfg_lds_bytes = 80 * 1024;
-    int cfg_force_direct = 0;
-    int cfg_generic = 0;            // 1 = always the generic (any row count) LDS kernel
-    int cfg_scan_waves = 32;        // find_max_coa of a volume: wavefronts per CU over the whole grid
-    int cfg_exact = 1;              // 1 = the exact-row-count kernel where one is built (see
-                                    //     qm_launch.hpp), 0 = the chunked kernels only
-    int64_t cfg_chunk_bytes = (int64_t)4 << 30;
-    int cfg_pair = 1;               // 1 = the 16-byte-operand kernel (qm_pair.hpp) where it applies
-    int cfg_screen = 0;             // 1 (opt-in): detect = float32 screening sweep + exact float64
-                                    // refinement (qm_screen.hpp); 0: every node-sample in float64
-    int cfg_screen_pairs = 0;       // pairs of samples per lane in the sweep (0 = automatic)
-    int cfg_screen_brick16 = 0;     // also try 16x8x8 bricks for the sweep
-    int cfg_screen_big = -1;        // 1: one 16-wave workgroup per CU with 160 KB of LDS; -1 = automatic
-    int cfg_shift = -1;                     // -1: where the table qualifies, 0: never, 1: as -1 (explicit)
-    int cfg_shift_waves = 0;                // workgroup shape: 4 (two per CU), 12 (one per CU), 0 = automatic
-    int cfg_shift_lazy = -1;                // detect loop flavour: -1 automatic, 0 eager, 1 lazy arg-max
-    int cfg_shift_tail = 1;                 // 1: a scan's remainder of <= 192 samples runs as one tail tile of
-                                            // 64 / 128 / 192 samples; 0: whole tiles only (round 3)
-    int cfg_shift_rows_direct = 1;
-
-    // per-step scratch of the screened detect (qm_screen.hpp) and its statistics
-    DevBuf<int32_t> d_scalar, d_counts, d_cells, d_work, d_flags;
-    DevBuf<int32_t> d_onq, d_cell, d_gmax, d_pm, d_sparams;
-    DevBuf<double> d_rowmax, d_ssum, d_cand_z;
-    DevBuf<int64_t> d_cand_idx;
-    int64_t screened_steps = 0, fallback_steps = 0, last_candidates = 0;
-    int last_plan_jp = 0, last_plan_big = 0;
-    int last_kernel = 0, last_j = 0;        // stacking kernel of the last launch: 0 chunked, 1 exact-row-count, 2 paired
-    int32_t *h_flags = nullptr;             // pinned ring of per-step (flags, candidates) pairs
-    int flags_pending = 0, flags_head = 0;  // not yet folded into the counters
-    int shift_lazy_last = 0;                // loop flavour the last shift-reuse launch took
-    int shift_tail_last = 0;                // samples per lane of the last launch's tail tile (0: none)
-    int last_batched = 1;                   // timesteps the last detect_batch put into one launch
-
-    // float64 travel-time grids in seconds (optional; on-device table serving)
-    DevBuf<double> d_grids;
-    DevBuf<int32_t> d_rows, d_served;
-    int gx = 0, gy = 0, gz = 0, g_rows = 0;
-
-    // onset stage scratch
-    DevBuf<double> d_sig, d_sta, d_lta, d_raw;
-    DevBuf<int32_t> d_onset_meta;
-
-    // scratch
-    DevBuf<double> d_onsets, d_pmax, d_psum, d_out_a, d_out_b, d_chunk, d_marg, d_marg_out;
-    int marg_tiles = 0;             // time tiles of the last marginal-map launch (rows of d_marg)
-    DevBuf<int64_t> d_pidx, d_out_i;
-    // locate fits: three map-sized work buffers, reduction partials, device-side scalars
-    DevBuf<double> d_fit_a, d_fit_b, d_fit_c, d_fit_part, d_fit_val, d_fit_win;
-    DevBuf<int64_t> d_fit_pidx;
-};
-
-namespace {
-
-struct DeviceGuard {
-    int prev = -1;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) (void)hipSetDevice(dev);
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
-int lds_cap_doubles(const qm_engine *e) { return e->cfg_lds_bytes / 8; }
-
-// 16-bit window offsets of the round-2 stacking kernels (brick_rel_kernel), on first use per table
-int ensure_rel(qm_engine *e) {
-    if (e->rel_built) return 0;
-    const qm::GridDesc &g = e->g;
-    if (e->d_rel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;
-    hipLaunchKernelGGL(qm::brick_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
-                       e->d_lut.p, reinterpret_cast<const int4 *>(e->d_bmeta.p), e->d_btotal.p,
-                       e->d_rel.p);
-    QM_HIP(hipGetLastError());
-    e->rel_built = true;
-    return 0;
-}
-
-// Samples per lane: explicit, the table's layout search's choice (load_lut), or the largest J
-// whose S row windows leave >= 20 % of the LDS budget for the delay spans (J = 4 up to 64 rows:
-// beyond 40 its pipelined kernels spill a few offset chunks per node, and only the exact-row-count
-// kernels are built for that).
-int eff_j(const qm_engine *e) {
-    const int S = e->n_rows_hint > 0 ? e->n_rows_hint : 1;
-    if (e->cfg_j > 0) return (e->cfg_j == 4 && S > qm::kJ4MaxRows) ? 2 : e->cfg_j;   // see below
-    if (e->auto_j > 0) return e->auto_j;
-    for (int j : {4, 2, 1}) {
-        if (j == 4 && S > qm::kJ4MaxRows) continue;
-        if ((int64_t)S * qm::kWave * j * 8 * 5 <= (int64_t)e->cfg_lds_bytes * 4) return j;
-    }
-    return 1;
-}
-
-// Samples per lane for one launch over n_chunk samples: never more than eff_j (the brick shape
-// was chosen for it), but fewer when the padding of the last time tile costs more than the
-// smaller tile's overhead (measured on C3/C4: J = 2 is ~1.12x, J = 1 ~1.4x the work of J = 4 per
-// sample) -- e.g. the Icequake example's 625-sample timestep runs 5 tiles of 128, not 3 of 256.
-int run_j(const qm_engine *e, int n_chunk) {
-    const int jmax = eff_j(e);
-    if (e->cfg_j > 0) return jmax;
-    int best = jmax;
-    double best_cost = 1e300;
-    for (int j : {4, 2, 1}) {
-        if (j > jmax) continue;
-        const int kt = qm::kWave * j;
-        const double cost = (double)((n_chunk + kt - 1) / kt) * kt * (j == 4 ? 1.0 : j == 2 ? 1.12 : 1.4);
-        if (cost < best_cost * 0.999) { best_cost = cost; best = j; }
-    }
-    return best;
-}
-
-// bricks whose windows do not fit the LDS budget for tile length 64*J
-int plan_wide(qm_engine *e, int J) {
-    const int KT = qm::kWave * J;
-    const int cap = lds_cap_doubles(e);
-    if (e->plan_j == J && e->plan_cap == cap) return 0;
-    std::vector<int32_t> wide;
-    for (int b = 0; b < e->g.nbricks; ++b) {
-        if (!qm::brick_fits(e->h_btotal[b], e->g.n_rows, KT, cap)) wide.push_back(b);
-    }
-    e->n_wide = (int)wide.size();
-    if (e->n_wide) {
-        if (e->d_wide.ensure(wide.size())) return 1;
-        QM_HIP(copy_in(e->d_wide.p, wide.data(), wide.size() * sizeof(int32_t), e->stream));
-        QM_HIP(hipStreamSynchronize(e->stream));
-    }
-    e->plan_j = J;
-    e->plan_cap = cap;
-    return 0;
-}
-
-// HIP status of a launcher of qm_launch.hpp -> this file's error convention
-#define QM_TABLE(call)                                                                       \
-    do {                                                                                     \
-        hipError_t err__ = (call);                                                           \
-        if (err__ != hipSuccess)                                                             \
-            return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__,   \
-                        __LINE__);                                                           \
-    } while (0)
 
 qm::LaunchShape stack_shape(const qm_engine *e, const qm::StackArgs &a, int groups, int threads,
                             size_t lds) {
@@ -601,89 +89,8 @@ int launch_stack_j(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_di
     return 0;
 }
 
-// ---- paired (16-byte operand) layout (qm_pair.hpp; row counts and constants: qm_launch.hpp) ----
 using qm::kPairLdsBytes;
 using qm::pair_jp_of;
-
-// pairs per lane for a launch over n_chunk samples; 0 = the chunked / exact kernels run.
-// pair = 1 (default): the volume-writing launches only -- there the paired layout pays (one
-// 16-byte store per pair, the stores under the next node's LDS stream: C3 locate window 6.8 ->
-// 6.4 ms); the fused detect gains nothing from it (the LDS array moves the same bytes and is
-// ~80 % busy either way, profiles/r02_pmc_*) and keeps the two-workgroups-per-CU b64 kernel.
-int pair_jp(const qm_engine *e, int n_chunk, bool volume) {
-    if (!e->cfg_pair || e->cfg_generic || e->cfg_force_direct || e->user_waves || e->user_lds ||
-        e->cfg_j > 0)
-        return 0;
-    const int jp = pair_jp_of(e->g.n_rows);
-    if (e->cfg_pair == 2) return jp;                   // forced (tests): detect too, any scan length
-    if (!volume) return 0;
-    // short scans run on shorter tiles (run_j): leave those to the chunked kernels
-    return (jp > 0 && run_j(e, n_chunk) == eff_j(e) && qm::kWave * eff_j(e) >= 128 * jp) ? jp : 0;
-}
-
-// Own brick grid (e->pg): the largest brick shape whose two staggered window copies fit 160 KB
-// for (almost) every brick; per-brick (min, span2, prefix) records and the 16-bit offset table.
-int ensure_pair_tables(qm_engine *e, int jp) {
-    const int KT = 128 * jp;
-    if (e->pair_kt == KT) return 0;
-    static const int kShapes[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4},
-                                     {2, 4, 4}, {2, 2, 4}, {2, 2, 2}, {1, 1, 2}, {1, 1, 1}};
-    const bool fixed = e->cfg_bx > 0;
-    const int n_shapes = fixed ? 1 : (int)(sizeof(kShapes) / sizeof(kShapes[0]));
-    qm::GridDesc g = e->g;
-    std::vector<int32_t> total, wide;
-    for (int s = 0; s < n_shapes; ++s) {
-        g = e->g;
-        if (!fixed) {
-            g.bx = std::min(kShapes[s][0], g.nx);
-            g.by = std::min(kShapes[s][1], g.ny);
-            g.bz = std::min(kShapes[s][2], g.nz);
-            g.nbx = (g.nx + g.bx - 1) / g.bx;
-            g.nby = (g.ny + g.by - 1) / g.by;
-            g.nbz = (g.nz + g.bz - 1) / g.bz;
-            g.nbricks = g.nbx * g.nby * g.nbz;
-            g.brick_nodes = g.bx * g.by * g.bz;
-        }
-        const size_t br = (size_t)g.nbricks * g.n_rows;
-        if (e->d_pmeta_raw.ensure(4 * br) || e->d_pmeta.ensure(4 * br) ||
-            e->d_ptotal.ensure(g.nbricks) || e->d_scalar.ensure(4))
-            return 1;
-        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
-        hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
-                           e->d_lut.p, reinterpret_cast<int4 *>(e->d_pmeta_raw.p), e->d_scalar.p);
-        hipLaunchKernelGGL(qm::screen_prefix_kernel, dim3((g.nbricks + 255) / 256), dim3(256), 0,
-                           e->stream, g, reinterpret_cast<const int4 *>(e->d_pmeta_raw.p),
-                           reinterpret_cast<int4 *>(e->d_pmeta.p), e->d_ptotal.p);
-        QM_HIP(hipGetLastError());
-        total.resize(g.nbricks);
-        QM_HIP(copy_back(total.data(), e->d_ptotal.p, (size_t)g.nbricks * sizeof(int32_t), e->stream));
-        QM_HIP(hipStreamSynchronize(e->stream));
-        wide.clear();
-        for (int b = 0; b < g.nbricks; ++b)
-            if (!qm::pair_fits(total[b], g.n_rows, KT, kPairLdsBytes)) wide.push_back(b);
-        if ((int64_t)wide.size() * 200 <= g.nbricks) break;    // <= 0.5 % on the slow path
-    }
-    e->n_pwide = (int)wide.size();
-    // an incoherent table (every shape leaves bricks that do not fit): the chunked kernels, whose
-    // single-copy windows are half the size, take it
-    // (with an explicit brick shape: whatever fits is paired, the rest goes to the direct kernel)
-    e->pair_ok = fixed ? (int)wide.size() < g.nbricks : (int64_t)wide.size() * 200 <= g.nbricks;
-    if (e->n_pwide) {
-        if (e->d_pwide.ensure(wide.size())) return 1;
-        QM_HIP(copy_in(e->d_pwide.p, wide.data(), wide.size() * sizeof(int32_t), e->stream));
-    }
-    if (e->pair_ok) {
-        if (e->d_prel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;
-        hipLaunchKernelGGL(qm::pair_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
-                           e->d_lut.p, reinterpret_cast<const int4 *>(e->d_pmeta.p), e->d_ptotal.p,
-                           KT, kPairLdsBytes, e->d_prel.p);
-        QM_HIP(hipGetLastError());
-    }
-    QM_HIP(hipStreamSynchronize(e->stream));           // `wide` is a stack-lifetime buffer
-    e->pg = g;
-    e->pair_kt = KT;
-    return 0;
-}
 
 // LDS launch over the bricks that fit the paired layout + direct launch over those that do not
 template <int JP, bool VOLUME>
@@ -726,161 +133,9 @@ bool pair_built(int S) { return S >= 1 && S <= qm::kPairMaxRows; }
 int build_shift_tables(qm_engine *e);
 
 void release_shift_tables(qm_engine *e) {
+    PoolReleaseScope one_wait;
     e->d_shraw.release(); e->d_shmeta.release(); e->d_shtotal.release(); e->d_shfit.release();
     e->d_shwide.release(); e->d_shstream.release();
-}
-
-// Outcome per resident table: the layout is built (shift_ok), or the table does not qualify, or the
-// tables could not be built -- most likely no memory for the record stream (8 S bytes per node, twice
-// the table): that, too, is "does not qualify": the buffers are released, the error is dropped and
-// the same step runs on the other kernels.
-int ensure_shift_tables(qm_engine *e) {
-    if (e->shift_built) return 0;
-    e->shift_ok = false;
-    const int rc = build_shift_tables(e);
-    if (rc != 0 || !e->shift_ok) {
-        e->shift_ok = false;
-        release_shift_tables(e);
-        if (rc != 0) {
-            (void)hipGetLastError();                    // (an allocation failure is not sticky)
-            g_error.clear();
-        }
-    }
-    e->shift_built = true;
-    return 0;
-}
-
-int build_shift_tables(qm_engine *e) {
-    const int S = e->g.n_rows;
-    // More rows than a CU's LDS holds windows for: row blocks (stack_shift_rows_kernel) -- bricks of
-    // 4x4x4 nodes = one 2x2x2 group per wavefront of the 8-wave workgroup, whose accumulators stay
-    // in registers while the rows are staged in nblk blocks of sb <= 64 rows.
-    const bool blocks = S > qm::kShiftMaxRows;
-    // two forms (qm_shift.hpp): blocks of <= 34 rows staged by LDS-direct loads into the idle half of
-    // a double-buffered LDS (default), or blocks of <= 64 staged through registers between two barriers
-    // (that one only from 97 rows on: at 65-96 two blocks of <= 48 rows stage as often as they
-    // compute and the chunked kernel with its 8x8x8 bricks is 4-5 % faster, profiles/r03_ab_runs.txt)
-    // (round 4, form 2: the LDS-direct staging with TWO 4-wave workgroups per CU on bricks of 4x4x2
-    // nodes, single-buffered -- stack_shift_rows4_kernel)
-    const int form = e->cfg_shift_rows_direct;          // 0 registers, 1 double-buffered 8 waves, 2 two x 4 waves
-    const bool direct = form != 0;
-    const bool quad = form == 2;
-    if (blocks && !direct && S <= 96 && e->cfg_shift != 1) return 0;
-    const int block_rows = direct ? 34 : qm::kShiftMaxRows;
-    const int nblk = blocks ? (S + block_rows - 1) / block_rows : 1;
-    const int sb = blocks ? ((S + nblk - 1) / nblk + 1) / 2 * 2 : S;
-    if (S > 1024 || (blocks && e->cfg_shift_waves != 0 &&
-                     e->cfg_shift_waves != (quad ? qm::kShiftWaves : qm::kShiftWaves8)))
-        return 0;
-    // a grid one node thick has half-empty 2x2x2 groups everywhere (e.g. the flat 1 x 1 x N view
-    // of the reference-signature migrate): leave it to the other kernels unless asked explicitly
-    if (e->cfg_shift < 0 && (e->g.nx < 2 || e->g.ny < 2 || e->g.nz < 2)) return 0;
-    // Workgroup shape (qm_shift.hpp): two 4-wave workgroups per CU up to ~32 rows; beyond, ONE 8-wave
-    // workgroup with all 160 KB (smaller bricks, 33-64 rows); 12 waves only on request.  Bricks are
-    // shaped so that their 2x2x2 groups deal evenly over the wavefronts.
-    static const int kShapes4[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4}, {2, 4, 4}};
-    static const int kShapes8[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4}, {4, 4, 4}};
-    static const int kShapes12[][3] = {{8, 8, 12}, {8, 8, 6}, {4, 8, 6}, {4, 4, 6}, {2, 4, 6}};
-    int candidates[2] = {qm::kShiftWaves, qm::kShiftWaves8};
-    int n_candidates = 2;
-    if (e->cfg_shift_waves != 0) {
-        candidates[0] = e->cfg_shift_waves;
-        n_candidates = 1;
-    } else if (blocks && quad) {
-        candidates[0] = qm::kShiftWaves;
-        n_candidates = 1;
-    } else if (S > 40) {                               // (80 KB cannot hold that many row windows)
-        candidates[0] = qm::kShiftWaves8;
-        n_candidates = 1;
-    }
-    const bool fixed = e->cfg_bx > 0 && !blocks;
-    const int n_shapes = fixed || blocks ? 1 : 5;
-    static const int kShapesBlocks[][3] = {{4, 4, 4}};
-    static const int kShapesBlocks4[][3] = {{4, 4, 2}};
-    int nw = candidates[0];
-    qm::GridDesc g = e->g;
-    std::vector<int32_t> fit, wide;
-    bool ok = false;
-    auto even_up = [](int v) { return v + (v & 1); };
-    for (int cand = 0; cand < n_candidates && !ok; ++cand) {
-    nw = candidates[cand];
-    const int (*kShapes)[3] = blocks ? (quad ? kShapesBlocks4 : kShapesBlocks) : nw == qm::kShiftWaves3 ? kShapes12
-                              : nw == qm::kShiftWaves8 ? kShapes8 : kShapes4;
-    for (int s = 0; s < n_shapes; ++s) {
-        g = e->g;
-        g.bx = std::min(even_up(fixed ? e->cfg_bx : kShapes[s][0]), even_up(g.nx));
-        g.by = std::min(even_up(fixed ? e->cfg_by : kShapes[s][1]), even_up(g.ny));
-        g.bz = std::min(even_up(fixed ? e->cfg_bz : kShapes[s][2]), even_up(g.nz));
-        g.nbx = (g.nx + g.bx - 1) / g.bx;
-        g.nby = (g.ny + g.by - 1) / g.by;
-        g.nbz = (g.nz + g.bz - 1) / g.bz;
-        g.nbricks = g.nbx * g.nby * g.nbz;
-        g.brick_nodes = g.bx * g.by * g.bz;
-        const size_t br = (size_t)g.nbricks * S;
-        const size_t nvb = (size_t)g.nbricks * nblk;               // (brick, row block) pairs
-        if (e->d_shraw.ensure(4 * br) || e->d_shmeta.ensure(4 * nvb * sb) ||
-            e->d_shtotal.ensure(nvb) || e->d_shfit.ensure(nvb) || e->d_scalar.ensure(8))
-            return 1;
-        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 8 * sizeof(int32_t), e->stream));
-        hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
-                           e->d_lut.p, reinterpret_cast<int4 *>(e->d_shraw.p), e->d_scalar.p);
-        hipLaunchKernelGGL(qm::shift_need_kernel, dim3((unsigned)nvb), dim3(256), 0, e->stream, g,
-                           e->d_lut.p, reinterpret_cast<const int4 *>(e->d_shraw.p),
-                           reinterpret_cast<int4 *>(e->d_shmeta.p), e->d_shtotal.p, e->d_shfit.p,
-                           reinterpret_cast<unsigned long long *>(e->d_scalar.p + 4),
-                           blocks && direct ? qm::kShiftPlane : qm::shift_plane(nw), nblk, sb);
-        QM_HIP(hipGetLastError());
-        fit.resize(nvb);
-        unsigned long long tally[2] = {0, 0};
-        QM_HIP(copy_back(fit.data(), e->d_shfit.p, nvb * sizeof(int32_t), e->stream));
-        QM_HIP(copy_back(tally, e->d_scalar.p + 4, sizeof(tally), e->stream));
-        QM_HIP(hipStreamSynchronize(e->stream));
-        e->shift_quads = (int64_t)tally[0];
-        e->shift_group_rows = (int64_t)tally[1];
-        wide.clear();
-        for (int b = 0; b < g.nbricks; ++b) {                      // a brick fits if all its blocks do
-            int all = 1;
-            for (int k = 0; k < nblk; ++k) all &= fit[(size_t)b * nblk + k];
-            fit[b] = all;
-            if (!all) wide.push_back(b);
-        }
-        ok = fixed ? (int)wide.size() < g.nbricks : (int64_t)wide.size() * 200 <= g.nbricks;
-        if (ok) break;
-    }
-    }
-    if (!ok) return 0;                                   // an incoherent table: the other kernels
-    const int rows2 = sb + (sb & 1);
-    const int64_t words = (int64_t)g.nbricks * nw * nblk * qm::shift_recs_per_wave(g, rows2, nw) *
-                          (qm::shift_rec_bytes(blocks) / 4);
-    if (blocks)                                          // per-brick verdicts for the kernels
-        QM_HIP(copy_in(e->d_shfit.p, fit.data(), (size_t)g.nbricks * sizeof(int32_t), e->stream));
-    // (+ slack: the loop loads one record past a wavefront's run and touches the line 16 records
-    // ahead with its L2 prefetch -- after the last run of the last brick that is past the stream)
-    if (e->d_shstream.ensure((size_t)words + 4096)) return 1;
-    const size_t hdr_bytes = (size_t)qm::shift_groups_per_brick(g) * rows2 * sizeof(uint2);
-    QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(qm::shift_stream_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_bytes));
-    hipLaunchKernelGGL(qm::shift_stream_kernel, dim3((unsigned)((size_t)g.nbricks * nblk)), dim3(256),
-                       hdr_bytes, e->stream, g, e->d_lut.p,
-                       reinterpret_cast<const int4 *>(e->d_shmeta.p), e->d_shtotal.p, e->d_shfit.p,
-                       rows2, nw, nblk, sb, qm::shift_packed(blocks) ? 1 : 0, e->d_shstream.p);
-    QM_HIP(hipGetLastError());
-    e->n_shwide = (int)wide.size();
-    if (e->n_shwide) {
-        if (e->d_shwide.ensure(wide.size())) return 1;
-        QM_HIP(copy_in(e->d_shwide.p, wide.data(), wide.size() * sizeof(int32_t), e->stream));
-    }
-    QM_HIP(hipStreamSynchronize(e->stream));           // `wide` is a stack-lifetime buffer
-    e->d_shraw.release();
-    e->shg = g;
-    e->shift_rows2 = rows2;
-    e->shift_nw = nw;
-    e->shift_nblk = nblk;
-    e->shift_sb = sb;
-    e->shift_direct = blocks && direct;
-    e->shift_quad = blocks && quad;
-    e->shift_ok = true;
-    return 0;
 }
 
 // does this launch take the shift-reuse kernel?  Whole 256-sample tiles plus, for what a scan leaves
@@ -962,7 +217,9 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
     return 0;
 }
 
-int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu, int rounds = 0) {
+}  // namespace
+
+int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu, int rounds) {
     // Workgroups all do the same amount of work, so the grid should be a whole number of
     // "rounds" over the resident slots (n_cu * blocks_per_cu): ntiles * groups <= rounds * slots,
     // as close from below as possible.  12 rounds measured best on C2/C3 (finer load balance
@@ -984,9 +241,8 @@ int auto_groups(const qm_engine *e, int ntiles, int units, int blocks_per_cu, in
 // e->d_pmax/d_pidx/d_psum as [*n_sets][n_chunk].
 int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_samples,
               int available, int sample0, int n_chunk, double *volume, int64_t vol_stride,
-              int accumulate, bool want_scan, int *n_sets, bool marginal = false,
-              int m0 = 0, int m1 = 0, const int32_t *run_if = nullptr, int n_steps = 1,
-              int64_t step_stride = 0, bool *batched = nullptr) {
+              int accumulate, bool want_scan, int *n_sets, bool marginal, int m0, int m1,
+              const int32_t *run_if, int n_steps, int64_t step_stride, bool *batched) {
     // n_steps > 1: that many timesteps in ONE launch (fused detect only) -- onset arrays step_stride
     // doubles apart, partial sets [*n_sets][n_steps * n_chunk].  Not every kernel can (row blocks, the
     // 12-wave shape): *batched = false then, nothing is launched and the caller goes step by step.
@@ -1166,332 +422,9 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     return 0;
 }
 
-// ---- float32 screening path (qm_screen.hpp) ---------------------------------------------------
-constexpr int kFlagRing = 1024;
-
-// fold the per-step outcomes that have reached the host into the counters (synchronises)
-int drain_flags(qm_engine *e) {
-    if (e->flags_pending == 0) return 0;
-    QM_HIP(hipStreamSynchronize(e->stream));
-    for (; e->flags_pending > 0; --e->flags_pending) {
-        const int32_t *f = e->h_flags + 2 * e->flags_head;
-        if (f[0] != 0) ++e->fallback_steps;
-        else ++e->screened_steps;
-        e->last_candidates = f[1];
-        e->flags_head = (e->flags_head + 1) % kFlagRing;
-    }
-    return 0;
-}
-
-// pairs of samples per lane: time tile = 128 * JP; 0 = this table is not screened
-// How the sweep is launched: JP pairs of samples per lane (time tile 128*JP) and either two
-// 8-wave workgroups per CU with 80 KB of LDS each, or ("big") one 16-wave workgroup with all
-// 160 KB -- twice the tile for the same rows, so fewer address / epilogue instructions per sample.
-struct ScreenPlan {
-    int jp = 0;                     // 0 = this table is not screened
-    bool big = false;
-    int kt() const { return 128 * jp; }
-    int lds_bytes(const qm_engine *e) const {
-        return big ? 160 * 1024 : (e->user_lds ? e->cfg_lds_bytes : 80 * 1024);
-    }
-    int window_bytes(const qm_engine *e) const {       // minus the cell-maximum row
-        return (lds_bytes(e) - kt() * 4) / 16 * 16;
-    }
-    int threads() const { return big ? 1024 : 512; }
-};
-
-bool screen_plan_feasible(const qm_engine *e, int S, const ScreenPlan &p) {
-    const int64_t rows_bytes = (int64_t)S * (8 * p.kt() - 8);
-    return S <= 64 && (p.big || p.jp < 4) && rows_bytes * 5 <= (int64_t)p.lds_bytes(e) * 4;
-}
-
-// plan for a scan of n_samples (0 = unknown: the most LDS-hungry plan that could be chosen, for
-// the brick-shape decision at load time)
-ScreenPlan screen_plan(const qm_engine *e, int S, int n_samples) {
-    ScreenPlan best;
-    if (!e->cfg_screen || e->cfg_force_direct || (e->user_waves && e->cfg_waves != 8)) return best;
-    double best_cost = 1e300;
-    // relative cost per sample, measured on C3 / C4-sized tables (tools/ab.py): with the integer
-    // sweep two pairs per lane in two 8-wave workgroups per CU run as fast as four pairs in one
-    // 16-wave workgroup, need no scratch and pad short scans less
-    const struct { int jp; bool big; double cost; } options[] = {
-        {2, false, 1.00}, {4, true, 1.005}, {2, true, 1.05}, {1, false, 1.35}, {1, true, 1.35}};
-    for (const auto &o : options) {
-        ScreenPlan p;
-        p.jp = o.jp;
-        p.big = o.big;
-        if (e->cfg_screen_pairs && o.jp != e->cfg_screen_pairs) continue;
-        if (e->cfg_screen_big >= 0 && (int)o.big != e->cfg_screen_big) continue;
-        if (!screen_plan_feasible(e, S, p)) continue;
-        double cost = o.cost;
-        if (n_samples > 0) cost *= (double)((n_samples + p.kt() - 1) / p.kt()) * p.kt();
-        // unknown length: the plan that leaves the least LDS to the delay spans (the binding one)
-        else cost = (double)p.window_bytes(e) - (double)S * (8 * p.kt() - 8);
-        if (cost < best_cost) {
-            best_cost = cost;
-            best = p;
-        }
-    }
-    return best;
-}
-
-// The sweep has its own brick grid (e->sg): its LDS budget and window layout differ from the
-// float64 kernel's, so the largest brick shape whose windows fit is chosen for it separately.
-int ensure_screen_tables(qm_engine *e, const ScreenPlan &plan) {
-    const int KT = plan.kt();
-    const int wb = plan.window_bytes(e);
-    if (e->screen_kt == KT && e->screen_wb == wb) return 0;
-    static const int kShapes[][3] = {{16, 8, 8}, {8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4},
-                                     {2, 4, 4},  {2, 2, 4}, {2, 2, 2}, {1, 1, 2}, {1, 1, 1}};
-    const bool fixed = e->cfg_bx > 0;
-    const int n_shapes = fixed ? 1 : (int)(sizeof(kShapes) / sizeof(kShapes[0]));
-    const int first = fixed ? 0 : (e->cfg_screen_brick16 ? 0 : 1);
-    qm::GridDesc g = e->g;
-    std::vector<int32_t> total, wide;
-    for (int s = first; s < std::max(n_shapes, first + 1); ++s) {
-        g = e->g;
-        if (!fixed) {
-            g.bx = std::min(kShapes[s][0], g.nx);
-            g.by = std::min(kShapes[s][1], g.ny);
-            g.bz = std::min(kShapes[s][2], g.nz);
-            g.nbx = (g.nx + g.bx - 1) / g.bx;
-            g.nby = (g.ny + g.by - 1) / g.by;
-            g.nbz = (g.nz + g.bz - 1) / g.bz;
-            g.nbricks = g.nbx * g.nby * g.nbz;
-            g.brick_nodes = g.bx * g.by * g.bz;
-        }
-        const size_t br = (size_t)g.nbricks * g.n_rows;
-        if (e->d_smeta_raw.ensure(4 * br) || e->d_smeta.ensure(4 * br) ||
-            e->d_stotal.ensure(g.nbricks) || e->d_scalar.ensure(4))
-            return 1;
-        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
-        hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
-                           e->d_lut.p, reinterpret_cast<int4 *>(e->d_smeta_raw.p), e->d_scalar.p);
-        hipLaunchKernelGGL(qm::screen_prefix_kernel, dim3((g.nbricks + 255) / 256), dim3(256), 0,
-                           e->stream, g, reinterpret_cast<const int4 *>(e->d_smeta_raw.p),
-                           reinterpret_cast<int4 *>(e->d_smeta.p), e->d_stotal.p);
-        QM_HIP(hipGetLastError());
-        total.resize(g.nbricks);
-        QM_HIP(copy_back(total.data(), e->d_stotal.p, (size_t)g.nbricks * sizeof(int32_t), e->stream));
-        QM_HIP(hipStreamSynchronize(e->stream));
-        wide.clear();
-        for (int b = 0; b < g.nbricks; ++b)
-            if (!qm::screen_fits(total[b], g.n_rows, KT, wb)) wide.push_back(b);
-        if ((int64_t)wide.size() * 200 <= g.nbricks) break;    // <= 0.5 % on the slow path
-    }
-    e->n_swide = (int)wide.size();
-    if (e->n_swide) {
-        if (e->d_swide.ensure(wide.size())) return 1;
-        QM_HIP(copy_in(e->d_swide.p, wide.data(), wide.size() * sizeof(int32_t), e->stream));
-    }
-    if (e->d_srel.ensure((size_t)g.nbricks * g.brick_nodes * g.row_pad)) return 1;
-    hipLaunchKernelGGL(qm::screen_rel_kernel, dim3(g.nbricks), dim3(256), 0, e->stream, g,
-                       e->d_lut.p, reinterpret_cast<const int4 *>(e->d_smeta.p), e->d_stotal.p, KT,
-                       wb, e->d_srel.p);
-    QM_HIP(hipGetLastError());
-    QM_HIP(hipStreamSynchronize(e->stream));           // `wide` is a stack-lifetime buffer
-    e->sg = g;
-    e->screen_kt = KT;
-    e->screen_wb = wb;
-    return 0;
-}
-
-template <int JP, int NCH>
-int launch_screen(qm_engine *e, qm::ScreenArgs &a, size_t lds, int threads) {
-    QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::screen_lds_kernel<JP, NCH>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((qm::screen_lds_kernel<JP, NCH>),
-                       dim3((unsigned)(a.ntiles * ((a.ngroups + 7) / 8 * 8))), dim3(threads), lds,
-                       e->stream, a);
-    QM_HIP(hipGetLastError());
-    return 0;
-}
-
-template <int JP>
-int launch_screen_jp(qm_engine *e, qm::ScreenArgs &a, size_t lds, int threads) {
-    switch (e->g.row_pad / 8) {
-        case 1: return launch_screen<JP, 1>(e, a, lds, threads);
-        case 2: return launch_screen<JP, 2>(e, a, lds, threads);
-        case 3: return launch_screen<JP, 3>(e, a, lds, threads);
-        case 4: return launch_screen<JP, 4>(e, a, lds, threads);
-        case 5: return launch_screen<JP, 5>(e, a, lds, threads);
-        case 6: return launch_screen<JP, 6>(e, a, lds, threads);
-        case 7: return launch_screen<JP, 7>(e, a, lds, threads);
-        case 8: return launch_screen<JP, 8>(e, a, lds, threads);
-        default: return fail("screening supports at most 64 table rows");
-    }
-}
-
-// Whole-scan detect through the screening path.  On success with *screened = true the partial
-// sets [*n_sets][ns] are in e->d_pmax/d_pidx/d_psum exactly as run_stack leaves them.  *screened =
-// false (nothing usable was produced) if some sample had more candidate cells than slots or the
-// onsets hold a non-finite value: the caller then runs the float64 kernel.
-int run_screen(qm_engine *e, const double *d_onsets, int T, int fsmp, int ns, int available,
-               int *n_sets, bool *screened) {
-    *screened = false;
-    const ScreenPlan plan = screen_plan(e, e->g.n_rows, ns);
-    const int JP = plan.jp;
-    if (JP == 0) return 0;
-    if (ensure_screen_tables(e, plan)) return 1;
-    e->last_plan_jp = plan.jp;
-    e->last_plan_big = plan.big ? 1 : 0;
-    const qm::GridDesc &g = e->sg;
-    if (!e->h_flags)
-        QM_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->h_flags),
-                             2 * kFlagRing * sizeof(int32_t), hipHostMallocDefault));
-    const int KT = 128 * JP;
-    const int ntiles = (ns + KT - 1) / KT;
-    const int64_t ns_pad = (int64_t)ntiles * KT;
-    const int S = g.n_rows;
-    const int n_fit = g.nbricks - e->n_swide;
-    if (n_fit < 2) return 0;                            // a single cell: nothing to screen
-    const int groups = n_fit > 0 ? (e->cfg_groups > 0 ? std::min(e->cfg_groups, g.nbricks)
-                                                       : auto_groups(e, ntiles, g.nbricks, plan.big ? 1 : 2))
-                                 : 0;
-    const int groups_direct =
-        e->n_swide > 0 ? (e->cfg_groups > 0 ? std::min(e->cfg_groups, e->n_swide)
-                                            : auto_groups(e, (ns + 63) / 64, e->n_swide, 4))
-                       : 0;
-    const int sets = groups_direct + 1;
-    constexpr int kGroupsPerBlock = 32;
-    if (e->d_onq.ensure((size_t)S * T) || e->d_rowmax.ensure(S) || e->d_sparams.ensure(4) ||
-        e->d_cell.ensure((size_t)g.nbricks * ns_pad) ||
-        e->d_gmax.ensure((size_t)std::max(1, groups) * ns_pad) || e->d_pm.ensure(ns) || e->d_ssum.ensure((size_t)std::max(1, groups) * ns) ||
-        e->d_counts.ensure(ns) || e->d_cells.ensure((size_t)ns * qm::kScreenSlots) ||
-        e->d_work.ensure((size_t)ns * qm::kScreenSlots) ||
-        e->d_flags.ensure(4) || e->d_cand_z.ensure((size_t)ns * qm::kScreenSlots) ||
-        e->d_cand_idx.ensure((size_t)ns * qm::kScreenSlots))
-        return 1;
-    const size_t need = (size_t)sets * ns;
-    if (e->d_pmax.ensure(need) || e->d_psum.ensure(need) || e->d_pidx.ensure(need)) return 1;
-
-    hipEvent_t ev_begin = e->ev0, ev_end = e->ev1;
-    if (e->log_timing) {
-        if (e->ev_used + 2 > e->ev_log.size()) {
-            for (int i = 0; i < 2; ++i) {
-                hipEvent_t ev;
-                QM_HIP(hipEventCreate(&ev));
-                e->ev_log.push_back(ev);
-            }
-        }
-        ev_begin = e->ev_log[e->ev_used];
-        ev_end = e->ev_log[e->ev_used + 1];
-        e->ev_used += 2;
-    }
-    hipStream_t s = e->stream;
-    QM_HIP(hipMemsetAsync(e->d_counts.p, 0, (size_t)ns * sizeof(int32_t), s));
-    QM_HIP(hipMemsetAsync(e->d_flags.p, 0, 4 * sizeof(int32_t), s));
-    // this step's fixed-point scale (device-side: max |L| -> k) and the quantised log-onsets
-    hipLaunchKernelGGL(qm::screen_rowmax_kernel, dim3(S), dim3(256), 0, s, d_onsets, T,
-                       e->d_rowmax.p);
-    hipLaunchKernelGGL(qm::screen_quantise_kernel, dim3(S), dim3(256), 0, s, d_onsets, T, S,
-                       available, (const double *)e->d_rowmax.p, e->d_onq.p,
-                       reinterpret_cast<qm::ScreenParams *>(e->d_sparams.p), e->d_flags.p);
-    QM_HIP(hipGetLastError());
-
-    qm::ScreenArgs a{};
-    a.g = g;
-    a.onsets_q = e->d_onq.p;
-    a.rel = e->d_srel.p;
-    a.brick_meta = e->d_smeta.p;
-    a.brick_total = e->d_stotal.p;
-    a.T = T;
-    a.fsmp = fsmp;
-    a.n_samples = ns;
-    a.ntiles = ntiles;
-    a.ngroups = groups;
-    a.window_bytes = plan.window_bytes(e);
-    a.params = reinterpret_cast<const qm::ScreenParams *>(e->d_sparams.p);
-    a.cell_max = e->d_cell.p;
-    a.group_max = e->d_gmax.p;
-    a.ns_pad = ns_pad;
-    a.part_sum = e->d_ssum.p;
-    QM_HIP(hipEventRecord(ev_begin, s));               // the timing log brackets the sweep kernel
-    if (groups > 0) {
-        const size_t lds = (size_t)plan.lds_bytes(e);
-        const int threads = plan.threads();
-        if (JP == 4 ? launch_screen_jp<4>(e, a, lds, threads)
-                    : JP == 2 ? launch_screen_jp<2>(e, a, lds, threads)
-                              : launch_screen_jp<1>(e, a, lds, threads))
-            return 1;
-    }
-    QM_HIP(hipEventRecord(ev_end, s));
-    if (groups_direct > 0) {
-        // bricks whose windows do not fit: exact float64 partial sets from the direct kernel
-        qm::StackArgs d{};
-        d.g = g;
-        d.onsets = d_onsets;
-        d.lut = e->d_lut.p;
-        d.T = T;
-        d.fsmp = fsmp;
-        d.n_samples = ns;
-        d.sample0 = 0;
-        d.n_chunk = ns;
-        d.ntiles = (ns + 63) / 64;
-        d.ngroups = groups_direct;
-        d.z_scale = 1.4426950408889634074 / (double)available;
-        d.want_scan = 1;
-        d.set0 = 0;
-        d.part_max = e->d_pmax.p;
-        d.part_idx = e->d_pidx.p;
-        d.part_sum = e->d_psum.p;
-        d.brick_list = e->d_swide.p;
-        d.n_list = e->n_swide;
-        d.n_nodes = e->n_nodes;
-        const size_t publish_bytes = (size_t)3 * 8 * 64 * sizeof(double);
-        bool built = false;
-        QM_TABLE(qm::launch_direct_detect(
-            1, d, {(unsigned)(d.ntiles * ((groups_direct + 7) / 8 * 8)), 512, publish_bytes, s},
-            &built));
-        if (!built) return fail("no direct stacking kernel built");
-    }
-    const unsigned tcols = (unsigned)((ns + 63) / 64);
-    hipLaunchKernelGGL(qm::screen_peak_kernel, dim3(tcols), dim3(256), 0, s,
-                       (const int32_t *)e->d_gmax.p, ns_pad, ns, groups, e->d_pm.p);
-    hipLaunchKernelGGL(qm::screen_candidates_kernel,
-                       dim3(tcols, (unsigned)std::max(1, (groups + kGroupsPerBlock - 1) / kGroupsPerBlock)),
-                       dim3(256), 0, s, (const int32_t *)e->d_cell.p, (const int32_t *)e->d_gmax.p,
-                       ns_pad, ns, g.nbricks, groups, kGroupsPerBlock, (const int32_t *)e->d_pm.p,
-                       reinterpret_cast<const qm::ScreenParams *>(e->d_sparams.p), e->d_counts.p,
-                       e->d_cells.p, e->d_work.p, e->d_flags.p);
-    QM_HIP(hipGetLastError());
-    qm::RefineArgs r{};
-    r.g = g;
-    r.onsets = d_onsets;
-    r.lut = e->d_lut.p;
-    r.T = T;
-    r.fsmp = fsmp;
-    r.n_samples = ns;
-    r.z_scale = 1.4426950408889634074 / (double)available;
-    r.cells = e->d_cells.p;
-    r.work = e->d_work.p;
-    r.flags = e->d_flags.p;
-    r.cand_z = e->d_cand_z.p;
-    r.cand_idx = e->d_cand_idx.p;
-    hipLaunchKernelGGL(qm::screen_refine_kernel, dim3((unsigned)(8 * e->n_cu)), dim3(256), 0, s, r);
-    hipLaunchKernelGGL(qm::screen_collect_kernel, dim3((ns + 63) / 64), dim3(256), 0, s,
-                       (const int32_t *)e->d_counts.p, (const double *)e->d_cand_z.p,
-                       (const int64_t *)e->d_cand_idx.p, (const double *)e->d_ssum.p, groups, ns,
-                       e->d_pmax.p + (size_t)groups_direct * ns,
-                       e->d_pidx.p + (size_t)groups_direct * ns,
-                       e->d_psum.p + (size_t)groups_direct * ns);
-    QM_HIP(hipGetLastError());
-    e->timed = !e->log_timing;
-    // the outcome travels to the host asynchronously (statistics only: the decision to redo the
-    // step in float64 is taken on the device, see detect_core)
-    if (e->flags_pending == kFlagRing && drain_flags(e)) return 1;
-    QM_HIP(hipMemcpyAsync(e->h_flags + 2 * ((e->flags_head + e->flags_pending) % kFlagRing),
-                          e->d_flags.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    ++e->flags_pending;
-    *n_sets = sets;
-    *screened = true;
-    return 0;
-}
-
 int combine(qm_engine *e, const double *pmax, const int64_t *pidx, const double *psum, int sets,
             int n, int mode, int64_t node_offset, int64_t n_nodes_total, double *o_max,
-            double *o_second, int64_t *o_idx, const int32_t *run_if = nullptr,
-            int64_t set_stride = 0) {
+            double *o_second, int64_t *o_idx, const int32_t *run_if, int64_t set_stride) {
     hipLaunchKernelGGL(qm::combine_kernel, dim3((n + qm::kWave - 1) / qm::kWave),
                        dim3(qm::kCombineWaves * qm::kWave), 0,
                        e->stream, pmax, pidx, psum, sets, n, set_stride > 0 ? set_stride : (int64_t)n,
@@ -1551,11 +484,6 @@ int stage_onsets(qm_engine *e, const double *onsets, int on_device, int T, const
     return 0;
 }
 
-// where the kernels write the three series; copies back afterwards if the caller is on host
-struct OutStage {
-    double *a, *b;
-    int64_t *i;
-};
 int stage_out(qm_engine *e, int n, int out_on_device, double *max_coa, double *max_norm,
               int64_t *idx, OutStage *st) {
     if (out_on_device) {
@@ -1566,6 +494,7 @@ int stage_out(qm_engine *e, int n, int out_on_device, double *max_coa, double *m
     *st = OutStage{e->d_out_a.p, e->d_out_b.p, e->d_out_i.p};
     return 0;
 }
+
 int fetch_out(qm_engine *e, int n, int out_on_device, const OutStage &st, double *max_coa,
               double *max_norm, int64_t *idx) {
     if (out_on_device) return 0;
@@ -1576,24 +505,8 @@ int fetch_out(qm_engine *e, int n, int out_on_device, const OutStage &st, double
     return 0;
 }
 
-}  // namespace
-
 // ------------------------------------------------------------------------------- C ABI
 extern "C" {
-
-const char *qm_last_error(void) { return g_error.c_str(); }
-
-int qm_release_cached_memory(void) {
-    std::lock_guard<std::mutex> lock(g_pool_mutex);
-    pool_trim_locked(0);
-    return 0;
-}
-
-int qm_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
-    return n;
-}
 
 int qm_engine_create(int device_id, qm_engine **out) {
     if (!out) return fail("qm_engine_create: out is NULL");
@@ -1619,6 +532,8 @@ void qm_engine_destroy(qm_engine *e) {
     if (!e) return;
     DeviceGuard guard(e->device);
     (void)hipStreamSynchronize(e->stream);
+    streams_orphan(e);
+    PoolReleaseScope one_wait;                          // every buffer of the engine behind ONE device-wide wait
     e->release_all();
     for (TableSlot &slot : e->slots) slot.state.release_all();
     e->d_grids.release(); e->d_rows.release(); e->d_served.release();
@@ -1816,293 +731,6 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "ny") *v = e->g.ny;
     else if (k == "nz") *v = e->g.nz;
     else return fail("unknown key '%s'", key);
-    return 0;
-}
-
-int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int32_t nx,
-                       int32_t ny, int32_t nz, int32_t n_rows, int64_t node_offset) {
-    if (!e || !lut) return fail("qm_engine_load_lut: NULL argument");
-    if (nx < 1 || ny < 1 || nz < 1 || n_rows < 1) return fail("bad table shape");
-    const int64_t n_nodes = (int64_t)nx * ny * nz;
-    if (n_nodes >= INT32_MAX) return fail("more than 2^31-1 nodes on one GPU is not supported");
-    DeviceGuard guard(e->device);
-    e->have_lut = false;
-    const size_t lut_elems = (size_t)n_nodes * n_rows;
-    if (e->d_lut.ensure(lut_elems) || e->d_scalar.ensure(4)) return 1;
-    if (lut_on_device)
-        QM_HIP(hipMemcpyAsync(e->d_lut.p, lut, lut_elems * sizeof(int32_t), hipMemcpyDeviceToDevice,
-                              e->stream));
-    else
-        QM_HIP(copy_in(e->d_lut.p, lut, lut_elems * sizeof(int32_t), e->stream));
-
-    // Brick shape: the configured one, or (brick_x == 0) the largest candidate whose windows fit
-    // the LDS budget for (almost) every brick -- larger bricks amortise window staging, smaller
-    // ones have smaller delay spans.  Bricks that still do not fit go to the direct kernel.
-    static const int kShapes[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4},
-                                     {2, 4, 4}, {2, 2, 4}, {2, 2, 2}, {1, 1, 2}, {1, 1, 1}};
-    const int n_shapes = e->cfg_bx > 0 ? 1 : (int)(sizeof(kShapes) / sizeof(kShapes[0]));
-    e->n_rows_hint = n_rows;
-    e->auto_j = 0;
-    qm::GridDesc g{};
-    // Per candidate shape ONE pass over the table (min / span per (brick, row), the bricks' totals,
-    // the table's largest delay); whether a shape's windows fit depends on the tile length and the
-    // LDS budget and is decided on the host from the cached totals -- the layout search below asks
-    // for up to seven (tile length, budget) pairs, which used to cost as many passes and host
-    // round trips per load.  `on_device`: the shape whose records d_bmeta / d_btotal hold.
-    std::vector<std::vector<int32_t>> totals(n_shapes);
-    std::vector<qm::GridDesc> shapes(n_shapes);
-    int on_device = -1;
-    auto measure = [&](int s) -> int {
-        qm::GridDesc &gs = shapes[s];
-        gs = qm::GridDesc{};
-        gs.nx = nx; gs.ny = ny; gs.nz = nz;
-        gs.bx = std::min(e->cfg_bx > 0 ? e->cfg_bx : kShapes[s][0], (int)nx);
-        gs.by = std::min(e->cfg_bx > 0 ? e->cfg_by : kShapes[s][1], (int)ny);
-        gs.bz = std::min(e->cfg_bx > 0 ? e->cfg_bz : kShapes[s][2], (int)nz);
-        gs.nbx = (nx + gs.bx - 1) / gs.bx;
-        gs.nby = (ny + gs.by - 1) / gs.by;
-        gs.nbz = (nz + gs.bz - 1) / gs.bz;
-        const int64_t nbricks = (int64_t)gs.nbx * gs.nby * gs.nbz;
-        if (nbricks >= INT32_MAX) return fail("too many bricks");
-        gs.nbricks = (int)nbricks;
-        gs.brick_nodes = gs.bx * gs.by * gs.bz;
-        gs.n_rows = n_rows;
-        gs.row_pad = (n_rows + 7) / 8 * 8;
-        const size_t br = (size_t)nbricks * n_rows;
-        if (e->d_bmeta.ensure(4 * br) || e->d_btotal.ensure(nbricks)) return 1;
-        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 4 * sizeof(int32_t), e->stream));
-        hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(gs.nbricks), dim3(64), 0, e->stream, gs,
-                           e->d_lut.p, reinterpret_cast<int4 *>(e->d_bmeta.p), e->d_scalar.p);
-        QM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(qm::brick_prefix_kernel, dim3((gs.nbricks + 255) / 256), dim3(256),
-                           0, e->stream, gs, reinterpret_cast<int4 *>(e->d_bmeta.p),
-                           e->d_btotal.p);
-        QM_HIP(hipGetLastError());
-        totals[s].resize(nbricks);
-        QM_HIP(copy_back(totals[s].data(), e->d_btotal.p, nbricks * sizeof(int32_t), e->stream));
-        QM_HIP(copy_back(&e->lut_max, e->d_scalar.p, sizeof(int32_t), e->stream));
-        QM_HIP(hipStreamSynchronize(e->stream));
-        on_device = s;
-        return 0;
-    };
-    // largest candidate shape whose windows fit for tile length 64 * J under the current budget
-    // (result: g and e->h_btotal; `chosen` = its index)
-    int chosen = 0;
-    auto search = [&](int J) -> int {
-        const int KT = qm::kWave * J;
-        for (int s = 0; s < n_shapes; ++s) {
-            if (totals[s].empty() && measure(s)) return 1;
-            chosen = s;
-            int64_t wide = 0;
-            for (int32_t t : totals[s])
-                if (!qm::brick_fits(t, n_rows, KT, lds_cap_doubles(e))) ++wide;
-            if (wide * 200 <= (int64_t)totals[s].size()) break;   // <= 0.5 % of the bricks on the slow path
-        }
-        g = shapes[chosen];
-        return 0;
-    };
-    if (e->cfg_j == 0 && e->cfg_bx == 0 && !e->user_waves && !e->user_lds) {
-        // Automatic layout.  All S windows of a brick sit in LDS together, so workgroup shape
-        // (two 8-wave workgroups with 80 KB each, or one 16-wave workgroup with all 160 KB --
-        // measured 4 % slower at equal bricks: barriers), samples per lane and brick size trade
-        // against each other: more samples per lane cost less per sample (measured 1.0 / 1.12 /
-        // 1.4 for 4 / 2 / 1) but leave less room for the delay spans, and smaller bricks amortise
-        // their staging over fewer nodes (measured on 20-200 rows: time ~ 1 + 30 / nodes per
-        // brick).  Up to 64 rows the samples per lane follow from the budget (eff_j) and an
-        // exact-row-count kernel exists for one of them (3 % faster); beyond, both 2 and 1 are
-        // tried.  C3 (30 rows) keeps 2 x 80 KB; 33-64 rows and coarse grids get 160 KB.
-        double best_cost = 1e300;
-        int best_j = 0, best_waves = 8, best_lds = 80 * 1024;
-        for (int single = 0; single < 2; ++single) {
-            e->cfg_waves = single ? 16 : 8;
-            e->cfg_lds_bytes = single ? 160 * 1024 : 80 * 1024;
-            const int j_budget = eff_j(e);
-            for (int j : {4, 2, 1}) {
-                if (j > j_budget || (j == 1 && j_budget > 1 && n_rows <= 64)) continue;
-                if (j == 4 && n_rows > 40 && !e->cfg_exact) continue;   // exact kernels only
-                if (search(j)) return 1;
-                // (four samples per lane beyond 40 rows keep a ring of four offset chunks in
-                // registers instead of the whole node's: 7 % ahead of two samples per lane at
-                // equal bricks on the C3 grid x 60 rows)
-                double cost = (j == 4 ? (n_rows > 40 ? 1.04 : 1.0) : j == 2 ? 1.12 : 1.4) *
-                              (1.0 + 30.0 / g.brick_nodes) * (single ? 1.04 : 1.0);
-                if (e->cfg_exact && qm::exact_built(n_rows, j)) cost *= 0.97;
-                if (cost < best_cost) {
-                    best_cost = cost;
-                    best_j = j;
-                    best_waves = e->cfg_waves;
-                    best_lds = e->cfg_lds_bytes;
-                }
-            }
-        }
-        e->cfg_waves = best_waves;
-        e->cfg_lds_bytes = best_lds;
-        e->auto_j = best_j;
-    } else if (!e->user_waves && !e->user_lds) {
-        // brick shape or samples per lane given: the workgroup shape by the row count alone
-        const bool big = n_rows > 40;
-        e->cfg_waves = big ? 16 : 8;
-        e->cfg_lds_bytes = big ? 160 * 1024 : 80 * 1024;
-    }
-    if (search(eff_j(e))) return 1;
-    if (on_device != chosen && measure(chosen)) return 1;   // the chosen shape's records on the device
-    g = shapes[chosen];
-    e->h_btotal = totals[chosen];
-    // (the window-offset table of the round-2 kernels -- 2 bytes per table entry padded to 8 rows --
-    // is built when one of them first runs: ensure_rel; tables the shift-reuse kernel takes never
-    // need it)
-    e->rel_built = false;
-    QM_HIP(hipStreamSynchronize(e->stream));
-    e->g = g;
-    e->n_nodes = n_nodes;
-    e->node_offset = node_offset;
-    e->tab_waves = e->cfg_waves;                        // (what the layout search left in the tunables)
-    e->tab_lds_bytes = e->cfg_lds_bytes;
-    e->plan_j = -1;
-    e->screen_kt = 0;
-    e->pair_kt = 0;
-    e->shift_built = false;
-    e->shift_ok = false;
-    e->have_lut = true;
-    return plan_wide(e, eff_j(e));
-}
-
-int qm_engine_table_select(qm_engine *e, uint64_t key, int32_t capacity, int32_t *resident) {
-    if (!e || !resident) return fail("qm_engine_table_select: NULL argument");
-    if (capacity < 0 || capacity > 64) return fail("qm_engine_table_select: capacity must be in 0..64");
-    *resident = 0;
-    if (e->cur_keyed && e->cur_key == key && e->have_lut) {
-        *resident = 1;
-        ++e->table_hits;
-        return 0;
-    }
-    DeviceGuard guard(e->device);
-    TableState &cur = *e;
-    // park the table being worked on (if it has a key: one loaded without a key is simply replaced)
-    if (e->have_lut && e->cur_keyed && capacity > 0) {
-        TableSlot *slot = nullptr;
-        for (TableSlot &sl : e->slots)
-            if (!sl.used) { slot = &sl; break; }
-        if (!slot && (int)e->slots.size() < capacity) {
-            e->slots.emplace_back();
-            slot = &e->slots.back();
-        }
-        if (!slot) {                                    // evict the least recently used
-            slot = &e->slots[0];
-            for (TableSlot &sl : e->slots)
-                if (sl.stamp < slot->stamp) slot = &sl;
-            // (frees device memory: hipFree waits for work that may still read it)
-            slot->state.release_all();
-            slot->state = TableState{};
-            ++e->table_evictions;
-        }
-        std::swap(cur, slot->state);                    // the engine now holds the slot's empty state
-        slot->key = e->cur_key;
-        slot->stamp = ++e->table_clock;
-        slot->used = true;
-    } else if (e->have_lut) {
-        // nothing may be parked: keep the buffers for the next table (load_lut reuses allocations)
-        e->have_lut = false;
-        e->shift_built = e->shift_ok = false;
-        e->pair_kt = 0;
-        e->screen_kt = 0;
-        e->plan_j = -1;
-    }
-    e->cur_key = key;
-    e->cur_keyed = true;
-    for (TableSlot &sl : e->slots) {
-        if (sl.used && sl.key == key) {
-            std::swap(cur, sl.state);                   // (the slot keeps the empty state)
-            sl.state.release_all();
-            sl.state = TableState{};
-            sl.used = false;
-            if (!e->user_waves && e->tab_waves) e->cfg_waves = e->tab_waves;
-            if (!e->user_lds && e->tab_lds_bytes) e->cfg_lds_bytes = e->tab_lds_bytes;
-            *resident = 1;
-            ++e->table_hits;
-            return 0;
-        }
-    }
-    ++e->table_misses;
-    return 0;
-}
-
-int qm_engine_grids_begin(qm_engine *e, int32_t nx, int32_t ny, int32_t nz, int32_t n_grids) {
-    if (!e) return fail("engine is NULL");
-    if (nx < 1 || ny < 1 || nz < 1 || n_grids < 1) return fail("bad grid shape");
-    DeviceGuard guard(e->device);
-    if (e->d_grids.ensure((size_t)n_grids * nx * ny * nz)) return 1;
-    e->gx = nx; e->gy = ny; e->gz = nz; e->g_rows = n_grids;
-    return 0;
-}
-
-int qm_engine_grids_set(qm_engine *e, int32_t index, const double *grid, int on_device) {
-    if (!e || !grid) return fail("NULL argument");
-    if (index < 0 || index >= e->g_rows) return fail("grid index %d out of range", index);
-    DeviceGuard guard(e->device);
-    const size_t n = (size_t)e->gx * e->gy * e->gz;
-    if (on_device)
-        QM_HIP(hipMemcpyAsync(e->d_grids.p + (size_t)index * n, grid, n * sizeof(double),
-                              hipMemcpyDeviceToDevice, e->stream));
-    else
-        QM_HIP(copy_in(e->d_grids.p + (size_t)index * n, grid, n * sizeof(double), e->stream));
-    return 0;
-}
-
-int qm_engine_serve(qm_engine *e, double sampling_rate, const int32_t *rows, int32_t n_rows,
-                    int32_t dfx, int32_t dfy, int32_t dfz, int64_t node_offset) {
-    if (!e || !rows) return fail("NULL argument");
-    if (e->g_rows < 1) return fail("no travel-time grids resident: call qm_engine_grids_begin/set");
-    if (n_rows < 1) return fail("no rows selected");
-    if (dfx < 1 || dfy < 1 || dfz < 1) return fail("decimation factors must be >= 1");
-    for (int i = 0; i < n_rows; ++i)
-        if (rows[i] < 0 || rows[i] >= e->g_rows) return fail("row %d selects grid %d of %d", i, rows[i], e->g_rows);
-    DeviceGuard guard(e->device);
-    qm::ServeArgs a{};
-    a.nxf = e->gx; a.nyf = e->gy; a.nzf = e->gz;
-    a.dfx = dfx; a.dfy = dfy; a.dfz = dfz;
-    // Grid3D.decimate (lut.py:121-122): new = 1 + (n - 1) // df ; c1 = (n - df*(new-1) - 1) // 2
-    a.nx = 1 + (e->gx - 1) / dfx; a.ny = 1 + (e->gy - 1) / dfy; a.nz = 1 + (e->gz - 1) / dfz;
-    a.c1x = (e->gx - dfx * (a.nx - 1) - 1) / 2;
-    a.c1y = (e->gy - dfy * (a.ny - 1) - 1) / 2;
-    a.c1z = (e->gz - dfz * (a.nz - 1) - 1) / 2;
-    a.S = n_rows;
-    a.rate = sampling_rate;
-    const int64_t n_out = (int64_t)a.nx * a.ny * a.nz;
-    if (e->d_rows.ensure(n_rows) || e->d_served.ensure((size_t)n_out * n_rows)) return 1;
-    QM_HIP(copy_in(e->d_rows.p, rows, n_rows * sizeof(int32_t), e->stream));
-    a.grids = e->d_grids.p;
-    a.rows = e->d_rows.p;
-    a.out = e->d_served.p;
-    // 256 nodes per workgroup while their rows fit 64 KB of LDS (up to 63 rows), else 64
-    const int pitch = (n_rows + 1) | 1;
-    const bool wide = (size_t)256 * pitch * sizeof(int32_t) <= 64 * 1024;
-    const int npb = wide ? 256 : 64;
-    const size_t lds = (size_t)npb * pitch * sizeof(int32_t);
-    if (lds > 64 * 1024) return fail("too many rows (%d) for the serving kernel", n_rows);
-    if (wide)
-        hipLaunchKernelGGL(qm::serve_table_kernel<256>, dim3((unsigned)((n_out + 255) / 256)), dim3(256),
-                           lds, e->stream, a);
-    else
-        hipLaunchKernelGGL(qm::serve_table_kernel<64>, dim3((unsigned)((n_out + 63) / 64)), dim3(256), lds,
-                           e->stream, a);
-    QM_HIP(hipGetLastError());
-    return qm_engine_load_lut(e, e->d_served.p, 1, a.nx, a.ny, a.nz, n_rows, node_offset);
-}
-
-int qm_engine_lut_download(qm_engine *e, int32_t *out) {
-    if (!e || !out) return fail("NULL argument");
-    if (!e->have_lut) return fail("no travel-time table resident");
-    DeviceGuard guard(e->device);
-    QM_HIP(copy_back(out, e->d_lut.p, (size_t)e->n_nodes * e->g.n_rows * sizeof(int32_t), e->stream));
-    QM_HIP(hipStreamSynchronize(e->stream));
-    return 0;
-}
-
-int qm_engine_lut_max(qm_engine *e, int32_t *max_delay) {
-    if (!e || !max_delay) return fail("NULL argument");
-    if (!e->have_lut) return fail("no travel-time table resident");
-    *max_delay = e->lut_max;
     return 0;
 }
 
@@ -2308,84 +936,6 @@ int qm_engine_marginal(qm_engine *e, const double *log_onsets, int onsets_on_dev
     return 0;
 }
 
-int qm_engine_onsets(qm_engine *e, const double *signals, int signals_on_device,
-                     int32_t n_traces, int32_t t_samples, const int32_t *trace_row, int32_t n_rows,
-                     const int32_t *nsta, const int32_t *nlta, int transform, int position,
-                     int32_t taper_pad, double min_onset_value, double *raw_onsets,
-                     double *log_onsets, int out_on_device) {
-    if (!e || !signals || !trace_row || !nsta || !nlta || !log_onsets)
-        return fail("qm_engine_onsets: NULL argument");
-    if (n_traces < 1 || n_rows < 1 || t_samples < 1) return fail("qm_engine_onsets: empty input");
-    if (transform != 0 && transform != 1) return fail("transform must be 0 (energy) or 1 (abs)");
-    if (position < 0 || position > 2)
-        return fail("position must be 0 (classic), 1 (centred) or 2 (recursive)");
-    std::vector<int> per_row(n_rows, 0);
-    for (int i = 0; i < n_traces; ++i) {
-        if (trace_row[i] < 0 || trace_row[i] >= n_rows) return fail("trace %d: row out of range", i);
-        ++per_row[trace_row[i]];
-    }
-    for (int r = 0; r < n_rows; ++r)
-        if (per_row[r] == 0) return fail("onset row %d has no trace", r);
-    DeviceGuard guard(e->device);
-    const size_t sig = (size_t)n_traces * t_samples, out = (size_t)n_rows * t_samples;
-    const double *d_sig = signals;
-    if (!signals_on_device) {
-        if (e->d_sig.ensure(sig)) return 1;
-        QM_HIP(copy_in(e->d_sig.p, signals, sig * sizeof(double), e->stream));
-        d_sig = e->d_sig.p;
-    }
-    if (e->d_sta.ensure(sig) || e->d_lta.ensure(sig) ||
-        e->d_onset_meta.ensure((size_t)n_traces + 2 * n_rows))
-        return 1;
-    std::vector<int32_t> meta(trace_row, trace_row + n_traces);
-    meta.insert(meta.end(), nsta, nsta + n_rows);
-    meta.insert(meta.end(), nlta, nlta + n_rows);
-    QM_HIP(copy_in(e->d_onset_meta.p, meta.data(), meta.size() * sizeof(int32_t), e->stream));
-    QM_HIP(hipStreamSynchronize(e->stream));            // `meta` is a stack-lifetime buffer
-    qm::OnsetArgs a{};
-    a.signals = d_sig;
-    a.trace_row = e->d_onset_meta.p;
-    a.nsta = e->d_onset_meta.p + n_traces;
-    a.nlta = e->d_onset_meta.p + n_traces + n_rows;
-    a.sta = e->d_sta.p;
-    a.lta = e->d_lta.p;
-    a.n_traces = n_traces; a.n_rows = n_rows; a.T = t_samples;
-    a.transform = transform; a.position = position; a.taper_pad = taper_pad;
-    a.min_onset_value = min_onset_value;
-    double *d_log = log_onsets, *d_raw = raw_onsets;
-    if (!out_on_device) {
-        if (e->d_onsets.ensure(out)) return 1;
-        d_log = e->d_onsets.p;
-        if (raw_onsets) {
-            if (e->d_raw.ensure(out)) return 1;
-            d_raw = e->d_raw.p;
-        }
-    }
-    a.raw = d_raw;
-    a.logged = d_log;
-    {
-        // one workgroup per trace; the transformed trace lives in LDS if it fits (20 480 samples)
-        const size_t lds = (size_t)t_samples * sizeof(double);
-        const int in_lds = lds <= 160 * 1024 ? 1 : 0;
-        if (in_lds)
-            QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&qm::stalta_sums_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(qm::stalta_sums_kernel, dim3(n_traces), dim3(256), in_lds ? lds : 0,
-                           e->stream, a, in_lds);
-        QM_HIP(hipGetLastError());
-    }
-    hipLaunchKernelGGL(qm::onset_rows_kernel, dim3((unsigned)((out + 255) / 256)), dim3(256), 0,
-                       e->stream, a);
-    QM_HIP(hipGetLastError());
-    if (!out_on_device) {
-        QM_HIP(copy_back(log_onsets, d_log, out * sizeof(double), e->stream));
-        if (raw_onsets)
-            QM_HIP(copy_back(raw_onsets, d_raw, out * sizeof(double), e->stream));
-        QM_HIP(hipStreamSynchronize(e->stream));
-    }
-    return 0;
-}
-
 int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
                            int32_t n_samples, int64_t n_nodes, double *max_coa,
                            double *max_norm_coa, int64_t *max_coa_idx, int out_on_device) {
@@ -2434,227 +984,6 @@ int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
     return fetch_out(e, n_samples, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
 }
 
-namespace {
-
-// Weights of one axis of the reference's filter as a function of d = i - j.
-// util.gaussian_3d (util.py:76-116) samples exp(-x^2 / (2 sgm^2)) at x = k - (n-1)/2,
-// k = 0..n-1; fftconvolve(..., mode="same") centres the full convolution at (n-1)//2, so
-// out[i] = sum_j in[j] * flt[i - j + (n-1)//2]: symmetric for odd n, shifted by half a node
-// for even n (which is why the reference filters twice, mirrored).  `mirror` gives the second
-// pass, w(d) -> w(-d).  Weights below 1e-20 of the peak are dropped: the reference's own FFT
-// round-off is four orders of magnitude above that.
-int axis_taps(int n, double sgm, bool mirror, qm::Taps *t) {
-    const int c = (n - 1) / 2;
-    const double half = 0.5 * (n - 1);
-    int R = (int)std::ceil(sgm * 9.6) + 1;              // exp(-(9.6)^2 / 2) = 1e-20
-    int lo = 0, hi = -1;
-    bool any = false;
-    for (int d = -R; d <= R; ++d) {
-        const int k = (mirror ? -d : d) + c;
-        if (k < 0 || k > n - 1) continue;
-        if (!any) lo = d;
-        hi = d;
-        any = true;
-    }
-    if (!any) return fail("gaussian filter: empty support");
-    if (hi - lo + 1 > qm::kMaxTaps)
-        return fail("gaussian filter: sgm %.3g needs %d taps, more than %d", sgm, hi - lo + 1,
-                    qm::kMaxTaps);
-    t->lo = lo;
-    t->n = hi - lo + 1;
-    for (int d = lo; d <= hi; ++d) {
-        const double x = (double)((mirror ? -d : d) + c) - half;
-        t->w[d - lo] = std::exp(-(x * x) / (2.0 * sgm * sgm));
-    }
-    return 0;
-}
-
-}  // namespace
-
-int qm_engine_locate_fits(qm_engine *e, const double *coa_map, int map_on_device, int32_t nx,
-                          int32_t ny, int32_t nz, double sgm, double cov_thresh,
-                          const double *node_spacing, double *norm_map, double *smoothed_map,
-                          int out_on_device, double *summary, double *gau_window,
-                          double *spline_window) {
-    if (!e || !coa_map || !node_spacing || !summary || !gau_window || !spline_window)
-        return fail("qm_engine_locate_fits: NULL argument");
-    if (nx < 1 || ny < 1 || nz < 1) return fail("qm_engine_locate_fits: empty grid");
-    if (!(sgm > 0.0)) return fail("qm_engine_locate_fits: sgm must be positive");
-    DeviceGuard guard(e->device);
-    const int64_t n = (int64_t)nx * ny * nz;
-    constexpr int NB = qm::kFitBlocks, BS = qm::kFitBlock;
-    if (e->d_fit_a.ensure((size_t)n) || e->d_fit_b.ensure((size_t)n) ||
-        e->d_fit_c.ensure((size_t)n) || e->d_fit_part.ensure((size_t)NB * 6) ||
-        e->d_fit_pidx.ensure(NB) || e->d_fit_val.ensure(32) || e->d_fit_win.ensure(343 + 125))
-        return 1;
-    hipStream_t s = e->stream;
-    const double *d_in = coa_map;
-    if (!map_on_device) {
-        QM_HIP(copy_in(e->d_fit_c.p, coa_map, (size_t)n * sizeof(double), s));
-        d_in = e->d_fit_c.p;
-    }
-    double *val = e->d_fit_val.p;
-    // device scalars: 0 map max, 1 map argmax, 2 pass-1 max, 3 -, 4 pass-2 max, 5 -,
-    // 6 smoothed mean, 7 smoothed argmax, 8..11 first moments, 12..17 second moments, 18 -
-    auto argmax = [&](const double *m, double *out_v, double *out_i) -> int {
-        hipLaunchKernelGGL(qm::argmax_partial_kernel, dim3(NB), dim3(BS), 0, s, m, n,
-                           e->d_fit_part.p, e->d_fit_pidx.p);
-        hipLaunchKernelGGL(qm::argmax_final_kernel, dim3(1), dim3(BS), 0, s, e->d_fit_part.p,
-                           e->d_fit_pidx.p, NB, out_v, out_i);
-        QM_HIP(hipGetLastError());
-        return 0;
-    };
-    const unsigned node_blocks = (unsigned)((n + BS - 1) / BS);
-    auto smooth = [&](const double *in, double *tmp, double *out, bool mirror,
-                      const double *div) -> int {
-        qm::Taps tx, ty, tz;
-        if (axis_taps(nx, sgm, mirror, &tx) || axis_taps(ny, sgm, mirror, &ty) ||
-            axis_taps(nz, sgm, mirror, &tz))
-            return 1;
-        hipLaunchKernelGGL(qm::smooth_axis_kernel, dim3(node_blocks), dim3(BS), 0, s, in, out,
-                           nx, ny, nz, 0, tx, div);
-        hipLaunchKernelGGL(qm::smooth_axis_kernel, dim3(node_blocks), dim3(BS), 0, s,
-                           (const double *)out, tmp, nx, ny, nz, 1, ty, (const double *)nullptr);
-        hipLaunchKernelGGL(qm::smooth_axis_kernel, dim3(node_blocks), dim3(BS), 0, s,
-                           (const double *)tmp, out, nx, ny, nz, 2, tz, (const double *)nullptr);
-        QM_HIP(hipGetLastError());
-        return 0;
-    };
-
-    // (1) coa_map / nanmax(coa_map)                                       scan.py:721
-    double *d_norm = (norm_map && out_on_device) ? norm_map : e->d_fit_a.p;
-    if (argmax(d_in, val + 0, val + 1)) return 1;
-    hipLaunchKernelGGL(qm::divide_kernel, dim3(NB), dim3(BS), 0, s, d_in, (const double *)val, n,
-                       d_norm);
-    if (argmax(d_norm, val + 18, val + 1)) return 1;
-
-    // (2) _gaufilt3d: filter, normalise, filter mirrored, normalise        scan.py:1033-1041
-    double *d_smooth = (smoothed_map && out_on_device) ? smoothed_map : e->d_fit_b.p;
-    double *d_tmp = e->d_fit_c.p;           // the staged input is dead once d_norm exists
-    if (smooth(d_norm, d_tmp, d_smooth, false, nullptr)) return 1;
-    if (argmax(d_smooth, val + 2, val + 3)) return 1;
-    // second pass: its first axis divides by the pass-1 maximum (the filter is linear)
-    {
-        // no axis may filter in place: x -> d_tmp, y -> d_smooth, z -> d_tmp
-        qm::Taps tx, ty, tz;
-        if (axis_taps(nx, sgm, true, &tx) || axis_taps(ny, sgm, true, &ty) ||
-            axis_taps(nz, sgm, true, &tz))
-            return 1;
-        hipLaunchKernelGGL(qm::smooth_axis_kernel, dim3(node_blocks), dim3(BS), 0, s,
-                           (const double *)d_smooth, d_tmp, nx, ny, nz, 0, tx,
-                           (const double *)(val + 2));
-        hipLaunchKernelGGL(qm::smooth_axis_kernel, dim3(node_blocks), dim3(BS), 0, s,
-                           (const double *)d_tmp, d_smooth, nx, ny, nz, 1, ty,
-                           (const double *)nullptr);
-        hipLaunchKernelGGL(qm::smooth_axis_kernel, dim3(node_blocks), dim3(BS), 0, s,
-                           (const double *)d_smooth, d_tmp, nx, ny, nz, 2, tz,
-                           (const double *)nullptr);
-        QM_HIP(hipGetLastError());
-    }
-    if (argmax(d_tmp, val + 4, val + 5)) return 1;
-    hipLaunchKernelGGL(qm::divide_kernel, dim3(NB), dim3(BS), 0, s, (const double *)d_tmp,
-                       (const double *)(val + 4), n, d_smooth);
-    if (argmax(d_smooth, val + 18, val + 7)) return 1;
-    hipLaunchKernelGGL(qm::sum_partial_kernel, dim3(NB), dim3(BS), 0, s,
-                       (const double *)d_smooth, n, e->d_fit_part.p);
-    hipLaunchKernelGGL(qm::sums_final_kernel, dim3(1), dim3(BS), 0, s,
-                       (const double *)e->d_fit_part.p, NB, 1, 1.0 / (double)n, val + 6);
-
-    // (3) _covfit3d on the normalised (unsmoothed) map                     scan.py:973-999
-    hipLaunchKernelGGL(qm::moments_partial_kernel<0>, dim3(NB), dim3(BS), 0, s,
-                       (const double *)d_norm, nx, ny, nz, cov_thresh, node_spacing[0],
-                       node_spacing[1], node_spacing[2], (const double *)nullptr,
-                       e->d_fit_part.p);
-    hipLaunchKernelGGL(qm::sums_final_kernel, dim3(4), dim3(BS), 0, s,
-                       (const double *)e->d_fit_part.p, NB, 4, 1.0, val + 8);
-    hipLaunchKernelGGL(qm::moments_partial_kernel<1>, dim3(NB), dim3(BS), 0, s,
-                       (const double *)d_norm, nx, ny, nz, cov_thresh, node_spacing[0],
-                       node_spacing[1], node_spacing[2], (const double *)(val + 8),
-                       e->d_fit_part.p);
-    hipLaunchKernelGGL(qm::sums_final_kernel, dim3(6), dim3(BS), 0, s,
-                       (const double *)e->d_fit_part.p, NB, 6, 1.0, val + 12);
-    hipLaunchKernelGGL(qm::moments_scale_kernel, dim3(1), dim3(64), 0, s, val + 12,
-                       (const double *)(val + 8));
-
-    // (4) the windows the Gaussian (7^3, smoothed map) and spline (5^3, normalised map) fits use
-    hipLaunchKernelGGL(qm::window_kernel, dim3(2), dim3(256), 0, s, (const double *)d_smooth, nx,
-                       ny, nz, 7, (const double *)(val + 7), e->d_fit_win.p);
-    hipLaunchKernelGGL(qm::window_kernel, dim3(1), dim3(128), 0, s, (const double *)d_norm, nx,
-                       ny, nz, 5, (const double *)(val + 1), e->d_fit_win.p + 343);
-    QM_HIP(hipGetLastError());
-
-    double h[32], w[343 + 125];
-    QM_HIP(copy_back(h, val, sizeof(h), s));
-    QM_HIP(copy_back(w, e->d_fit_win.p, sizeof(w), s));
-    if (norm_map && !out_on_device)
-        QM_HIP(copy_back(norm_map, d_norm, (size_t)n * sizeof(double), s));
-    if (smoothed_map && !out_on_device)
-        QM_HIP(copy_back(smoothed_map, d_smooth, (size_t)n * sizeof(double), s));
-    QM_HIP(hipStreamSynchronize(s));
-    if (h[1] < 0) return fail("qm_engine_locate_fits: the map holds no finite value");
-    summary[0] = h[0];                      // nanmax of the input map
-    summary[1] = h[1];                      // first argmax of the normalised map (flat index)
-    summary[2] = h[6];                      // mean of the smoothed map
-    summary[3] = h[7];                      // first argmax of the smoothed map
-    summary[4] = h[8];                      // total weight above the threshold
-    for (int k = 0; k < 3; ++k) summary[5 + k] = h[9 + k] / h[8];     // xe, ye, ze
-    for (int k = 0; k < 6; ++k) summary[8 + k] = h[12 + k];
-    summary[14] = h[2];
-    summary[15] = h[4];
-    std::memcpy(gau_window, w, 343 * sizeof(double));
-    std::memcpy(spline_window, w + 343, 125 * sizeof(double));
-    return 0;
-}
-
-int qm_engine_rbf_peak(qm_engine *e, const double *weights, int32_t n, int32_t upscale,
-                       double *peak_value, int64_t *peak_index) {
-    if (!e || !weights || !peak_value || !peak_index)
-        return fail("qm_engine_rbf_peak: NULL argument");
-    if (n < 2 || n > 9 || upscale < 1 || upscale > 64)
-        return fail("qm_engine_rbf_peak: need 2 <= n <= 9 centres per axis and 1 <= upscale <= 64");
-    DeviceGuard guard(e->device);
-    const int m = (n - 1) * upscale + 1;
-    const int64_t fine = (int64_t)m * m * m;
-    constexpr int NB = qm::kFitBlocks, BS = qm::kFitBlock;
-    if (e->d_fit_a.ensure((size_t)fine) || e->d_fit_win.ensure(9 * 9 * 9) ||
-        e->d_fit_part.ensure((size_t)NB * 6) || e->d_fit_pidx.ensure(NB) || e->d_fit_val.ensure(32))
-        return 1;
-    hipStream_t s = e->stream;
-    QM_HIP(copy_in(e->d_fit_win.p, weights, (size_t)n * n * n * sizeof(double), s));
-    hipLaunchKernelGGL(qm::rbf_dense_kernel, dim3((unsigned)((fine + BS - 1) / BS)), dim3(BS), 0, s,
-                       (const double *)e->d_fit_win.p, (int)n, m, (double)(n - 1) / (double)(m - 1),
-                       e->d_fit_a.p);
-    hipLaunchKernelGGL(qm::argmax_partial_kernel, dim3(NB), dim3(BS), 0, s,
-                       (const double *)e->d_fit_a.p, fine, e->d_fit_part.p, e->d_fit_pidx.p);
-    hipLaunchKernelGGL(qm::argmax_final_kernel, dim3(1), dim3(BS), 0, s, e->d_fit_part.p,
-                       e->d_fit_pidx.p, NB, e->d_fit_val.p, e->d_fit_val.p + 1);
-    QM_HIP(hipGetLastError());
-    double h[2];
-    QM_HIP(copy_back(h, e->d_fit_val.p, sizeof(h), s));
-    QM_HIP(hipStreamSynchronize(s));
-    if (h[1] < 0) return fail("qm_engine_rbf_peak: the interpolant holds no finite value");
-    *peak_value = h[0];
-    *peak_index = (int64_t)h[1];
-    return 0;
-}
-
-int qm_exp2f_max_error(qm_engine *e, float lo, float hi, double *max_rel_error) {
-    if (!e || !max_rel_error) return fail("qm_exp2f_max_error: NULL argument");
-    if (!(lo <= hi) || (lo < 0.f) != (hi < 0.f))
-        return fail("qm_exp2f_max_error: need lo <= hi of one sign");
-    DeviceGuard guard(e->device);
-    constexpr int kBlocks = 4096;
-    if (e->d_fit_part.ensure(kBlocks)) return 1;
-    hipLaunchKernelGGL(qm::exp2f_error_kernel, dim3(kBlocks), dim3(256), 0, e->stream, lo, hi,
-                       e->d_fit_part.p);
-    QM_HIP(hipGetLastError());
-    std::vector<double> h(kBlocks);
-    QM_HIP(copy_back(h.data(), e->d_fit_part.p, kBlocks * sizeof(double), e->stream));
-    QM_HIP(hipStreamSynchronize(e->stream));
-    *max_rel_error = *std::max_element(h.begin(), h.end());
-    return 0;
-}
-
 int qm_engine_kernel_log(qm_engine *e, double *total_ms, int32_t *n_calls) {
     if (!e || !total_ms || !n_calls) return fail("NULL argument");
     DeviceGuard guard(e->device);
@@ -2681,207 +1010,6 @@ int qm_engine_last_kernel_ms(qm_engine *e, double *ms) {
     QM_HIP(hipEventElapsedTime(&f, e->ev0, e->ev1));
     *ms = f;
     return 0;
-}
-
-// ---------------------------------------------------------------- reference-compatible part
-// A process-wide engine on device $QM_HIP_DEVICE (default 0).  These two entry points receive
-// host arrays and no grid shape (qmlib.h:28-32), so the node axis is bricked along the flat
-// index.  They cannot report errors through their signature (void, like the reference).  On a
-// failure (no device, a travel time beyond the post-pad -- undefined behaviour in the reference --
-// ...) the message goes to stderr, the outputs are filled with NaN (indices 0) so that nothing
-// downstream can mistake them for results, and qm_compat_status() returns non-zero with the text
-// in qm_last_error(); with QM_HIP_COMPAT_ON_ERROR=abort the process is aborted instead.
-static std::mutex g_compat_mutex;
-static qm_engine *g_compat = nullptr;
-static int g_compat_status = 0;
-
-// what the resident table of the compat engine was built from: the reference's caller passes the
-// served table on every call (scan.py:629-634 -> lib.py:53-60), usually with unchanged content
-struct CompatTable {
-    uint64_t hash = 0, hash2 = 0;       // two independent 64-bit content hashes (see table_hash)
-    int64_t n_nodes = -1;
-    int32_t n_rows = -1;
-    int32_t gx = 0, gy = 0, gz = 0;     // grid shape it was loaded with (QM_HIP_GRID), 0 = flat
-    bool valid = false;
-};
-static CompatTable g_compat_table;
-
-extern "C++" {
-// run fn(lo, hi, thread) over [0, n) on a few host threads
-template <typename F>
-static void parallel_ranges(size_t n, size_t grain, F fn) {
-    size_t want = (n + grain - 1) / grain;
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t nt = std::max<size_t>(1, std::min<size_t>({want, hw ? hw : 4u, (size_t)32}));
-    if (nt == 1) {
-        fn(0, n, 0);
-        return;
-    }
-    std::vector<std::thread> pool;
-    const size_t per = (n + nt - 1) / nt;
-    for (size_t t = 0; t < nt; ++t) {
-        const size_t lo = t * per, hi = std::min(n, lo + per);
-        if (lo >= hi) break;
-        pool.emplace_back(fn, lo, hi, t);
-    }
-    for (auto &th : pool) th.join();
-}
-
-// Two independent 64-bit content hashes of the whole table (every word, order-sensitive; threads
-// combined in order): a multiply-xorshift chain and a rotate-add chain with other constants, read in
-// one pass.  The resident table is reused only if BOTH match (and the shape): a stale table would
-// need a simultaneous collision of two unrelated 64-bit functions.  QM_HIP_COMPAT_REUPLOAD=1
-// re-uploads on every call regardless.
-static void table_hash(const int32_t *p, size_t n, uint64_t *h1, uint64_t *h2) {
-    std::vector<uint64_t> part(32, 0), part2(32, 0);
-    parallel_ranges(n, (size_t)1 << 22, [&](size_t lo, size_t hi, size_t t) {
-        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)lo;
-        uint64_t g = 0xD6E8FEB86659FD93ull + (uint64_t)lo * 0x2545F4914F6CDD1Dull;
-        for (size_t i = lo; i < hi; ++i) {
-            const uint64_t w = (uint32_t)p[i];
-            h ^= w;
-            h *= 0xFF51AFD7ED558CCDull;
-            h ^= h >> 29;
-            g = ((g << 23) | (g >> 41)) + (w + 0x9FB21C651E98DF25ull) * 0xA24BAED4963EE407ull;
-        }
-        part[t] = h;
-        part2[t] = g;
-    });
-    uint64_t h = n, g = ~(uint64_t)n;
-    for (uint64_t v : part) h = (h ^ v) * 0xC4CEB9FE1A85EC53ull + 0x632BE59BD9B4E019ull;
-    for (uint64_t v : part2) g = ((g << 31) | (g >> 33)) ^ (v * 0x94D049BB133111EBull);
-    *h1 = h;
-    *h2 = g;
-}
-
-static bool any_nonzero(const double *p, size_t n) {
-    std::atomic<bool> found{false};
-    parallel_ranges(n, (size_t)1 << 22, [&](size_t lo, size_t hi, size_t) {
-        // 8-byte words compared as integers: -0.0 counts as non-zero, which only costs an upload
-        const uint64_t *w = reinterpret_cast<const uint64_t *>(p);
-        for (size_t i = lo; i < hi && !found.load(std::memory_order_relaxed);) {
-            const size_t stop = std::min(hi, i + 4096);
-            uint64_t acc = 0;
-            for (; i < stop; ++i) acc |= w[i];
-            if (acc) found.store(true, std::memory_order_relaxed);
-        }
-    });
-    return found.load();
-}
-}  // extern "C++"
-
-static qm_engine *compat_engine() {
-    if (!g_compat) {
-        const char *dev = getenv("QM_HIP_DEVICE");
-        if (qm_engine_create(dev ? atoi(dev) : 0, &g_compat)) g_compat = nullptr;
-    }
-    return g_compat;
-}
-
-static bool compat_failed(int rc, const char *what) {
-    if (!rc) return false;
-    g_compat_status = rc;
-    fprintf(stderr, "qmlib (HIP) %s: %s\n", what, qm_last_error());
-    const char *mode = getenv("QM_HIP_COMPAT_ON_ERROR");
-    if (mode && strcmp(mode, "abort") == 0) abort();
-    return true;
-}
-
-int qm_compat_status(void) { return g_compat_status; }
-
-void qm_table_hash(const int32_t *table, int64_t n_words, uint64_t *hash_a, uint64_t *hash_b) {
-    uint64_t a = 0, b = 0;
-    if (table && n_words > 0) table_hash(table, (size_t)n_words, &a, &b);
-    if (hash_a) *hash_a = a;
-    if (hash_b) *hash_b = b;
-}
-
-void migrate(double *onsets, int32_t *lookup_tables, double *map4d, int32_t fsmp, int32_t lsmp,
-             int32_t n_samples, int32_t n_stations, int32_t available, int64_t n_nodes,
-             int64_t threads) {
-    (void)threads;
-    std::lock_guard<std::mutex> lock(g_compat_mutex);
-    g_compat_status = 0;
-    const size_t total = (size_t)(n_nodes > 0 ? n_nodes : 0) * (size_t)(n_samples > 0 ? n_samples : 0);
-    auto poison = [&]() {
-        for (size_t i = 0; i < total; ++i) map4d[i] = std::nan("");
-    };
-    qm_engine *e = compat_engine();
-    if (!e) {
-        compat_failed(1, "migrate/create");
-        return poison();
-    }
-    if (n_nodes < 1 || n_nodes >= INT32_MAX || n_stations < 1) {
-        compat_failed(fail("migrate: bad sizes (n_nodes=%lld, n_stations=%d)", (long long)n_nodes,
-                           n_stations), "migrate");
-        return poison();
-    }
-    // The reference's signature carries no grid shape (lib.py:112-123 passes the flat node count),
-    // so by default the table is bricked 1 x 1 x 32 along the flat index.  A caller who knows the
-    // shape can say so -- QM_HIP_GRID=nx,ny,nz (nx*ny*nz must equal n_nodes) -- and gets the
-    // engine's own 3-D bricks (8 x 8 x 8 where they fit) and the kernels that go with them.
-    int gx = 0, gy = 0, gz = 0;
-    if (const char *shape = getenv("QM_HIP_GRID")) {
-        long long a = 0, b = 0, c = 0;
-        if (sscanf(shape, "%lld,%lld,%lld", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0 &&
-            a * b * c == (long long)n_nodes) {
-            gx = (int)a; gy = (int)b; gz = (int)c;
-        } else {
-            compat_failed(fail("migrate: QM_HIP_GRID='%s' does not describe %lld nodes", shape,
-                               (long long)n_nodes), "migrate");
-            return poison();
-        }
-    }
-    // table: re-uploaded (and its brick tables rebuilt) only when its content changed
-    uint64_t h = 0, h2 = 0;
-    table_hash(lookup_tables, (size_t)n_nodes * n_stations, &h, &h2);
-    const char *reup = getenv("QM_HIP_COMPAT_REUPLOAD");
-    const bool force = reup && atoi(reup) != 0;
-    if (force || !(g_compat_table.valid && e->have_lut && g_compat_table.hash == h &&
-                   g_compat_table.hash2 == h2 && g_compat_table.n_nodes == n_nodes &&
-                   g_compat_table.n_rows == n_stations && g_compat_table.gx == gx &&
-                   g_compat_table.gy == gy && g_compat_table.gz == gz)) {
-        g_compat_table.valid = false;
-        e->cfg_bx = gx ? 0 : 1;
-        e->cfg_by = gx ? 0 : 1;
-        e->cfg_bz = gx ? 0 : 32;
-        if (compat_failed(qm_engine_load_lut(e, lookup_tables, 0, gx ? gx : 1, gx ? gy : 1,
-                                             gx ? gz : (int32_t)n_nodes, n_stations, 0),
-                          "migrate/load"))
-            return poison();
-        g_compat_table.hash = h;
-        g_compat_table.hash2 = h2;
-        g_compat_table.n_nodes = n_nodes;
-        g_compat_table.n_rows = n_stations;
-        g_compat_table.gx = gx; g_compat_table.gy = gy; g_compat_table.gz = gz;
-        g_compat_table.valid = true;
-    }
-    // the reference adds on top of map4d; the Python binding always passes zeros (lib.py:101),
-    // so only pay for the upload when something is there (QM_HIP_ASSUME_ZERO_MAP=1 skips the
-    // check: the caller vouches for a zeroed map, as the reference's own binding passes)
-    const char *zero = getenv("QM_HIP_ASSUME_ZERO_MAP");
-    const int accumulate = (zero && atoi(zero) != 0) ? 0 : (any_nonzero(map4d, total) ? 1 : 0);
-    if (compat_failed(qm_engine_migrate(e, onsets, 0, fsmp + lsmp + n_samples, fsmp, lsmp,
-                                        available, n_nodes, map4d, 0, accumulate, nullptr, nullptr,
-                                        nullptr, 0), "migrate"))
-        poison();
-}
-
-void find_max_coa(double *map4d, double *max_coa, double *max_norm_coa, int64_t *max_coa_idx,
-                  int32_t n_samples, int64_t n_nodes, int64_t threads) {
-    (void)threads;
-    std::lock_guard<std::mutex> lock(g_compat_mutex);
-    g_compat_status = 0;
-    qm_engine *e = compat_engine();
-    if (!e || compat_failed(qm_engine_find_max_coa(e, map4d, 0, n_samples, n_nodes, max_coa,
-                                                   max_norm_coa, max_coa_idx, 0),
-                            "find_max_coa")) {
-        if (!e) compat_failed(1, "find_max_coa/create");
-        for (int32_t i = 0; i < n_samples; ++i) {
-            max_coa[i] = max_norm_coa[i] = std::nan("");
-            max_coa_idx[i] = 0;
-        }
-    }
 }
 
 }  // extern "C"

@@ -18,8 +18,9 @@
 #include <stdint.h>
 
 // The stacking kernels are templates, instantiated family by family in the launch-table units
-// (qm_launch_*.hip); the plain kernels of this header are compiled by the engine's translation
-// unit only, which defines QM_ENGINE_TU before including it.
+// (qm_launch_*.hip); each plain kernel of this header is compiled by ONE of the engine's translation
+// units, the one that launches it: QM_TU_TABLES (qm_tables.hip), QM_TU_STEPS (qm_engine.hip),
+// QM_TU_WIDEN (qm_widen.hip), QM_TU_SCREEN (qm_screen.hip) -- each defines its macro before including it.
 namespace qm {
 
 constexpr int kWave = 64;
@@ -137,7 +138,7 @@ __device__ __forceinline__ int brick_walk_node(const GridDesc &g, int x0, int y0
 }
 
 // one workgroup per brick, thread r <-> table row r: min / span of the clamped delays.
-#ifdef QM_ENGINE_TU
+#ifdef QM_TU_TABLES
 __global__ void brick_minmax_kernel(GridDesc g, const int32_t *__restrict__ lut,
                                     int4 *__restrict__ meta, int32_t *__restrict__ global_max) {
     const int b = blockIdx.x;
@@ -157,9 +158,9 @@ __global__ void brick_minmax_kernel(GridDesc g, const int32_t *__restrict__ lut,
         atomicMax(global_max, hi);
     }
 }
-#endif  // QM_ENGINE_TU
+#endif  // QM_TU_TABLES
 
-#ifdef QM_ENGINE_TU
+#ifdef QM_TU_TABLES
 __global__ void brick_prefix_kernel(GridDesc g, int4 *__restrict__ meta,
                                     int32_t *__restrict__ btotal) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -171,11 +172,11 @@ __global__ void brick_prefix_kernel(GridDesc g, int4 *__restrict__ meta,
     }
     btotal[b] = (int32_t)(run > INT32_MAX ? INT32_MAX : run);
 }
-#endif  // QM_ENGINE_TU
+#endif  // QM_TU_TABLES
 
 // Brick-relative window offsets: rel[b][m][r] = 8 * (off_r + clamp(tt) - min_r) BYTES, uint16,
 // one row of row_pad entries per node, nodes in walk order (see brick_walk_node).
-#ifdef QM_ENGINE_TU
+#ifdef QM_TU_TABLES
 __global__ void brick_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
                                  const int4 *__restrict__ meta,
                                  const int32_t *__restrict__ btotal,
@@ -199,7 +200,7 @@ __global__ void brick_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
         rel[(int64_t)b * per + i] = v;
     }
 }
-#endif  // QM_ENGINE_TU
+#endif  // QM_TU_TABLES
 
 // ---------------------------------------------------------------------------------------
 // Onset stage on the device: STALTAOnset._onset (quakemigrate/signal/onsets/stalta.py:491-548,
@@ -327,7 +328,7 @@ __device__ __forceinline__ void stalta_recurrence(const OnsetArgs &a, const doub
     }
 }
 
-#ifdef QM_ENGINE_TU
+#ifdef QM_TU_WIDEN
 __global__ __launch_bounds__(256) void stalta_sums_kernel(OnsetArgs a, int in_lds) {
     extern __shared__ double fx[];
     const int tr = blockIdx.x;
@@ -345,10 +346,10 @@ __global__ __launch_bounds__(256) void stalta_sums_kernel(OnsetArgs a, int in_ld
     if (in_lds) stalta_recurrence<true>(a, fx, x, S, L, ns, nl, n);
     else stalta_recurrence<false>(a, fx, x, S, L, ns, nl, n);
 }
-#endif  // QM_ENGINE_TU
+#endif  // QM_TU_WIDEN
 
 // thread <-> (row, sample); the components of a row are consecutive traces
-#ifdef QM_ENGINE_TU
+#ifdef QM_TU_WIDEN
 __global__ void onset_rows_kernel(OnsetArgs a) {
 #pragma clang fp contract(off)                           // numpy squares, then adds (stalta.py:544)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,7 +388,7 @@ __global__ void onset_rows_kernel(OnsetArgs a) {
     if (a.raw) a.raw[i] = onset;
     a.logged[i] = log(onset < 0.01 ? 0.01 : onset);                    // lib.py:93-94
 }
-#endif  // QM_ENGINE_TU
+#endif  // QM_TU_WIDEN
 
 // ---------------------------------------------------------------------------------------
 // Table serving on the device (what LUT.serve_traveltimes does on the host every timestep,
@@ -408,7 +409,7 @@ struct ServeArgs {
     double rate;
 };
 
-#ifdef QM_ENGINE_TU
+#ifdef QM_TU_TABLES
 // NPB nodes x all rows per workgroup of 256 threads: thread t reads the grids of node t, t + 256, ...
 // of the workgroup row by row (coalesced along the nodes, eight loads in flight), the rounded
 // delays are transposed through LDS, and the workgroup's NPB x S block of the table -- contiguous
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(256) void serve_table_kernel(ServeArgs a) {
         a.out[n0 * S + i] = tile[node * pitch + s];
     }
 }
-#endif  // QM_ENGINE_TU
+#endif  // QM_TU_TABLES
 
 // ---------------------------------------------------------------------------------------
 // exp in float64, in the base-2 domain, without the device library's special-case handling: the
@@ -1470,7 +1471,7 @@ __global__ __launch_bounds__(1024) void stack_direct_kernel(StackArgs a_launch) 
 // Values are compared as stored (already exponentiated).  HBM-read bound: 8 bytes per node-sample.
 // ---------------------------------------------------------------------------------------
 constexpr int kScanWaves = 16;                         // tiles per workgroup, at most
-#ifdef QM_ENGINE_TU
+#ifdef QM_TU_STEPS
 __global__ __launch_bounds__(kScanWaves * kWave) void scan_volume_kernel(
     const double *__restrict__ vol, int64_t vol_stride, int n_chunk, int64_t n_nodes,
     int64_t nodes_per_set, double *__restrict__ part_max, int64_t *__restrict__ part_idx,
@@ -1515,10 +1516,10 @@ __global__ __launch_bounds__(kScanWaves * kWave) void scan_volume_kernel(
         part_sum[o] = total;
     }
 }
-#endif  // QM_ENGINE_TU
+#endif  // QM_TU_STEPS
 
 // per-tile marginal sums -> marginal map (fixed tile order: deterministic)
-#ifdef QM_ENGINE_TU
+#ifdef QM_TU_STEPS
 __global__ void marginal_reduce_kernel(const double *__restrict__ part, int ntiles, int64_t n,
                                        double *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1527,7 +1528,7 @@ __global__ void marginal_reduce_kernel(const double *__restrict__ part, int ntil
     for (int t = 0; t < ntiles; ++t) s += part[(int64_t)t * n + i];
     out[i] = s;
 }
-#endif  // QM_ENGINE_TU
+#endif  // QM_TU_STEPS
 
 // ---------------------------------------------------------------------------------------
 // Combine partial sets ([n_sets][n]): lanes <-> samples, the 4 wavefronts of a workgroup split
@@ -1537,7 +1538,7 @@ __global__ void marginal_reduce_kernel(const double *__restrict__ part, int ntil
 // Set s of each array starts at element s * set_stride (n for [n_sets][n] arrays; 3 n for the
 // packed [n_sets][3][n] layout of the cross-GPU all-gather).
 // ---------------------------------------------------------------------------------------
-#ifdef QM_ENGINE_TU
+#ifdef QM_TU_STEPS
 constexpr int kCombineWaves = 16;
 __global__ __launch_bounds__(kCombineWaves * kWave) void combine_kernel(
     const double *__restrict__ part_max, const int64_t *__restrict__ part_idx,
@@ -1606,6 +1607,6 @@ __global__ __launch_bounds__(kCombineWaves * kWave) void combine_kernel(
         out_idx[t] = (bi == kNoIndex) ? 0 : bi;
     }
 }
-#endif  // QM_ENGINE_TU
+#endif  // QM_TU_STEPS
 
 }  // namespace qm

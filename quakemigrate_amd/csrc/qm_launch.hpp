@@ -2,7 +2,7 @@
 //
 // The exact-row-count, paired and chunked stacking kernels are ~250 template instantiations; each
 // family (split by detect / volume-writing) is instantiated in its own translation unit
-// (qm_launch_*.hip) so that the library builds on several cores, and the engine (qm_engine.hip)
+// (qm_launch_*.hip) so that the library builds on several cores, and the engine (qm_engine.hip, qm_screen.hip)
 // reaches them through the plain functions declared here.  A launcher sets the kernel's dynamic
 // LDS limit, launches it and returns the HIP status; `*built = false` (status hipSuccess) means
 // that no kernel of the family is built for the arguments -- the caller falls back.

@@ -45,7 +45,7 @@ __host__ __device__ __forceinline__ bool pair_fits(int64_t p_total, int n_rows, 
 
 // offsets of the paired layout (one launch per (table, tile length)); smeta = (min, span2, P, 0)
 // per (brick, row) as screen_prefix_kernel builds it
-#ifdef QM_ENGINE_TU
+#ifdef QM_TU_TABLES
 __global__ void pair_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
                                 const int4 *__restrict__ smeta,
                                 const int32_t *__restrict__ stotal, int kt, int lds_bytes,
@@ -70,7 +70,7 @@ __global__ void pair_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
         rel[(int64_t)b * per + i] = v;
     }
 }
-#endif  // QM_ENGINE_TU
+#endif  // QM_TU_TABLES
 
 // Stage both copies of every row window of brick b (a.brick_meta = smeta).  One global load per
 // element, two LDS stores.
@@ -397,9 +397,12 @@ __device__ __forceinline__ void stack_pair_body(const StackArgs &a, double *win)
 }
 
 template <int JP, bool VOLUME, int S>
-__global__ __launch_bounds__(1024) void stack_pair_kernel(StackArgs a) {
+__global__ __launch_bounds__(1024) void stack_pair_kernel(StackArgs a_launch) {
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int KT = 128 * JP;
+    // (several timesteps per launch -- pair = 2 puts the fused detect here: this workgroup's step's
+    // onsets and its columns of the partial sets, as in the other stacking kernels)
+    const StackArgs a = step_view(a_launch);
     int tile, group;
     stack_tile_group(a, tile, group);
     if (group >= a.ngroups) return;                   // grid is padded to a multiple of 8 groups

@@ -91,6 +91,7 @@ __host__ __device__ __forceinline__ bool screen_fits(int64_t p_total, int n_rows
            12 * p_total + 4 * kt <= kMaxSpanBytes;
 }
 
+#ifdef QM_TU_SCREEN
 // ---- per step: max |L| per row, then the quantised copy of the log-onsets -----------------------
 __global__ __launch_bounds__(256) void screen_rowmax_kernel(const double *__restrict__ onsets,
                                                             int T, double *__restrict__ row_absmax) {
@@ -155,7 +156,9 @@ __global__ __launch_bounds__(256) void screen_quantise_kernel(
         if (bad) atomicOr(flags, bad);
     }
 }
+#endif  // QM_TU_SCREEN
 
+#ifdef QM_TU_TABLES
 // ---- per table: span2 prefixes and the staggered-copy offset table -----------------------------
 __global__ void screen_prefix_kernel(GridDesc g, const int4 *__restrict__ meta,
                                      int4 *__restrict__ smeta, int32_t *__restrict__ stotal) {
@@ -196,6 +199,7 @@ __global__ void screen_rel_kernel(GridDesc g, const int32_t *__restrict__ lut,
         rel[(int64_t)b * per + i] = v;
     }
 }
+#endif  // QM_TU_TABLES
 
 // ---- the integer sweep ------------------------------------------------------------------------
 template <int JP>
@@ -459,6 +463,7 @@ __global__ __launch_bounds__(1024) void screen_lds_kernel(ScreenArgs a) {
     }
 }
 
+#ifdef QM_TU_SCREEN
 // ---- candidates --------------------------------------------------------------------------------
 // integer maximum of every sample over the workgroups: peak[t]
 __global__ __launch_bounds__(256) void screen_peak_kernel(const int32_t *__restrict__ group_max,
@@ -512,6 +517,7 @@ __global__ __launch_bounds__(256) void screen_candidates_kernel(
         }
     }
 }
+#endif  // QM_TU_SCREEN
 
 // ---- exact re-evaluation of the candidate cells: one workgroup per work-list entry -------------
 struct RefineArgs {
@@ -527,6 +533,7 @@ struct RefineArgs {
     int64_t *cand_idx;
 };
 
+#ifdef QM_TU_SCREEN
 __global__ __launch_bounds__(256) void screen_refine_kernel(RefineArgs a) {
     __shared__ double sz[4];
     __shared__ int64_t si[4];
@@ -595,7 +602,9 @@ __global__ __launch_bounds__(256) void screen_refine_kernel(RefineArgs a) {
         }
     }
 }
+#endif  // QM_TU_SCREEN
 
+#ifdef QM_TU_SCREEN
 // one partial set (log2-domain maximum, local node index, sum) from the candidates and the
 // workgroups' sums -- the same form stack_lds_kernel publishes, so combine_kernel finishes it.
 __global__ __launch_bounds__(256) void screen_collect_kernel(
@@ -653,5 +662,6 @@ __global__ __launch_bounds__(256) void exp2f_error_kernel(float lo, float hi,
     }
     if (threadIdx.x == 0) block_max[blockIdx.x] = red[0];
 }
+#endif  // QM_TU_SCREEN
 
 }  // namespace qm

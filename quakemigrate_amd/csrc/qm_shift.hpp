@@ -18,7 +18,7 @@
 // slot s = window samples 4s, 4s+1; plane B = 4s+2, 4s+3) so that a window quad of every lane is
 // one aligned, conflict-free ds_read_b128 per plane.  Two 4-wave workgroups per CU, 80 KB each.
 // The per-(group, row) schedule (register indices, window address, quad count) is a stream of
-// 64-byte records built once per table (shift_stream_kernel) and read with scalar loads.
+// 32-byte records built once per table (shift_stream_kernel) and read with scalar loads.
 #pragma once
 
 #include "qm_kernels.hpp"
@@ -54,8 +54,8 @@ __host__ __device__ constexpr int shift_lds_bytes(int nw) {
     return nw == kShiftWaves3 ? kShiftLdsBytes3 : nw == kShiftWaves8 ? kShiftLdsBytes8 : kShiftLdsBytes;
 }
 constexpr int kShiftMaxRows = 64;                       // table rows the stream builder handles
-static_assert(QM_EXP2_DEGREE_SUM == 8 && QM_EXP2_DEGREE_VOLUME == 10,
-              "the generated loops carry the degree-8 (detect) and degree-10 (stored values) 2^f");
+static_assert(QM_EXP2_DEGREE_SUM == 8 && QM_EXP2_DEGREE_VOLUME == kShiftVolumeDegree,
+              "the generated loops carry the degree-8 (detect) 2^f and the stored values' degree");
 
 // Record geometry: 64 bytes with the eight register indices as dwords, or 32 bytes with them as bytes
 // of two dwords ("packed": gen_shift_asm.py says which loops take which).  Row blocks and the other
@@ -165,7 +165,7 @@ __device__ __forceinline__ void shift_window(const int (&d)[8], int &e0, int &nq
     nq = nq < 2 ? 2 : nq;
 }
 
-#ifdef QM_ENGINE_TU
+#ifdef QM_TU_TABLES
 // Pass 1, one workgroup per brick: slots every row window needs (the furthest slot a lane may
 // touch: e0/4 + 63 + the quads fetched), their prefix, and whether the brick fits.
 // meta_raw = (min, span, ., .) per (brick, row) from brick_minmax_kernel.
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
         rec[shift_rec_hdr(packed) + 1] = h.y;
     }
 }
-#endif  // QM_ENGINE_TU
+#endif  // QM_TU_TABLES
 
 #ifdef QM_SHIFT_TU
 // Stage the row windows of brick b for the tile starting at t_first: window sample u of row r goes

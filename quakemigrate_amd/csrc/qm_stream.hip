@@ -1,0 +1,239 @@
+// qm_stream.hip -- the continuous detect sweep as a native pipeline (C ABI part 3, include/qmhip.h).
+//
+// The reference's QuakeScan._continuous_compute (quakemigrate/signal/scan.py:407-470; the loop
+// itself :434-448) walks the timesteps serially: read -> onsets -> migrate -> find_max_coa -> append.
+// Timesteps are independent given their onsets, so the hot-path part of that loop is a pipeline over
+// a ring of `depth` slots, each holding `steps_per_launch` timesteps:
+//
+//   caller's thread : qm_stream_push   CPU copy of a step's log-onsets into the slot's PINNED input
+//   copy stream     : H2D of the slot's inputs                 (overlaps the previous launch's kernel)
+//   engine's stream : ONE fused-detect launch for the slot's K steps (qm_engine_detect_batch),
+//                     results written PACKED as [3][K x n_samples] float64
+//   download stream : ONE D2H of the packed results into the slot's pinned output
+//   caller's thread : qm_stream_pop    CPU copy of a step's three series to the caller
+//
+// Round 4 drove the same pipeline from Python (three D2H copies, three events and NumPy staging per
+// launch): with the copies inside the clock the example-sized grids lost 30-40 % of their kernel
+// rate and K steps per launch bought nothing (profiles/r04_bench_{C1,E1,E2}_k*.json).  Here a launch
+// costs the host one memcpy per pushed step and a handful of enqueues; ordering is HIP events, the
+// host blocks only in qm_stream_pop, and only for the oldest launch.  The caller's pointers are never
+// handed to the HIP runtime.
+#include "qm_engine.hpp"
+
+#include <deque>
+
+struct qm_stream {
+    qm_engine *e = nullptr;
+    int n_rows = 0, T = 0, fsmp = 0, lsmp = 0, available = 0, ns = 0, K = 1, depth = 2;
+    int64_t n_nodes_total = 0;
+    hipStream_t copy_stream = nullptr, down_stream = nullptr;
+    struct Slot {
+        double *h_on = nullptr;         // pinned [K][n_rows][T]
+        double *d_on = nullptr;         // device, the same
+        double *d_out = nullptr;        // device [3][K * ns]: max_coa, max_norm_coa, indices (int64 bits)
+        double *h_out = nullptr;        // pinned, the same
+        hipEvent_t copied = nullptr;    // the inputs are on the device
+        hipEvent_t computed = nullptr;  // the launch has written d_out (and read d_on)
+        hipEvent_t done = nullptr;      // the results are in h_out
+        int n = 0;                      // steps launched from this slot
+        int taken = 0;                  // ... of which popped
+        bool in_flight = false;
+    };
+    std::vector<Slot> slots;
+    std::deque<int> order;              // slots in flight, oldest first
+    int fill_slot = 0, fill_n = 0;      // slot being filled, steps pushed into it so far
+    int64_t launched_steps = 0, popped_steps = 0, launches = 0;
+};
+
+namespace {
+
+size_t step_in(const qm_stream *s) { return (size_t)s->n_rows * s->T; }
+
+int alive(const qm_stream *s, const char *what) {
+    if (!s) return fail("%s: NULL argument", what);
+    if (!s->e) return fail("%s: the stream's engine has been destroyed", what);
+    return 0;
+}
+
+void free_slot(qm_stream::Slot &sl) {
+    if (sl.h_on) (void)hipHostFree(sl.h_on);
+    if (sl.h_out) (void)hipHostFree(sl.h_out);
+    if (sl.d_on) pool_free(sl.d_on);
+    if (sl.d_out) pool_free(sl.d_out);
+    for (hipEvent_t ev : {sl.copied, sl.computed, sl.done})
+        if (ev) (void)hipEventDestroy(ev);
+    sl = qm_stream::Slot{};
+}
+
+// everything the stream holds on its engine's device goes back (the engine's device is current)
+void release_stream(qm_stream *s) {
+    (void)hipStreamSynchronize(s->e->stream);
+    if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
+    if (s->down_stream) (void)hipStreamSynchronize(s->down_stream);
+    {
+        PoolReleaseScope one_wait;
+        for (qm_stream::Slot &sl : s->slots) free_slot(sl);
+    }
+    if (s->copy_stream) park_stream(s->e->device, s->copy_stream);
+    if (s->down_stream) park_stream(s->e->device, s->down_stream);
+    s->copy_stream = s->down_stream = nullptr;
+    s->order.clear();
+}
+
+// H2D, the launch and D2H of the slot being filled: enqueue only
+int launch_slot(qm_stream *s) {
+    qm_engine *e = s->e;
+    qm_stream::Slot &sl = s->slots[s->fill_slot];
+    const int n = s->fill_n;
+    if (!e->have_lut || e->g.n_rows != s->n_rows)
+        return fail("qm_stream: the engine's resident table changed under the stream (%d rows, the stream "
+                    "was made for %d)", e->have_lut ? e->g.n_rows : 0, s->n_rows);
+    const size_t kns = (size_t)s->K * s->ns;
+    QM_HIP(hipMemcpyAsync(sl.d_on, sl.h_on, (size_t)n * step_in(s) * sizeof(double), hipMemcpyHostToDevice,
+                          s->copy_stream));
+    QM_HIP(hipEventRecord(sl.copied, s->copy_stream));
+    QM_HIP(hipStreamWaitEvent(e->stream, sl.copied, 0));
+    if (qm_engine_detect_batch(e, sl.d_on, 1, n, s->T, s->fsmp, s->lsmp, s->available, s->n_nodes_total,
+                               sl.d_out, sl.d_out + kns, reinterpret_cast<int64_t *>(sl.d_out + 2 * kns), 1))
+        return 1;
+    QM_HIP(hipEventRecord(sl.computed, e->stream));
+    QM_HIP(hipStreamWaitEvent(s->down_stream, sl.computed, 0));
+    // (one copy of all three rows; a partly filled slot's rows are K * ns apart all the same)
+    QM_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, 3 * kns * sizeof(double), hipMemcpyDeviceToHost, s->down_stream));
+    QM_HIP(hipEventRecord(sl.done, s->down_stream));
+    sl.n = n;
+    sl.taken = 0;
+    sl.in_flight = true;
+    s->order.push_back(s->fill_slot);
+    s->launched_steps += n;
+    ++s->launches;
+    s->fill_slot = (s->fill_slot + 1) % s->depth;
+    s->fill_n = 0;
+    return 0;
+}
+
+}  // namespace
+
+void streams_orphan(qm_engine *e) {
+    for (qm_stream *s : e->streams) {
+        release_stream(s);
+        s->e = nullptr;
+    }
+    e->streams.clear();
+}
+
+extern "C" {
+
+int qm_stream_create(qm_engine *e, int32_t t_samples, int32_t fsmp, int32_t lsmp, int32_t available,
+                     int64_t n_nodes_total, int32_t steps_per_launch, int32_t depth, qm_stream **out) {
+    if (!e || !out) return fail("qm_stream_create: NULL argument");
+    *out = nullptr;
+    if (steps_per_launch < 1 || steps_per_launch > 4096)
+        return fail("qm_stream_create: steps_per_launch must be in 1..4096 (got %d)", steps_per_launch);
+    if (depth < 2 || depth > 64) return fail("qm_stream_create: depth must be in 2..64 (got %d)", depth);
+    int ns = 0;
+    if (check_step(e, t_samples, fsmp, lsmp, available, &ns)) return 1;
+    if ((int64_t)steps_per_launch * ns >= INT32_MAX) return fail("qm_stream_create: too many samples per launch");
+    DeviceGuard guard(e->device);
+    qm_stream *s = new qm_stream();
+    s->e = e;
+    s->n_rows = e->g.n_rows;
+    s->T = t_samples; s->fsmp = fsmp; s->lsmp = lsmp; s->available = available; s->ns = ns;
+    s->K = steps_per_launch; s->depth = depth;
+    s->n_nodes_total = n_nodes_total > 0 ? n_nodes_total : e->n_nodes;
+    auto bail = [&](int rc) {
+        qm_stream_destroy(s);
+        return rc;
+    };
+    if (acquire_stream(e->device, &s->copy_stream) != hipSuccess ||
+        acquire_stream(e->device, &s->down_stream) != hipSuccess)
+        return bail(fail("qm_stream_create: no HIP stream"));
+    s->slots.resize((size_t)depth);
+    const size_t in_bytes = (size_t)s->K * step_in(s) * sizeof(double);
+    const size_t out_bytes = 3 * (size_t)s->K * ns * sizeof(double);
+    for (qm_stream::Slot &sl : s->slots) {
+        hipError_t r = hipHostMalloc(reinterpret_cast<void **>(&sl.h_on), in_bytes, hipHostMallocDefault);
+        if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&sl.h_out), out_bytes, hipHostMallocDefault);
+        if (r == hipSuccess) r = pool_alloc(reinterpret_cast<void **>(&sl.d_on), in_bytes);
+        if (r == hipSuccess) r = pool_alloc(reinterpret_cast<void **>(&sl.d_out), out_bytes);
+        for (hipEvent_t *ev : {&sl.copied, &sl.computed, &sl.done})
+            if (r == hipSuccess) r = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+        if (r != hipSuccess)
+            return bail(fail("qm_stream_create: %s (%d steps of %zu bytes per slot, %d slots)",
+                             hipGetErrorString(r), s->K, step_in(s) * sizeof(double), depth));
+    }
+    e->streams.push_back(s);
+    *out = s;
+    return 0;
+}
+
+void qm_stream_destroy(qm_stream *s) {
+    if (!s) return;
+    if (s->e) {                                         // (else: orphaned by qm_engine_destroy)
+        DeviceGuard guard(s->e->device);
+        release_stream(s);
+        auto &list = s->e->streams;
+        list.erase(std::remove(list.begin(), list.end(), s), list.end());
+    }
+    delete s;
+}
+
+int qm_stream_push(qm_stream *s, const double *log_onsets) {
+    if (!log_onsets) return fail("qm_stream_push: NULL argument");
+    if (alive(s, "qm_stream_push")) return 1;
+    qm_stream::Slot &sl = s->slots[s->fill_slot];
+    if (s->fill_n == 0 && sl.in_flight) {
+        (void)fail("qm_stream_push: all %d slots hold results that have not been popped", s->depth);
+        return 2;
+    }
+    // (the slot's previous H2D has finished: its launch's results were popped)
+    host_copy(sl.h_on + (size_t)s->fill_n * step_in(s), log_onsets, step_in(s) * sizeof(double));
+    if (++s->fill_n < s->K) return 0;
+    DeviceGuard guard(s->e->device);
+    return launch_slot(s);
+}
+
+int qm_stream_flush(qm_stream *s) {
+    if (alive(s, "qm_stream_flush")) return 1;
+    if (s->fill_n == 0) return 0;
+    DeviceGuard guard(s->e->device);
+    return launch_slot(s);
+}
+
+int qm_stream_pop(qm_stream *s, int32_t n_steps, double *max_coa, double *max_norm_coa,
+                  int64_t *max_coa_idx) {
+    if (!max_coa || !max_norm_coa || !max_coa_idx) return fail("qm_stream_pop: NULL argument");
+    if (alive(s, "qm_stream_pop")) return 1;
+    if (n_steps < 0 || n_steps > s->launched_steps - s->popped_steps)
+        return fail("qm_stream_pop: %d steps asked for, %lld launched and not yet popped (%d pushed into "
+                    "a launch that has not gone out: qm_stream_flush)", n_steps,
+                    (long long)(s->launched_steps - s->popped_steps), s->fill_n);
+    DeviceGuard guard(s->e->device);
+    const size_t ns = (size_t)s->ns, kns = (size_t)s->K * ns;
+    for (int k = 0; k < n_steps;) {
+        qm_stream::Slot &sl = s->slots[s->order.front()];
+        QM_HIP(hipEventSynchronize(sl.done));
+        const int take = std::min(n_steps - k, sl.n - sl.taken);
+        const double *src = sl.h_out + (size_t)sl.taken * ns;
+        std::memcpy(max_coa + (size_t)k * ns, src, (size_t)take * ns * sizeof(double));
+        std::memcpy(max_norm_coa + (size_t)k * ns, src + kns, (size_t)take * ns * sizeof(double));
+        std::memcpy(max_coa_idx + (size_t)k * ns, src + 2 * kns, (size_t)take * ns * sizeof(int64_t));
+        k += take;
+        sl.taken += take;
+        s->popped_steps += take;
+        if (sl.taken == sl.n) {
+            sl.in_flight = false;
+            s->order.pop_front();
+        }
+    }
+    return 0;
+}
+
+int qm_stream_pending(qm_stream *s, int32_t *launched_not_popped, int32_t *pushed_not_launched) {
+    if (alive(s, "qm_stream_pending")) return 1;
+    if (launched_not_popped) *launched_not_popped = (int32_t)(s->launched_steps - s->popped_steps);
+    if (pushed_not_launched) *pushed_not_launched = s->fill_n;
+    return 0;
+}
+
+}  // extern "C"

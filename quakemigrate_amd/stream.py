@@ -3,22 +3,25 @@
 Continuous detect sweep with copies overlapped with compute (BASELINE.json configs[4]:
 "continuous 24 h synthetic stream ... overlapped H2D copy + compute on HIP streams").
 
-The reference's ``QuakeScan._continuous_compute`` (quakemigrate/signal/scan.py:407-470)
-walks the timesteps serially: read -> onsets -> migrate -> find_max_coa -> append.  Here the
-hot-path part of that loop is pipelined on two HIP streams per GPU:
-
-    copy stream    : H2D of the log-onsets of step i+1   (pinned, double-buffered)
-    compute stream : fused detect of step i, D2H of its three series (pinned)
-
-Timesteps are independent given their onsets ("long-context"), so the only
-ordering is buffer reuse, expressed with HIP events.  PyTorch supplies the streams, events and
-pinned memory (plumbing); the compute is the engine's HIP kernels.
+The reference's ``QuakeScan._continuous_compute`` (quakemigrate/signal/scan.py:407-470; the loop
+:434-448) walks the timesteps serially: read -> onsets -> migrate -> find_max_coa -> append.  The
+hot-path part of that loop is the library's native pipeline (``qm_stream_*``, include/qmhip.h part 3,
+csrc/qm_stream.hip): a pinned ring of ``depth`` slots of ``steps_per_launch`` timesteps, H2D on a copy
+stream, one fused-detect launch per slot, one packed D2H per launch, HIP events for the ordering.
+This class is the thin caller: it pushes windows, pops results in order, and nothing else -- no
+torch, no per-step staging in Python (round 4's Python loop cost the example-sized grids 30-40 % of
+their kernel rate once the copies were inside the clock).
 """
 
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
-import torch
+
+from quakemigrate_amd.core import lib as _lib
+
+_qm = _lib.qmlib
 
 
 class StreamingDetector:
@@ -30,119 +33,100 @@ class StreamingDetector:
         ``log(clip(., 0.01))``).
     fsmp, lsmp, available : as in ``Engine.detect``.
     n_nodes_total : node count of the full grid (normalisation).
-    depth : number of launches in flight (>= 2).
-    steps_per_launch : timesteps stacked by ONE launch (``Engine.detect_batch``).  Timesteps are
+    depth : slots of the ring = launches that may be in flight or un-popped (>= 2).
+    steps_per_launch : timesteps stacked by ONE launch (``qm_engine_detect_batch``).  Timesteps are
         independent given their onsets, so K of them can share a launch: on the grids the
         reference's examples use (1e4 - 3e5 nodes) one timestep is a few workgroup rounds and a
         fraction of a millisecond, and K steps per launch are what fills the GPU and amortises the
         launch, the combine and the copies' latencies.  Results are identical step for step.
+    device : accepted for compatibility with round 4's signature; the engine's device is used.
     """
 
     def __init__(self, engine, n_rows, t_samples, fsmp, lsmp, available, n_nodes_total=None,
                  depth=2, device=None, steps_per_launch=1):
+        if engine.n_rows is None:
+            raise _lib.QMHipError("no travel-time table resident: call load_lut first")
+        if int(n_rows) != engine.n_rows:
+            raise ValueError("Mismatch between number of stations for data and LUT, "
+                             f"{int(n_rows)}:{engine.n_rows}")
         self.engine = engine
+        self.n_rows, self.t_samples = int(n_rows), int(t_samples)
         self.fsmp, self.lsmp, self.available = int(fsmp), int(lsmp), int(available)
-        self.n_samples = int(t_samples) - self.fsmp - self.lsmp
-        self.n_nodes_total = n_nodes_total
-        self.device = torch.device("cuda", engine.device) if device is None else device
+        self.n_samples = self.t_samples - self.fsmp - self.lsmp
         self.depth = max(2, int(depth))
         self.k = max(1, int(steps_per_launch))
-        self.copy_stream = torch.cuda.Stream(self.device)
-        self.compute_stream = torch.cuda.Stream(self.device)
-        shape = (self.k, int(n_rows), int(t_samples))
-        ns = self.n_samples
-        self.h_on = [torch.empty(shape, dtype=torch.float64).pin_memory()
-                     for _ in range(self.depth)]
-        # NumPy views of the pinned input buffers: the host-side copy into them is a plain
-        # single-threaded memcpy.  (torch's CPU copy_ fans a 1-2 MB copy out over its OpenMP
-        # pool; after a blocking wait the pool has to be woken up, which on a 256-core host costs
-        # tens of milliseconds every few steps -- 4x the whole step at C2 size.)
-        self.h_on_np = [t.numpy() for t in self.h_on]
-        self.d_on = [torch.empty(shape, dtype=torch.float64, device=self.device)
-                     for _ in range(self.depth)]
-        self.d_out = [(torch.empty((self.k, ns), dtype=torch.float64, device=self.device),
-                       torch.empty((self.k, ns), dtype=torch.float64, device=self.device),
-                       torch.empty((self.k, ns), dtype=torch.int64, device=self.device))
-                      for _ in range(self.depth)]
-        self.h_out = [(torch.empty((self.k, ns), dtype=torch.float64).pin_memory(),
-                       torch.empty((self.k, ns), dtype=torch.float64).pin_memory(),
-                       torch.empty((self.k, ns), dtype=torch.int64).pin_memory())
-                      for _ in range(self.depth)]
-        self.copied = [torch.cuda.Event() for _ in range(self.depth)]      # H2D landed
-        self.consumed = [torch.cuda.Event() for _ in range(self.depth)]    # kernel read it
-        self.done = [torch.cuda.Event() for _ in range(self.depth)]        # outputs on host
+        total = engine.n_nodes if n_nodes_total is None else int(n_nodes_total)
+        h = ctypes.c_void_p()
+        _lib._check(_qm.qm_stream_create(engine._h, self.t_samples, self.fsmp, self.lsmp,
+                                         self.available, total, self.k, self.depth, ctypes.byref(h)))
+        self._h = h
+        import weakref
 
+        self._finalizer = weakref.finalize(self, _qm.qm_stream_destroy, h)
+
+    def close(self):
+        self._finalizer()
+
+    # -- the three calls --------------------------------------------------------------
+    def push(self, window):
+        """One timestep's log-onsets (n_rows, t_samples) into the pipeline.  False: every slot holds
+        results that have not been popped (``pop`` first, then push again)."""
+        w = np.ascontiguousarray(window, dtype=np.float64)
+        if w.shape != (self.n_rows, self.t_samples):
+            raise ValueError(f"window of shape {w.shape}, the stream takes {(self.n_rows, self.t_samples)}")
+        rc = _qm.qm_stream_push(self._h, w.ctypes.data_as(ctypes.c_void_p))
+        if rc == 2:
+            return False
+        _lib._check(rc)
+        return True
+
+    def flush(self):
+        _lib._check(_qm.qm_stream_flush(self._h))
+
+    def pending(self):
+        """(timesteps launched and not yet popped, timesteps pushed into a launch that has not gone out)"""
+        a, b = ctypes.c_int32(), ctypes.c_int32()
+        _lib._check(_qm.qm_stream_pending(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
+
+    def pop(self, n_steps=1):
+        """The next ``n_steps`` timesteps' ``(max_coa, max_norm_coa, max_coa_idx)``, each
+        ``(n_steps, n_samples)``; blocks until their launch has finished."""
+        n, ns = int(n_steps), self.n_samples
+        a, b = np.empty((n, ns)), np.empty((n, ns))
+        c = np.empty((n, ns), dtype=np.int64)
+        _lib._check(_qm.qm_stream_pop(self._h, n, a.ctypes.data_as(ctypes.c_void_p),
+                                      b.ctypes.data_as(ctypes.c_void_p), c.ctypes.data_as(ctypes.c_void_p)))
+        return a, b, c
+
+    # -- the loop -----------------------------------------------------------------------
     def run(self, windows, on_result=None):
         """
         ``windows``: iterable of float64 arrays (n_rows, t_samples), one per timestep, already
         logged.  Returns a list of ``(max_coa, max_norm_coa, max_coa_idx)`` NumPy triples (or
         calls ``on_result(step, triple)`` and returns the number of steps).
         """
-        eng = self.engine
-        eng.set_stream(self.compute_stream.cuda_stream)
         results = []
-        pending = []                                   # (first step, slot, steps) in flight
-        it = iter(windows)
+        step = 0
 
-        def take():
-            """up to k windows from the iterator"""
-            batch = []
-            for w in it:
-                batch.append(w)
-                if len(batch) == self.k:
-                    break
-            return batch
-
-        def stage(launch, slot, batch):
-            # the slot's previous contents must have been consumed by its kernel
-            if launch >= self.depth:
-                self.consumed[slot].synchronize()
-            for j, array in enumerate(batch):
-                np.copyto(self.h_on_np[slot][j], array)
-            with torch.cuda.stream(self.copy_stream):
-                n = len(batch)
-                self.d_on[slot][:n].copy_(self.h_on[slot][:n], non_blocking=True)
-                self.copied[slot].record(self.copy_stream)
-
-        def collect(first, slot, n):
-            self.done[slot].synchronize()
+        def take(n):
+            nonlocal step
+            a, b, c = self.pop(n)
             for j in range(n):
-                triple = tuple(t.numpy()[j].copy() for t in self.h_out[slot])
+                triple = (a[j], b[j], c[j])
                 if on_result is None:
                     results.append(triple)
                 else:
-                    on_result(first + j, triple)
+                    on_result(step, triple)
+                step += 1
 
-        nxt = take()
-        launch, step = 0, 0
-        if nxt:
-            stage(0, 0, nxt)
-        while nxt:
-            slot = launch % self.depth
-            cur, nxt = nxt, take()
-            if nxt:                                    # copy of launch+1 overlaps compute of launch
-                stage(launch + 1, (launch + 1) % self.depth, nxt)
-            if len(pending) >= self.depth:             # the slot's host outputs must be free
-                collect(*pending.pop(0))
-            n = len(cur)
-            with torch.cuda.stream(self.compute_stream):
-                self.compute_stream.wait_event(self.copied[slot])
-                if self.k == 1:
-                    eng.detect(self.d_on[slot][0], self.fsmp, self.lsmp, self.available,
-                               n_nodes_total=self.n_nodes_total,
-                               out=tuple(t[0] for t in self.d_out[slot]))
-                else:
-                    eng.detect_batch(self.d_on[slot][:n], self.fsmp, self.lsmp, self.available,
-                                     n_nodes_total=self.n_nodes_total,
-                                     out=tuple(t[:n] for t in self.d_out[slot]))
-                self.consumed[slot].record(self.compute_stream)
-                for h, d in zip(self.h_out[slot], self.d_out[slot]):
-                    h[:n].copy_(d[:n], non_blocking=True)
-                self.done[slot].record(self.compute_stream)
-            pending.append((step, slot, n))
-            step += n
-            launch += 1
-        while pending:
-            collect(*pending.pop(0))
-        eng.set_stream(None)
+        for w in windows:
+            while not self.push(w):
+                take(min(self.k, self.pending()[0]))     # the oldest launch's timesteps
+        self.flush()
+        left = self.pending()[0]
+        while left > 0:
+            n = min(self.k, left)
+            take(n)
+            left -= n
         return results if on_result is None else step

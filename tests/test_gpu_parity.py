@@ -2326,6 +2326,7 @@ BATCH_SHAPES = [  # recipe, grid, rows, samples, engine configuration
     ("E1", (15, 14, 9), 24, 700, {}),                   # a coarse grid: the exact-row-count kernel
     ("E2", (12, 11, 9), 46, 300, {}),                   # ... 41-64 rows
     ("C2", (13, 11, 9), 20, 401, {"exact": 0}),         # the chunked kernel
+    ("C2", (13, 11, 9), 20, 401, {"pair": 2}),          # the paired kernel as the detect kernel
     ("C3", (19, 17, 13), 30, 401, {"force_direct": 1}),  # the direct kernel
     ("C3", (12, 9, 10), 70, 300, {}),                   # row blocks: no step axis, step by step inside
     ("C3", (19, 17, 13), 30, 300, {"screen": 1}),       # the screened detect: step by step inside
@@ -2506,7 +2507,7 @@ def test_changing_availability_alternates_between_parked_tables(lib, oracle, dev
 
 def test_host_volume_larger_than_the_bounce_buffer(lib, oracle):
     """Results reach host memory -- and inputs the device -- through a 32 MB pinned bounce buffer
-    (qm_engine.hip copy_back / copy_in):
+    (qm_runtime.hip copy_back / copy_in):
     a 200 MB volume whole (one linear copy in seven pieces) and in time chunks (strided rows, several
     row groups per chunk) is the device-resident volume; pre-filled with NaN."""
     import torch
@@ -2542,7 +2543,7 @@ def test_host_volume_larger_than_the_bounce_buffer(lib, oracle):
 
 def test_engines_made_and_destroyed_reuse_device_memory(lib, oracle):
     """Device memory of destroyed engines is parked in the process and handed to the next engine
-    (qm_engine.hip pool_alloc): a run of engines over two tables of different
+    (qm_runtime.hip pool_alloc): a run of engines over two tables of different
     size -- each made, used once, destroyed -- returns the oracle's series every time, also right
     after the parked blocks went back to the driver (``release_cached_memory``)."""
     cases = [synth.make_case("C2", step=1, grid=(21, 17, 12), rows=9, n_samples=300),
@@ -2558,3 +2559,111 @@ def test_engines_made_and_destroyed_reuse_device_memory(lib, oracle):
         eng.close()
         if i == 7:
             lib.release_cached_memory()
+
+
+# ---- round 5: ADVICE r04 ---------------------------------------------------------------------------
+def test_foreign_load_on_the_shared_engine_does_not_inherit_the_scans_table_key(lib, oracle):
+    """The default engine is shared: the reference-signature lib.migrate_and_find_max loads ITS table
+    without a key between two steps of a MigrationScan.  The scan's key must not stick to the foreign
+    table (same shape: silently wrong results before the fix): every scan step equals the oracle on the
+    scan's table, every lib call the oracle on its own (qm_engine_load_lut)."""
+    from quakemigrate_amd import scan
+
+    case = synth.make_case("C3", step=1, grid=(18, 16, 12), rows=6, n_samples=300)
+    other = synth.make_case("C2", step=2, grid=(18, 16, 12), rows=6, n_samples=300)   # same shape, other delays
+    assert other.traveltimes.shape == case.traveltimes.shape and not np.array_equal(other.traveltimes, case.traveltimes)
+    rate = 50
+    keys = [f"ST{i}_{'P' if i < 3 else 'S'}" for i in range(6)]
+    avail = dict.fromkeys(keys, 1)
+
+    class OnsetData:
+        sampling_rate = rate
+        availability = avail
+
+    class Onset:
+        def calculate_onsets(self, data):
+            return case.onsets, OnsetData()
+
+    class Lut:
+        def serve_traveltimes(self, sampling_rate, availability):
+            return case.traveltimes
+
+        def index2coord(self, idx, unravel=True):
+            return np.stack(np.unravel_index(idx, case.grid), axis=-1) * 1.0
+
+    class Data:
+        starttime = 0.0
+
+    want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available, threads=4)
+    want_other = oracle.detect(other.onsets, other.traveltimes, other.fsmp, other.lsmp, other.available, threads=4)
+    s = scan.MigrationScan(Lut(), Onset(), case.fsmp / rate, case.lsmp / rate)     # the default engine
+    for _ in range(3):
+        _, a, b, coord, _ = s._compute(Data())
+        _assert_series((a, b, np.ravel_multi_index(coord.astype(int).T, case.grid)), want)
+        got = lib.migrate_and_find_max(other.onsets, other.traveltimes, other.fsmp, other.lsmp, other.available)
+        _assert_series(got, want_other)
+
+
+def test_alternating_tables_through_a_cache_of_one_are_built_once(lib, oracle):
+    """One resident + one parked table hold an alternating pair: the requested table is looked up
+    before anything is evicted (the LRU slot was freed just before it was needed)."""
+    cases = [synth.make_case("C3", step=1, grid=(18, 16, 12), rows=6, n_samples=300),
+             synth.make_case("C2", step=2, grid=(18, 16, 12), rows=7, n_samples=300)]
+    lons = [oracle.log_onsets(c.onsets) for c in cases]
+    wants = [oracle.detect(c.onsets, c.traveltimes, c.fsmp, c.lsmp, c.available, threads=4) for c in cases]
+    eng = lib.Engine(0)
+    for i in range(8):
+        k = i % 2
+        if not eng.select_table(("pair", k), capacity=1):
+            eng.load_lut(cases[k].traveltimes)
+        _assert_series(eng.detect(lons[k], cases[k].fsmp, cases[k].lsmp, cases[k].available), wants[k])
+    assert eng.get("table_misses") == 2 and eng.get("table_evictions") == 0 and eng.get("table_hits") == 6
+    eng.close()
+
+
+# ---- round 5: the native streaming pipeline (qm_stream_*, include/qmhip.h part 3) --------------------
+def test_native_stream_push_pop_semantics(lib, oracle):
+    """qm_stream_push / flush / pop: a full ring refuses a push until the oldest launch is popped,
+    results come out in push order whatever the pop sizes, a partly filled launch goes out on flush,
+    popping more than was launched is an error, and a stream whose engine is destroyed refuses calls
+    instead of touching freed memory."""
+    from quakemigrate_amd.stream import StreamingDetector
+
+    cases = [synth.make_case("C1", step=s, grid=(23, 20, 19), n_samples=300, table=(s == 0)) for s in range(11)]
+    c0 = cases[0]
+    wins = [oracle.log_onsets(c.onsets) for c in cases]
+    eng = lib.Engine(0)
+    eng.load_lut(c0.traveltimes)
+    single = [eng.detect(w, c0.fsmp, c0.lsmp, c0.available) for w in wins]
+    _assert_series(single[3], oracle.detect(cases[3].onsets, c0.traveltimes, c0.fsmp, c0.lsmp, c0.available, threads=4))
+    sd = StreamingDetector(eng, c0.available, wins[0].shape[1], c0.fsmp, c0.lsmp, c0.available, depth=2,
+                           steps_per_launch=3)
+    for w in wins[:6]:
+        assert sd.push(w)
+    assert sd.pending() == (6, 0)
+    assert not sd.push(wins[6])                            # both slots hold un-popped results
+    a, b, c = sd.pop(2)                                    # part of the oldest launch: its slot stays taken
+    assert not sd.push(wins[6])
+    a2, b2, c2 = sd.pop(1)
+    assert sd.push(wins[6]) and sd.push(wins[7])           # the freed slot fills again
+    assert sd.pending() == (3, 2)
+    with pytest.raises(lib.QMHipError):
+        sd.pop(4)                                          # only three are launched
+    sd.flush()                                             # the partly filled launch goes out
+    assert sd.pending() == (5, 0)
+    rest = sd.pop(5)
+    got = [tuple(x[j] for x in (a, b, c)) for j in range(2)] + [(a2[0], b2[0], c2[0])] + \
+          [tuple(x[j] for x in rest) for j in range(5)]
+    for g, w in zip(got, single[:8]):
+        assert all(np.array_equal(x, y) for x, y in zip(g, w))
+    # the whole list through run(), three windows left over at the end
+    got = sd.run(iter(wins))
+    assert len(got) == 11
+    for g, w in zip(got, single):
+        assert all(np.array_equal(x, y) for x, y in zip(g, w))
+    with pytest.raises(ValueError):
+        sd.push(wins[0][:, :-1])
+    eng.close()                                            # the stream is orphaned, not dangling
+    with pytest.raises(lib.QMHipError):
+        sd.push(wins[0])
+    sd.close()

@@ -14,10 +14,13 @@ for spec in "$@"; do
       -o build_variants/qm_launch_shift_$name.o 2>&1 | grep -E "error|Spill" 
   objs=$(ls $C/build/*.o | grep -v qm_launch_shift)
   if [ "${QM_VARIANT_ENGINE:-0}" = "1" ]; then
-    # knobs that change the record stream's format also change its builder (qm_engine.hip includes the loop's constants)
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DQM_SHIFT_ASM_INC="\"$inc\"" -c $C/qm_engine.hip \
-        -o build_variants/qm_engine_$name.o 2>&1 | grep -E "error"
-    objs=$(echo "$objs" | grep -v qm_engine.hip.o)" build_variants/qm_engine_$name.o"
+    # knobs that change the record stream's format or the loop's constants also change the stream's
+    # builder (qm_tables.hip) and the launch geometry (qm_engine.hip): both include the generated file
+    for unit in qm_tables qm_engine; do
+      hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DQM_SHIFT_ASM_INC="\"$inc\"" -c $C/$unit.hip \
+          -o build_variants/${unit}_$name.o 2>&1 | grep -E "error"
+      objs=$(echo "$objs" | grep -v "/$unit.hip.o")" build_variants/${unit}_$name.o"
+    done
   fi
   hipcc --offload-arch=gfx950 -shared -fPIC -o build_variants/libqmhip_$name.so $objs build_variants/qm_launch_shift_$name.o || exit 1
 done
