@@ -135,6 +135,12 @@ int qm_engine_synchronize(qm_engine *e);
  * samples -- runs as ONE tail tile of 64 / 128 / 192 samples with 1 / 2 / 3 samples per lane, so a
  * 401-sample locate window costs 448 samples instead of 512 and scans shorter than a tile run here
  * too; 0 = whole tiles only, the last one pulled back over its predecessor: same bits either way),
+ * "tie_rule" (default 0: among the nodes of a sample the largest float64 sum wins, the lowest flat index
+ * among equal sums; 1 = the reference's rule on near-ties, opt-in: the nodes whose sums lie within two
+ * ulps of the sample's largest are compared on a correctly rounded exp(sum / available), lowest index
+ * among equal values -- migratelib.c:98-105 as its scalar-libm build computes it; applies to the final
+ * series of qm_engine_detect / detect_batch (step by step then) / migrate / marginal, not to partial
+ * sets that leave the engine; values unchanged; qm_engine_get "tie_pairs", "tie_overflow_samples"),
  * "pair" (default 1: the 16-byte-operand kernel for volume-writing launches the shift-reuse
  * kernel does not take; 2 = for every launch, 0 = off), "rounds" (grid size of the automatic
  * group count), "scan_waves" (find_max_coa of a volume: wavefronts per CU over the whole grid).
@@ -317,6 +323,13 @@ int qm_engine_onsets(qm_engine *e, const double *signals, int signals_on_device,
                      int32_t n_rows, const int32_t *nsta, const int32_t *nlta, int transform,
                      int position, int32_t taper_pad, double min_onset_value,
                      double *raw_onsets, double *log_onsets, int out_on_device);
+
+/* exp(x) rounded to nearest from a double-double evaluation (csrc/qm_ties.hpp): the function the
+ * opt-in arg-max rule "tie_rule" = 1 compares near-tied nodes on (the reference exponentiates, then
+ * compares: migratelib.c:60-62, :98-105).  Host code, exported for the tests that pin it. */
+double qm_exp_correctly_rounded(double x);
+/* ... and the GPU's evaluation of the same source, host arrays in and out (the tests pin the two together) */
+int qm_engine_exp_correctly_rounded(qm_engine *e, const double *x, int64_t n, double *out);
 
 /* Self-check behind the screened detect's error bound (qm_screen.hpp): the largest relative
  * deviation of the device's v_exp_f32 from the float64 exp2 over EVERY float32 in [lo, hi]

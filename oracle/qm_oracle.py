@@ -204,6 +204,28 @@ def np_find_max_coa(map4d):
     return max_coa, max_coa * n_nodes / total, idx
 
 
+def np_argmax_exp_rule(onsets, traveltimes, first_idx, last_idx, available, prelogged=False):
+    """
+    The reference's arg-max as its scalar-libm build computes it (migratelib.c:60-62 then :98-105):
+    stacks in ascending row order, x = stack * (1 / available), a correctly rounded exp(x) --
+    80-bit arithmetic rounded to float64 here -- and the FIRST node reaching the largest value.
+    What the engine's opt-in ``tie_rule = 1`` is specified as (csrc/qm_ties.hpp); pinned on
+    tests/golden/near_ties_scalar.npz (the reference's two C files built with -fno-tree-vectorize).
+    """
+    lon = onsets if prelogged else log_onsets(onsets)
+    *grid, n_rows = traveltimes.shape
+    n_nodes = int(np.prod(grid))
+    n_samples = lon.shape[1] - first_idx - last_idx
+    tt = np.maximum(traveltimes.reshape(n_nodes, n_rows), 0).astype(np.int64)
+    k = np.arange(n_samples, dtype=np.int64)[None, :]
+    acc = np.zeros((n_nodes, n_samples))
+    for r in range(n_rows):                       # ascending row order
+        acc += lon[r][tt[:, r][:, None] + first_idx + k]
+    x = acc * (1.0 / float(available))            # the product the -Ofast builds form
+    coa = np.exp(x.astype(np.longdouble)).astype(np.float64)
+    return np.argmax(coa, axis=0).astype(np.int64)
+
+
 # --------------------------------------------------------------------------
 # Table serving (host-side NumPy in the reference)
 # --------------------------------------------------------------------------

@@ -112,6 +112,9 @@ qmlib.qm_engine_find_max_coa.argtypes = [_vp, _vp, ctypes.c_int, c_int32,
                                          c_int64, _vp, _vp, _vp, ctypes.c_int]
 qmlib.qm_exp2f_max_error.argtypes = [_vp, ctypes.c_float, ctypes.c_float,
                                      ctypes.POINTER(ctypes.c_double)]
+qmlib.qm_exp_correctly_rounded.argtypes = [ctypes.c_double]
+qmlib.qm_exp_correctly_rounded.restype = ctypes.c_double
+qmlib.qm_engine_exp_correctly_rounded.argtypes = [_vp, c_dPt, c_int64, c_dPt]
 qmlib.qm_stream_create.argtypes = [_vp, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32, c_int32,
                                    ctypes.POINTER(_vp)]
 qmlib.qm_stream_destroy.argtypes = [_vp]
@@ -200,6 +203,14 @@ class Engine:
         out = ctypes.c_double()
         _check(qmlib.qm_exp2f_max_error(self._h, float(lo), float(hi), ctypes.byref(out)))
         return float(out.value)
+
+    def exp_correctly_rounded(self, x):
+        """``exp(x)`` rounded to nearest, evaluated on the GPU (csrc/qm_ties.hpp: what the opt-in
+        ``tie_rule = 1`` compares near-tied nodes on)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty_like(x)
+        _check(qmlib.qm_engine_exp_correctly_rounded(self._h, x.reshape(-1), x.size, out.reshape(-1)))
+        return out
 
     def kernel_log(self):
         """(total ms, launches) of the stacking kernels since the last call."""

@@ -376,6 +376,12 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     a.part_idx = e->d_pidx.p;
     a.part_sum = e->d_psum.p;
     *n_sets = sets;
+    e->last_g = a.g;
+    e->last_groups_lds = groups_lds;
+    e->last_groups_direct = groups_direct;
+    e->last_list = !use_direct || e->cfg_force_direct ? nullptr
+                   : shift ? e->d_shwide.p : jp > 0 ? e->d_pwide.p : e->d_wide.p;
+    e->last_n_list = !use_direct ? 0 : e->cfg_force_direct ? nbricks_now : n_wide_now;
 
     // a conditional launch (the fallback of a screened step) is not part of the timing log: it
     // returns at once unless the step has to be redone
@@ -453,8 +459,72 @@ int detect_core(qm_engine *e, const double *d_on, int T, int fsmp, int ns, int a
     if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, &sets, false, 0, 0,
                   run_if))
         return 1;
-    return combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, mode, e->node_offset,
-                   n_nodes_total, o_max, o_second, o_idx, run_if);
+    if (combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, mode, e->node_offset,
+                n_nodes_total, o_max, o_second, o_idx, run_if))
+        return 1;
+    // (the reference's rule on near-ties: final series of this engine's own nodes only -- the partial
+    // sets of a sharded detect leave the engine before anyone knows the global maximum)
+    if (e->cfg_tie_rule && mode == 1 && !screened)
+        return refine_ties(e, d_on, T, fsmp, available, 0, ns, sets, o_idx);
+    return 0;
+}
+
+// tie_rule = 1 (qm_ties.hpp): the index series of the launch whose partial sets lie in d_pmax, refined
+int refine_ties(qm_engine *e, const double *d_on, int T, int fsmp, int available, int sample0,
+                int n_chunk, int sets, int64_t *o_idx) {
+    const int n = n_chunk;
+    const int max_pairs = qm::kTieMaxSets * n;
+    const int max_cands = 4 * n + 65536;
+    if (e->d_tie_z.ensure(n) || e->d_tie_pairs.ensure(2 * (size_t)max_pairs) || e->d_tie_imin.ensure(n) ||
+        e->d_tie_count.ensure(4) || e->d_tie_emax.ensure(n) || e->d_tie_cands.ensure(2 * (size_t)max_cands) ||
+        e->d_tie_keys.ensure(max_cands))
+        return 1;
+    hipStream_t s = e->stream;
+    QM_HIP(hipMemsetAsync(e->d_tie_count.p, 0, 4 * sizeof(int32_t), s));
+    int2 *pairs = reinterpret_cast<int2 *>(e->d_tie_pairs.p);
+    hipLaunchKernelGGL(qm::tie_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
+                       (const double *)e->d_pmax.p, sets, n, (int64_t)n, e->d_tie_z.p, pairs,
+                       e->d_tie_count.p, max_pairs, e->d_tie_emax.p, e->d_tie_imin.p, e->d_tie_count.p + 1);
+    QM_HIP(hipGetLastError());
+    // how many pairs there are is known on the device only: the evaluation is launched for the number a
+    // generic step has (one per sample) with room to spare, and again for the rest if a step has more
+    int32_t h[2] = {0, 0};
+    QM_HIP(copy_back(h, e->d_tie_count.p, sizeof(h), s));
+    e->tie_pairs_last = h[0];
+    e->tie_overflow_samples += h[1];
+    ++e->tie_refined_steps;
+    if (h[0] == 0) return 0;
+    qm::TieArgs a{};
+    a.g = e->last_g;
+    a.onsets = d_on;
+    a.lut = e->d_lut.p;
+    a.T = T; a.fsmp = fsmp; a.sample0 = sample0; a.n_chunk = n;
+    a.z_scale = 1.4426950408889634074 / (double)available;
+    a.recip = 1.0 / (double)available;
+    a.groups_lds = e->last_groups_lds;
+    a.groups_direct = e->last_groups_direct;
+    a.brick_list = e->last_list;
+    a.n_list = e->last_n_list;
+    // workgroups per pair: ~2048 nodes each
+    const int64_t per_set = (int64_t)e->n_nodes / std::max(1, e->last_groups_lds + e->last_groups_direct);
+    a.chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, per_set / 2048));
+    a.zbest = e->d_tie_z.p;
+    a.pairs = pairs;
+    a.n_pairs = e->d_tie_count.p;
+    a.emax = e->d_tie_emax.p;
+    a.imin = e->d_tie_imin.p;
+    a.cands = reinterpret_cast<int2 *>(e->d_tie_cands.p);
+    a.cand_keys = e->d_tie_keys.p;
+    a.n_cands = e->d_tie_count.p + 2;
+    a.max_cands = max_cands;
+    const unsigned grid = (unsigned)((int64_t)h[0] * a.chunks);
+    hipLaunchKernelGGL(qm::tie_eval_kernel<0>, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(qm::tie_pick_kernel, dim3(256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(qm::tie_eval_kernel<1>, dim3(grid), dim3(256), 0, s, a);   // (returns at once unless the list overflowed)
+    hipLaunchKernelGGL(qm::tie_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
+                       (const int32_t *)e->d_tie_imin.p, n, e->node_offset, o_idx + sample0);
+    QM_HIP(hipGetLastError());
+    return 0;
 }
 
 int check_step(qm_engine *e, int T, int fsmp, int lsmp, int available, int *n_samples) {
@@ -547,6 +617,8 @@ void qm_engine_destroy(qm_engine *e) {
     e->d_onq.release(); e->d_sparams.release();
     e->d_cell.release(); e->d_gmax.release(); e->d_pm.release(); e->d_rowmax.release(); e->d_ssum.release();
     e->d_cand_z.release(); e->d_cand_idx.release();
+    e->d_tie_z.release(); e->d_tie_pairs.release(); e->d_tie_imin.release(); e->d_tie_count.release();
+    e->d_tie_emax.release(); e->d_tie_cands.release(); e->d_tie_keys.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
     for (hipEvent_t ev : e->ev_log) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -633,6 +705,9 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
         e->shift_built = false;
     } else if (k == "shift_tail") {
         e->cfg_shift_tail = v ? 1 : 0;
+    } else if (k == "tie_rule") {
+        if (v != 0 && v != 1) return fail("tie_rule must be 0 (largest sum) or 1 (the reference's exp rule)");
+        e->cfg_tie_rule = (int)v;
     } else if (k == "shift_lazy") {
         if (v < -1 || v > 1) return fail("shift_lazy must be -1 (automatic), 0 or 1");
         e->cfg_shift_lazy = (int)v;
@@ -692,6 +767,10 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "shift_tail") *v = e->cfg_shift_tail;
     else if (k == "shift_tail_spl") *v = e->shift_tail_last;
     else if (k == "steps_per_launch") *v = e->last_batched;
+    else if (k == "tie_rule") *v = e->cfg_tie_rule;
+    else if (k == "tie_refined_steps") *v = e->tie_refined_steps;
+    else if (k == "tie_overflow_samples") *v = e->tie_overflow_samples;
+    else if (k == "tie_pairs") *v = e->tie_pairs_last;
     else if (k == "table_hits") *v = e->table_hits;
     else if (k == "table_misses") *v = e->table_misses;
     else if (k == "table_evictions") *v = e->table_evictions;
@@ -821,7 +900,7 @@ int qm_engine_detect_batch(qm_engine *e, const double *log_onsets, int onsets_on
     if (stage_out(e, n_all, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st)) return 1;
     bool batched = false;
     int sets = 0;
-    if (n_steps > 1 && !e->cfg_screen) {
+    if (n_steps > 1 && !e->cfg_screen && !e->cfg_tie_rule) {
         if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, &sets, false, 0, 0,
                       nullptr, n_steps, (int64_t)per_step, &batched))
             return 1;
@@ -864,6 +943,8 @@ int qm_engine_migrate(qm_engine *e, const double *log_onsets, int onsets_on_devi
         if (want_scan && combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, 1,
                                  e->node_offset, n_nodes_total, st.a, st.b, st.i))
             return 1;
+        if (want_scan && e->cfg_tie_rule && refine_ties(e, d_on, T, fsmp, available, 0, ns, sets, st.i))
+            return 1;
     } else {
         // host volume: stream it through a device chunk buffer, time-chunk by time-chunk
         const int KT = qm::kWave * eff_j(e);
@@ -883,6 +964,8 @@ int qm_engine_migrate(qm_engine *e, const double *log_onsets, int onsets_on_devi
             if (want_scan && combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, nk, 1,
                                      e->node_offset, n_nodes_total, st.a + k0, st.b + k0,
                                      st.i + k0))
+                return 1;
+            if (want_scan && e->cfg_tie_rule && refine_ties(e, d_on, T, fsmp, available, k0, nk, sets, st.i))
                 return 1;
             QM_HIP(copy_back_2d(map4d + k0, (size_t)ns * sizeof(double), e->d_chunk.p,
                                     nk * sizeof(double), nk * sizeof(double), e->n_nodes, e->stream));
@@ -927,6 +1010,8 @@ int qm_engine_marginal(qm_engine *e, const double *log_onsets, int onsets_on_dev
     QM_HIP(hipGetLastError());
     if (want_scan && combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, 1,
                              e->node_offset, n_nodes_total, st.a, st.b, st.i))
+        return 1;
+    if (want_scan && e->cfg_tie_rule && refine_ties(e, d_on, T, fsmp, available, 0, ns, sets, st.i))
         return 1;
     if (!map_on_device) {
         QM_HIP(copy_back(coa_map, d_map, (size_t)e->n_nodes * sizeof(double), e->stream));
@@ -982,6 +1067,21 @@ int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
         }
     }
     return fetch_out(e, n_samples, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
+}
+
+double qm_exp_correctly_rounded(double x) { return qm::exp_correctly_rounded(x); }
+
+int qm_engine_exp_correctly_rounded(qm_engine *e, const double *x, int64_t n, double *out) {
+    if (!e || !x || !out) return fail("qm_engine_exp_correctly_rounded: NULL argument");
+    if (n < 1) return 0;
+    DeviceGuard guard(e->device);
+    if (e->d_fit_a.ensure((size_t)n) || e->d_fit_b.ensure((size_t)n)) return 1;
+    QM_HIP(copy_in(e->d_fit_a.p, x, (size_t)n * sizeof(double), e->stream));
+    hipLaunchKernelGGL(qm::exp_cr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream,
+                       (const double *)e->d_fit_a.p, n, e->d_fit_b.p);
+    QM_HIP(hipGetLastError());
+    QM_HIP(copy_back(out, e->d_fit_b.p, (size_t)n * sizeof(double), e->stream));
+    return 0;
 }
 
 int qm_engine_kernel_log(qm_engine *e, double *total_ms, int32_t *n_calls) {

@@ -33,6 +33,7 @@
 #include "qm_screen.hpp"
 #include "qm_pair.hpp"
 #include "qm_shift.hpp"
+#include "qm_ties.hpp"
 
 #pragma GCC visibility push(hidden)
 
@@ -212,6 +213,8 @@ struct qm_engine : TableState {
     int cfg_shift_tail = 1;                 // 1: a scan's remainder of <= 192 samples runs as one tail tile of
                                             // 64 / 128 / 192 samples; 0: whole tiles only (round 3)
     int cfg_shift_rows_direct = 1;
+    int cfg_tie_rule = 0;                   // 0: largest float64 sum, lowest index among equal ones (default);
+                                            // 1: the reference's rule on near-ties (qm_ties.hpp)
 
     // per-step scratch of the screened detect (qm_screen.hpp) and its statistics
     DevBuf<int32_t> d_scalar, d_counts, d_cells, d_work, d_flags;
@@ -226,6 +229,14 @@ struct qm_engine : TableState {
     int shift_lazy_last = 0;                // loop flavour the last shift-reuse launch took
     int shift_tail_last = 0;                // samples per lane of the last launch's tail tile (0: none)
     int last_batched = 1;                   // timesteps the last detect_batch put into one launch
+    // which bricks the partial sets of the last stacking launch stand for (qm_ties.hpp)
+    qm::GridDesc last_g{};
+    int last_groups_lds = 0, last_groups_direct = 0, last_n_list = 0;
+    const int32_t *last_list = nullptr;
+    DevBuf<double> d_tie_z;
+    DevBuf<int32_t> d_tie_pairs, d_tie_imin, d_tie_count, d_tie_cands;
+    DevBuf<unsigned long long> d_tie_emax, d_tie_keys;
+    int64_t tie_refined_steps = 0, tie_overflow_samples = 0, tie_pairs_last = 0;
 
     // float64 travel-time grids in seconds (optional; on-device table serving)
     DevBuf<double> d_grids;
@@ -303,6 +314,8 @@ int combine(qm_engine *e, const double *pmax, const int64_t *pidx, const double 
             int n, int mode, int64_t node_offset, int64_t n_nodes_total, double *o_max,
             double *o_second, int64_t *o_idx, const int32_t *run_if = nullptr,
             int64_t set_stride = 0);
+int refine_ties(qm_engine *e, const double *d_on, int T, int fsmp, int available, int sample0,
+                int n_chunk, int sets, int64_t *o_idx);
 int detect_core(qm_engine *e, const double *d_on, int T, int fsmp, int ns, int available, int mode,
                 int64_t n_nodes_total, double *o_max, double *o_second, int64_t *o_idx);
 int check_step(qm_engine *e, int T, int fsmp, int lsmp, int available, int *n_samples);

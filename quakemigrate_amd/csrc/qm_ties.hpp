@@ -1,0 +1,259 @@
+// qm_ties.hpp -- the reference's arg-max rule on near-ties, opt-in ("tie_rule" = 1).
+//
+// The reference exponentiates every stack and THEN looks for the maximum with a strict '>'
+// (migratelib.c:60-62 exp(stack * (1 / available)), :98-105 the scan): two nodes whose float64 stacks
+// differ by an ulp or two can round to the same exp() value -- the lower flat index then wins -- so
+// on a near-tie the index it returns is a property of exp()'s rounding.  The engine's default keeps
+// the largest float64 z = stack * log2(e) / available, lowest index among equal ones: identical on
+// equal sums and wherever the maximum stands alone, different on 11 % of the samples of the
+// adversarial twin fixtures (profiles/r04_near_tie_study.txt).
+//
+// tie_rule = 1 adds a refinement AFTER the stacking launch and its combine, from what they leave
+// behind (the partial sets: per (set of bricks, sample) the largest z):
+//   1. tie_pairs_kernel: per sample the largest z over the sets, and the sets whose maximum lies
+//      within `slack` of it -- only they can hold a node whose exp() ties with the maximum's.  Generic
+//      data: one (set, sample) pair per sample.
+//   2. tie_eval_kernel: every node of such a set is stacked again for that ONE sample, rows in
+//      ascending order (the reference's sum, bit for bit); nodes within the slack form x = stack *
+//      (1 / available) as the reference does and a CORRECTLY ROUNDED exp(x) (double-double
+//      arithmetic below: what glibc's scalar exp returns in all but ~1e-3 of its arguments), take
+//      part in the sample's largest exp (atomic max on the bit pattern: positive doubles order as
+//      integers) and go on a candidate list; tie_pick_kernel then takes, per sample, the lowest flat
+//      index among the listed nodes that reach the largest exp.  (A list that overflows -- several
+//      whole sets of equal nodes -- is replaced by a second stacking pass, tie_eval_kernel<1>.)
+//   3. tie_apply_kernel: the index series takes the refined index.  Values are left as they are
+//      (2^z of the largest z: the same maximum within 1e-15).
+// A sample with more than kTieMaxSets candidate sets (flat data: everything ties) keeps the default
+// rule's index, which for EQUAL sums is the reference's; the count is reported
+// (qm_engine_get "tie_overflow_samples").
+// slack: exp(x1) and exp(x2) can round to one double only if |x1 - x2| <= 2^-52 (one ulp of the result,
+// relative), i.e. |z1 - z2| <= 1.4427 * 2^-52; z and x are both products of the same stack with a
+// rounded constant (half an ulp each, relative).  slack = 4e-16 + 2^-50 |z| covers both with room; a
+// wider net only costs evaluations, never correctness.
+#pragma once
+
+#include "qm_kernels.hpp"
+
+namespace qm {
+
+// ---- correctly rounded exp in double-double arithmetic ------------------------------------------
+// (every function below switches floating-point contraction OFF: device code is compiled with
+// -ffp-contract=fast, which fuses a product into an addition ACROSS statements -- s = p.h + p.l with
+// p.h = a * b becomes fma(a, b, p.l) -- and silently breaks the error-free transformations: the first
+// device build was off by 3 ulps on 97 % of its arguments while the host build of the same source
+// was exact)
+struct DD {
+    double h, l;
+};
+__host__ __device__ __forceinline__ DD dd_two_sum(double a, double b) {
+#pragma clang fp contract(off)
+    const double s = a + b, bb = s - a;
+    return {s, (a - (s - bb)) + (b - bb)};
+}
+__host__ __device__ __forceinline__ DD dd_quick(double a, double b) {     // |a| >= |b|
+#pragma clang fp contract(off)
+    const double s = a + b;
+    return {s, b - (s - a)};
+}
+__host__ __device__ __forceinline__ DD dd_two_prod(double a, double b) {
+#pragma clang fp contract(off)
+    const double p = a * b;
+    return {p, __builtin_fma(a, b, -p)};
+}
+__host__ __device__ __forceinline__ DD dd_add(DD a, DD b) {
+#pragma clang fp contract(off)
+    DD s = dd_two_sum(a.h, b.h);
+    const DD t = dd_two_sum(a.l, b.l);
+    s.l += t.h;
+    s = dd_quick(s.h, s.l);
+    s.l += t.l;
+    return dd_quick(s.h, s.l);
+}
+__host__ __device__ __forceinline__ DD dd_mul(DD a, DD b) {
+#pragma clang fp contract(off)
+    DD p = dd_two_prod(a.h, b.h);
+    p.l += a.h * b.l + a.l * b.h;
+    return dd_quick(p.h, p.l);
+}
+
+// exp(x) rounded to nearest from a double-double evaluation (relative error ~2^-95 before the final
+// rounding: the result is the correctly rounded one unless exp(x) lies within ~2^-95 of the midpoint
+// of two doubles).  x = k ln2 + r, |r| <= ln2 / 2 (ln2 as a triple double, k ln2_hi exact);
+// exp(r) = exp(r / 64)^64 with a degree-12 Taylor polynomial of r / 64 (|r / 64| < 0.0055:
+// truncation 2^-119) and six squarings.
+__host__ __device__ inline double exp_correctly_rounded(double x) {
+#pragma clang fp contract(off)
+    if (!(x == x)) return x;                                        // NaN
+    if (x > 709.782712893384) return __builtin_inf();
+    if (x < -745.2) return 0.0;
+    constexpr double kInvLn2 = 0x1.71547652b82fep+0;
+    constexpr double kLn2Hi = 0x1.62e42fee00000p-1;                  // 32 significant bits: k * hi is exact
+    constexpr double kLn2Lo = 0x1.a39ef35793c76p-33, kLn2LoLo = 0x1.cc01f97b57a08p-87;
+    const double k = __builtin_rint(x * kInvLn2);
+    DD r = dd_two_sum(x, -k * kLn2Hi);
+    DD t = dd_two_prod(k, kLn2Lo);
+    r = dd_add(r, DD{-t.h, -t.l});
+    r = dd_add(r, DD{-k * kLn2LoLo, 0.0});
+    r.h *= 0.015625;                                                // / 64: exact
+    r.l *= 0.015625;
+    // 1 / n!, n = 12 .. 2, as double-doubles
+    constexpr double ch[11] = {0x1.1eed8eff8d898p-29, 0x1.ae64567f544e4p-26, 0x1.27e4fb7789f5cp-22,
+                               0x1.71de3a556c734p-19, 0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-13,
+                               0x1.6c16c16c16c17p-10, 0x1.1111111111111p-7,  0x1.5555555555555p-5,
+                               0x1.5555555555555p-3,  0x1.0000000000000p-1};
+    constexpr double cl[11] = {-0x1.2aec959e14c06p-83, -0x1.c062e06d1f209p-80, 0x1.cbbc05b4fa99ap-76,
+                               -0x1.c154f8ddc6c00p-73, 0x1.a01a01a01a01ap-76,  0x1.a01a01a01a01ap-73,
+                               -0x1.f49f49f49f49fp-65, 0x1.1111111111111p-63,  0x1.5555555555555p-59,
+                               0x1.5555555555555p-57,  0.0};
+    DD p{ch[0], cl[0]};
+    for (int i = 1; i < 11; ++i) p = dd_add(dd_mul(p, r), DD{ch[i], cl[i]});
+    p = dd_add(dd_mul(p, r), DD{1.0, 0.0});                         // ... + r
+    p = dd_add(dd_mul(p, r), DD{1.0, 0.0});                         // ... + 1
+    for (int i = 0; i < 6; ++i) p = dd_mul(p, p);
+    // (h + l rounded to nearest is h: the pair is normalised; 2^k scales exactly above the subnormals)
+    return __builtin_ldexp(p.h, (int)k);
+}
+
+// ---- the refinement ---------------------------------------------------------------------------
+constexpr int kTieMaxSets = 8;          // candidate sets per sample beyond which the default index stays
+
+__host__ __device__ __forceinline__ double tie_slack(double zb) {
+    return 4.0e-16 + 0x1p-50 * (zb < 0 ? -zb : zb);
+}
+
+struct TieArgs {
+    GridDesc g;                    // the brick grid of the launch whose sets are refined
+    const double *onsets;          // [S][T] log-onsets of this step
+    const int32_t *lut;            // [N][S]
+    int T, fsmp, sample0, n_chunk;
+    double z_scale, recip;         // log2(e) / available; 1 / available (the reference's factor)
+    int groups_lds, groups_direct; // set s < groups_lds: bricks s, s + groups_lds, ...; else the direct launch's
+    const int32_t *brick_list;     // ... bricks list[i], i = s - groups_lds, + groups_direct, ... (nullptr: all)
+    int n_list;
+    int chunks;                    // workgroups per (set, sample) pair
+    const double *zbest;           // [n_chunk] largest z over the sets
+    const int2 *pairs;             // work list: (set, sample)
+    const int32_t *n_pairs;        // its length (device)
+    unsigned long long *emax;      // [n_chunk] bit pattern of the largest correctly rounded exp
+    int32_t *imin;                 // [n_chunk] lowest local node index reaching it
+    int2 *cands;                   // candidate list: (local node, sample) ...
+    unsigned long long *cand_keys; // ... and the bit pattern of its exp
+    int32_t *n_cands;              // candidates seen (may exceed max_cands: the list then does not count)
+    int max_cands;
+};
+
+#ifdef QM_TU_STEPS
+// One thread per sample: the largest z over the sets, the sets within the slack -> work list.
+__global__ __launch_bounds__(256) void tie_pairs_kernel(const double *__restrict__ pmax, int sets, int n,
+                                                        int64_t set_stride, double *__restrict__ zbest,
+                                                        int2 *__restrict__ pairs, int32_t *__restrict__ n_pairs,
+                                                        int max_pairs, unsigned long long *__restrict__ emax,
+                                                        int32_t *__restrict__ imin,
+                                                        int32_t *__restrict__ overflow) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double zb = -__builtin_inf();
+    for (int s = 0; s < sets; ++s) {
+        const double v = pmax[(int64_t)s * set_stride + t];
+        zb = v > zb ? v : zb;                               // (a NaN never wins)
+    }
+    zbest[t] = zb;
+    emax[t] = 0ull;
+    imin[t] = INT32_MAX;
+    if (!(zb > -__builtin_inf())) return;                   // nothing finite: the default's (0, index 0) stays
+    const double lo = zb - tie_slack(zb);
+    int count = 0;
+    for (int s = 0; s < sets; ++s) count += pmax[(int64_t)s * set_stride + t] >= lo ? 1 : 0;
+    if (count > kTieMaxSets) {
+        atomicAdd(overflow, 1);
+        return;
+    }
+    const int at = atomicAdd(n_pairs, count);
+    if (at + count > max_pairs) {                           // (cannot happen: max_pairs = kTieMaxSets * n)
+        atomicAdd(overflow, 1);
+        return;
+    }
+    int k = 0;
+    for (int s = 0; s < sets; ++s)
+        if (pmax[(int64_t)s * set_stride + t] >= lo) pairs[at + k++] = make_int2(s, t);
+}
+
+// Workgroup = (pair, chunk): the nodes of the pair's set, for the pair's one sample.
+template <int PASS>
+__global__ __launch_bounds__(256) void tie_eval_kernel(TieArgs a) {
+    const int pair = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+    if (pair >= *a.n_pairs) return;
+    if (PASS == 1 && *a.n_cands <= a.max_cands) return;     // the candidate list held them all
+    const int2 w = a.pairs[pair];
+    const int set = w.x, t = w.y;
+    const GridDesc &g = a.g;
+    const int S = g.n_rows;
+    const double zb = a.zbest[t], lo = zb - tie_slack(zb);
+    const int64_t col = (int64_t)t + a.sample0 + a.fsmp;
+    const bool direct = set >= a.groups_lds;
+    const int first = direct ? set - a.groups_lds : set;
+    const int stride = direct ? a.groups_direct : a.groups_lds;
+    const int n_list = direct ? (a.brick_list ? a.n_list : g.nbricks) : g.nbricks;
+    unsigned long long best = 0ull;
+    int best_node = INT32_MAX;
+    for (int i = first + chunk * stride; i < n_list; i += a.chunks * stride) {
+        const int b = (direct && a.brick_list) ? a.brick_list[i] : i;
+        int x0, y0, z0, vx, vy, vz;
+        brick_extents(g, b, x0, y0, z0, vx, vy, vz);
+        const int nvalid = vx * vy * vz;
+        for (int m = threadIdx.x; m < nvalid; m += blockDim.x) {
+            const int node = brick_walk_node(g, x0, y0, z0, vy, vz, m);
+            const int32_t *row = a.lut + (int64_t)node * S;
+            double stack = 0.0;
+            for (int r = 0; r < S; ++r) {                   // ascending rows: migratelib.c:54-59
+                int d = row[r];
+                d = d < 0 ? 0 : d;
+                stack += a.onsets[(int64_t)r * a.T + d + col];
+            }
+            if (!(stack * a.z_scale >= lo)) continue;
+            const double e = exp_correctly_rounded(stack * a.recip);
+            const unsigned long long key = (unsigned long long)__double_as_longlong(e);
+            if (PASS == 0) {
+                best = key > best ? key : best;
+                const int at = atomicAdd(a.n_cands, 1);
+                if (at < a.max_cands) {
+                    a.cands[at] = make_int2(node, t);
+                    a.cand_keys[at] = key;
+                }
+            } else if (key == a.emax[t]) {
+                best_node = node < best_node ? node : best_node;
+            }
+        }
+    }
+    if (PASS == 0) {
+        if (best) atomicMax(&a.emax[t], best);
+    } else if (best_node != INT32_MAX) {
+        atomicMin(&a.imin[t], best_node);
+    }
+}
+
+// the device's evaluation of exp_correctly_rounded (the tests pin it to the host's, bit for bit)
+__global__ __launch_bounds__(256) void exp_cr_kernel(const double *__restrict__ x, int64_t n,
+                                                     double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = exp_correctly_rounded(x[i]);
+}
+
+// the lowest node among the listed candidates that reach their sample's largest exp
+__global__ __launch_bounds__(256) void tie_pick_kernel(TieArgs a) {
+    const int n = *a.n_cands;
+    if (n > a.max_cands) return;                            // (tie_eval_kernel<1> does it)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int2 c = a.cands[i];
+        if (a.cand_keys[i] == a.emax[c.y]) atomicMin(&a.imin[c.y], c.x);
+    }
+}
+
+__global__ __launch_bounds__(256) void tie_apply_kernel(const int32_t *__restrict__ imin, int n,
+                                                        int64_t node_offset, int64_t *__restrict__ o_idx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n && imin[t] != INT32_MAX) o_idx[t] = node_offset + imin[t];
+}
+#endif  // QM_TU_STEPS
+
+}  // namespace qm

@@ -2667,3 +2667,92 @@ def test_native_stream_push_pop_semantics(lib, oracle):
     with pytest.raises(lib.QMHipError):
         sd.push(wins[0])
     sd.close()
+
+
+# ---- round 5: the reference's arg-max rule on near-ties, opt-in (csrc/qm_ties.hpp) -------------------
+def _near_tie_families():
+    g, t = load_golden("permuted_twins"), load_golden("near_ties_scalar")
+    yield ("permuted", g["onsets"], g["traveltimes"], int(g["fsmp"]), int(g["lsmp"]), int(g["available"]),
+           g["max_coa_idx"], t["permuted_idx_scalar"])
+    yield ("mirror", t["mirror_onsets"], t["mirror_traveltimes"], int(t["mirror_fsmp"]), int(t["mirror_lsmp"]),
+           int(t["mirror_available"]), t["mirror_idx_vec"], t["mirror_idx_scalar"])
+
+
+@pytest.mark.parametrize("cfg", [{}, {"shift": 0}, {"shift_lazy": 0}, {"force_direct": 1}, {"pair": 2}])
+def test_tie_rule_exp_reproduces_the_references_scalar_build(lib, oracle, cfg):
+    """tie_rule = 1: on the two families whose every sample is a near-tie, the index series equals the
+    reference's two C files built with -fno-tree-vectorize (glibc's scalar exp) on EVERY sample
+    (fixture near_ties_scalar, oracle/make_golden_ties.py) -- whatever stacking kernel ran --, stays
+    within 8.5 % of the -Ofast build (which differs from its own scalar twin that much), the values
+    are the default path's bits, and an engine without the key computes what it always did."""
+    for name, onsets, tt, fsmp, lsmp, avail, idx_vec, idx_scalar in _near_tie_families():
+        lon = oracle.log_onsets(onsets)
+        base = lib.Engine(0, **cfg)
+        base.load_lut(tt)
+        a0, b0, c0 = base.detect(lon, fsmp, lsmp, avail)
+        base.close()
+        eng = lib.Engine(0, tie_rule=1, **cfg)
+        eng.load_lut(tt)
+        a, b, c = eng.detect(lon, fsmp, lsmp, avail)
+        assert np.array_equal(c, idx_scalar), (name, cfg, float(np.mean(c != idx_scalar)))
+        assert np.mean(c != idx_vec) <= 0.085, (name, float(np.mean(c != idx_vec)))
+        assert np.array_equal(a, a0) and np.array_equal(b, b0)
+        assert 0.08 < np.mean(c != c0) < 0.14                  # ... and the default rule is the other one
+        assert eng.get("tie_overflow_samples") == 0 and eng.get("tie_pairs") >= len(c)
+        # the same refinement behind the volume-writing and the marginal-map launches' scans, and K steps
+        vol = np.zeros((int(np.prod(tt.shape[:3])), len(c)))
+        series = (np.zeros(len(c)), np.zeros(len(c)), np.zeros(len(c), dtype=np.int64))
+        eng.migrate(lon, fsmp, lsmp, avail, vol, scan_out=series)
+        assert np.array_equal(series[2], idx_scalar)
+        series = (np.zeros(len(c)), np.zeros(len(c)), np.zeros(len(c), dtype=np.int64))
+        eng.marginal_map(lon, fsmp, lsmp, avail, 0, len(c), scan_out=series)
+        assert np.array_equal(series[2], idx_scalar)
+        k3 = eng.detect_batch(np.stack([lon, lon, lon]), fsmp, lsmp, avail)
+        assert all(np.array_equal(k3[2][k], idx_scalar) for k in range(3)) and eng.get("steps_per_launch") == 1
+        eng.close()
+
+
+def test_tie_rule_exp_changes_nothing_where_the_maximum_stands_alone(lib, oracle):
+    """Generic data has no near-ties: with tie_rule = 1 the series are the default's, bit for bit
+    (a shift-reuse table, a coarse one, a sharded engine's node offset); flat data -- every node ties,
+    more candidate sets than the refinement follows -- keeps the default's index 0 and says so."""
+    for recipe, grid, rows, ns, kw in (("C3", (19, 17, 13), 30, 401, {}), ("E1", (15, 14, 9), 24, 300, {}),
+                                       ("C3", (19, 17, 13), 30, 300, {"node_offset": 12345})):
+        case = synth.make_case(recipe, step=2, grid=grid, rows=rows, n_samples=ns)
+        lon = oracle.log_onsets(case.onsets)
+        out = []
+        for rule in (0, 1):
+            eng = lib.Engine(0, tie_rule=rule)
+            eng.load_lut(case.traveltimes, node_offset=kw.get("node_offset", 0))
+            out.append(eng.detect(lon, case.fsmp, case.lsmp, case.available, n_nodes_total=10 ** 6))
+            if rule:
+                assert eng.get("tie_refined_steps") == 1 and eng.get("tie_overflow_samples") == 0
+            eng.close()
+        assert all(np.array_equal(x, y) for x, y in zip(*out)), recipe
+    case = synth.make_case("C3", step=1, grid=(24, 24, 16), rows=12, n_samples=130, quiet=True)
+    eng = lib.Engine(0, tie_rule=1, groups=64)
+    eng.load_lut(case.traveltimes)
+    a, b, c = eng.detect(oracle.log_onsets(case.onsets), case.fsmp, case.lsmp, case.available)
+    assert (c == 0).all() and eng.get("tie_overflow_samples") == 130
+    eng.close()
+    # ... and with few sets the refinement follows them: every node is a candidate (far more than the
+    # candidate list holds: the second stacking pass takes over), all exps are equal, index 0
+    eng = lib.Engine(0, tie_rule=1, groups=4)
+    eng.load_lut(case.traveltimes)
+    a, b, c = eng.detect(oracle.log_onsets(case.onsets), case.fsmp, case.lsmp, case.available)
+    assert (c == 0).all() and eng.get("tie_overflow_samples") == 0 and eng.get("tie_pairs") == 4 * 130
+    eng.close()
+
+
+def test_device_exp_correctly_rounded_is_the_hosts(lib):
+    """The GPU's evaluation of csrc/qm_ties.hpp's exp (device code is compiled with fused
+    contraction across statements, which the double-double arithmetic switches off: the first build
+    was 3 ulps off) equals the host's -- which tests/test_host.py pins to mpmath -- on every argument."""
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.uniform(-12, 12, 200000), rng.uniform(0, 3, 100000), rng.uniform(-700, 700, 20000),
+                         [0.0, -0.0, 1.0, 709.0, -740.0, 800.0, -800.0, np.nan]])
+    eng = lib.Engine(0)
+    dev = eng.exp_correctly_rounded(xs)
+    eng.close()
+    host = np.array([lib.qmlib.qm_exp_correctly_rounded(float(v)) for v in xs])
+    assert np.array_equal(dev, host, equal_nan=True), float(np.mean(dev != host))

@@ -591,3 +591,21 @@ def test_timeit_logs_the_references_line(caplog):
     assert [lvl for lvl, _ in msgs] == [logging.INFO, logging.DEBUG]
     assert all(m.startswith(" " * 21 + "Elapsed time: ") and m.endswith(" seconds.") for _, m in msgs)
     assert lib.migrate.__wrapped__ is not None and lib.find_max_coa.__name__ == "find_max_coa"
+
+
+def test_exp_correctly_rounded_is_correctly_rounded(built):
+    """qm_exp_correctly_rounded (csrc/qm_ties.hpp: the function the opt-in tie_rule = 1 compares
+    near-tied nodes on; host + device code, the same source) against mpmath's exp rounded to
+    nearest, over the range coalescence exponents live in and beyond -- every argument, every bit."""
+    mpmath = pytest.importorskip("mpmath")
+    from quakemigrate_amd.core import lib
+
+    f = lib.qmlib.qm_exp_correctly_rounded
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.uniform(-12, 12, 3000), rng.uniform(0, 3, 3000), rng.uniform(-1e-3, 1e-3, 500),
+                         rng.uniform(-700, 700, 500), [0.0, -0.0, 1.0, -1.0, 0.5, 709.0, -740.0, 1e-300]])
+    with mpmath.workprec(200):
+        want = np.array([float(mpmath.exp(mpmath.mpf(float(x)))) for x in xs])
+    got = np.array([f(float(x)) for x in xs])
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:5]
+    assert np.isnan(f(float("nan"))) and f(800.0) == np.inf and f(-800.0) == 0.0

@@ -238,3 +238,20 @@ def test_locate_fit_restatements_match_reference_calculate_location(oracle, name
     np.testing.assert_allclose(np.diag(np.sqrt(np.abs(cov))),
                                g[f"{name}_covariance_uncertainty"], rtol=1e-13, atol=1e-300)
     assert np.array_equal(oracle.np_splineloc(coa), g[f"{name}_spline"])
+
+
+def test_exp_rule_restatement_matches_the_references_scalar_build(oracle):
+    """The arg-max rule of the opt-in tie_rule = 1 (oracle.np_argmax_exp_rule: correctly rounded
+    exp, first maximum) reproduces the reference's own two C files built with -fno-tree-vectorize
+    (glibc's scalar exp) on EVERY sample of the two near-tie families -- and differs from the
+    -Ofast build (libmvec) on ~8 % of them, as that build differs from its scalar twin."""
+    g = load_golden("permuted_twins")
+    t = load_golden("near_ties_scalar")
+    idx = oracle.np_argmax_exp_rule(g["onsets"], g["traveltimes"], int(g["fsmp"]), int(g["lsmp"]),
+                                    int(g["available"]))
+    assert np.array_equal(idx, t["permuted_idx_scalar"])
+    assert 0.06 < np.mean(idx != g["max_coa_idx"]) < 0.10
+    idx = oracle.np_argmax_exp_rule(t["mirror_onsets"], t["mirror_traveltimes"], int(t["mirror_fsmp"]),
+                                    int(t["mirror_lsmp"]), int(t["mirror_available"]))
+    assert np.array_equal(idx, t["mirror_idx_scalar"])
+    assert 0.06 < np.mean(idx != t["mirror_idx_vec"]) < 0.10

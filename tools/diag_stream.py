@@ -1,6 +1,9 @@
-"""Where does StreamingDetector spend its time on short steps?  (development aid)"""
-import cProfile
-import pstats
+"""Where does the native streaming pipeline (qm_stream_*) spend its time?  (development aid)
+
+usage: diag_stream.py CONFIG K [depth] [steps]
+Prints per step: wall with the copies inside, the stacking kernel's own time (HIP events), the host's time in
+push / pop, against the resident step."""
+import json
 import sys
 import time
 import pathlib
@@ -13,33 +16,55 @@ from quakemigrate_amd import synth  # noqa: E402
 from quakemigrate_amd.core import lib  # noqa: E402
 from quakemigrate_amd.stream import StreamingDetector  # noqa: E402
 
-cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+cfg, K = sys.argv[1], int(sys.argv[2])
+depth = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 400
 case = synth.make_case(cfg, step=0)
-host = np.ascontiguousarray(np.log(np.clip(case.onsets, 0.01, np.inf)))
+wins = [np.ascontiguousarray(np.log(np.clip(synth.make_case(cfg, step=s, table=False).onsets, 0.01, np.inf)))
+        for s in range(8)]
 eng = lib.Engine(0)
-eng.load_lut(case.traveltimes)
-sd = StreamingDetector(eng, case.available, host.shape[1], case.fsmp, case.lsmp, case.available, depth=3)
-sd.run(host for _ in range(3))
-torch.cuda.synchronize()
-for steps in (30,):
-    t0 = time.perf_counter()
-    sd.run(host for _ in range(steps))
-    torch.cuda.synchronize()
-    print(cfg, "streaming ms/step", (time.perf_counter() - t0) / steps * 1e3)
-pr = cProfile.Profile()
-pr.enable()
-sd.run(host for _ in range(30))
-torch.cuda.synchronize()
-pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
-# resident-input loop for comparison
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
-d = torch.from_numpy(host).cuda()
-out = tuple(torch.empty(case.n_samples, dtype=t, device="cuda") for t in (torch.float64, torch.float64, torch.int64))
-eng.detect(d, case.fsmp, case.lsmp, case.available, out=out)
+eng.load_lut(case.traveltimes)
+S, T = wins[0].shape
+dev = torch.from_numpy(np.stack(wins[:K])).cuda()
+out = tuple(torch.empty((K, case.n_samples), dtype=d, device="cuda") for d in (torch.float64, torch.float64, torch.int64))
+for _ in range(3):
+    eng.detect_batch(dev, case.fsmp, case.lsmp, case.available, out=out)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(30):
-    eng.detect(d, case.fsmp, case.lsmp, case.available, out=out)
+for _ in range(steps // K):
+    eng.detect_batch(dev, case.fsmp, case.lsmp, case.available, out=out)
 torch.cuda.synchronize()
-print(cfg, "resident ms/step", (time.perf_counter() - t0) / 30 * 1e3)
+resident = (time.perf_counter() - t0) / (steps // K * K)
+sd = StreamingDetector(eng, S, T, case.fsmp, case.lsmp, case.available, depth=depth, steps_per_launch=K)
+sd.run(wins[i % 8] for i in range(4 * K))
+eng.config("log_timing", 1)
+t_push = t_pop = 0.0
+n_full = 0
+t0 = time.perf_counter()
+done = 0
+for i in range(steps):
+    w = wins[i % 8]
+    while True:
+        a = time.perf_counter()
+        ok = sd.push(w)
+        t_push += time.perf_counter() - a
+        if ok:
+            break
+        n_full += 1
+        a = time.perf_counter()
+        sd.pop(min(K, sd.pending()[0]))
+        t_pop += time.perf_counter() - a
+        done += K
+sd.flush()
+a = time.perf_counter()
+left = sd.pending()[0]
+sd.pop(left)
+t_pop += time.perf_counter() - a
+wall = (time.perf_counter() - t0) / steps
+kms, calls = eng.kernel_log()
+print(json.dumps({"config": cfg, "K": K, "depth": depth, "steps": steps, "resident_ms": round(resident * 1e3, 4),
+                  "with_copies_ms": round(wall * 1e3, 4), "ratio": round(wall / resident, 3),
+                  "kernel_ms_per_step": round(kms / steps, 4), "launches": calls,
+                  "host_push_ms_per_step": round(t_push / steps * 1e3, 4),
+                  "host_pop_ms_per_step": round(t_pop / steps * 1e3, 4), "ring_full": n_full}))
