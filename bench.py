@@ -200,11 +200,22 @@ def stored_traffic(label, kernel_name, algorithmic_bytes):
     if not files:
         return None, None
     try:
-        rec = json.load(open(files[-1])).get(label)
+        stored = json.load(open(files[-1]))
+        rec = stored.get(label)
     except (OSError, ValueError):
         return None, None
     if not rec or rec.get("kernel") != kernel_name:
         return None, None
+    # the counts belong to the code they were measured on: the stacking kernels' sources must be the
+    # ones this run was built from (tools/pmc_traffic.py: kernel_code_digest), else nothing is reported
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_traffic
+        if stored.get("_kernel_code") != pmc_traffic.kernel_code_digest():
+            return None, {"stale": "profiles/" + os.path.basename(files[-1]) + " was measured on other kernel "
+                                   "sources than this tree's (tools/pmc_traffic.py); not reported"}
+    finally:
+        sys.path.pop(0)
     total = rec["fetch_bytes"] + rec["write_bytes"]
     detail = {"fetch_bytes": rec["fetch_bytes"], "write_bytes": rec["write_bytes"],
               "fetch_bytes_if_128B_requests_tallied_at_64B": rec["fetch_bytes_upper"],
@@ -212,10 +223,11 @@ def stored_traffic(label, kernel_name, algorithmic_bytes):
               "ratio_to_algorithmic": total / algorithmic_bytes,
               "ratio_to_algorithmic_upper": (rec["fetch_bytes_upper"] + rec["write_bytes"]) / algorithmic_bytes,
               "source": "profiles/" + os.path.basename(files[-1]) + " <- " + ", ".join(rec["source"]),
+              "measured_in_this_run": False, "kernel_code": stored.get("_kernel_code"),
               "note": "separate rocprofv3 --pmc passes over one launch of this kernel on this workload "
                       "(FETCH_SIZE, WRITE_SIZE: KB); on gfx950 FETCH_SIZE counts the 128-byte requests "
                       "of wide reads at 64 bytes (MI355X_MICROARCH.md), hence the upper figure; beyond "
-                      "the table the kernel reads its record stream (8 S bytes per node) once per step"}
+                      "the table the kernel reads its record stream (4 S bytes per node) once per step"}
     return total, detail
 
 

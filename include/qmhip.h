@@ -102,55 +102,70 @@ void qm_engine_destroy(qm_engine *e);
 int qm_engine_set_stream(qm_engine *e, void *hip_stream, int use_own);
 int qm_engine_synchronize(qm_engine *e);
 
-/* tunables, set BEFORE qm_engine_load_lut: "brick_x","brick_y","brick_z"
- * (node-brick shape; brick_x = 0, the default, picks the largest shape whose
- * windows fit LDS for >= 99.5 % of the bricks), "samples_per_lane" (0 = by table width (default), 1, 2, 4: time tile = 64*J
- * samples),
- * "waves" (wavefronts per workgroup), "groups" (brick groups per time tile,
- * 0 = auto), "lds_bytes" (window budget per workgroup), "force_direct"
- * (1 = bypass the LDS-tiled kernel; debugging / cross-check),
- * "screen" (default 0 = every node-sample in float64; 1 = opt-in screened detect, qm_screen.hpp:
- * detect / detect_partial run an exact-integer (fixed-point) sweep over every node-sample and
- * re-evaluate in float64, in the reference's operation order, every (brick, sample) cell that
- * can hold the maximum -- max_coa and max_coa_idx are bit-identical to screen = 0, max_norm_coa
- * is within 6.7e-7 relative of it by a deterministic bound whose preconditions are checked per
- * step on the device; a step that fails one is redone in float64), "screen_pairs" /
- * "screen_big" (sweep launch shape, 0 / -1 = automatic), "exact" (default 1: the
- * exact-row-count float64 kernel), "shift" (default -1: the fused detect, the volume-writing
- * and the marginal-map launches run the shift-reuse kernel, qm_shift.hpp -- 2x2x2 node groups
- * stacked from register windows, 0.56 LDS operands per add at C3 -- where the table qualifies: up
- * to 64 rows, every group's delay spread within 20 samples for >= 99.5 % of the bricks, no grid
- * dimension of 1; launches on tables of more than 64 rows run its row-block form -- 4x4x4
- * bricks, the accumulators in registers while the rows pass through a double-buffered LDS in blocks
- * of <= 34, staged by LDS-direct loads ("shift_rows_direct" = 0: blocks of <= 64 staged through
- * registers instead, from 97 rows on); 0 = never, i.e. the round-2 kernels; 1 = as -1, also on
- * grids one node thick), "shift_waves" (0 = automatic: two 4-wave workgroups per CU up to ~32 rows, one 8-wave
- * workgroup with all 160 KB beyond; 4 / 8 force one; 12 = one 12-wave workgroup with the
- * wavefronts' running state in LDS: same bits, measured no faster), "shift_lazy" (default -1: the
- * detect loop keeps only the group maximum per node and recovers the arg-max where a group
- * reaches the wavefront's running maximum, when a wavefront sees >= 160 groups per launch -- same
- * maximum, arg-max and max_coa bits, max_norm_coa within the rounding of the sum's terms (1e-15);
- * -2 % at C3; 0 / 1 force the eager / lazy flavour; read back = what the last launch took),
- * "shift_tail" (default 1: what a scan leaves beyond its whole 256-sample tiles -- up to 192
- * samples -- runs as ONE tail tile of 64 / 128 / 192 samples with 1 / 2 / 3 samples per lane, so a
- * 401-sample locate window costs 448 samples instead of 512 and scans shorter than a tile run here
- * too; 0 = whole tiles only, the last one pulled back over its predecessor: same bits either way),
- * "tie_rule" (default 0: among the nodes of a sample the largest float64 sum wins, the lowest flat index
- * among equal sums; 1 = the reference's rule on near-ties, opt-in: the nodes whose sums lie within two
- * ulps of the sample's largest are compared on a correctly rounded exp(sum / available), lowest index
- * among equal values -- migratelib.c:98-105 as its scalar-libm build computes it; applies to the final
- * series of qm_engine_detect / detect_batch (step by step then) / migrate / marginal, not to partial
- * sets that leave the engine; values unchanged; qm_engine_get "tie_pairs", "tie_overflow_samples"),
- * "pair" (default 1: the 16-byte-operand kernel for volume-writing launches the shift-reuse
- * kernel does not take; 2 = for every launch, 0 = off), "rounds" (grid size of the automatic
- * group count), "scan_waves" (find_max_coa of a volume: wavefronts per CU over the whole grid).
- * qm_engine_get additionally reports "screened_steps", "fallback_steps" (steps redone in
- * float64 on the device: too many candidate cells -- flat all-ties data --, non-finite onsets,
- * a dynamic range outside the bound's preconditions), "last_candidates", and of the shift-reuse
- * layout once built: "shift_ok", "shift_brick_nodes", "shift_wide_bricks" (bricks left to the direct
- * kernel), "shift_row_blocks" (1, or the blocks a brick's rows are staged in),
- * "shift_operands_per_add_x1000", "shift_tail_spl" (samples per lane of the last launch's tail
- * tile, 0 = none); "last_kernel" = 3 when the last launch used it. */
+/* Tunables (qm_engine_config) and read-outs (qm_engine_get).  Nothing has to be set: every default is
+ * the automatic choice, every setting gives the same max_coa / max_coa_idx bits
+ * and the same stored values unless the row says otherwise.  Layout keys take effect at the next
+ * qm_engine_load_lut / qm_engine_serve.
+ *
+ * key (config)          values [default]         meaning
+ * --------------------  -----------------------  -------------------------------------------------------
+ * -- precision / rule (opt-in; the only keys that change results) --
+ * screen                0 / 1 [0]                1: screened detect (qm_screen.hpp): exact-integer sweep over
+ *                                                every node-sample + float64 re-evaluation of every cell that
+ *                                                can hold the maximum; max_coa, max_coa_idx identical,
+ *                                                max_norm_coa within 6.7e-7 (checked bound, else redone in f64)
+ * tie_rule              0 / 1 [0]                0: largest float64 sum, lowest flat index among equal sums;
+ *                                                1: the reference's rule on near-ties (csrc/qm_ties.hpp): sums
+ *                                                within two ulps of a sample's largest compared on a correctly
+ *                                                rounded exp(sum / available), lowest index among equal values
+ *                                                (migratelib.c:98-105 as its scalar-libm build computes it);
+ *                                                final series of detect / detect_batch (step by step) /
+ *                                                migrate / marginal; values unchanged
+ * -- layout of the round-2 kernels (qm_kernels.hpp, qm_pair.hpp) --
+ * brick_x, _y, _z       0..64 [0 = automatic]    node-brick shape; automatic = the largest of 8x8x8 .. 1x1x1
+ *                                                whose windows fit LDS for >= 99.5 % of the bricks
+ * samples_per_lane      0, 1, 2, 4 [0]           time tile = 64 x this; 0 = by table width and scan length
+ * waves                 1..16 [by table]         wavefronts per workgroup
+ * lds_bytes             1 KiB..160 KiB [by table] window budget per workgroup
+ * groups                >= 0 [0 = automatic]     brick groups per time tile (= partial sets)
+ * rounds                1..1024 [12; 3 for       grid size of the automatic group count, in rounds over the
+ *                       bricks of <= 64 nodes]   resident workgroup slots
+ * exact                 0 / 1 [1]                the exact-row-count kernels where one is built
+ * pair                  0, 1, 2 [1]              16-byte-operand kernel: 1 = volume-writing launches the
+ *                                                shift-reuse kernel does not take, 2 = every launch, 0 = never
+ * generic, force_direct 0 / 1 [0]                the any-row-count LDS kernel / the direct (no LDS) kernel
+ *                                                for everything: cross-checks
+ * scan_waves            1..4096 [32]             find_max_coa of a volume: wavefronts per CU
+ * chunk_bytes           >= 1 MiB [4 GiB]         device chunk of a HOST volume (migrate / find_max_coa)
+ * -- the shift-reuse kernel (qm_shift.hpp) --
+ * shift                 -1, 0, 1 [-1]            -1: where the table qualifies (every 2x2x2 group's delay
+ *                                                spread <= 20 samples for >= 99.5 % of the bricks, no grid
+ *                                                dimension of 1); 0: never (round-2 kernels); 1: as -1, also
+ *                                                on grids one node thick
+ * shift_waves           0, 4, 8, 12 [0]          workgroup shape: automatic = two 4-wave workgroups per CU up to
+ *                                                ~32 rows, one 8-wave workgroup (all 160 KB) to 64 rows; 12 =
+ *                                                running state in LDS (measured no faster)
+ * shift_lazy            -1, 0, 1 [-1]            detect loop flavour: lazy arg-max recovery from 160 groups per
+ *                                                wavefront on (max_norm_coa within 1e-15 of the eager one)
+ * shift_tail            0 / 1 [1]                a scan's remainder of <= 192 samples as ONE tail tile of
+ *                                                64 / 128 / 192 samples; 0 = whole 256-sample tiles only
+ * shift_rows_direct     0, 1, 2 [1]              tables of > 64 rows (row blocks): 1 = blocks of <= 34 rows,
+ *                                                double-buffered LDS, LDS-direct loads; 0 = blocks of <= 64
+ *                                                through registers; 2 = two 4-wave workgroups per CU
+ * -- screened detect's launch shape --
+ * screen_pairs          0, 1, 2, 4 [0]           pairs of samples per lane in the sweep
+ * screen_big            -1, 0, 1 [-1]            one 16-wave workgroup with 160 KB
+ * screen_brick16        0 / 1 [0]                also try 16x8x8 bricks
+ * -- measurement --
+ * log_timing            0 / 1 [0]                HIP events around every stacking launch (qm_engine_kernel_log)
+ *
+ * read-outs (qm_engine_get), besides the keys above: n_cu, n_nodes, n_rows, nx, ny, nz, n_bricks,
+ * n_wide_bricks, mean_span; last_kernel (0 chunked, 1 exact-row-count, 2 paired, 3 shift-reuse),
+ * last_kernel_j, steps_per_launch (timesteps the last detect_batch put into one launch);
+ * shift_ok, shift_brick_nodes, shift_wide_bricks, shift_row_blocks, shift_operands_per_add_x1000,
+ * shift_tail_spl; pair_brick_nodes, pair_wide_bricks, pair_tile; screened_steps, fallback_steps,
+ * last_candidates, screen_brick_nodes; tie_refined_steps, tie_pairs, tie_overflow_samples;
+ * table_hits, table_misses, table_evictions, tables_parked, table_bytes, tables_parked_bytes. */
 int qm_engine_config(qm_engine *e, const char *key, int64_t value);
 int qm_engine_get(qm_engine *e, const char *key, int64_t *value);
 

@@ -76,6 +76,10 @@ PACKED_SHIFT64 = os.environ.get("QM_SHIFT_PACKED_SHIFT64", "1") == "1"   # round
 def rec_bytes(packed):
     return 32 if packed else 64
 PF_AHEAD = int(os.environ.get("QM_SHIFT_PF", "16"))   # records ahead (0: no prefetch)
+PF_EVERY = int(os.environ.get("QM_SHIFT_PF_EVERY", "2"))   # 2: one prefetch per PAIR of rows (two 32-byte records:
+                                                            # the same 128-byte line either way; C3 -0.4 %, C4 -0.7 %,
+                                                            # locate volume -1.7 %, profiles/r05_ab_runs.txt); 1: per row.
+                                                            # No prefetch at all: C3 +12 %, C4 +17 %.
 PLANE2 = 40896           # plane A -> plane B, bytes (two 4-wave workgroups per CU, 80 KB each): 128 q + 64
                          # keeps the staging stores conflict-free
 PLANE3 = 51136           # the same for the 12-wave workgroup (one per CU: 100 KB of windows + 60 KB of
@@ -323,11 +327,11 @@ def row_iter(e, p, first):
     issue_window(e, q, hdr)
     for pos, g in enumerate(node_order()):
         node_adds(e, p, g, first)
-        if pos == 3 and PF_AHEAD:
+        if pos == 3 and PF_AHEAD and (PF_EVERY == 1 or p == 0):
             # pull the record PF_AHEAD rows ahead into L2 with a vector load nobody waits for (its
             # own counter, vmcnt): the scalar load then finds it there instead of in HBM
             e(f"global_load_dword v{VPF}, v{VZERO}, {s2(SPF)}")
-            e(f"s_add_u32 s{SPF}, s{SPF}, {REC}")
+            e(f"s_add_u32 s{SPF}, s{SPF}, {REC * (2 if PF_EVERY == 2 else 1)}")
             e(f"s_addc_u32 s{SPF + 1}, s{SPF + 1}, 0")
 
 

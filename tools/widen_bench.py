@@ -121,6 +121,32 @@ def main():
         out["gaussian_location_max_abs_diff_nodes"] = float(np.max(np.abs(fits.gaussian - loc)))
     print(json.dumps(out), flush=True)
 
+    # ---- the drop-in symbol: migrate() with the reference's signature at the locate window -----
+    # (host arrays in and out: lib.py:99-123 -- the volume, 8 B per node-sample, comes back through the
+    # pinned two-half bounce buffer, DMA overlapped with the CPU copy; the table is resident after the
+    # first call, the volume is known to be zero)
+    import os
+
+    case = synth.make_case("C3L")
+    ns = case.n_samples
+    os.environ["QM_HIP_GRID"] = ",".join(str(g) for g in grid)
+    os.environ["QM_HIP_ASSUME_ZERO_MAP"] = "1"
+    lib.migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available)       # table upload, sizing
+    t0 = time.perf_counter()
+    m = lib.migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available)
+    dt = time.perf_counter() - t0
+    gb = 8.0 * n * ns / 1e9
+    t0 = time.perf_counter()
+    host = np.empty((n, ns))
+    host[...] = 0.0
+    t_alloc = time.perf_counter() - t0
+    out = {"row": "drop-in migrate", "what": f"lib.migrate (reference signature, host arrays) at the C3 locate window: "
+                                            f"{grid} x {ns} samples, {gb:.1f} GB volume to the host",
+           "wall_s": round(dt, 3), "volume_GBps_wall": round(gb / dt, 1),
+           "zero_filling_a_host_volume_of_that_size_s": round(t_alloc, 3),
+           "checksum": float(m[::7, ::5, ::3].sum())}
+    print(json.dumps(out), flush=True)
+
 
 if __name__ == "__main__":
     main()
