@@ -8,7 +8,8 @@ does not qualify at all), quantised onsets in half of the trials (exact ties), n
 group counts: the automatic engine against Engine(shift=0) (maxima bit for bit, indices) and the
 oracle; every fourth trial also the volume-writing variant against the oracle's volume, every third
 the marginalised map of a random window against the time sum of that volume, every fifth a batch of
-two or three timesteps in one launch against the steps one by one.
+two or three timesteps in one launch against the steps one by one, every seventh the opt-in tie_rule = 1
+against the oracle's restatement of the reference's exp rule.
 On a mismatch the trial's diagnosis is printed before the assertion (which kernel, which nodes and
 samples, whether a second run moves): the round-4 GPU-sharing study started from these lines.
 usage: fuzz_shift.py [trials] [seed]      (QM_FUZZ_ONLY=trial [QM_FUZZ_REPEAT=n]: that trial of the seed only)"""
@@ -121,6 +122,15 @@ for trial in range(trials):
                                                err_msg=str((trial, grid, S, ns, i0, i1, cfg)))
                     assert np.array_equal(series[2], want[2]) and np.array_equal(series[0], res_first[0]), \
                         (trial, "marginal scan", cfg)
+                if trial % 7 == 0:                                 # (round 5) the opt-in exp rule on near-ties
+                    te = lib.Engine(0, tie_rule=1, **cfg)
+                    te.load_lut(tt)
+                    tied = te.detect(lon, fsmp, lsmp, avail)
+                    if te.get("tie_overflow_samples") == 0:
+                        rule = qm_oracle.np_argmax_exp_rule(lon, tt, fsmp, lsmp, avail, prelogged=True)
+                        assert np.array_equal(tied[2], rule), (trial, "tie_rule", cfg, np.flatnonzero(tied[2] != rule)[:8])
+                    assert np.array_equal(tied[0], res_first[0]) and np.array_equal(tied[1], res_first[1]), (trial, "tie_rule values")
+                    te.close()
                 if trial % 5 == 0:
                     lons = np.stack([lon] + [np.roll(lon, 7 * (j + 1), axis=1) for j in range(k - 1)])
                     both = eng.detect_batch(lons, fsmp, lsmp, avail)

@@ -22,12 +22,14 @@ def main():
     ap.add_argument("--sweep", default="default")
     ap.add_argument("--ns", type=int, default=0, help="override n_samples")
     ap.add_argument("--rows", type=int, default=0, help="override the number of table rows")
+    ap.add_argument("--x-range", default="", help="x-planes lo,hi of the grid (one rank's slab of a sharded config)")
     ap.add_argument("--volume", action="store_true", help="materialising path (device volume)")
     ap.add_argument("--marginal", action="store_true",
                     help="the marginalised map of the central half of the scan instead of the volume")
     args = ap.parse_args()
     t0 = time.time()
-    case = synth.make_case(args.config, n_samples=args.ns or None, rows=args.rows or None)
+    xr = tuple(int(v) for v in args.x_range.split(",")) if args.x_range else None
+    case = synth.make_case(args.config, n_samples=args.ns or None, rows=args.rows or None, x_range=xr)
     vol = None
     cmap = None
     if args.marginal:
