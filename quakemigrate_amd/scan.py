@@ -2,6 +2,7 @@
 """
 Host-side counterpart of ``QuakeScan._compute`` for the migrate / find_max_coa path.
 
+``MigrationScan.continuous_compute(...)`` is the loop around it (reference ``scan.py:407-470``).
 ``MigrationScan._compute(data, event=None)`` reproduces the glue of the reference's
 ``quakemigrate/signal/scan.py:593-647`` around the hot path -- onset plugin ->
 served travel-time table -> ``fsmp`` / ``lsmp`` -> ``available`` -> migrate ->
@@ -56,6 +57,39 @@ def _lut_token(lut):
 
 class LUTPhasesException(Exception):
     """Mirror of ``quakemigrate.util.LUTPhasesException`` (util.py)."""
+
+
+class _NoDataException(Exception):
+    def __init__(self, msg="no data"):
+        super().__init__(msg)
+        self.msg = msg
+
+
+class ArchiveEmptyException(_NoDataException):
+    """Mirror of ``quakemigrate.util.ArchiveEmptyException`` (carries ``.msg``)."""
+
+
+class DataGapException(_NoDataException):
+    """Mirror of ``quakemigrate.util.DataGapException``."""
+
+
+class DataAvailabilityException(_NoDataException):
+    """Mirror of ``quakemigrate.util.DataAvailabilityException``."""
+
+
+# the reference's own exception objects (raised by ITS archive / onset classes when both packages are
+# installed) are recognised by name: nothing of the reference is imported here
+_NO_DATA = ("ArchiveEmptyException", "DataGapException", "DataAvailabilityException")
+
+
+def _shift(t, seconds):
+    """``t + seconds`` for obspy ``UTCDateTime`` (adds floats) and ``datetime`` alike."""
+    try:
+        return t + seconds
+    except TypeError:
+        import datetime as _dt
+
+        return t + _dt.timedelta(seconds=float(seconds))
 
 
 def time2sample(time, sampling_rate):
@@ -224,6 +258,107 @@ class MigrationScan:
         times = event.mw_times(self.scan_rate)
         return times, max_coa, max_coa_n, coord, map4d, onset_data
 
+
+    # -- the loop around the path ------------------------------------------------------
+    def continuous_compute(self, archive, starttime, n_steps, timestep, scan_rate, sink,
+                           steps_per_launch=1, depth=3):
+        """
+        ``QuakeScan._continuous_compute`` (reference scan.py:407-470): coalescence between two
+        timestamps in increments of ``timestep`` -- per timestep read the waveforms, compute the onsets,
+        migrate, scan, hand ``(time, max_coa, max_coa_n, coord)`` to ``sink.append`` -- with the
+        reference's behaviour around the path: a timestep whose data raise ``ArchiveEmptyException`` /
+        ``DataGapException`` / ``DataAvailabilityException`` becomes an all-zero timestep
+        (``sink.empty(starttime, timestep, i, e.msg, ucf)``, scan.py:449-458) with an all-zero
+        availability row, and ``sink.write()`` closes the run if the last append did not.
+
+        ``archive``: ``read_waveform_data(w_beg, w_end)`` (the reference's ``Archive``);
+        ``sink``: the reference's ``ScanmSEED`` duck-typed (``append`` / ``empty`` / ``write`` /
+        ``written``; ``quakemigrate_amd.scanmseed.CoalescenceSink`` is one without obspy).
+        The window arithmetic is the reference's (``w_beg = starttime + timestep * i - pre_pad``,
+        ``w_end = starttime + timestep * (i + 1) - 1 / scan_rate + post_pad``).
+
+        What differs is only WHEN the GPU works: timesteps are independent given their onsets, so
+        their log-onsets go through the native pipeline (``qm_stream_*``: H2D, one fused launch per
+        ``steps_per_launch`` timesteps, D2H on their own streams) while the host reads and
+        pre-processes the next timestep; results reach the sink in timestep order.  A change of
+        station availability (another served table) or a data gap drains the pipeline first.
+
+        Returns the availability rows (list of dicts, one per timestep; scan.py:428, 448, 458).
+        """
+        from collections import deque
+
+        from quakemigrate_amd.stream import StreamingDetector
+
+        if self.stage != "detect":
+            raise ValueError("continuous_compute is the detect stage's loop")
+        ucf = getattr(self.lut, "unit_conversion_factor", 1.0)
+        rows = []
+        pending = deque()                  # timesteps in the pipeline: (time, onset_data), oldest first
+        state = {"stream": None, "key": None}
+
+        def emit(n):
+            a, b, c = state["stream"].pop(n)
+            for j in range(n):
+                time, onset_data = pending.popleft()
+                coord = self.lut.index2coord(c[j], unravel=True)
+                logging.debug(f"1-D con shape : {a[j].shape}")
+                sink.append(time, a[j], b[j], coord, ucf)
+
+        def drain():
+            if state["stream"] is not None:
+                state["stream"].flush()
+                while pending:
+                    emit(min(state["stream"].k, len(pending)))
+
+        for i in range(n_steps):
+            w_beg = _shift(_shift(starttime, timestep * i), -self.pre_pad)
+            w_end = _shift(_shift(starttime, timestep * (i + 1) - 1 / scan_rate), self.post_pad)
+            logging.debug(f" Processing : {w_beg}-{w_end} ".center(110, "~"))
+            try:
+                data = archive.read_waveform_data(w_beg, w_end)
+                onsets, onset_data = self.onset.calculate_onsets(data)
+            except Exception as e:  # noqa: BLE001
+                if type(e).__name__ not in _NO_DATA:
+                    raise
+                drain()
+                sink.empty(starttime, timestep, i, getattr(e, "msg", str(e)), ucf)
+                rows.append(None)
+                continue
+            # (another availability = another table: what is in the pipeline belongs to the one
+            # that is resident NOW and has to go through before the engine switches)
+            if (onset_data.sampling_rate, tuple(onset_data.availability.items())) != self._resident_key:
+                drain()
+            eng = self._ensure_table(onset_data.sampling_rate, onset_data.availability)
+            fsmp = time2sample(self.pre_pad, onset_data.sampling_rate)
+            lsmp = time2sample(self.post_pad, onset_data.sampling_rate)
+            avail = int(np.sum([value for _, value in onset_data.availability.items()]))
+            onsets = np.ascontiguousarray(np.log(np.clip(onsets, 0.01, np.inf)))      # lib.py:93-94
+            n_onsets, t_samples = onsets.shape
+            if n_onsets != eng.n_rows:
+                raise ValueError("Mismatch between number of stations for data and LUT, "
+                                 f"{n_onsets}:{eng.n_rows}")
+            if onsets.size < t_samples - lsmp:
+                raise ValueError("Data array smaller than coalescence array.")
+            key = (self._resident_key, t_samples, fsmp, lsmp, avail)
+            if key != state["key"]:                      # another table or window shape: a new pipeline
+                drain()
+                if state["stream"] is not None:
+                    state["stream"].close()
+                state["stream"] = StreamingDetector(eng, n_onsets, t_samples, fsmp, lsmp, avail,
+                                                    depth=depth, steps_per_launch=steps_per_launch)
+                state["key"] = key
+            stream = state["stream"]
+            while not stream.push(onsets):
+                emit(min(stream.k, stream.pending()[0]))
+            pending.append((_shift(data.starttime, self.pre_pad), onset_data))
+            rows.append(dict(onset_data.availability))
+        drain()
+        if state["stream"] is not None:
+            state["stream"].close()
+        if not getattr(sink, "written", False):
+            sink.write()
+        columns = next((list(r) for r in rows if r is not None), [])
+        return [r if r is not None else dict.fromkeys(columns, 0) for r in rows]
 
     def marginal_coalescence(self, data, first_sample, end_sample):
         """

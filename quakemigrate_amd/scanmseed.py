@@ -23,6 +23,7 @@ library behind obspy's writer) does, which reproduces the reference's files byte
 from __future__ import annotations
 
 import datetime as _dt
+import logging
 import struct
 from dataclasses import dataclass
 
@@ -265,3 +266,81 @@ def read_scanmseed(path, ucf=1.0):
     cols = {ch: ints[ch] / f[ch] for ch in CHANNELS}
     cols["int"] = ints
     return start[CHANNELS[0]], rate, cols
+
+
+# --------------------------------------------------------------------------------------
+# The detect loop's sink
+# --------------------------------------------------------------------------------------
+class CoalescenceSink:
+    """
+    The reference's ``ScanmSEED`` object (quakemigrate/io/scanmseed.py:27-220) without obspy, as far
+    as the detect loop uses it (``QuakeScan._continuous_compute``, signal/scan.py:421-466):
+    ``append`` clips, quantises and appends one timestep to the five int32 channels
+    (scanmseed.py:74-131) and writes a day's file when the stream reaches the day line or crosses it
+    (scanmseed.py:133-150: the part before midnight is written, the rest kept); ``empty`` appends an
+    all-zero timestep (scanmseed.py:152-180); ``write`` writes what is held (one
+    ``<year>_<julday>.scanmseed`` per day, scanmseed.py:182-220).  Times are ``datetime`` (UTC).
+    """
+
+    def __init__(self, directory, sampling_rate, continuous_write=False):
+        import pathlib
+
+        self.directory = pathlib.Path(directory)
+        self.sampling_rate = float(sampling_rate)
+        self.continuous_write = continuous_write
+        self.written = False
+        self.starttime = None
+        self.series = {ch: np.zeros(0, dtype=np.int32) for ch in CHANNELS}
+        self.files = []
+
+    def _endtime(self):
+        n = len(self.series["COA"])
+        return self.starttime + _dt.timedelta(seconds=(n - 1) / self.sampling_rate)
+
+    def append(self, starttime, max_coa, max_coa_n, coord, ucf):
+        new = quantise(max_coa, max_coa_n, coord, ucf)
+        if self.starttime is None or len(self.series["COA"]) == 0:
+            self.starttime = starttime
+        else:
+            expect = self._endtime() + _dt.timedelta(seconds=1.0 / self.sampling_rate)
+            if abs((starttime - expect).total_seconds()) > 0.5 / self.sampling_rate:
+                raise ValueError(f"timestep starting {starttime} does not continue the stream ending "
+                                 f"{self._endtime()}")
+        for ch in CHANNELS:
+            self.series[ch] = np.concatenate([self.series[ch], new[ch]])
+        self.written = False
+        delta = _dt.timedelta(seconds=1.0 / self.sampling_rate)
+        start, end = self.starttime, self._endtime()
+        midnight = _dt.datetime(start.year, start.month, start.day) + _dt.timedelta(days=1)
+        if end == midnight - delta:                       # passed the day line: write, start afresh
+            self.write()
+            self.starttime = None
+            self.series = {ch: np.zeros(0, dtype=np.int32) for ch in CHANNELS}
+        elif end >= midnight:
+            logging.debug("Timestep doesn't fall at midnight!")
+            keep = int(round((midnight - start).total_seconds() * self.sampling_rate))
+            rest = {ch: self.series[ch][keep:] for ch in CHANNELS}
+            self.series = {ch: self.series[ch][:keep] for ch in CHANNELS}
+            self.write()
+            self.starttime, self.series = midnight, rest
+            self.written = False                          # (residual data not yet in a file)
+        if self.continuous_write and not self.written:
+            self.write()
+
+    def empty(self, starttime, timestep, i, msg, ucf):
+        logging.info(msg)
+        n = int(round(timestep * int(self.sampling_rate)))            # util.time2sample
+        start = starttime + _dt.timedelta(seconds=timestep * i)
+        self.append(start, np.zeros(n), np.zeros(n), np.zeros((n, 3)), ucf)
+
+    def write(self, write_start=None, write_end=None):
+        if self.starttime is None or len(self.series["COA"]) == 0:
+            self.written = True
+            return
+        self.directory.mkdir(parents=True, exist_ok=True)
+        t = self.starttime
+        path = self.directory / f"{t.year}_{t.timetuple().tm_yday:03d}.scanmseed"
+        write_scanmseed(path, t, self.sampling_rate, self.series)
+        if path not in self.files:
+            self.files.append(path)
+        self.written = True

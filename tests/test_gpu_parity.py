@@ -2756,3 +2756,91 @@ def test_device_exp_correctly_rounded_is_the_hosts(lib):
     eng.close()
     host = np.array([lib.qmlib.qm_exp_correctly_rounded(float(v)) for v in xs])
     assert np.array_equal(dev, host, equal_nan=True), float(np.mean(dev != host))
+
+
+# ---- round 5: the loop around the path (reference scan.py:407-470) ------------------------------------
+@pytest.mark.parametrize("k", [1, 3])
+def test_continuous_compute_mirrors_the_references_loop(lib, oracle, tmp_path, k):
+    """MigrationScan.continuous_compute = QuakeScan._continuous_compute's behaviour around the path: the
+    reference's window arithmetic, a timestep whose data raise DataGapException / ArchiveEmptyException
+    becomes an all-zero timestep with an all-zero availability row (scan.py:449-458), a change of station
+    availability switches tables mid-run, and the sink receives every timestep in order -- while the
+    timesteps go through the native pipeline (K per launch).  Every computed timestep equals the oracle
+    on its own table; the written .scanmseed decodes to the quantised series."""
+    import datetime as dt
+
+    from quakemigrate_amd import scan, scanmseed as sm
+
+    case = synth.make_case("C3", step=1, grid=(20, 18, 12), rows=8, n_samples=300)
+    rate, n_steps = 50, 9
+    keys = [f"ST{i}_{'P' if i < 4 else 'S'}" for i in range(8)]
+    full = dict.fromkeys(keys, 1)
+    less = {**full, "ST2_P": 0}
+    avail_of = [full, full, None, full, less, less, None, full, full]       # None: no data
+    onsets_of = [synth.make_case("C3", step=s, grid=(20, 18, 12), rows=8, n_samples=300, table=False).onsets
+                 for s in range(n_steps)]
+    timestep, pre, post = 300 / rate, case.fsmp / rate, case.lsmp / rate
+    t0 = dt.datetime(2024, 5, 17, 10, 0, 0)
+    seen = []
+
+    class Data:
+        def __init__(self, i, w_beg):
+            self.i, self.starttime = i, w_beg
+
+    class Archive:
+        def read_waveform_data(self, w_beg, w_end):
+            i = len(seen)
+            seen.append((w_beg, w_end))
+            if avail_of[i] is None:
+                raise (scan.DataGapException if i == 2 else scan.ArchiveEmptyException)(f"no data in step {i}")
+            return Data(i, w_beg)
+
+    class OnsetData:
+        sampling_rate = rate
+
+        def __init__(self, availability):
+            self.availability = availability
+
+    class Onset:
+        def calculate_onsets(self, data):
+            a = avail_of[data.i]
+            rows = [j for j, key in enumerate(keys) if a[key] == 1]
+            return onsets_of[data.i][rows], OnsetData(dict(a))
+
+    class Lut:
+        unit_conversion_factor = 1000.0
+
+        def serve_traveltimes(self, sampling_rate, availability):
+            rows = [j for j, key in enumerate(keys) if availability[key] == 1]
+            return np.ascontiguousarray(case.traveltimes[..., rows])
+
+        def index2coord(self, idx, unravel=True):
+            return np.stack(np.unravel_index(idx, case.grid), axis=-1) * 0.5
+
+    eng = lib.Engine(0)
+    s = scan.MigrationScan(Lut(), Onset(), pre, post, engine=eng)
+    sink = sm.CoalescenceSink(tmp_path, rate)
+    rows = s.continuous_compute(Archive(), t0, n_steps, timestep, rate, sink, steps_per_launch=k)
+    # the reference's windows (scan.py:435-438)
+    for i, (w_beg, w_end) in enumerate(seen):
+        assert w_beg == t0 + dt.timedelta(seconds=timestep * i - pre)
+        assert w_end == t0 + dt.timedelta(seconds=timestep * (i + 1) - 1 / rate + post)
+    assert [r for r in rows] == [a if a is not None else dict.fromkeys(keys, 0) for a in avail_of]
+    assert sink.written and len(sink.files) == 1
+    start, sr, cols = sm.read_scanmseed(sink.files[0], ucf=1000.0)
+    assert start == t0 and sr == rate and len(cols["int"]["COA"]) == n_steps * 300
+    for i in range(n_steps):
+        got = {ch: cols["int"][ch][300 * i:300 * (i + 1)] for ch in sm.CHANNELS}
+        if avail_of[i] is None:
+            assert all((got[ch] == 0).all() for ch in sm.CHANNELS)
+            continue
+        sel = [j for j, key in enumerate(keys) if avail_of[i][key] == 1]
+        a, b, c = oracle.detect(onsets_of[i][sel], np.ascontiguousarray(case.traveltimes[..., sel]),
+                                case.fsmp, case.lsmp, len(sel), threads=4)
+        want = sm.quantise(a, b, np.stack(np.unravel_index(c, case.grid), axis=-1) * 0.5, 1000.0)
+        assert np.array_equal(got["X"], want["X"]) and np.array_equal(got["Y"], want["Y"]) and \
+            np.array_equal(got["Z"], want["Z"])
+        assert np.abs(got["COA"].astype(np.int64) - want["COA"]).max() <= 1          # (1e-5 quantisation of 1e-13 apart values)
+        assert np.abs(got["COA_N"].astype(np.int64) - want["COA_N"]).max() <= 1
+    assert eng.get("table_misses") == 2 and eng.get("table_hits") >= 1                # two tables, switched back to
+    eng.close()

@@ -71,3 +71,50 @@ def test_quantisation_follows_data2int():
     # what Trigger reads back (scanmseed.py:300-305)
     f = sm.scale_factors(1000.0)
     np.testing.assert_allclose(q["COA"][:3] / f["COA"], coa[:3], atol=5e-6)
+
+
+def test_coalescence_sink_follows_the_references_day_line_rules(tmp_path):
+    """CoalescenceSink = the reference's ScanmSEED as the detect loop uses it (io/scanmseed.py:74-180):
+    timesteps are appended quantised, a stream that reaches the day line is written and restarted, one
+    that crosses it is written up to midnight and the rest kept, empty() appends zeros, write() closes
+    the run; the files decode to what went in."""
+    import datetime as dt
+
+    from quakemigrate_amd import scanmseed as sm
+
+    rate, n = 50, 3000                                   # 60-s timesteps
+    rng = np.random.default_rng(3)
+    sink = sm.CoalescenceSink(tmp_path, rate)
+    t0 = dt.datetime(2024, 2, 29, 23, 57, 0)             # three steps to midnight, then two more
+    steps = []
+    for i in range(5):
+        coa = 2.0 + np.cumsum(rng.uniform(-0.01, 0.01, n))
+        coa[1000:1300] += np.minimum(np.arange(300), 299 - np.arange(300)) * 160.0   # a peak beyond the 21474 clip
+        coa_n = 1.0 + rng.uniform(0, 0.5, n)
+        coord = np.cumsum(rng.uniform(-0.01, 0.01, (n, 3)), axis=0)
+        if i == 3:
+            sink.empty(t0, 60.0, i, "gap", 1000.0)
+            coa, coa_n, coord = np.zeros(n), np.zeros(n), np.zeros((n, 3))
+        else:
+            sink.append(t0 + dt.timedelta(seconds=60 * i), coa, coa_n, coord, 1000.0)
+        steps.append(sm.quantise(coa, coa_n, coord, 1000.0))
+        if i == 2:                                       # the day line was reached exactly: written, restarted
+            assert sink.written and len(sink.files) == 1 and len(sink.series["COA"]) == 0
+    assert not sink.written
+    sink.write()
+    assert [p.name for p in sink.files] == ["2024_060.scanmseed", "2024_061.scanmseed"]
+    start, sr, cols = sm.read_scanmseed(sink.files[0], ucf=1000.0)
+    assert start == t0 and sr == rate
+    for ch in sm.CHANNELS:
+        assert np.array_equal(cols["int"][ch], np.concatenate([s[ch] for s in steps[:3]]))
+    start, _, cols = sm.read_scanmseed(sink.files[1], ucf=1000.0)
+    assert start == dt.datetime(2024, 3, 1)
+    for ch in sm.CHANNELS:
+        assert np.array_equal(cols["int"][ch], np.concatenate([s[ch] for s in steps[3:]]))
+    assert cols["int"]["COA"].max() <= 2147400000 and (cols["int"]["COA"][:n] == 0).all()
+    # a timestep that CROSSES midnight: the part before it is written, the rest kept
+    sink = sm.CoalescenceSink(tmp_path / "b", rate)
+    sink.append(dt.datetime(2024, 2, 29, 23, 59, 30), np.ones(n), np.ones(n), np.zeros((n, 3)), 1.0)
+    assert len(sink.files) == 1 and not sink.written and len(sink.series["COA"]) == n // 2
+    with pytest.raises(ValueError):
+        sink.append(dt.datetime(2024, 3, 1, 0, 5, 0), np.ones(n), np.ones(n), np.zeros((n, 3)), 1.0)
