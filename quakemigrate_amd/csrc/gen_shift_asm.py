@@ -76,6 +76,7 @@ PACKED_SHIFT64 = os.environ.get("QM_SHIFT_PACKED_SHIFT64", "1") == "1"   # round
 def rec_bytes(packed):
     return 32 if packed else 64
 PF_AHEAD = int(os.environ.get("QM_SHIFT_PF", "16"))   # records ahead (0: no prefetch)
+NEXT_RUN = os.environ.get("QM_SHIFT_NEXT_RUN", "1") == "1"   # round 5: prefetch the head of the wavefront's next run
 PF_EVERY = int(os.environ.get("QM_SHIFT_PF_EVERY", "2"))   # 2: one prefetch per PAIR of rows (two 32-byte records:
                                                             # the same 128-byte line either way; C3 -0.4 %, C4 -0.7 %,
                                                             # locate volume -1.7 %, profiles/r05_ab_runs.txt); 1: per row.
@@ -710,9 +711,13 @@ def body(degree, volume):
     group = e.label("grp")
     pair = e.label("pair")
     nopair = e.label("np")
-    if BLOCK:
-        # the first lines of this wavefront's next run (the next brick's first block), into L2
+    if BLOCK or NEXT_RUN:
+        # the first lines of this wavefront's NEXT run (its next brick; row blocks: the next brick's first
+        # block), into L2: one fire-and-forget load, lane l touches byte 64 l -- 4 KB = 128 records.  (The
+        # per-row prefetch runs PF_AHEAD records ahead INSIDE a run; a run's first records would otherwise
+        # be fetched from HBM by the scalar loads that wait for them.)
         e(f"global_load_dword v{VPF}, %[nxoff], %[nxrun]")
+    if BLOCK:
         carry = e.label("cy")
         e("s_bitcmp1_b32 %[flags], 0")                         # first block of the brick: zero
         e(f"s_cbranch_scc0 {carry}")
@@ -782,7 +787,8 @@ def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False,
     print(f"__device__ __forceinline__ void {name}("
           + ("" if lds_state else f"double (&vmax)[{spl}], double (&vsum)[{spl}], int (&vidx)[{spl}],"))
     print("        const void *stream, " + ("unsigned flags, const void *next_run, unsigned next_off, "
-                                            if block else "int ngroups, ") + "int npairs, unsigned lane_addr, "
+                                            if block else "int ngroups, const void *next_run, unsigned next_off, ")
+          + "int npairs, unsigned lane_addr, "
           + ("unsigned state_addr, " if lds_state else "")
           + ("unsigned lane_addr_b, " if far else "") + "int nz, "
           f"int nynz, double scale, const double (&c)[{degree + 1}]"
@@ -820,7 +826,9 @@ def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False,
     if far:
         ins += ['[laneb] "v"(lane_addr_b)']
     if block:
-        ins += ['[flags] "s"(flags)', '[nxrun] "s"(next_run)', '[nxoff] "v"(next_off)']
+        ins += ['[flags] "s"(flags)']
+    if block or NEXT_RUN:
+        ins += ['[nxrun] "s"(next_run)', '[nxoff] "v"(next_off)']
     if marginal:
         ins += ['[vlo] "s"(vlo)', '[vhi] "s"(vhi)']
         ins += [f'[w{k}] "v"(w[{k}])' for k in range(spl)]

@@ -518,49 +518,55 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
         const int mine = (nvg - wave + NW - 1) / NW;                       // groups of this wave
         if (mine <= 0) continue;
         const char *run = s.stream + shift_run_record(b, wave, 0, NW, 1, rpw) * kShiftRec;
+        // this wavefront's next run (its next brick that runs here; none: this one again, harmless):
+        // the loop pulls its head into L2 (gen_shift_asm.py: NEXT_RUN)
+        int nb = b + a.ngroups;
+        while (nb < g.nbricks && !s.sfit[nb]) nb += a.ngroups;
+        const char *next_run = s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, 1, rpw) * kShiftRec;
+        const unsigned next_off = (unsigned)lane * 64u;
         const unsigned lane_addr_b = lane_addr + (unsigned)kShiftPlane8;   // (8-wave shape: plane B)
-        (void)lane_addr_b;
+        (void)lane_addr_b; (void)next_run; (void)next_off;
 #define QM_TAIL_CALL(JJ)                                                                              \
         if constexpr (MODE == kShiftMarginal)                                                         \
-            shift_tail##JJ##_marginal(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz,       \
+            shift_tail##JJ##_marginal(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz,       \
                                       a.z_scale, c, marg_tile, weight, node_off, lane_x16, lane_x32); \
         else if constexpr (MODE == kShiftVolume)                                                      \
-            shift_tail##JJ##_volume(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz,         \
+            shift_tail##JJ##_volume(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz,         \
                                     a.z_scale, c, vol_tile, vol_stride_bytes, (unsigned)lane * (8u * JJ), \
                                     slot_lanes);                                                      \
         else                                                                                          \
-            shift_tail##JJ##_detect(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz,         \
+            shift_tail##JJ##_detect(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz,         \
                                     a.z_scale, c)
         if constexpr (J == 1) { QM_TAIL_CALL(1); }
         else if constexpr (J == 2) { QM_TAIL_CALL(2); }
         else if constexpr (J == 3) { QM_TAIL_CALL(3); }
 #undef QM_TAIL_CALL
         else if constexpr (kLdsState)
-            shift_groups_detect3(run, mine, npairs, lane_addr, state_addr, nz, nynz, a.z_scale, c);
+            shift_groups_detect3(run, mine, next_run, next_off, npairs, lane_addr, state_addr, nz, nynz, a.z_scale, c);
         else if constexpr (NW == kShiftWaves8 && MODE == kShiftMarginal)
-            shift_groups_marginal8(vmax, vsum, vidx, run, mine, npairs, lane_addr, lane_addr_b, nz, nynz,
+            shift_groups_marginal8(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, lane_addr_b, nz, nynz,
                                    a.z_scale, c, marg_tile, weight, node_off, lane_x16, lane_x32);
         else if constexpr (MODE == kShiftMarginal)
-            shift_groups_marginal(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz, a.z_scale, c,
+            shift_groups_marginal(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz, a.z_scale, c,
                                   marg_tile, weight, node_off, lane_x16, lane_x32);
         else if constexpr (NW == kShiftWaves8 && MODE == kShiftVolume)
-            shift_groups_volume8(vmax, vsum, vidx, run, mine, npairs, lane_addr, lane_addr_b, nz, nynz,
+            shift_groups_volume8(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, lane_addr_b, nz, nynz,
                                  a.z_scale, c, vol_tile, vol_stride_bytes, (unsigned)lane * 32u, store_lanes);
         else if constexpr (NW == kShiftWaves8) {
             if (s.lazy)
-                shift_groups_detect8_lazy(vmax, vsum, vidx, run, mine, npairs, lane_addr, lane_addr_b, nz,
+                shift_groups_detect8_lazy(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, lane_addr_b, nz,
                                           nynz, a.z_scale, c);
             else
-                shift_groups_detect8(vmax, vsum, vidx, run, mine, npairs, lane_addr, lane_addr_b, nz, nynz,
+                shift_groups_detect8(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, lane_addr_b, nz, nynz,
                                      a.z_scale, c);
         }
         else if constexpr (MODE == kShiftVolume)
-            shift_groups_volume(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz, a.z_scale, c,
+            shift_groups_volume(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz, a.z_scale, c,
                                 vol_tile, vol_stride_bytes, (unsigned)lane * 32u, store_lanes);
         else if (s.lazy)
-            shift_groups_detect_lazy(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz, a.z_scale, c);
+            shift_groups_detect_lazy(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz, a.z_scale, c);
         else
-            shift_groups_detect(vmax, vsum, vidx, run, mine, npairs, lane_addr, nz, nynz, a.z_scale, c);
+            shift_groups_detect(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz, a.z_scale, c);
     }
     if (!a.want_scan) return;
     if constexpr (kLdsState) {
