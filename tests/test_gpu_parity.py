@@ -2759,7 +2759,7 @@ def test_device_exp_correctly_rounded_is_the_hosts(lib):
 
 
 # ---- round 5: the loop around the path (reference scan.py:407-470) ------------------------------------
-@pytest.mark.parametrize("k", [1, 3])
+@pytest.mark.parametrize("k", [1, 3, None])
 def test_continuous_compute_mirrors_the_references_loop(lib, oracle, tmp_path, k):
     """MigrationScan.continuous_compute = QuakeScan._continuous_compute's behaviour around the path: the
     reference's window arithmetic, a timestep whose data raise DataGapException / ArchiveEmptyException
