@@ -2702,6 +2702,7 @@ def test_tie_rule_exp_reproduces_the_references_scalar_build(lib, oracle, cfg):
         # the same refinement behind the volume-writing and the marginal-map launches' scans, and K steps
         vol = np.zeros((int(np.prod(tt.shape[:3])), len(c)))
         series = (np.zeros(len(c)), np.zeros(len(c)), np.zeros(len(c), dtype=np.int64))
+        eng.config("chunk_bytes", 1 << 20)                     # (the mirror family's host volume: two time chunks)
         eng.migrate(lon, fsmp, lsmp, avail, vol, scan_out=series)
         assert np.array_equal(series[2], idx_scalar)
         series = (np.zeros(len(c)), np.zeros(len(c)), np.zeros(len(c), dtype=np.int64))
@@ -2844,3 +2845,27 @@ def test_continuous_compute_mirrors_the_references_loop(lib, oracle, tmp_path, k
         assert np.abs(got["COA_N"].astype(np.int64) - want["COA_N"]).max() <= 1
     assert eng.get("table_misses") == 2 and eng.get("table_hits") >= 1                # two tables, switched back to
     eng.close()
+
+
+def test_continuous_detect_example(lib, oracle, tmp_path):
+    """examples/continuous_detect.py: the reference's loop with plugin objects on the default engine: twelve
+    timesteps across midnight (two .scanmseed files), one archive gap -> an all-zero timestep; the injected
+    events of the other timesteps are found."""
+    import importlib.util
+
+    from conftest import ROOT
+    from quakemigrate_amd import scanmseed as sm
+
+    spec = importlib.util.spec_from_file_location("continuous_detect", ROOT / "examples" / "continuous_detect.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sink, availability, cases = mod.run(tmp_path)
+    assert [p.name for p in sink.files] == ["2024_138.scanmseed", "2024_139.scanmseed"]
+    assert [i for i, row in enumerate(availability) if not any(row.values())] == [4]
+    coa = np.concatenate([sm.read_scanmseed(p, ucf=1000.0)[2]["COA"] for p in sink.files])
+    ns = cases[0].n_samples
+    assert len(coa) == 12 * ns and (coa[4 * ns:5 * ns] == 0).all()
+    for i in (0, 3, 5, 11):
+        a, _, _ = oracle.detect(cases[i].onsets, cases[0].traveltimes, cases[0].fsmp, cases[0].lsmp,
+                                cases[0].available, threads=4)
+        np.testing.assert_allclose(coa[i * ns:(i + 1) * ns], np.minimum(a, 21474.0), atol=5.1e-6)
