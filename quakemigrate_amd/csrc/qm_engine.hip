@@ -560,18 +560,19 @@ int stage_out(qm_engine *e, int n, int out_on_device, double *max_coa, double *m
         *st = OutStage{max_coa, max_norm, idx};
         return 0;
     }
-    if (e->d_out_a.ensure(n) || e->d_out_b.ensure(n) || e->d_out_i.ensure(n)) return 1;
-    *st = OutStage{e->d_out_a.p, e->d_out_b.p, e->d_out_i.p};
+    // (the three series back to back in ONE buffer: they travel to the host as one copy, fetch_out)
+    if (e->d_out_a.ensure(3 * (size_t)n)) return 1;
+    *st = OutStage{e->d_out_a.p, e->d_out_a.p + n, reinterpret_cast<int64_t *>(e->d_out_a.p + 2 * (size_t)n)};
     return 0;
 }
 
 int fetch_out(qm_engine *e, int n, int out_on_device, const OutStage &st, double *max_coa,
               double *max_norm, int64_t *idx) {
     if (out_on_device) return 0;
-    QM_HIP(copy_back(max_coa, st.a, n * sizeof(double), e->stream));
-    QM_HIP(copy_back(max_norm, st.b, n * sizeof(double), e->stream));
-    QM_HIP(copy_back(idx, st.i, n * sizeof(int64_t), e->stream));
-    QM_HIP(hipStreamSynchronize(e->stream));
+    // one DMA of the packed [3][n] buffer, three CPU copies out of the pinned half (round 4: three
+    // DMAs with a wait each -- two round trips more per host-array call)
+    void *dst[3] = {max_coa, max_norm, idx};
+    QM_HIP(copy_back_pieces(dst, st.a, 3, (size_t)n * sizeof(double), e->stream));
     return 0;
 }
 
@@ -610,7 +611,7 @@ void qm_engine_destroy(qm_engine *e) {
     e->d_sig.release(); e->d_sta.release(); e->d_lta.release(); e->d_raw.release();
     e->d_onset_meta.release(); e->d_scalar.release();
     e->d_onsets.release(); e->d_pmax.release(); e->d_psum.release(); e->d_out_a.release();
-    e->d_out_b.release(); e->d_chunk.release(); e->d_marg.release(); e->d_marg_out.release(); e->d_pidx.release(); e->d_out_i.release();
+    e->d_chunk.release(); e->d_marg.release(); e->d_marg_out.release(); e->d_pidx.release();
     e->d_fit_a.release(); e->d_fit_b.release(); e->d_fit_c.release(); e->d_fit_part.release();
     e->d_fit_val.release(); e->d_fit_win.release(); e->d_fit_pidx.release();
     e->d_counts.release(); e->d_cells.release(); e->d_work.release(); e->d_flags.release();

@@ -56,6 +56,9 @@ hipError_t acquire_stream(int device, hipStream_t *out);
 void park_stream(int device, hipStream_t s);
 hipError_t copy_back(void *dst, const void *src, size_t bytes, hipStream_t s);
 hipError_t copy_in(void *dst, const void *src, size_t bytes, hipStream_t s);
+// `pieces` consecutive device pieces of `bytes` each to `pieces` separate host destinations: one DMA
+// where they fit a half together
+hipError_t copy_back_pieces(void *const *dst, const void *src, int pieces, size_t bytes, hipStream_t s);
 hipError_t copy_back_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width,
                         size_t height, hipStream_t s);
 hipError_t copy_in_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width,
@@ -248,9 +251,9 @@ struct qm_engine : TableState {
     DevBuf<int32_t> d_onset_meta;
 
     // scratch
-    DevBuf<double> d_onsets, d_pmax, d_psum, d_out_a, d_out_b, d_chunk, d_marg, d_marg_out;
+    DevBuf<double> d_onsets, d_pmax, d_psum, d_out_a, d_chunk, d_marg, d_marg_out;
     int marg_tiles = 0;             // time tiles of the last marginal-map launch (rows of d_marg)
-    DevBuf<int64_t> d_pidx, d_out_i;
+    DevBuf<int64_t> d_pidx;
     // locate fits: three map-sized work buffers, reduction partials, device-side scalars
     DevBuf<double> d_fit_a, d_fit_b, d_fit_c, d_fit_part, d_fit_val, d_fit_win;
     DevBuf<int64_t> d_fit_pidx;

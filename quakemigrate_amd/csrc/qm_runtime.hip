@@ -61,6 +61,9 @@ struct Bounce {
     std::mutex mutex;
     char *half[2] = {nullptr, nullptr};
     hipEvent_t landed[2] = {nullptr, nullptr};      // the DMA that last touched the half is done
+    bool in_flight[2] = {false, false};             // ... and has not been waited for yet (uploads return
+                                                    // without waiting: the data is in pinned memory, the
+                                                    // copy is ordered on the stream like the kernel after it)
 };
 static std::mutex g_bounce_map_mutex;
 static std::vector<std::pair<int, Bounce *>> g_bounces;    // (device, buffer): never freed
@@ -133,11 +136,18 @@ static hipError_t bounce_pipeline(bool download, size_t pieces, hipStream_t s, I
     std::lock_guard<std::mutex> lock(b->mutex);
     hipError_t r = ensure_bounce(b);
     if (r != hipSuccess) return r;
+    // a half whose last DMA (an upload's) nobody has waited for yet must land before it is touched again
+    auto settle = [&](int h) -> hipError_t {
+        if (!b->in_flight[h]) return hipSuccess;
+        b->in_flight[h] = false;
+        return hipEventSynchronize(b->landed[h]);
+    };
     if (download) {
         // DMA of piece i runs while the CPU empties piece i - 1
         for (size_t i = 0; i <= pieces; ++i) {
             if (i < pieces) {
-                r = issue(i, b->half[i & 1]);
+                r = settle((int)(i & 1));
+                if (r == hipSuccess) r = issue(i, b->half[i & 1]);
                 if (r == hipSuccess) r = hipEventRecord(b->landed[i & 1], s);
                 if (r != hipSuccess) return r;
             }
@@ -149,18 +159,18 @@ static hipError_t bounce_pipeline(bool download, size_t pieces, hipStream_t s, I
         }
         return hipSuccess;
     }
-    // upload: the CPU fills piece i while the DMA of piece i - 1 drains the other half
+    // upload: the CPU fills piece i while the DMA of piece i - 1 drains the other half.  Returns when the
+    // caller's data is in pinned memory (it may be a temporary); the DMA itself is stream-ordered work.
     for (size_t i = 0; i < pieces; ++i) {
-        if (i >= 2) {
-            r = hipEventSynchronize(b->landed[i & 1]);          // the half's previous DMA has read it
-            if (r != hipSuccess) return r;
-        }
+        r = settle((int)(i & 1));
+        if (r != hipSuccess) return r;
         host(i, b->half[i & 1]);
         r = issue(i, b->half[i & 1]);
         if (r == hipSuccess) r = hipEventRecord(b->landed[i & 1], s);
         if (r != hipSuccess) return r;
+        b->in_flight[i & 1] = true;
     }
-    return hipStreamSynchronize(s);
+    return hipSuccess;
 }
 
 hipError_t copy_back(void *dst, const void *src, size_t bytes, hipStream_t s) {
@@ -172,6 +182,20 @@ hipError_t copy_back(void *dst, const void *src, size_t bytes, hipStream_t s) {
                                   hipMemcpyDeviceToHost, s);
         },
         [&](size_t i, char *half) { host_copy(static_cast<char *>(dst) + i * kBounceHalf, half, len(i)); });
+}
+hipError_t copy_back_pieces(void *const *dst, const void *src, int pieces, size_t bytes, hipStream_t s) {
+    if ((size_t)pieces * bytes > kBounceHalf) {          // (too long for one half: piece by piece)
+        for (int i = 0; i < pieces; ++i) {
+            const hipError_t r = copy_back(dst[i], static_cast<const char *>(src) + (size_t)i * bytes, bytes, s);
+            if (r != hipSuccess) return r;
+        }
+        return hipSuccess;
+    }
+    return bounce_pipeline(true, 1, s,
+        [&](size_t, char *half) { return hipMemcpyAsync(half, src, (size_t)pieces * bytes, hipMemcpyDeviceToHost, s); },
+        [&](size_t, char *half) {
+            for (int i = 0; i < pieces; ++i) std::memcpy(dst[i], half + (size_t)i * bytes, bytes);
+        });
 }
 hipError_t copy_in(void *dst, const void *src, size_t bytes, hipStream_t s) {
     const size_t pieces = (bytes + kBounceHalf - 1) / kBounceHalf;
