@@ -363,10 +363,10 @@ int qm_engine_find_max_coa(qm_engine *e, const double *map4d, int map_on_device,
  * onsets -> migrate -> find_max_coa -> append), with host-resident onsets going in and the three
  * series coming out per timestep.  A ring of `depth` slots of `steps_per_launch` timesteps each;
  * qm_stream_push copies one timestep's log-onsets (host f64 [n_rows][t_samples], the resident table's
- * row count) into pinned memory and, when a slot is full, enqueues its H2D copy (own stream), ONE
+ * row count) into pinned memory and, when a slot is full, enqueues its H2D copy (own stream) and ONE
  * fused-detect launch for its timesteps on the engine's stream (qm_engine_detect_batch: every
- * timestep's bits are the single-step call's) and ONE D2H copy of the packed results (own stream);
- * nothing waits.  qm_stream_pop hands out the results of the oldest timesteps in push order and is the
+ * timestep's bits are the single-step call's) whose last kernel writes the results straight into the
+ * slot's pinned host buffer; nothing waits.  qm_stream_pop hands out the results of the oldest timesteps in push order and is the
  * only call that blocks (for the launch they belong to).
  * qm_stream_push returns 0, or 2 when every slot holds results that have not been popped (pop, then
  * push again), or 1 on error.  qm_stream_flush launches a partly filled slot (end of the data).

@@ -53,7 +53,7 @@ void park_stream(int device, hipStream_t s) {
 // per DEVICE (its own lock: engines on different GPUs of a threaded process do not queue behind each
 // other), 32 MB in two halves that ping-pong: while the DMA engine fills / drains one half the CPU
 // copies the other (round 5; round 4's single buffer did DMA -> wait -> memcpy strictly in turn), and
-// pieces of 4 MB and more are copied by a few host threads (one core moves ~10 GB/s, a PCIe 5 link
+// pieces of 2 MB and more are copied by a few host threads (one core moves ~10 GB/s, a PCIe 5 link
 // four times that).  (The statistics-only flag ring of the screened sweep is pinned memory of its own
 // and stays asynchronous.)
 static constexpr size_t kBounceHalf = 16u << 20;
@@ -90,9 +90,10 @@ static hipError_t ensure_bounce(Bounce *b) {               // (caller holds b->m
     b->half[1] = p + kBounceHalf;
     return hipSuccess;
 }
-// CPU copy of n bytes; pieces of >= 4 MB on up to 8 threads
+// CPU copy of n bytes; from 2 MB on, on up to 8 threads of >= 1 MB each (one core moves ~8 GB/s: a
+// 3 MB timestep of a long-window config would otherwise cost the pushing thread 0.4 ms)
 void host_copy(void *dst, const void *src, size_t n) {
-    constexpr size_t kGrain = (size_t)2 << 20;
+    constexpr size_t kGrain = (size_t)1 << 20;
     unsigned hw = std::thread::hardware_concurrency();
     const size_t nt = std::min<size_t>({n / kGrain, hw ? hw : 4u, (size_t)8});
     if (nt < 2) {

@@ -7,34 +7,35 @@
 //
 //   caller's thread : qm_stream_push   CPU copy of a step's log-onsets into the slot's PINNED input
 //   copy stream     : H2D of the slot's inputs                 (overlaps the previous launch's kernel)
-//   engine's stream : ONE fused-detect launch for the slot's K steps (qm_engine_detect_batch),
-//                     results written PACKED as [3][K x n_samples] float64
-//   download stream : ONE D2H of the packed results into the slot's pinned output
-//   caller's thread : qm_stream_pop    CPU copy of a step's three series to the caller
+//   engine's stream : ONE fused-detect launch for the slot's K steps (qm_engine_detect_batch); its
+//                     combine kernel writes the results, packed as [3][K x n_samples] float64, STRAIGHT
+//                     into the slot's pinned host buffer (a few KB per timestep; no D2H command)
+//   caller's thread : qm_stream_pop    waits for the launch's event, CPU copy of a step's three series
 //
-// Round 4 drove the same pipeline from Python (three D2H copies, three events and NumPy staging per
+// Round 4 drove a pipeline like this from Python (three D2H copies, three events and NumPy staging per
 // launch): with the copies inside the clock the example-sized grids lost 30-40 % of their kernel
 // rate and K steps per launch bought nothing (profiles/r04_bench_{C1,E1,E2}_k*.json).  Here a launch
 // costs the host one memcpy per pushed step and a handful of enqueues; ordering is HIP events, the
-// host blocks only in qm_stream_pop, and only for the oldest launch.  The caller's pointers are never
-// handed to the HIP runtime.
+// host blocks only in qm_stream_pop, and only for the oldest launch: 8 timesteps per launch run at
+// x1.00 of the resident step on those grids.  The caller's pointers are never handed to the HIP
+// runtime.
 #include "qm_engine.hpp"
 
 #include <deque>
+
 
 struct qm_stream {
     qm_engine *e = nullptr;
     int n_rows = 0, T = 0, fsmp = 0, lsmp = 0, available = 0, ns = 0, K = 1, depth = 2;
     int64_t n_nodes_total = 0;
-    hipStream_t copy_stream = nullptr, down_stream = nullptr;
+    hipStream_t copy_stream = nullptr;
     struct Slot {
         double *h_on = nullptr;         // pinned [K][n_rows][T]
         double *d_on = nullptr;         // device, the same
-        double *d_out = nullptr;        // device [3][K * ns]: max_coa, max_norm_coa, indices (int64 bits)
-        double *h_out = nullptr;        // pinned, the same
+        double *h_out = nullptr;        // pinned [3][K * ns]: max_coa, max_norm_coa, indices (int64 bits) --
+                                        // written by the kernels themselves
         hipEvent_t copied = nullptr;    // the inputs are on the device
-        hipEvent_t computed = nullptr;  // the launch has written d_out (and read d_on)
-        hipEvent_t done = nullptr;      // the results are in h_out
+        hipEvent_t done = nullptr;      // the launch has finished: the results are in h_out
         int n = 0;                      // steps launched from this slot
         int taken = 0;                  // ... of which popped
         bool in_flight = false;
@@ -59,8 +60,7 @@ void free_slot(qm_stream::Slot &sl) {
     if (sl.h_on) (void)hipHostFree(sl.h_on);
     if (sl.h_out) (void)hipHostFree(sl.h_out);
     if (sl.d_on) pool_free(sl.d_on);
-    if (sl.d_out) pool_free(sl.d_out);
-    for (hipEvent_t ev : {sl.copied, sl.computed, sl.done})
+    for (hipEvent_t ev : {sl.copied, sl.done})
         if (ev) (void)hipEventDestroy(ev);
     sl = qm_stream::Slot{};
 }
@@ -69,14 +69,12 @@ void free_slot(qm_stream::Slot &sl) {
 void release_stream(qm_stream *s) {
     (void)hipStreamSynchronize(s->e->stream);
     if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
-    if (s->down_stream) (void)hipStreamSynchronize(s->down_stream);
     {
         PoolReleaseScope one_wait;
         for (qm_stream::Slot &sl : s->slots) free_slot(sl);
     }
     if (s->copy_stream) park_stream(s->e->device, s->copy_stream);
-    if (s->down_stream) park_stream(s->e->device, s->down_stream);
-    s->copy_stream = s->down_stream = nullptr;
+    s->copy_stream = nullptr;
     s->order.clear();
 }
 
@@ -93,14 +91,16 @@ int launch_slot(qm_stream *s) {
                           s->copy_stream));
     QM_HIP(hipEventRecord(sl.copied, s->copy_stream));
     QM_HIP(hipStreamWaitEvent(e->stream, sl.copied, 0));
+    // The results are a few KB per timestep: the combine kernel writes them STRAIGHT into the slot's
+    // pinned host buffer (pinned memory is device-accessible under one address; the event behind the
+    // launch makes them visible to the host) -- no D2H copy command, no third stream.  (With a copy on a
+    // download stream of its own, 8 timesteps per launch ran at x1.03-1.09 of the resident step on the
+    // example-sized grids; now x1.00, profiles/r05_ab_runs.txt.)
+    double *out = sl.h_out;
     if (qm_engine_detect_batch(e, sl.d_on, 1, n, s->T, s->fsmp, s->lsmp, s->available, s->n_nodes_total,
-                               sl.d_out, sl.d_out + kns, reinterpret_cast<int64_t *>(sl.d_out + 2 * kns), 1))
+                               out, out + kns, reinterpret_cast<int64_t *>(out + 2 * kns), 1))
         return 1;
-    QM_HIP(hipEventRecord(sl.computed, e->stream));
-    QM_HIP(hipStreamWaitEvent(s->down_stream, sl.computed, 0));
-    // (one copy of all three rows; a partly filled slot's rows are K * ns apart all the same)
-    QM_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, 3 * kns * sizeof(double), hipMemcpyDeviceToHost, s->down_stream));
-    QM_HIP(hipEventRecord(sl.done, s->down_stream));
+    QM_HIP(hipEventRecord(sl.done, e->stream));
     sl.n = n;
     sl.taken = 0;
     sl.in_flight = true;
@@ -145,8 +145,7 @@ int qm_stream_create(qm_engine *e, int32_t t_samples, int32_t fsmp, int32_t lsmp
         qm_stream_destroy(s);
         return rc;
     };
-    if (acquire_stream(e->device, &s->copy_stream) != hipSuccess ||
-        acquire_stream(e->device, &s->down_stream) != hipSuccess)
+    if (acquire_stream(e->device, &s->copy_stream) != hipSuccess)
         return bail(fail("qm_stream_create: no HIP stream"));
     s->slots.resize((size_t)depth);
     const size_t in_bytes = (size_t)s->K * step_in(s) * sizeof(double);
@@ -155,8 +154,7 @@ int qm_stream_create(qm_engine *e, int32_t t_samples, int32_t fsmp, int32_t lsmp
         hipError_t r = hipHostMalloc(reinterpret_cast<void **>(&sl.h_on), in_bytes, hipHostMallocDefault);
         if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void **>(&sl.h_out), out_bytes, hipHostMallocDefault);
         if (r == hipSuccess) r = pool_alloc(reinterpret_cast<void **>(&sl.d_on), in_bytes);
-        if (r == hipSuccess) r = pool_alloc(reinterpret_cast<void **>(&sl.d_out), out_bytes);
-        for (hipEvent_t *ev : {&sl.copied, &sl.computed, &sl.done})
+        for (hipEvent_t *ev : {&sl.copied, &sl.done})
             if (r == hipSuccess) r = hipEventCreateWithFlags(ev, hipEventDisableTiming);
         if (r != hipSuccess)
             return bail(fail("qm_stream_create: %s (%d steps of %zu bytes per slot, %d slots)",
