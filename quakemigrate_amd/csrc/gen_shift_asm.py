@@ -77,6 +77,9 @@ def rec_bytes(packed):
     return 32 if packed else 64
 PF_AHEAD = int(os.environ.get("QM_SHIFT_PF", "16"))   # records ahead (0: no prefetch)
 NEXT_RUN = os.environ.get("QM_SHIFT_NEXT_RUN", "1") == "1"   # round 5: prefetch the head of the wavefront's next run
+NEXT_META = os.environ.get("QM_SHIFT_NEXT_META", "0") == "1"  # ... and the next brick's row-window metadata: flat on the
+                                                              # loops that take all groups of a brick (C3 -0.1 %, C4 -0.2 %:
+                                                              # off); the row-block loops always do it (-2.5 %)
 PF_EVERY = int(os.environ.get("QM_SHIFT_PF_EVERY", "2"))   # 2: one prefetch per PAIR of rows (two 32-byte records:
                                                             # the same 128-byte line either way; C3 -0.4 %, C4 -0.7 %,
                                                             # locate volume -1.7 %, profiles/r05_ab_runs.txt); 1: per row.
@@ -717,6 +720,11 @@ def body(degree, volume):
         # per-row prefetch runs PF_AHEAD records ahead INSIDE a run; a run's first records would otherwise
         # be fetched from HBM by the scalar loads that wait for them.)
         e(f"global_load_dword v{VPF}, %[nxoff], %[nxrun]")
+        # ... and the row-window metadata (16 bytes per row) that the staging of the next brick (row blocks:
+        # of the block AFTER the next) will read, 4 KB of it: the staging otherwise waits for HBM twice in a
+        # row, once for the metadata and once for the samples they point at
+        if BLOCK or NEXT_META:
+            e(f"global_load_dword v{VPF}, %[nxoff], %[mdrun]")
     if BLOCK:
         carry = e.label("cy")
         e("s_bitcmp1_b32 %[flags], 0")                         # first block of the brick: zero
@@ -786,8 +794,8 @@ def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False,
           f"hard VGPRs v{VB}..v{VEND - 1}, SGPRs s{SB}..s{SEND - 1}")
     print(f"__device__ __forceinline__ void {name}("
           + ("" if lds_state else f"double (&vmax)[{spl}], double (&vsum)[{spl}], int (&vidx)[{spl}],"))
-    print("        const void *stream, " + ("unsigned flags, const void *next_run, unsigned next_off, "
-                                            if block else "int ngroups, const void *next_run, unsigned next_off, ")
+    print("        const void *stream, " + ("unsigned flags, const void *next_run, unsigned next_off, const void *next_meta, "
+                                            if block else "int ngroups, const void *next_run, unsigned next_off, const void *next_meta, ")
           + "int npairs, unsigned lane_addr, "
           + ("unsigned state_addr, " if lds_state else "")
           + ("unsigned lane_addr_b, " if far else "") + "int nz, "
@@ -827,6 +835,8 @@ def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False,
         ins += ['[laneb] "v"(lane_addr_b)']
     if block:
         ins += ['[flags] "s"(flags)']
+    if block or (NEXT_RUN and NEXT_META):
+        ins += ['[mdrun] "s"(next_meta)']
     if block or NEXT_RUN:
         ins += ['[nxrun] "s"(next_run)', '[nxoff] "v"(next_off)']
     if marginal:

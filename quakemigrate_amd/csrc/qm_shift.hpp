@@ -524,49 +524,51 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
         while (nb < g.nbricks && !s.sfit[nb]) nb += a.ngroups;
         const char *next_run = s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, 1, rpw) * kShiftRec;
         const unsigned next_off = (unsigned)lane * 64u;
+        const void *next_meta = s.smeta + (int64_t)(nb < g.nbricks ? nb : b) * g.n_rows;
+        (void)next_meta;
         const unsigned lane_addr_b = lane_addr + (unsigned)kShiftPlane8;   // (8-wave shape: plane B)
         (void)lane_addr_b; (void)next_run; (void)next_off;
 #define QM_TAIL_CALL(JJ)                                                                              \
         if constexpr (MODE == kShiftMarginal)                                                         \
-            shift_tail##JJ##_marginal(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz,       \
+            shift_tail##JJ##_marginal(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz,       \
                                       a.z_scale, c, marg_tile, weight, node_off, lane_x16, lane_x32); \
         else if constexpr (MODE == kShiftVolume)                                                      \
-            shift_tail##JJ##_volume(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz,         \
+            shift_tail##JJ##_volume(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz,         \
                                     a.z_scale, c, vol_tile, vol_stride_bytes, (unsigned)lane * (8u * JJ), \
                                     slot_lanes);                                                      \
         else                                                                                          \
-            shift_tail##JJ##_detect(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz,         \
+            shift_tail##JJ##_detect(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz,         \
                                     a.z_scale, c)
         if constexpr (J == 1) { QM_TAIL_CALL(1); }
         else if constexpr (J == 2) { QM_TAIL_CALL(2); }
         else if constexpr (J == 3) { QM_TAIL_CALL(3); }
 #undef QM_TAIL_CALL
         else if constexpr (kLdsState)
-            shift_groups_detect3(run, mine, next_run, next_off, npairs, lane_addr, state_addr, nz, nynz, a.z_scale, c);
+            shift_groups_detect3(run, mine, next_run, next_off, next_meta, npairs, lane_addr, state_addr, nz, nynz, a.z_scale, c);
         else if constexpr (NW == kShiftWaves8 && MODE == kShiftMarginal)
-            shift_groups_marginal8(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, lane_addr_b, nz, nynz,
+            shift_groups_marginal8(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, lane_addr_b, nz, nynz,
                                    a.z_scale, c, marg_tile, weight, node_off, lane_x16, lane_x32);
         else if constexpr (MODE == kShiftMarginal)
-            shift_groups_marginal(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz, a.z_scale, c,
+            shift_groups_marginal(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz, a.z_scale, c,
                                   marg_tile, weight, node_off, lane_x16, lane_x32);
         else if constexpr (NW == kShiftWaves8 && MODE == kShiftVolume)
-            shift_groups_volume8(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, lane_addr_b, nz, nynz,
+            shift_groups_volume8(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, lane_addr_b, nz, nynz,
                                  a.z_scale, c, vol_tile, vol_stride_bytes, (unsigned)lane * 32u, store_lanes);
         else if constexpr (NW == kShiftWaves8) {
             if (s.lazy)
-                shift_groups_detect8_lazy(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, lane_addr_b, nz,
+                shift_groups_detect8_lazy(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, lane_addr_b, nz,
                                           nynz, a.z_scale, c);
             else
-                shift_groups_detect8(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, lane_addr_b, nz, nynz,
+                shift_groups_detect8(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, lane_addr_b, nz, nynz,
                                      a.z_scale, c);
         }
         else if constexpr (MODE == kShiftVolume)
-            shift_groups_volume(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz, a.z_scale, c,
+            shift_groups_volume(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz, a.z_scale, c,
                                 vol_tile, vol_stride_bytes, (unsigned)lane * 32u, store_lanes);
         else if (s.lazy)
-            shift_groups_detect_lazy(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz, a.z_scale, c);
+            shift_groups_detect_lazy(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz, a.z_scale, c);
         else
-            shift_groups_detect(vmax, vsum, vidx, run, mine, next_run, next_off, npairs, lane_addr, nz, nynz, a.z_scale, c);
+            shift_groups_detect(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz, a.z_scale, c);
     }
     if (!a.want_scan) return;
     if constexpr (kLdsState) {
@@ -611,6 +613,24 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
 // (amdgpu_waves_per_eu(6, 6) is what keeps the compiler below v80 = kShiftBlockVgprs: it plans for
 // six wavefronts per SIMD, i.e. 80 registers, and treats the rest as reserved; the generated loop's
 // hard registers above bring the kernel to 248, two wavefronts per SIMD)
+// Row blocks: the metadata (row-window records, 16 bytes per row) of the block whose staging FOLLOWS the
+// next one's -- two steps ahead in the workgroup's sequence (brick b: blocks 0 .. nblk-1, then its next
+// brick nb) --, for the generated loop's prefetch.  A hint: past the end it points at this brick's own.
+__device__ __forceinline__ const void *shift_meta_ahead(const ShiftArgs &s, const GridDesc &g, int b, int nb,
+                                                        int k) {
+    int pb = b, pk = k + 2;
+    if (pk >= s.nblk) {
+        pb = nb;
+        pk -= s.nblk;
+        if (pk >= s.nblk) {                       // (a single block per brick: the brick after the next)
+            pb = nb + s.a.ngroups;
+            pk = 0;
+        }
+    }
+    if (pb >= g.nbricks) pb = b, pk = 0;
+    return s.smeta + ((int64_t)pb * s.nblk + pk) * s.sb;
+}
+
 #ifndef QM_ROWS_RB               // rows in flight per wavefront and staging pass, 64-sample chunks per row
 #define QM_ROWS_RB 3             // (3 x 5: the most that leaves the compiler without spills below v80)
 #define QM_ROWS_U 5
@@ -649,6 +669,7 @@ void stack_shift_rows_kernel(ShiftArgs s) {
         while (nb < g.nbricks && !s.sfit[nb]) nb += a.ngroups;
         const char *next_run = s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, s.nblk, rpw) * kShiftRecBlocks;
         for (int k = 0; k < s.nblk; ++k) {
+            const void *next_meta = shift_meta_ahead(s, g, b, nb, k);
             const int row0 = k * s.sb;
             const int rows = g.n_rows - row0 < s.sb ? g.n_rows - row0 : s.sb;
             __syncthreads();                          // previous block fully consumed
@@ -659,7 +680,7 @@ void stack_shift_rows_kernel(ShiftArgs s) {
                 const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRecBlocks;
                 const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
                     (int)((k == 0 ? 1u : 0u) | (k == s.nblk - 1 ? 2u : 0u)));
-                shift_group_rows8(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                shift_group_rows8(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
                                   (rows + 1) / 2, lane_addr, lane_addr + (unsigned)kShiftPlane8, g.nz,
                                   g.ny * g.nz, a.z_scale, c);
             }
@@ -802,6 +823,7 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
         const char *next_run =
             s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, s.nblk, rpw) * kShiftRecBlocks;
         for (int k = 0; k < s.nblk; ++k) {
+            const void *next_meta = shift_meta_ahead(s, g, b, nb, k);
             // the next block (of this brick, or the first of the next) into the idle half
             double *idle = win + (cur ^ 1) * (kShiftHalfBytes / 8);
             if (k + 1 < s.nblk)
@@ -814,16 +836,16 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
                 const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
                     (int)((k == 0 ? 1u : 0u) | (k == s.nblk - 1 ? 2u : 0u)));
                 if constexpr (VOLUME)
-                    shift_group_rows_volume(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                    shift_group_rows_volume(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
                                             (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes),
                                             g.nz, g.ny * g.nz, a.z_scale, c, a.volume + t_first,
                                             (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u, store_lanes);
                 else if (s.lazy)
-                    shift_group_rows_lazy(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                    shift_group_rows_lazy(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
                                           (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes),
                                           g.nz, g.ny * g.nz, a.z_scale, c);
                 else
-                    shift_group_rows(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                    shift_group_rows(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
                                      (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes), g.nz,
                                      g.ny * g.nz, a.z_scale, c);
             }
@@ -891,6 +913,7 @@ void stack_shift_rows4_kernel(ShiftArgs s) {
         const char *next_run =
             s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, s.nblk, rpw) * kShiftRecBlocks;
         for (int k = 0; k < s.nblk; ++k) {
+            const void *next_meta = shift_meta_ahead(s, g, b, nb, k);
             // everyone is done with the block in LDS; this block's rows in, by LDS-direct loads
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             stage_shift_block_direct<NW>(s, win, b * s.nblk + k, k * s.sb, rows_of(k), wave, lane, t_first);
@@ -900,15 +923,15 @@ void stack_shift_rows4_kernel(ShiftArgs s) {
                 const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
                     (int)((k == 0 ? 1u : 0u) | (k == s.nblk - 1 ? 2u : 0u)));
                 if constexpr (VOLUME)
-                    shift_group_rows_volume(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                    shift_group_rows_volume(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
                                             (rows_of(k) + 1) / 2, lane_addr, g.nz, g.ny * g.nz, a.z_scale, c,
                                             a.volume + t_first, (unsigned)(a.vol_stride * 8),
                                             (unsigned)lane * 32u, store_lanes);
                 else if (s.lazy)
-                    shift_group_rows_lazy(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                    shift_group_rows_lazy(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
                                           (rows_of(k) + 1) / 2, lane_addr, g.nz, g.ny * g.nz, a.z_scale, c);
                 else
-                    shift_group_rows(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u,
+                    shift_group_rows(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
                                      (rows_of(k) + 1) / 2, lane_addr, g.nz, g.ny * g.nz, a.z_scale, c);
             }
         }

@@ -259,7 +259,8 @@ int build_shift_tables(qm_engine *e) {
         g.brick_nodes = g.bx * g.by * g.bz;
         const size_t br = (size_t)g.nbricks * S;
         const size_t nvb = (size_t)g.nbricks * nblk;               // (brick, row block) pairs
-        if (e->d_shraw.ensure(4 * br) || e->d_shmeta.ensure(4 * nvb * sb) ||
+        // (d_shmeta: + 4 KB of slack -- the row-block loops prefetch that much metadata ahead)
+        if (e->d_shraw.ensure(4 * br) || e->d_shmeta.ensure(4 * nvb * sb + 1024) ||
             e->d_shtotal.ensure(nvb) || e->d_shfit.ensure(nvb) || e->d_scalar.ensure(8))
             return 1;
         QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 8 * sizeof(int32_t), e->stream));
