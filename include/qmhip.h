@@ -164,7 +164,8 @@ int qm_engine_synchronize(qm_engine *e);
  * last_kernel_j, steps_per_launch (timesteps the last detect_batch put into one launch);
  * shift_ok, shift_brick_nodes, shift_wide_bricks, shift_row_blocks, shift_operands_per_add_x1000,
  * shift_tail_spl; pair_brick_nodes, pair_wide_bricks, pair_tile; screened_steps, fallback_steps,
- * last_candidates, screen_brick_nodes; tie_refined_steps, tie_pairs, tie_overflow_samples;
+ * last_candidates, screen_brick_nodes; tie_refined_steps, tie_pairs and tie_overflow_samples (of the last
+ * refined launch);
  * table_hits, table_misses, table_evictions, tables_parked, table_bytes, tables_parked_bytes. */
 int qm_engine_config(qm_engine *e, const char *key, int64_t value);
 int qm_engine_get(qm_engine *e, const char *key, int64_t *value);

@@ -358,9 +358,18 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         // (bricks of <= 64 nodes -- coarse grids with wide tables, 4 nodes per wavefront and brick: a
         // workgroup's fixed costs weigh more than the grid's tail, three rounds instead of twelve:
         // E2 0.418 -> 0.394 ms, profiles/r04_rounds_sweep.txt)
-        const int rounds = (!shift && jp == 0 && !e->user_rounds && e->g.brick_nodes <= 64) ? 3 : 0;
+        int rounds = (!shift && jp == 0 && !e->user_rounds && e->g.brick_nodes <= 64) ? 3 : 0;
+        // (tie_rule = 1 stacks one SET of bricks again per sample, qm_ties.hpp: eight times as many,
+        // smaller sets -- the refinement's cost falls with the set size, the stacking launch loses ~1 %)
         groups_lds = e->cfg_groups > 0 ? std::min(e->cfg_groups, nbricks_now)
                                        : auto_groups(e, a.ntiles, nbricks_now, lds_blocks_per_cu, rounds);
+        if (e->cfg_tie_rule && want_scan && !e->user_rounds && e->cfg_groups == 0) {
+            // ... but never sets of fewer than four bricks: the workgroup's fixed costs (C2: +8 % on the
+            // stacking launch at one brick per set)
+            const int fine = auto_groups(e, a.ntiles, std::max(1, nbricks_now / 4), lds_blocks_per_cu,
+                                         8 * (rounds > 0 ? rounds : e->cfg_rounds));
+            groups_lds = std::max(groups_lds, fine);
+        }
     }
     if (use_direct) {
         const int units = e->cfg_force_direct ? nbricks_now : n_wide_now;
@@ -482,18 +491,16 @@ int refine_ties(qm_engine *e, const double *d_on, int T, int fsmp, int available
     hipStream_t s = e->stream;
     QM_HIP(hipMemsetAsync(e->d_tie_count.p, 0, 4 * sizeof(int32_t), s));
     int2 *pairs = reinterpret_cast<int2 *>(e->d_tie_pairs.p);
-    hipLaunchKernelGGL(qm::tie_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
+    hipLaunchKernelGGL(qm::tie_pairs_kernel, dim3((n + 63) / 64), dim3(64, qm::kTieSetLanes), 0, s,
                        (const double *)e->d_pmax.p, sets, n, (int64_t)n, e->d_tie_z.p, pairs,
                        e->d_tie_count.p, max_pairs, e->d_tie_emax.p, e->d_tie_imin.p, e->d_tie_count.p + 1);
     QM_HIP(hipGetLastError());
-    // how many pairs there are is known on the device only: the evaluation is launched for the number a
-    // generic step has (one per sample) with room to spare, and again for the rest if a step has more
-    int32_t h[2] = {0, 0};
-    QM_HIP(copy_back(h, e->d_tie_count.p, sizeof(h), s));
-    e->tie_pairs_last = h[0];
-    e->tie_overflow_samples += h[1];
+    // How many pairs there are is known on the device only, and nobody waits for it: the evaluation is
+    // launched for what a generic step has (one pair per sample) with room to spare; workgroups beyond the
+    // list return at once, a longer list is covered by the grid's stride.  The
+    // counters travel to the host when somebody asks (qm_engine_get "tie_pairs", "tie_overflow_samples").
     ++e->tie_refined_steps;
-    if (h[0] == 0) return 0;
+    e->tie_counts_pending = true;
     qm::TieArgs a{};
     a.g = e->last_g;
     a.onsets = d_on;
@@ -517,7 +524,7 @@ int refine_ties(qm_engine *e, const double *d_on, int T, int fsmp, int available
     a.cand_keys = e->d_tie_keys.p;
     a.n_cands = e->d_tie_count.p + 2;
     a.max_cands = max_cands;
-    const unsigned grid = (unsigned)((int64_t)h[0] * a.chunks);
+    const unsigned grid = (unsigned)((int64_t)(n + 1024) * a.chunks);
     hipLaunchKernelGGL(qm::tie_eval_kernel<0>, dim3(grid), dim3(256), 0, s, a);
     hipLaunchKernelGGL(qm::tie_pick_kernel, dim3(256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(qm::tie_eval_kernel<1>, dim3(grid), dim3(256), 0, s, a);   // (returns at once unless the list overflowed)
@@ -770,8 +777,17 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "steps_per_launch") *v = e->last_batched;
     else if (k == "tie_rule") *v = e->cfg_tie_rule;
     else if (k == "tie_refined_steps") *v = e->tie_refined_steps;
-    else if (k == "tie_overflow_samples") *v = e->tie_overflow_samples;
-    else if (k == "tie_pairs") *v = e->tie_pairs_last;
+    else if (k == "tie_overflow_samples" || k == "tie_pairs") {
+        if (e->tie_counts_pending) {                       // (the last refinement's counters: now)
+            DeviceGuard guard(e->device);
+            int32_t h[2] = {0, 0};
+            QM_HIP(copy_back(h, e->d_tie_count.p, sizeof(h), e->stream));
+            e->tie_pairs_last = h[0];
+            e->tie_overflow_last = h[1];
+            e->tie_counts_pending = false;
+        }
+        *v = k == "tie_pairs" ? e->tie_pairs_last : e->tie_overflow_last;
+    }
     else if (k == "table_hits") *v = e->table_hits;
     else if (k == "table_misses") *v = e->table_misses;
     else if (k == "table_evictions") *v = e->table_evictions;

@@ -239,7 +239,8 @@ struct qm_engine : TableState {
     DevBuf<double> d_tie_z;
     DevBuf<int32_t> d_tie_pairs, d_tie_imin, d_tie_count, d_tie_cands;
     DevBuf<unsigned long long> d_tie_emax, d_tie_keys;
-    int64_t tie_refined_steps = 0, tie_overflow_samples = 0, tie_pairs_last = 0;
+    int64_t tie_refined_steps = 0, tie_overflow_last = 0, tie_pairs_last = 0;
+    bool tie_counts_pending = false;        // the last refinement's counters are still on the device
 
     // float64 travel-time grids in seconds (optional; on-device table serving)
     DevBuf<double> d_grids;

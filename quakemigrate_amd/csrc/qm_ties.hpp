@@ -12,7 +12,8 @@
 // behind (the partial sets: per (set of bricks, sample) the largest z):
 //   1. tie_pairs_kernel: per sample the largest z over the sets, and the sets whose maximum lies
 //      within `slack` of it -- only they can hold a node whose exp() ties with the maximum's.  Generic
-//      data: one (set, sample) pair per sample.
+//      data: one (set, sample) pair per sample.  (With the rule on, a launch publishes eight times as
+//      many, smaller sets -- run_stack --: what a pair costs is its set's nodes.)
 //   2. tie_eval_kernel: every node of such a set is stacked again for that ONE sample, rows in
 //      ascending order (the reference's sum, bit for bit); nodes within the slack form x = stack *
 //      (1 / available) as the reference does and a CORRECTLY ROUNDED exp(x) (double-double
@@ -143,100 +144,116 @@ struct TieArgs {
 };
 
 #ifdef QM_TU_STEPS
-// One thread per sample: the largest z over the sets, the sets within the slack -> work list.
-__global__ __launch_bounds__(256) void tie_pairs_kernel(const double *__restrict__ pmax, int sets, int n,
-                                                        int64_t set_stride, double *__restrict__ zbest,
-                                                        int2 *__restrict__ pairs, int32_t *__restrict__ n_pairs,
-                                                        int max_pairs, unsigned long long *__restrict__ emax,
-                                                        int32_t *__restrict__ imin,
-                                                        int32_t *__restrict__ overflow) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+// Workgroup = 64 samples x kTieSetLanes set-lanes (thread (x, y) scans sets y, y + kTieSetLanes, ...: a
+// single thread per sample would walk thousands of sets one load at a time): the largest z over the
+// sets, the sets within the slack -> work list.
+constexpr int kTieSetLanes = 16;
+__global__ __launch_bounds__(64 * kTieSetLanes) void tie_pairs_kernel(
+    const double *__restrict__ pmax, int sets, int n, int64_t set_stride, double *__restrict__ zbest,
+    int2 *__restrict__ pairs, int32_t *__restrict__ n_pairs, int max_pairs, unsigned long long *__restrict__ emax,
+    int32_t *__restrict__ imin, int32_t *__restrict__ overflow) {
+    __shared__ double smax[kTieSetLanes][64];
+    __shared__ int scount[kTieSetLanes][64];
+    __shared__ int sbase[64];
+    const int x = threadIdx.x, y = threadIdx.y;
+    const int t = blockIdx.x * 64 + x;
+    const bool live = t < n;
     double zb = -__builtin_inf();
-    for (int s = 0; s < sets; ++s) {
-        const double v = pmax[(int64_t)s * set_stride + t];
-        zb = v > zb ? v : zb;                               // (a NaN never wins)
-    }
-    zbest[t] = zb;
-    emax[t] = 0ull;
-    imin[t] = INT32_MAX;
-    if (!(zb > -__builtin_inf())) return;                   // nothing finite: the default's (0, index 0) stays
+    if (live)
+        for (int s = y; s < sets; s += kTieSetLanes) {
+            const double v = pmax[(int64_t)s * set_stride + t];
+            zb = v > zb ? v : zb;                               // (a NaN never wins)
+        }
+    smax[y][x] = zb;
+    __syncthreads();
+    for (int k = 0; k < kTieSetLanes; ++k) zb = smax[k][x] > zb ? smax[k][x] : zb;
+    const bool finite = zb > -__builtin_inf();                  // nothing finite: the default's (0, index 0) stays
     const double lo = zb - tie_slack(zb);
     int count = 0;
-    for (int s = 0; s < sets; ++s) count += pmax[(int64_t)s * set_stride + t] >= lo ? 1 : 0;
-    if (count > kTieMaxSets) {
-        atomicAdd(overflow, 1);
-        return;
+    if (live && finite)
+        for (int s = y; s < sets; s += kTieSetLanes) count += pmax[(int64_t)s * set_stride + t] >= lo ? 1 : 0;
+    scount[y][x] = count;
+    __syncthreads();
+    if (y == 0 && live) {
+        int total = 0;
+        for (int k = 0; k < kTieSetLanes; ++k) total += scount[k][x];
+        zbest[t] = zb;
+        emax[t] = 0ull;
+        imin[t] = INT32_MAX;
+        int base = -1;
+        if (total > kTieMaxSets) {
+            atomicAdd(overflow, 1);
+        } else if (total > 0) {
+            base = atomicAdd(n_pairs, total);
+            if (base + total > max_pairs) {                     // (cannot happen: max_pairs = kTieMaxSets * n)
+                atomicAdd(overflow, 1);
+                base = -1;
+            }
+        }
+        sbase[x] = base;
     }
-    const int at = atomicAdd(n_pairs, count);
-    if (at + count > max_pairs) {                           // (cannot happen: max_pairs = kTieMaxSets * n)
-        atomicAdd(overflow, 1);
-        return;
-    }
-    int k = 0;
-    for (int s = 0; s < sets; ++s)
-        if (pmax[(int64_t)s * set_stride + t] >= lo) pairs[at + k++] = make_int2(s, t);
+    __syncthreads();
+    if (!live || !finite || sbase[x] < 0) return;
+    int at = sbase[x];
+    for (int k = 0; k < y; ++k) at += scount[k][x];
+    for (int s = y; s < sets; s += kTieSetLanes)
+        if (pmax[(int64_t)s * set_stride + t] >= lo) pairs[at++] = make_int2(s, t);
 }
 
 // Workgroup = (pair, chunk): the nodes of the pair's set, for the pair's one sample.
 template <int PASS>
 __global__ __launch_bounds__(256) void tie_eval_kernel(TieArgs a) {
-    const int pair = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
-    if (pair >= *a.n_pairs) return;
+    // (the grid is sized for a generic step's pairs; a step with more is covered by the stride)
+    const int n_pairs = *a.n_pairs, chunk = blockIdx.x % a.chunks, stride = gridDim.x / a.chunks;
     if (PASS == 1 && *a.n_cands <= a.max_cands) return;     // the candidate list held them all
-    const int2 w = a.pairs[pair];
-    const int set = w.x, t = w.y;
     const GridDesc &g = a.g;
     const int S = g.n_rows;
-    const double zb = a.zbest[t], lo = zb - tie_slack(zb);
-    const int64_t col = (int64_t)t + a.sample0 + a.fsmp;
-    const bool direct = set >= a.groups_lds;
-    const int first = direct ? set - a.groups_lds : set;
-    const int stride = direct ? a.groups_direct : a.groups_lds;
-    const int n_list = direct ? (a.brick_list ? a.n_list : g.nbricks) : g.nbricks;
-    unsigned long long best = 0ull;
-    int best_node = INT32_MAX;
-    for (int i = first + chunk * stride; i < n_list; i += a.chunks * stride) {
-        const int b = (direct && a.brick_list) ? a.brick_list[i] : i;
-        int x0, y0, z0, vx, vy, vz;
-        brick_extents(g, b, x0, y0, z0, vx, vy, vz);
-        const int nvalid = vx * vy * vz;
-        for (int m = threadIdx.x; m < nvalid; m += blockDim.x) {
-            const int node = brick_walk_node(g, x0, y0, z0, vy, vz, m);
-            const int32_t *row = a.lut + (int64_t)node * S;
-            double stack = 0.0;
-            for (int r = 0; r < S; ++r) {                   // ascending rows: migratelib.c:54-59
-                int d = row[r];
-                d = d < 0 ? 0 : d;
-                stack += a.onsets[(int64_t)r * a.T + d + col];
-            }
-            if (!(stack * a.z_scale >= lo)) continue;
-            const double e = exp_correctly_rounded(stack * a.recip);
-            const unsigned long long key = (unsigned long long)__double_as_longlong(e);
-            if (PASS == 0) {
-                best = key > best ? key : best;
-                const int at = atomicAdd(a.n_cands, 1);
-                if (at < a.max_cands) {
-                    a.cands[at] = make_int2(node, t);
-                    a.cand_keys[at] = key;
+    for (int pair = blockIdx.x / a.chunks; pair < n_pairs; pair += stride) {
+        const int2 w = a.pairs[pair];
+        const int set = w.x, t = w.y;
+        const double zb = a.zbest[t], lo = zb - tie_slack(zb);
+        const int64_t col = (int64_t)t + a.sample0 + a.fsmp;
+        const bool direct = set >= a.groups_lds;
+        const int first = direct ? set - a.groups_lds : set;
+        const int step = direct ? a.groups_direct : a.groups_lds;
+        const int n_list = direct ? (a.brick_list ? a.n_list : g.nbricks) : g.nbricks;
+        unsigned long long best = 0ull;
+        int best_node = INT32_MAX;
+        for (int i = first + chunk * step; i < n_list; i += a.chunks * step) {
+            const int b = (direct && a.brick_list) ? a.brick_list[i] : i;
+            int x0, y0, z0, vx, vy, vz;
+            brick_extents(g, b, x0, y0, z0, vx, vy, vz);
+            const int nvalid = vx * vy * vz;
+            for (int m = threadIdx.x; m < nvalid; m += blockDim.x) {
+                const int node = brick_walk_node(g, x0, y0, z0, vy, vz, m);
+                const int32_t *row = a.lut + (int64_t)node * S;
+                double stack = 0.0;
+                for (int r = 0; r < S; ++r) {               // ascending rows: migratelib.c:54-59
+                    int d = row[r];
+                    d = d < 0 ? 0 : d;
+                    stack += a.onsets[(int64_t)r * a.T + d + col];
                 }
-            } else if (key == a.emax[t]) {
-                best_node = node < best_node ? node : best_node;
+                if (!(stack * a.z_scale >= lo)) continue;
+                const double e = exp_correctly_rounded(stack * a.recip);
+                const unsigned long long key = (unsigned long long)__double_as_longlong(e);
+                if (PASS == 0) {
+                    best = key > best ? key : best;
+                    const int at = atomicAdd(a.n_cands, 1);
+                    if (at < a.max_cands) {
+                        a.cands[at] = make_int2(node, t);
+                        a.cand_keys[at] = key;
+                    }
+                } else if (key == a.emax[t]) {
+                    best_node = node < best_node ? node : best_node;
+                }
             }
         }
+        if (PASS == 0) {
+            if (best) atomicMax(&a.emax[t], best);
+        } else if (best_node != INT32_MAX) {
+            atomicMin(&a.imin[t], best_node);
+        }
     }
-    if (PASS == 0) {
-        if (best) atomicMax(&a.emax[t], best);
-    } else if (best_node != INT32_MAX) {
-        atomicMin(&a.imin[t], best_node);
-    }
-}
-
-// the device's evaluation of exp_correctly_rounded (the tests pin it to the host's, bit for bit)
-__global__ __launch_bounds__(256) void exp_cr_kernel(const double *__restrict__ x, int64_t n,
-                                                     double *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = exp_correctly_rounded(x[i]);
 }
 
 // the lowest node among the listed candidates that reach their sample's largest exp
@@ -247,6 +264,13 @@ __global__ __launch_bounds__(256) void tie_pick_kernel(TieArgs a) {
         const int2 c = a.cands[i];
         if (a.cand_keys[i] == a.emax[c.y]) atomicMin(&a.imin[c.y], c.x);
     }
+}
+
+// the device's evaluation of exp_correctly_rounded (the tests pin it to the host's, bit for bit)
+__global__ __launch_bounds__(256) void exp_cr_kernel(const double *__restrict__ x, int64_t n,
+                                                     double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = exp_correctly_rounded(x[i]);
 }
 
 __global__ __launch_bounds__(256) void tie_apply_kernel(const int32_t *__restrict__ imin, int n,

@@ -2696,7 +2696,10 @@ def test_tie_rule_exp_reproduces_the_references_scalar_build(lib, oracle, cfg):
         a, b, c = eng.detect(lon, fsmp, lsmp, avail)
         assert np.array_equal(c, idx_scalar), (name, cfg, float(np.mean(c != idx_scalar)))
         assert np.mean(c != idx_vec) <= 0.085, (name, float(np.mean(c != idx_vec)))
-        assert np.array_equal(a, a0) and np.array_equal(b, b0)
+        # (values: the same maxima; the normalised ones within rounding -- the refinement runs on finer
+        # sets of bricks, i.e. another order of the sum over the nodes)
+        assert np.array_equal(a, a0)
+        np.testing.assert_allclose(b, b0, rtol=1e-13)
         assert 0.08 < np.mean(c != c0) < 0.14                  # ... and the default rule is the other one
         assert eng.get("tie_overflow_samples") == 0 and eng.get("tie_pairs") >= len(c)
         # the same refinement behind the volume-writing and the marginal-map launches' scans, and K steps
@@ -2729,7 +2732,8 @@ def test_tie_rule_exp_changes_nothing_where_the_maximum_stands_alone(lib, oracle
             if rule:
                 assert eng.get("tie_refined_steps") == 1 and eng.get("tie_overflow_samples") == 0
             eng.close()
-        assert all(np.array_equal(x, y) for x, y in zip(*out)), recipe
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2]), recipe
+        np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-13)
     case = synth.make_case("C3", step=1, grid=(24, 24, 16), rows=12, n_samples=130, quiet=True)
     eng = lib.Engine(0, tie_rule=1, groups=64)
     eng.load_lut(case.traveltimes)
