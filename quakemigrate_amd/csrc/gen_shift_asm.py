@@ -248,6 +248,15 @@ def issue_window(e, q, hdr):
         for m in range(NQMIN):
             for line in quad_reads(WIN[q], m):
                 e(line)
+    if "maskq" in EXP:
+        # experiment: the optional quads under an EXEC mask instead of behind branches
+        for m in range(NQMIN, NQMAX):
+            e(f"s_cmp_gt_u32 s{hdr + 1}, {m}")
+            e("s_cselect_b64 exec, -1, 0")
+            for line in (contig_reads(WIN[q], m) if CONTIG else quad_reads(WIN[q], m)):
+                e(line)
+        e("s_mov_b64 exec, -1")
+        return
     done = e.label("rd")
     for m in range(NQMIN, NQMAX):
         e(f"s_cmp_le_u32 s{hdr + 1}, {m}")
