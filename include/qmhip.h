@@ -12,7 +12,9 @@
  * identical signatures, so the UNMODIFIED reference front-end runs on this
  * library.  Part 2 is the handle API (resident travel-time table, fused
  * stack + exp + scan that never materialises the 4-D volume) that this
- * repository's own host side (quakemigrate_amd/) drives.
+ * repository's own host side (quakemigrate_amd/) drives.  Part 3 is the
+ * continuous detect sweep as a pipeline (pinned ring, copies overlapped with
+ * compute) -- the loop of QuakeScan._continuous_compute around part 2's call.
  *
  * Conventions: every function of part 2 returns 0 on success, non-zero on
  * failure; qm_last_error() returns a thread-local message.  `*_on_device`
