@@ -257,6 +257,21 @@ def issue_window(e, q, hdr):
                 e(line)
         e("s_mov_b64 exec, -1")
         return
+    if "outofline" in EXP and NQMAX > NQMIN:
+        # experiment: the common case (no optional quad) falls through a NOT-taken branch; the optional
+        # quads' reads sit out of line (e.tail, emitted behind the loop) and jump back
+        more, back = e.label("mq"), e.label("bk")
+        e(f"s_cmp_gt_u32 s{hdr + 1}, {NQMIN}")
+        e(f"s_cbranch_scc1 {more}")
+        e(f"{back}:")
+        tail = [f"{more}:"]
+        for m in range(NQMIN, NQMAX):
+            if m > NQMIN:
+                tail += [f"s_cmp_le_u32 s{hdr + 1}, {m}", f"s_cbranch_scc1 {back}"]
+            tail += (contig_reads(WIN[q], m) if CONTIG else quad_reads(WIN[q], m))
+        tail.append(f"s_branch {back}")
+        e.tail = getattr(e, "tail", []) + tail
+        return
     done = e.label("rd")
     for m in range(NQMIN, NQMAX):
         e(f"s_cmp_le_u32 s{hdr + 1}, {m}")
@@ -783,6 +798,12 @@ def body(degree, volume):
         e(f"{end}:")
     else:
         e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    if getattr(e, "tail", None):
+        end = e.label("end")
+        e(f"s_branch {end}")
+        for line in e.tail:
+            e(line)
+        e(f"{end}:")
     return e.lines
 
 
