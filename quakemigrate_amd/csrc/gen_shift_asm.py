@@ -84,6 +84,8 @@ PF_EVERY = int(os.environ.get("QM_SHIFT_PF_EVERY", "2"))   # 2: one prefetch per
                                                             # the same 128-byte line either way; C3 -0.4 %, C4 -0.7 %,
                                                             # locate volume -1.7 %, profiles/r05_ab_runs.txt); 1: per row.
                                                             # No prefetch at all: C3 +12 %, C4 +17 %.
+STAGING = False          # (set by body(): the pair of rows being emitted carries the staging step)
+STAGE_IN_LOOP = os.environ.get("QM_SHIFT_STAGE_IN_LOOP", "1") == "1"   # row blocks, round 5: see stage_step
 PLANE2 = 40896           # plane A -> plane B, bytes (two 4-wave workgroups per CU, 80 KB each): 128 q + 64
                          # keeps the staging stores conflict-free
 PLANE3 = 51136           # the same for the 12-wave workgroup (one per CU: 100 KB of windows + 60 KB of
@@ -161,7 +163,7 @@ SB = 48                  # first hard SGPR (s_load_dwordx16 / x8 destinations)
 def configure_scalars(packed):
     """hard SGPR plan; the record buffers shrink with packed records"""
     global PACKED, REC, NBUF, BUF, R_HDR, R_BASE, ST, SBASE, SMASK, SPAIRS, SNODE, STAB, SOFF, SPF, SVA
-    global SNEGINF, SMAGIC, SEND
+    global SNEGINF, SMAGIC, SEND, SG_META, SG_ROW, SG_AFTER, SG_SRC, SG_T, SG_LDS
     PACKED = packed
     REC = rec_bytes(packed)  # bytes per stream record
     NBUF = REC // 4          # dwords of a record
@@ -180,6 +182,15 @@ def configure_scalars(packed):
     SNEGINF = ST + 16        # -inf (pair)
     SMAGIC = ST + 18         # 1.5 * 2^52 (pair): z + magic has rint(z) in its low dword
     SEND = ST + 20
+    if BLOCK and STAGE_IN_LOOP:
+        # row blocks, round 5: the NEXT block's staging is issued from inside the row loop (stage_step)
+        SG_META = (SEND + 3) & ~3     # the staging row's window record (min delay, span, first slot, slots)
+        SG_ROW = SG_META + 4          # the row this wavefront stages next
+        SG_AFTER = SG_META + 5        # vector loads of its own the call has issued since its last staging load
+        SG_SRC = SG_META + 6          # (pair) the chunk's global address
+        SG_T = SG_META + 8            # (pair) temporaries
+        SG_LDS = SG_META + 10         # LDS address of the row's first slot, plane A
+        SEND = SG_META + 12
     assert STAB % 2 == 0 and SB % 4 == 0 and SVA % 2 == 0 and SPF % 2 == 0 and SNEGINF % 2 == 0 and SEND <= 102
 
 
@@ -313,6 +324,82 @@ def node_adds(e, p, g, first):
         e(f"v_add_f64 {a}, {w}, {'0' if first else a}")
 
 
+def stage_step(e):
+    """Row blocks: stage ONE row window of the workgroup's next block (LDS-direct loads: global memory -> LDS
+    at M0 + 16 lane, no registers) from inside the row loop, one row per pair of rows added.  Round 5: issued as
+    a burst in front of the loop -- 20 loads per wavefront, all eight wavefronts at once -- the loads queued up
+    in the CU's one vector-memory path and every wavefront stood still until its own were accepted: 15 % of a
+    128-row step (the loop without any staging: 55.1 -> 44.9 ms, profiles/r05_ab_runs.txt).  Spread over the
+    block they cost their issue slots.  Everything is wave-uniform: the row's record (s_load_dwordx4 one step
+    ahead) gives the window's first sample, first slot and slot count; slots 0-63 and 64-(slots - 1) of both
+    planes are four loads with the row pointer as their scalar base and lane * 32 as offset (plane B: the
+    instruction offset 16 moves the global AND the LDS address, so its M0 is 16 short); EXEC masks the second
+    chunk.  M0 is shared with the register-index mode: the step sits between two nodes, the next one's
+    s_set_gpr_idx_on rewrites the bits the mode reads.  The kernel hands over rows only when every window of
+    the table lies inside the onsets' rows for this tile (no partial slots) and holds at most 127 slots."""
+    skip = e.label("sg")
+    m, t = SG_META, SG_T
+    if "stgnoload" in EXP or "stgsame" in EXP:
+        # timing experiments (wrong results): the step without its loads / every load from the block's first row
+        inner = Emitter()
+        inner.nlabel = e.nlabel + 100
+        EXP.discard("stgnoload") if False else None
+        saved = set(EXP)
+        EXP.difference_update({"stgnoload", "stgsame"})
+        stage_step(inner)
+        EXP.update(saved)
+        for line in inner.lines:
+            if "stgnoload" in saved and line.startswith("global_load_lds"):
+                line = "s_nop 0"
+            if "stgsame" in saved and (line.startswith(f"s_mul_i32 s{SG_SRC}") or line.startswith(f"s_mul_hi_u32 s{SG_SRC + 1}")):
+                line = line.split(",")[0] + ", 0"
+                line = line.replace("s_mul_i32", "s_mov_b32").replace("s_mul_hi_u32", "s_mov_b32")
+            e(line)
+        e.nlabel = inner.nlabel
+        return
+    e(f"s_cmp_ge_u32 s{SG_ROW}, %[stgn]")
+    e(f"s_cbranch_scc1 {skip}")
+    e(f"s_mul_i32 s{SG_SRC}, s{SG_ROW}, %[stgt8]")              # row * bytes per onset row (64 bits)
+    e(f"s_mul_hi_u32 s{SG_SRC + 1}, s{SG_ROW}, %[stgt8]")
+    e(f"s_ashr_i32 s{t + 1}, s{m}, 31")                         # + 8 * (the window's first sample)
+    e(f"s_mov_b32 s{t}, s{m}")
+    e(f"s_lshl_b64 {s2(t)}, {s2(t)}, 3")
+    e(f"s_add_u32 s{SG_SRC}, s{SG_SRC}, s{t}")
+    e(f"s_addc_u32 s{SG_SRC + 1}, s{SG_SRC + 1}, s{t + 1}")
+    e(f"s_add_u32 s{SG_SRC}, s{SG_SRC}, %[stglo]")
+    e(f"s_addc_u32 s{SG_SRC + 1}, s{SG_SRC + 1}, %[stghi]")
+    e(f"s_lshl_b32 s{SG_LDS}, s{m + 2}, 4")
+    e(f"s_add_u32 s{SG_LDS}, s{SG_LDS}, %[stglds]")
+    e(f"s_mov_b32 m0, s{SG_LDS}")
+    e("s_nop 0")
+    e(f"global_load_lds_dwordx4 %[lane32], {s2(SG_SRC)}")
+    e(f"s_add_u32 m0, s{SG_LDS}, {PLANE - 16}")
+    e("s_nop 0")
+    e(f"global_load_lds_dwordx4 %[lane32], {s2(SG_SRC)} offset:16")
+    e(f"s_sub_u32 s{t}, s{m + 3}, 64")                          # slots 64 ..: 0-63 of them
+    e(f"s_bfm_b64 exec, s{t}, 0")
+    e(f"s_add_u32 s{SG_SRC}, s{SG_SRC}, 2048")
+    e(f"s_addc_u32 s{SG_SRC + 1}, s{SG_SRC + 1}, 0")
+    e(f"s_add_u32 m0, s{SG_LDS}, 1024")
+    e("s_nop 0")
+    e(f"global_load_lds_dwordx4 %[lane32], {s2(SG_SRC)}")
+    e(f"s_add_u32 m0, s{SG_LDS}, {1024 + PLANE - 16}")
+    e("s_nop 0")
+    e(f"global_load_lds_dwordx4 %[lane32], {s2(SG_SRC)} offset:16")
+    e("s_mov_b64 exec, -1")
+    e(f"s_mov_b32 s{SG_AFTER}, 0")
+    e(f"s_add_u32 s{SG_ROW}, s{SG_ROW}, %[stgstride]")
+    e(f"{skip}:")
+
+
+def stage_record(e):
+    """the record of the row the wavefront stages next (the buffer has slack past its end).  Issued at a row's
+    top beside the stream's: in the step itself, two thirds into a row, it was still on its way to L2 and
+    back at the next row's top (every wait there is a wait for everything) -- 9 % of a 128-row step."""
+    e(f"s_lshl_b32 s{SG_T}, s{SG_ROW}, 4")
+    e(f"s_load_dwordx4 s[{SG_META}:{SG_META + 3}], %[stgmeta], s{SG_T}")
+
+
 def row_iter(e, p, first):
     """row of parity p: its record is in BUF[p], its window in WIN[p].  The next row's window is
     requested before this row's adds (a block of reads at the row's start: spread between the adds,
@@ -327,6 +414,8 @@ def row_iter(e, p, first):
     if "nosmem" not in EXP:
         e(f"s_add_u32 s{SOFF}, s{SOFF}, {REC}")
         e(f"s_load_dwordx{NBUF} s[{BUF[q]}:{BUF[q] + NBUF - 1}], {s2(STAB)}, s{SOFF}")
+    if p == 0 and STAGING:
+        stage_record(e)
     if "interleave" in EXP:
         # experiment: one body per quad count, the next row's reads dealt two per node behind the
         # first nodes' adds (all issued by the row's middle)
@@ -361,6 +450,10 @@ def row_iter(e, p, first):
             e(f"global_load_dword v{VPF}, v{VZERO}, {s2(SPF)}")
             e(f"s_add_u32 s{SPF}, s{SPF}, {REC * (2 if PF_EVERY == 2 else 1)}")
             e(f"s_addc_u32 s{SPF + 1}, s{SPF + 1}, 0")
+            if BLOCK and STAGE_IN_LOOP and (STAGING or FAR):
+                e(f"s_add_u32 s{SG_AFTER}, s{SG_AFTER}, 1")
+        if pos == 5 and p == 1 and STAGING:
+            stage_step(e)
 
 
 def node_index(e, g, to_vgpr=True):
@@ -733,6 +826,11 @@ def body(degree, volume):
         e(f"v_mov_b32 v{VMAG + 1}, 0x43380000")
     e(f"s_add_u32 s{SPF}, s{STAB}, {PF_AHEAD * REC}")
     e(f"s_addc_u32 s{SPF + 1}, s{STAB + 1}, 0")
+    if BLOCK and STAGE_IN_LOOP:
+        e(f"s_mov_b32 s{SG_AFTER}, 0")
+        if not FAR:
+            e(f"s_mov_b32 s{SG_ROW}, %[stgrow]")
+            stage_record(e)
     e("s_waitcnt lgkmcnt(0)")
     issue_window(e, 0, BUF[1] + R_HDR)
     group = e.label("grp")
@@ -756,11 +854,31 @@ def body(degree, volume):
         for r in range(ACC, ACC + 64):
             e(f"v_mov_b32 v{r}, 0")
         e(f"{carry}:")
+    global STAGING
+    STAGING = BLOCK and STAGE_IN_LOOP and not FAR
     e(f"{group}:")
     row_iter(e, 0, True)
     row_iter(e, 1, False)
     e(f"s_sub_u32 s{SPAIRS}, %[npairs], 2")                    # borrow <=> the group has one pair
     e(f"s_cbranch_scc1 {nopair}")
+    if STAGING:
+        # pairs of rows WITH the staging step while this wavefront has rows of the next block left to stage
+        # (five of a block's seventeen), then the plain loop: the step's bookkeeping -- its skip test, the
+        # record load, the count of loads behind the last staging load -- costs a pair of rows 4 %
+        plain, staged = e.label("pl"), e.label("st")
+        e(f"s_cmp_lt_u32 s{SG_ROW}, %[stgn]")
+        e(f"s_cbranch_scc0 {plain}")
+        e(f"{staged}:")
+        row_iter(e, 0, False)
+        row_iter(e, 1, False)
+        e(f"s_sub_u32 s{SPAIRS}, s{SPAIRS}, 1")
+        e(f"s_cbranch_scc1 {nopair}")
+        e(f"s_cmp_lt_u32 s{SG_ROW}, %[stgn]")
+        e(f"s_cbranch_scc1 {staged}")
+        e(f"{plain}:")
+        e(f"s_add_u32 s{SG_AFTER}, s{SG_AFTER}, s{SPAIRS}")     # the plain loop: s[SPAIRS] + 1 more pairs, one
+        e(f"s_add_u32 s{SG_AFTER}, s{SG_AFTER}, 1")            # prefetch each
+        STAGING = False
     e(f"{pair}:")
     row_iter(e, 0, False)
     row_iter(e, 1, False)
@@ -770,6 +888,18 @@ def body(degree, volume):
     if BLOCK:
         more = e.label("mb")
         e("s_set_gpr_idx_off")
+        if STAGE_IN_LOOP and not FAR:
+            # rows of the next block that this block's pairs of rows did not cover (a short last block in
+            # front of a full one)
+            again, done = e.label("sa"), e.label("sd")
+            e(f"{again}:")
+            e(f"s_cmp_ge_u32 s{SG_ROW}, %[stgn]")
+            e(f"s_cbranch_scc1 {done}")
+            stage_record(e)
+            e("s_waitcnt lgkmcnt(0)")
+            stage_step(e)
+            e(f"s_branch {again}")
+            e(f"{done}:")
         e("s_bitcmp1_b32 %[flags], 1")                         # last block: exponentiate, reduce
         e(f"s_cbranch_scc0 {more}")
         epilogue(e, degree, volume)
@@ -784,12 +914,18 @@ def body(degree, volume):
         # no more loads are outstanding than this call issued itself -- its stream prefetches, one
         # per row, which nobody needs to wait for (a full vmcnt(0) here cost a round trip to HBM
         # per block).  2 * npairs of them at least: wait down to the largest step below that.
+        # (round 5: the count is kept by the loop -- one prefetch per PAIR of rows since PF_EVERY = 2, and the
+        # staging loads the loop itself now issues for the next block reset it)
         end = e.label("wv")
         e("s_waitcnt lgkmcnt(0)")
-        e(f"s_lshl_b32 s{SPAIRS}, %[npairs], 1")
-        for step in (32, 24, 16, 8):
+        if STAGE_IN_LOOP:
+            count, steps = SG_AFTER, (24, 16, 12, 8, 4)
+        else:
+            count, steps = SPAIRS, (32, 24, 16, 8)
+            e(f"s_lshl_b32 s{SPAIRS}, %[npairs], {1 if PF_EVERY == 1 else 0}")
+        for step in steps:
             nxt = e.label("ws")
-            e(f"s_cmp_ge_u32 s{SPAIRS}, {step}")
+            e(f"s_cmp_ge_u32 s{count}, {step}")
             e(f"s_cbranch_scc0 {nxt}")
             e(f"s_waitcnt vmcnt({step})")
             e(f"s_branch {end}")
@@ -827,6 +963,7 @@ def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False,
     print("        const void *stream, " + ("unsigned flags, const void *next_run, unsigned next_off, const void *next_meta, "
                                             if block else "int ngroups, const void *next_run, unsigned next_off, const void *next_meta, ")
           + "int npairs, unsigned lane_addr, "
+          + ("const ShiftStageNext &stage, " if block and STAGE_IN_LOOP and not far else "")
           + ("unsigned state_addr, " if lds_state else "")
           + ("unsigned lane_addr_b, " if far else "") + "int nz, "
           f"int nynz, double scale, const double (&c)[{degree + 1}]"
@@ -839,6 +976,9 @@ def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False,
           + ") {")
     print("    const unsigned long long sp = (unsigned long long)stream;")
     print("    const unsigned tablo = (unsigned)sp, tabhi = (unsigned)(sp >> 32);")
+    if block and STAGE_IN_LOOP and not far:
+        print("    const unsigned long long gp = (unsigned long long)stage.src;")
+        print("    const unsigned stglo = (unsigned)gp, stghi = (unsigned)(gp >> 32);")
     print(f"    const unsigned long long cl = (unsigned long long)__double_as_longlong(c[{degree}]);")
     print("    const unsigned clo = (unsigned)cl, chi = (unsigned)(cl >> 32);")
     if marginal:
@@ -865,6 +1005,10 @@ def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False,
         ins += ['[laneb] "v"(lane_addr_b)']
     if block:
         ins += ['[flags] "s"(flags)']
+    if block and STAGE_IN_LOOP and not far:
+        ins += ['[stgmeta] "s"(stage.meta)', '[stgn] "s"(stage.rows)', '[stgrow] "s"(stage.first_row)',
+                '[stgstride] "s"(stage.stride)', '[stglo] "s"(stglo)', '[stghi] "s"(stghi)',
+                '[stgt8] "s"(stage.row_bytes)', '[stglds] "s"(stage.lds)', '[lane32] "v"(stage.lane32)']
     if block or (NEXT_RUN and NEXT_META):
         ins += ['[mdrun] "s"(next_meta)']
     if block or NEXT_RUN:
@@ -906,6 +1050,7 @@ def main():
     print(f"constexpr bool kShiftPackedGroups = {'true' if PACKED_GROUPS else 'false'};   // 32-byte records (register indices as bytes)")
     print(f"constexpr bool kShiftPackedBlocks = {'true' if PACKED_BLOCKS else 'false'};   // ... of the row-block loops")
     print(f"constexpr int kShiftBlockVgprs = {VB_BLOCK};   // row-block flavour: the compiler's own code stays below")
+    print(f"constexpr bool kShiftStageInLoop = {'true' if STAGE_IN_LOOP else 'false'};   // row blocks: the next block's staging issued by the row loop")
     print(f"constexpr int kShiftVolumeDegree = {VOLUME_DEGREE};   // 2^f polynomial of the volume-writing flavours")
     print(f"constexpr int kShiftMarginalDegree = {MARGINAL_DEGREE};   // 2^f polynomial of the marginal-map flavours")
     for degree, volume, lds_state, far, lazy, block, name in (

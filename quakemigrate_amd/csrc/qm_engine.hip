@@ -177,6 +177,8 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         s.nw = e->shift_nw;
         s.nblk = e->shift_nblk;
         s.sb = e->shift_sb;
+        s.stage_slots = e->shift_stage_slots;
+        s.stage_reach = e->shift_stage_reach;
         // groups a wavefront sees before its running maximum is reset: bricks per workgroup x
         // groups per (brick, wavefront)
         const int64_t life = ((int64_t)e->shg.nbricks / std::max(1, a.ngroups)) *

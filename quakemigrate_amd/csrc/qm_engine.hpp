@@ -140,6 +140,7 @@ struct TableState {
     DevBuf<uint32_t> d_shstream;
     int n_shwide = 0, shift_rows2 = 0;
     int shift_nblk = 1, shift_sb = 0;       // row blocks (tables of more than 64 rows): blocks, rows per block
+    int shift_stage_slots = 0, shift_stage_reach = 0;   // ... largest row window (slots), furthest sample it holds
     bool shift_direct = false;              // ... staged by LDS-direct loads (stack_shift_rows2_kernel)
     bool shift_quad = false;                // ... by two 4-wave workgroups per CU (stack_shift_rows4_kernel)
     bool shift_built = false, shift_ok = false;

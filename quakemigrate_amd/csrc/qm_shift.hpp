@@ -25,6 +25,19 @@
 
 namespace qm {
 
+// Row blocks: the rows of the workgroup's NEXT block that a wavefront's row loop stages itself while it adds
+// the current one (gen_shift_asm.py, stage_step).  rows = 0: nothing (no block follows, or the kernel has
+// staged it: a tile whose windows reach past the onsets' last samples, a wavefront without a group).
+struct ShiftStageNext {
+    const void *meta;        // the block's row-window records (smeta: 16 bytes per row)
+    int rows;                // rows of the block
+    int first_row, stride;   // this wavefront's rows: first_row, first_row + stride, ...
+    const void *src;         // onsets + (the block's first table row) * T + fsmp + sample0 + t_first
+    unsigned row_bytes;      // 8 T
+    unsigned lds;            // LDS byte address of the half the block goes to
+    unsigned lane32;         // lane * 32
+};
+
 #ifndef QM_SHIFT_ASM_INC                     // (development: tools/shift_variants.sh swaps the loop)
 #define QM_SHIFT_ASM_INC "qm_shift_asm.inc"
 #endif
@@ -94,6 +107,8 @@ struct ShiftArgs {
     int lazy;                    // detect: the loop flavour that recovers the arg-max lazily
     int nblk;                    // row blocks per brick (1: all rows of a brick are staged at once)
     int sb;                      // rows per block (even; the last block may hold fewer)
+    int stage_slots;             // row blocks: the largest slot count of a row window (the loop's staging: <= 127)
+    int stage_reach;             // ... and the furthest sample past a tile's first that a window holds
 };
 
 // a wavefront that sees at least this many 2x2x2 groups between two resets of its running
@@ -176,7 +191,9 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
                                                          int32_t *__restrict__ sfit,
                                                          unsigned long long *__restrict__ tally,
                                                          int plane_bytes, int nblk, int sb) {
-    // tally[0] += quads the loop fetches, tally[1] += (group, row) pairs: operands per add
+    // tally[0] += quads the loop fetches, tally[1] += (group, row) pairs: operands per add; tally[2] = the
+    // largest slot count of a row window, tally[3] = the furthest window sample past a tile's first one (what
+    // the row-block kernels need to know before they let the row loop stage: ShiftArgs::stage_slots / _reach)
     // Row blocks (nblk > 1): workgroup vb = (brick, block) handles rows [k sb, k sb + S) of brick b;
     // smeta / stotal / sfit are per (brick, block), sb rows apart.
     __shared__ int need[kShiftMaxRows];
@@ -211,6 +228,9 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
             const int4 raw = meta_raw[(int64_t)b * g.n_rows + r0 + r];
             smeta[(int64_t)vb * sb + r] = make_int4(raw.x, raw.y, run, need[r]);
             run += need[r];
+            atomicMax(&tally[2], (unsigned long long)need[r]);
+            const int reach = raw.x + 4 * need[r];
+            atomicMax(&tally[3], (unsigned long long)(reach > 0 ? reach : 0));
         }
         stotal[vb] = run;
         const int zero_row = (S & 1) ? 64 + kShiftNqMin : 0;   // all-zero window of the padding row
@@ -703,6 +723,16 @@ void stack_shift_rows_kernel(ShiftArgs s) {
 constexpr int kShiftHalfBytes = 80 * 1024;
 static_assert(2 * kShiftPlane <= kShiftHalfBytes, "a half holds both planes");
 
+// the all-zero window of the padding row of a block with an odd row count
+__device__ __forceinline__ void stage_shift_zero_row(const ShiftArgs &s, double *half, int vb, int S, int wave,
+                                                     int lane) {
+    if ((S & 1) && wave == 0) {
+        const int z = s.stotal[vb];
+        for (int u = lane; u < 4 * (64 + kShiftNqMin); u += kWave)
+            half[((u & 2) ? kShiftPlane / 8 : 0) + 2 * (z + (u >> 2)) + (u & 1)] = 0.0;
+    }
+}
+
 template <int NW>
 __device__ __forceinline__ void stage_shift_block_direct(const ShiftArgs &s, double *half, int vb,
                                                          int row0, int S, int wave, int lane,
@@ -752,6 +782,43 @@ __device__ __forceinline__ void stage_shift_block_direct(const ShiftArgs &s, dou
         const int first = m.x + a.fsmp + a.sample0 + t_first;      // index inside the row
         const int room = a.T - first;
         const double *src = a.onsets + (int64_t)(row0 + r) * a.T + first;
+#ifndef QM_ROWS_STAGE_SLOW
+        if (room >= 4 * m.w) {
+            // Every slot of the window lies inside the row (all rows but those that reach the onsets' last
+            // samples): everything about the loads is wave-uniform except the lane's 32 bytes, so the pair
+            // of loads per 64 slots is issued with scalar bookkeeping only -- EXEC = the chunk's slots, M0 =
+            // the plane's LDS address, the row pointer as the instruction's scalar base (the instruction
+            // offset moves the global AND the LDS address: plane B's M0 is 16 short).  Round 5: the
+            // compiler's per-lane form of this loop (the code below) was 18 % of a 128-row step.
+            // (wave-uniform by construction; said again for the 4-wave form, whose metadata arrive in VGPRs)
+            const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane(
+                (int)((unsigned)(uintptr_t)((lds_f64 *)half) + 16u * (unsigned)m.z));
+            const unsigned long long sp = (unsigned long long)src;
+            src = (const double *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sp >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)sp));
+            const int slots = __builtin_amdgcn_readfirstlane(m.w);
+            const unsigned lane32 = (unsigned)lane * 32u;
+            for (int c = 0; c < slots; c += kWave) {
+                const int n = slots - c < kWave ? slots - c : kWave;
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "s_lshr_b64 exec, -1, %[sh]\n\t"
+                             "s_mov_b32 m0, %[ma]\n\t"
+                             "s_nop 0\n\t"
+                             "global_load_lds_dwordx4 %[vo], %[src]\n\t"
+                             "s_mov_b32 m0, %[mb]\n\t"
+                             "s_nop 0\n\t"
+                             "global_load_lds_dwordx4 %[vo], %[src] offset:16\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sv] "=&s"(saved)
+                             : [sh] "s"(kWave - n), [ma] "s"(la + 16u * (unsigned)c),
+                               [mb] "s"(la + 16u * (unsigned)c + (unsigned)kShiftPlane - 16u), [vo] "v"(lane32),
+                               [src] "s"(src + 4 * c)
+                             : "memory", "m0");
+            }
+            continue;
+        }
+#endif
         for (int c = 0; c * kWave < m.w; ++c) {
             const int slot = c * kWave + lane;
             if (slot < m.w) {
@@ -772,11 +839,7 @@ __device__ __forceinline__ void stage_shift_block_direct(const ShiftArgs &s, dou
             }
         }
     }
-    if ((S & 1) && wave == 0) {                                    // the padding row's zero window
-        const int z = s.stotal[vb];
-        for (int u = lane; u < 4 * (64 + kShiftNqMin); u += kWave)
-            half[((u & 2) ? kShiftPlane / 8 : 0) + 2 * (z + (u >> 2)) + (u & 1)] = 0.0;
-    }
+    stage_shift_zero_row(s, half, vb, S, wave, lane);
 }
 
 template <bool VOLUME, int NW>
@@ -807,6 +870,11 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
     const int rows2max = s.sb + (s.sb & 1);
     const int64_t rpw = shift_recs_per_wave(g, rows2max, NW);
     auto rows_of = [&](int k) { return g.n_rows - k * s.sb < s.sb ? g.n_rows - k * s.sb : s.sb; };
+    // The row loop stages the next block itself (gen_shift_asm.py, stage_step) where its scalar-only form
+    // holds: every window of the table inside the onsets' rows for this tile, at most 127 slots each.
+    const int tile_room = a.T - (a.fsmp + a.sample0 + t_first);
+    const bool in_loop = kShiftStageInLoop && s.stage_slots <= 127 && tile_room >= s.stage_reach &&
+                         a.T < (1 << 28);
     int b = group;
     while (b < g.nbricks && !s.sfit[b]) b += a.ngroups;            // (others: the direct kernel's job)
     int cur = 0;                                                   // half the current block lies in
@@ -826,11 +894,26 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
             const void *next_meta = shift_meta_ahead(s, g, b, nb, k);
             // the next block (of this brick, or the first of the next) into the idle half
             double *idle = win + (cur ^ 1) * (kShiftHalfBytes / 8);
-            if (k + 1 < s.nblk)
-                stage_shift_block_direct<NW>(s, idle, b * s.nblk + k + 1, (k + 1) * s.sb, rows_of(k + 1),
-                                             wave, lane, t_first);
-            else if (nb < g.nbricks)
-                stage_shift_block_direct<NW>(s, idle, nb * s.nblk, 0, rows_of(0), wave, lane, t_first);
+            const bool follows = k + 1 < s.nblk || nb < g.nbricks;
+            const int vbn = k + 1 < s.nblk ? b * s.nblk + k + 1 : nb * s.nblk;
+            const int kn = k + 1 < s.nblk ? k + 1 : 0;
+            ShiftStageNext stage{};
+            stage.meta = s.smeta;
+#ifndef QM_ROWS_EXP_NOSTAGE      // (timing experiment: wrong results)
+            if (follows && in_loop && mine) {
+                stage_shift_zero_row(s, idle, vbn, rows_of(kn), wave, lane);
+                stage.meta = s.smeta + (int64_t)vbn * s.sb;
+                stage.rows = rows_of(kn);
+                stage.first_row = wave;
+                stage.stride = NW;
+                stage.src = a.onsets + (int64_t)kn * s.sb * a.T + a.fsmp + a.sample0 + t_first;
+                stage.row_bytes = (unsigned)a.T * 8u;
+                stage.lds = (unsigned)(uintptr_t)((lds_f64 *)idle);
+                stage.lane32 = (unsigned)lane * 32u;
+            } else if (follows) {
+                stage_shift_block_direct<NW>(s, idle, vbn, kn * s.sb, rows_of(kn), wave, lane, t_first);
+            }
+#endif
             if (mine) {
                 const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRecBlocks;
                 const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
@@ -838,22 +921,24 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
                 if constexpr (VOLUME)
                     shift_group_rows_volume(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
                                             (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes),
-                                            g.nz, g.ny * g.nz, a.z_scale, c, a.volume + t_first,
+                                            stage, g.nz, g.ny * g.nz, a.z_scale, c, a.volume + t_first,
                                             (unsigned)(a.vol_stride * 8), (unsigned)lane * 32u, store_lanes);
                 else if (s.lazy)
                     shift_group_rows_lazy(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
                                           (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes),
-                                          g.nz, g.ny * g.nz, a.z_scale, c);
+                                          stage, g.nz, g.ny * g.nz, a.z_scale, c);
                 else
                     shift_group_rows(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
-                                     (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes), g.nz,
-                                     g.ny * g.nz, a.z_scale, c);
+                                     (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes), stage,
+                                     g.nz, g.ny * g.nz, a.z_scale, c);
             }
             // this wavefront's staging loads are in LDS (the loop has waited for them, leaving only
             // its own stream prefetches in flight; a wavefront without a group waits here), then
             // everyone's; the current half is free
             if (!mine || VOLUME) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef QM_ROWS_EXP_NOBARRIER    // (timing experiment: wrong results)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
             cur ^= 1;
         }
         b = nb;
@@ -919,20 +1004,22 @@ void stack_shift_rows4_kernel(ShiftArgs s) {
             stage_shift_block_direct<NW>(s, win, b * s.nblk + k, k * s.sb, rows_of(k), wave, lane, t_first);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (mine) {
+                ShiftStageNext no_stage{};               // (one buffer: nothing for the loop to stage ahead)
+                no_stage.meta = s.smeta;
                 const char *run = s.stream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRecBlocks;
                 const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
                     (int)((k == 0 ? 1u : 0u) | (k == s.nblk - 1 ? 2u : 0u)));
                 if constexpr (VOLUME)
                     shift_group_rows_volume(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
-                                            (rows_of(k) + 1) / 2, lane_addr, g.nz, g.ny * g.nz, a.z_scale, c,
+                                            (rows_of(k) + 1) / 2, lane_addr, no_stage, g.nz, g.ny * g.nz, a.z_scale, c,
                                             a.volume + t_first, (unsigned)(a.vol_stride * 8),
                                             (unsigned)lane * 32u, store_lanes);
                 else if (s.lazy)
                     shift_group_rows_lazy(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
-                                          (rows_of(k) + 1) / 2, lane_addr, g.nz, g.ny * g.nz, a.z_scale, c);
+                                          (rows_of(k) + 1) / 2, lane_addr, no_stage, g.nz, g.ny * g.nz, a.z_scale, c);
                 else
                     shift_group_rows(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
-                                     (rows_of(k) + 1) / 2, lane_addr, g.nz, g.ny * g.nz, a.z_scale, c);
+                                     (rows_of(k) + 1) / 2, lane_addr, no_stage, g.nz, g.ny * g.nz, a.z_scale, c);
             }
         }
         b = nb;

@@ -261,9 +261,9 @@ int build_shift_tables(qm_engine *e) {
         const size_t nvb = (size_t)g.nbricks * nblk;               // (brick, row block) pairs
         // (d_shmeta: + 4 KB of slack -- the row-block loops prefetch that much metadata ahead)
         if (e->d_shraw.ensure(4 * br) || e->d_shmeta.ensure(4 * nvb * sb + 1024) ||
-            e->d_shtotal.ensure(nvb) || e->d_shfit.ensure(nvb) || e->d_scalar.ensure(8))
+            e->d_shtotal.ensure(nvb) || e->d_shfit.ensure(nvb) || e->d_scalar.ensure(12))
             return 1;
-        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 8 * sizeof(int32_t), e->stream));
+        QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 12 * sizeof(int32_t), e->stream));
         hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
                            e->d_lut.p, reinterpret_cast<int4 *>(e->d_shraw.p), e->d_scalar.p);
         hipLaunchKernelGGL(qm::shift_need_kernel, dim3((unsigned)nvb), dim3(256), 0, e->stream, g,
@@ -273,12 +273,14 @@ int build_shift_tables(qm_engine *e) {
                            blocks && direct ? qm::kShiftPlane : qm::shift_plane(nw), nblk, sb);
         QM_HIP(hipGetLastError());
         fit.resize(nvb);
-        unsigned long long tally[2] = {0, 0};
+        unsigned long long tally[4] = {0, 0, 0, 0};
         QM_HIP(copy_back(fit.data(), e->d_shfit.p, nvb * sizeof(int32_t), e->stream));
         QM_HIP(copy_back(tally, e->d_scalar.p + 4, sizeof(tally), e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
         e->shift_quads = (int64_t)tally[0];
         e->shift_group_rows = (int64_t)tally[1];
+        e->shift_stage_slots = (int)std::min<unsigned long long>(tally[2], 1u << 30);
+        e->shift_stage_reach = (int)std::min<unsigned long long>(tally[3], 1u << 30);
         wide.clear();
         for (int b = 0; b < g.nbricks; ++b) {                      // a brick fits if all its blocks do
             int all = 1;
