@@ -452,8 +452,8 @@ def row_iter(e, p, first):
             e(f"s_addc_u32 s{SPF + 1}, s{SPF + 1}, 0")
             if BLOCK and STAGE_IN_LOOP and (STAGING or FAR):
                 e(f"s_add_u32 s{SG_AFTER}, s{SG_AFTER}, 1")
-        if pos == 5 and p == 1 and STAGING:
-            stage_step(e)
+        if pos == 5 and p == 1 and STAGING and "stgtail" not in EXP:    # (stgtail: every step left to the loop
+            stage_step(e)                                               # behind the rows -- a test of that loop)
 
 
 def node_index(e, g, to_vgpr=True):
