@@ -84,6 +84,13 @@ PF_EVERY = int(os.environ.get("QM_SHIFT_PF_EVERY", "2"))   # 2: one prefetch per
                                                             # the same 128-byte line either way; C3 -0.4 %, C4 -0.7 %,
                                                             # locate volume -1.7 %, profiles/r05_ab_runs.txt); 1: per row.
                                                             # No prefetch at all: C3 +12 %, C4 +17 %.
+# Records by PAIRS (round 5 experiment, not kept): one s_load_dwordx16 per pair of rows, issued at the pair's top for
+# the NEXT pair -- two rows of lead instead of one.  With every record load a scalar-cache hit (timing experiment
+# "smemhit": every row re-reads one record) the C4 slab runs 5.1 % faster and C3 1 %, which looked like record loads
+# coming back from L2 a little later than one row lasts; but with two rows of lead the C4 slab takes 171.1 / 171.2 ms
+# against 171.5 / 171.1 (profiles/r05_ab_runs.txt) -- the experiment's gain is its uniform rows (one window address,
+# the smallest quad count), not the loads' latency.  "far": the 8-wave flavours; "all"; "none" (default).
+PAIR16 = os.environ.get("QM_SHIFT_PAIR16", "none")
 STAGING = False          # (set by body(): the pair of rows being emitted carries the staging step)
 STAGE_IN_LOOP = os.environ.get("QM_SHIFT_STAGE_IN_LOOP", "1") == "1"   # row blocks, round 5: see stage_step
 PLANE2 = 40896           # plane A -> plane B, bytes (two 4-wave workgroups per CU, 80 KB each): 128 q + 64
@@ -108,9 +115,10 @@ def configure(lds_state, far=False, lazy=False, block=False, spl=4, contig=False
     written by the group merge, the per-node temporaries move into window 1 -- 167 VGPRs in all,
     three wavefronts per SIMD."""
     global LDS_STATE, FAR, PLANE, VB, ACC, WIN, VADDR, VADDRB, VNODE, VC, VPF, VZERO, VEND, VMAG
-    global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR, LAZY, BLOCK, SPL, CONTIG, MARGINAL
+    global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR, LAZY, BLOCK, SPL, CONTIG, MARGINAL, VDUMMY
     BLOCK = block            # one group per call, accumulators kept between calls (row blocks)
-    configure_scalars(PACKED_BLOCKS if block else PACKED_GROUPS)
+    configure_scalars(PACKED_BLOCKS if block else PACKED_GROUPS,
+                      not block and not contig and not lds_state and (PAIR16 == "all" or (PAIR16 == "far" and far)))
     SPL = spl                # samples per lane (4: full tiles; 1..3: tail tiles)
     CONTIG = contig          # row windows staged contiguously (tail tiles)
     MARGINAL = marginal      # the marginalised map instead of the volume
@@ -155,13 +163,18 @@ def configure(lds_state, far=False, lazy=False, block=False, spl=4, contig=False
     VZERO = VPF + 1
     VMAG = (VZERO + 2) & ~1      # 1.5 * 2^52 as a VGPR pair (lazy flavour: z is folded into FMAs)
     VEND = VMAG + 2 if lazy else VZERO + 1
+    if PAIRBUF:
+        VDUMMY = VEND        # destination of the dummy LDS read (pair_rows)
+        VEND += 1
 
 
 SB = 48                  # first hard SGPR (s_load_dwordx16 / x8 destinations)
 
 
-def configure_scalars(packed):
+def configure_scalars(packed, pair16=False):
     """hard SGPR plan; the record buffers shrink with packed records"""
+    global PAIRBUF
+    PAIRBUF = pair16 and packed
     global PACKED, REC, NBUF, BUF, R_HDR, R_BASE, ST, SBASE, SMASK, SPAIRS, SNODE, STAB, SOFF, SPF, SVA
     global SNEGINF, SMAGIC, SEND, SG_META, SG_ROW, SG_AFTER, SG_SRC, SG_T, SG_LDS
     PACKED = packed
@@ -170,7 +183,7 @@ def configure_scalars(packed):
     BUF = [SB, SB + NBUF]
     R_HDR = 2 if packed else 8     # dwords of the next row's header inside a record (LDS offset, quad count)
     R_BASE = 4 if packed else 10   # ... of the group's first node and valid-node mask (row 0 of a group)
-    ST = SB + 2 * NBUF       # [ST:ST+1], [ST+2:ST+3] compare masks
+    ST = SB + (32 if PAIRBUF else 2 * NBUF)     # [ST:ST+1], [ST+2:ST+3] compare masks
     SBASE = ST + 4
     SMASK = ST + 5
     SPAIRS = ST + 6
@@ -299,8 +312,9 @@ def node_order():
     return (0, 4, 1, 5, 2, 6, 3, 7) if PACKED and PACKED_SHIFT64 else tuple(range(8))
 
 
-def node_adds(e, p, g, first):
+def node_adds(e, p, g, first, rec=None):
     first = first and not BLOCK          # (row blocks: the accumulators are zeroed, or carry on)
+    rec = BUF[p] if rec is None else rec
     if "noidx" in EXP:
         e("s_nop 0")
     else:
@@ -309,10 +323,10 @@ def node_adds(e, p, g, first):
             # instruction takes bits [7:0] of its operand, so nodes 0 and 4 use the dwords as they
             # are; round 5: the pair of dwords is shifted as ONE 64-bit scalar before nodes (1, 5),
             # (2, 6), (3, 7) -- three SALU instructions per row instead of six
-            reg = BUF[p] + g // 4
+            reg = rec + g // 4
             if PACKED_SHIFT64:
                 if g in (1, 2, 3):
-                    e(f"s_lshr_b64 {s2(BUF[p])}, {s2(BUF[p])}, 8")
+                    e(f"s_lshr_b64 {s2(rec)}, {s2(rec)}, 8")
             elif g % 4:
                 e(f"s_lshr_b32 s{reg}, s{reg}, 8")
             e(f"s_set_gpr_idx_on s{reg}, 1")
@@ -412,7 +426,8 @@ def row_iter(e, p, first):
         e(f"s_mov_b32 s{SBASE}, s{BUF[p] + R_BASE}")
         e(f"s_mov_b32 s{SMASK}, s{BUF[p] + R_BASE + 1}")
     if "nosmem" not in EXP:
-        e(f"s_add_u32 s{SOFF}, s{SOFF}, {REC}")
+        if "smemhit" not in EXP:      # (smemhit: every row loads the run's second record again -- scalar-cache hits)
+            e(f"s_add_u32 s{SOFF}, s{SOFF}, {REC}")
         e(f"s_load_dwordx{NBUF} s[{BUF[q]}:{BUF[q] + NBUF - 1}], {s2(STAB)}, s{SOFF}")
     if p == 0 and STAGING:
         stage_record(e)
@@ -454,6 +469,32 @@ def row_iter(e, p, first):
                 e(f"s_add_u32 s{SG_AFTER}, s{SG_AFTER}, 1")
         if pos == 5 and p == 1 and STAGING and "stgtail" not in EXP:    # (stgtail: every step left to the loop
             stage_step(e)                                               # behind the rows -- a test of that loop)
+
+
+def pair_rows(e, U, V, first):
+    """PAIRBUF: the two rows whose records lie in s[U:U+15]; the next pair's are requested into s[V:V+15] at the
+    pair's top and waited for at the NEXT pair's top.  The second row's top may therefore not wait for
+    everything: its wait is lgkmcnt(1), and a dummy LDS read behind the first row's window reads makes that mean
+    'every window read has landed' whether or not the scalar load has (LDS reads return in order)."""
+    for half in (0, 1):
+        rec = U + 8 * half
+        hdr = rec + R_HDR
+        e("s_waitcnt lgkmcnt(0)" if half == 0 else "s_waitcnt lgkmcnt(1)")
+        if half == 0:
+            if first:
+                e(f"s_mov_b32 s{SBASE}, s{rec + R_BASE}")
+                e(f"s_mov_b32 s{SMASK}, s{rec + R_BASE + 1}")
+            e(f"s_add_u32 s{SOFF}, s{SOFF}, {2 * REC}")
+            e(f"s_load_dwordx16 s[{V}:{V + 15}], {s2(STAB)}, s{SOFF}")
+        issue_window(e, 1 - half, hdr)
+        if half == 0:
+            e(f"ds_read_b32 v{VDUMMY}, v{VADDR}")
+        for pos, g in enumerate(node_order()):
+            node_adds(e, half, g, first and half == 0, rec)
+            if pos == 3 and PF_AHEAD and half == 0:
+                e(f"global_load_dword v{VPF}, v{VZERO}, {s2(SPF)}")
+                e(f"s_add_u32 s{SPF}, s{SPF}, {2 * REC}")
+                e(f"s_addc_u32 s{SPF + 1}, s{SPF + 1}, 0")
 
 
 def node_index(e, g, to_vgpr=True):
@@ -813,8 +854,14 @@ def body(degree, volume):
     e(f"s_mov_b32 s{STAB}, %[tablo]")
     e(f"s_mov_b32 s{STAB + 1}, %[tabhi]")
     # prologue: lead-in record (header of row 0) and row 0's record; window of row 0
-    e(f"s_load_dwordx{NBUF} s[{BUF[1]}:{BUF[1] + NBUF - 1}], {s2(STAB)}, 0")
-    e(f"s_load_dwordx{NBUF} s[{BUF[0]}:{BUF[0] + NBUF - 1}], {s2(STAB)}, {REC}")
+    if PAIRBUF:
+        # the lead-in record (row 0's header) into the second pair buffer, rows 0 and 1 into the first
+        X, Y = SB, SB + 16
+        e(f"s_load_dwordx{NBUF} s[{Y}:{Y + NBUF - 1}], {s2(STAB)}, 0")
+        e(f"s_load_dwordx16 s[{X}:{X + 15}], {s2(STAB)}, {REC}")
+    else:
+        e(f"s_load_dwordx{NBUF} s[{BUF[1]}:{BUF[1] + NBUF - 1}], {s2(STAB)}, 0")
+        e(f"s_load_dwordx{NBUF} s[{BUF[0]}:{BUF[0] + NBUF - 1}], {s2(STAB)}, {REC}")
     e(f"s_mov_b32 s{SOFF}, {REC}")
     e(f"s_mov_b32 s{SNEGINF}, 0")
     e(f"s_mov_b32 s{SNEGINF + 1}, 0xfff00000")
@@ -832,7 +879,7 @@ def body(degree, volume):
             e(f"s_mov_b32 s{SG_ROW}, %[stgrow]")
             stage_record(e)
     e("s_waitcnt lgkmcnt(0)")
-    issue_window(e, 0, BUF[1] + R_HDR)
+    issue_window(e, 0, (SB + 16 if PAIRBUF else BUF[1]) + R_HDR)
     group = e.label("grp")
     pair = e.label("pair")
     nopair = e.label("np")
@@ -856,6 +903,33 @@ def body(degree, volume):
         e(f"{carry}:")
     global STAGING
     STAGING = BLOCK and STAGE_IN_LOOP and not FAR
+    if PAIRBUF:
+        # pairs of rows alternate between the two pair buffers; a group starts in the first one
+        X, Y = SB, SB + 16
+        after_x, after_y = e.label("ax"), e.label("ay")
+        e(f"{group}:")
+        pair_rows(e, X, Y, True)
+        e(f"s_sub_u32 s{SPAIRS}, %[npairs], 2")                # borrow <=> the group has one pair
+        e(f"s_cbranch_scc1 {after_x}")
+        e(f"{pair}:")
+        pair_rows(e, Y, X, False)
+        e(f"s_sub_u32 s{SPAIRS}, s{SPAIRS}, 1")
+        e(f"s_cbranch_scc1 {after_y}")
+        pair_rows(e, X, Y, False)
+        e(f"s_sub_u32 s{SPAIRS}, s{SPAIRS}, 1")
+        e(f"s_cbranch_scc0 {pair}")
+        e(f"{after_x}:")
+        # an odd number of pairs: the next group's first pair is on its way into the second buffer
+        e("s_waitcnt lgkmcnt(0)")
+        for k in range(0, 16, 2):
+            e(f"s_mov_b64 {s2(X + k)}, {s2(Y + k)}")
+        e(f"{after_y}:")
+        epilogue(e, degree, volume)
+        e("s_sub_u32 %[ng], %[ng], 1")
+        e("s_cmp_lg_u32 %[ng], 0")
+        e(f"s_cbranch_scc1 {group}")
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        return e.lines
     e(f"{group}:")
     row_iter(e, 0, True)
     row_iter(e, 1, False)

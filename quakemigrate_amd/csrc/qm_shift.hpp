@@ -547,6 +547,9 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
         const void *next_meta = s.smeta + (int64_t)(nb < g.nbricks ? nb : b) * g.n_rows;
         (void)next_meta;
         const unsigned lane_addr_b = lane_addr + (unsigned)kShiftPlane8;   // (8-wave shape: plane B)
+#ifdef QM_SHIFT_DEPHASE          // (experiment: the second wavefront of every SIMD starts its rows late)
+        if (NW == kShiftWaves8 && (wave & 4)) __builtin_amdgcn_s_sleep(QM_SHIFT_DEPHASE);
+#endif
         (void)lane_addr_b; (void)next_run; (void)next_off;
 #define QM_TAIL_CALL(JJ)                                                                              \
         if constexpr (MODE == kShiftMarginal)                                                         \

@@ -1633,6 +1633,8 @@ SHIFT_SHAPES = [  # recipe, grid, rows, scanned samples
     ("C3", (25, 24, 10), 36, 450),       # ... beyond: one 8-wave workgroup per CU with all 160 KB
     ("C4", (33, 26, 18), 47, 513),       # (plane B through its own address register)
     ("C4", (20, 21, 22), 64, 300),       # the widest table the shift-reuse kernel takes
+    ("C3", (18, 17, 12), 34, 600),       # 8-wave shape, an ODD number of row pairs (17): the record pairs'
+    ("C4", (14, 15, 12), 37, 300),       # buffers swap roles between groups; ... with a padding row (19 pairs)
 ]
 
 
