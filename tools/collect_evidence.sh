@@ -5,6 +5,7 @@ cd "$(dirname "$0")/.."
 O=gpurun_out/${1:?tag}; R=${2:?round prefix}
 for f in $O/bench_*.json $O/enqueue_*.json; do [ -f "$f" ] && cp $f profiles/${R}_$(basename $f); done
 [ -f $O/bench_lines.txt ] && cp $O/bench_lines.txt profiles/${R}_bench_lines.txt
+[ -f $O/row_blocks.txt ] && cp $O/row_blocks.txt profiles/${R}_row_blocks.txt
 [ -f $O/pytest_gpu.log ] && { tail -14 $O/pytest_gpu.log; tail -1 $O/smoke.log; } > profiles/${R}_pytest_gpu_tail.txt
 [ -f $O/bench_C3_headline_only_kernel_stats.csv ] && cp $O/bench_C3_headline_only_kernel_stats.csv profiles/${R}_bench_C3_headline_only_kernel_stats.csv
 [ -f $O/pmc_traffic.json ] && cp $O/pmc_traffic.json profiles/${R}_pmc_traffic.json

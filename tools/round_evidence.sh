@@ -3,7 +3,7 @@
 #   suite    the GPU suite + smoke()
 #   bench    every bench line: C3 headline (with cpu_baseline, step_with_copies, table_switch, locate rooflines),
 #            its round-2 / round-3 forms, C2, C1 / E1 / E2 / E2F with 1 and 8 timesteps per launch, a C4 slab,
-#            the C5 stream and the literal 720-step day
+#            the C5 stream and the literal 720-step day; tables of 66 / 128 / 200 rows (row blocks)
 #   ranks    N > 1 plumbing on one GPU (two gloo ranks; a one-rank RCCL group), the enqueue budget of a sharded step
 #   stats    rocprofv3 --kernel-trace --stats of a bench command whose only launches of the headline kernel are
 #            the warm-up and timed steps (its average must agree with the bench line's own HIP-event clock)
@@ -49,6 +49,9 @@ if has bench; then
   python bench.py --config C5 --steps 30 --warmup 3 > $OUT/bench_C5_stream.json 2>> $OUT/bench.err
   python bench.py --config C5 --steps 720 --warmup 3 > $OUT/bench_C5_24h.json 2>> $OUT/bench.err
   line $OUT/bench_*.json | tee $OUT/bench_lines.txt
+  # tables of more than 64 rows (row blocks) on the C3 grid x 1536 samples, and a 401-sample volume on one
+  { for r in 66 128 200; do python tools/ab.py --config C3 --case "{\"rows\": $r, \"n_samples\": 1536}" - | sed "s/^-/rows $r/"; done
+    python tools/ab.py --config C3 --mode volume --case '{"rows": 128, "n_samples": 401}' - | sed "s/^-/rows 128 volume/"; } 2>&1 | grep -v amdgpu.ids | tee $OUT/row_blocks.txt
 fi
 if has ranks; then
   # N > 1 plumbing on one GPU (gloo rendezvous; RCCL refuses two ranks on one device): self-launch
