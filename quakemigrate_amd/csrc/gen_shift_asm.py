@@ -51,6 +51,16 @@ m = sum_k w_k * 2^z_k (w = 1.0 inside the window [m0, m1), 0.0 outside: exact), 
 by DPP moves (quad_perm, row_half_mirror, row_mirror, row_bcast 15 / 31: the total lands in lane
 63) and one 8-byte store per (node, tile) from that lane.
 
+Round 5: every loop reads 32-byte records (one 64-bit shift per node pair); the row-block flavours ("ONE
+group, one block of its rows per call") also STAGE: while a wavefront adds the rows of the block in LDS it
+issues the LDS-direct loads that bring its share of the workgroup's NEXT block into the idle half --
+stage_step, one row window per pair of rows, scalar bookkeeping only -- and then falls into a plain pair loop.
+
+Timing experiments (QM_SHIFT_EXP=..., wrong results by construction unless noted; tools/shift_variants.sh builds
+a library per setting): nosmem, nowait, noidx, smemhit (every row re-reads one record), interleave, maskq,
+outofline (right results), stgnoload / stgsame (the staging step without its loads / every load from one row),
+stgtail (right results: every staging step left to the loop behind the rows).
+
 Usage: python gen_shift_asm.py > qm_shift_asm.inc   (committed; build() checks it is current).
 """
 
