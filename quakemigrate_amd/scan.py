@@ -365,6 +365,92 @@ class MigrationScan:
         columns = next((list(r) for r in rows if r is not None), [])
         return [r if r is not None else dict.fromkeys(columns, 0) for r in rows]
 
+    def locate_compute(self, archive, triggers, marginal_window, sgm=0.8, cov_thresh=0.90, on_event=None):
+        """
+        ``QuakeScan._locate_events``' loop around the path (reference scan.py:472-545), up to and including
+        ``_calculate_location``: per triggered event read ``trigger_time -/+ (2 * marginal_window + pad)``
+        (scan.py:497-498), compute the onsets, migrate and scan the ``4 * marginal_window * rate + 1``
+        samples of ``event.mw_times`` (event.py:398-420); the origin time is the FIRST maximum of the
+        coalescence series (``idxmax``, event.py:239-240); an event whose trigger time is not strictly
+        inside ``otime -/+ marginal_window`` is dropped (``in_marginal_window``, event.py:369-396), as is
+        one whose data raise ``ArchiveEmptyException`` / ``DataGapException`` / ``DataAvailabilityException``
+        (scan.py:513-519); the series are trimmed to ``otime - mw <= t <= otime + mw`` and the 4-D map to the
+        same samples WITHOUT the last one (``trim2window`` slices ``index[0]:index[-1]``, event.py:430-435:
+        the reference's marginal sum runs over one sample fewer than its trimmed series has rows); the
+        marginalised map is normalised and fitted three ways (scan.py:719-733).
+
+        What differs is that the 4-D map never exists: the first pass is the fused detect kernel over the
+        event's window (series only), which fixes the origin time; the second sums the marginal window's
+        samples inside the stacking kernel (``calculate_location``) -- two launches of a few milliseconds
+        on a C3-sized grid instead of a 13 GB volume.
+
+        ``triggers``: iterable of ``(uid, trigger_time)``; time stamps only need ``t + timedelta`` /
+        ``t + seconds`` (``_shift``).  ``on_event(result)`` is called per located event (the reference writes
+        and picks there).  Returns the list of results, each a dict: ``uid, trigger_time, otime, times0``
+        (time stamp of the first trimmed sample), ``first_sample, last_sample`` (trimmed series, inclusive,
+        in scanned samples), ``max_coa, max_coa_n, coord`` (trimmed), ``coa_map`` (normalised), ``fits``
+        (:class:`locate.LocationFits`), ``onset_data``.
+        """
+        from quakemigrate_amd import locate
+
+        if self.stage != "locate":
+            raise ValueError("locate_compute is the locate stage's loop")
+        mw = float(marginal_window)
+        results = []
+        triggers = list(triggers)
+        for n, (uid, trigger_time) in enumerate(triggers):
+            w_beg = _shift(trigger_time, -2 * mw - self.pre_pad)
+            w_end = _shift(trigger_time, 2 * mw + self.post_pad)
+            logging.info(f"\tEVENT - {n + 1} of {len(triggers)} - {uid}")
+            try:
+                data = archive.read_waveform_data(w_beg, w_end)
+                onsets, onset_data = self.onset.calculate_onsets(data)
+            except Exception as e:  # noqa: BLE001
+                if type(e).__name__ not in _NO_DATA:
+                    raise
+                logging.info(getattr(e, "msg", str(e)))
+                continue
+            rate = onset_data.sampling_rate
+            eng = self._ensure_table(rate, onset_data.availability)
+            fsmp, lsmp = time2sample(self.pre_pad, rate), time2sample(self.post_pad, rate)
+            avail = int(np.sum([value for _, value in onset_data.availability.items()]))
+            onsets = np.ascontiguousarray(np.log(np.clip(onsets, 0.01, np.inf)))      # lib.py:93-94
+            n_onsets, t_samples = onsets.shape
+            n_samples = t_samples - fsmp - lsmp
+            if n_onsets != eng.n_rows:
+                raise ValueError("Mismatch between number of stations for data and LUT, "
+                                 f"{n_onsets}:{eng.n_rows}")
+            if onsets.size < n_samples + fsmp:
+                raise ValueError("Data array smaller than coalescence array.")
+            series = (np.zeros(n_samples), np.zeros(n_samples), np.zeros(n_samples, dtype=np.int64))
+            eng.detect(onsets, fsmp, lsmp, avail, out=series)                          # pass 1: the origin time
+            i_max = int(np.nanargmax(series[0]))                                       # idxmax: the first maximum
+            # times[i] = trigger_time - 2 mw + i / rate (event.py:412-420)
+            offset = i_max / rate - 2 * mw                                             # otime - trigger_time
+            if not (-mw < offset < mw):                                                # event.py:381-383
+                logging.info(f"\tEvent {uid} is outside marginal window.")
+                continue
+            eps = 1e-6                                                                 # (time stamps are whole ns)
+            first = max(0, int(np.ceil(i_max - mw * rate - eps)))
+            last = min(n_samples - 1, int(np.floor(i_max + mw * rate + eps)))
+            marginal = eng.marginal_map(onsets, fsmp, lsmp, avail, first, last)        # pass 2: samples [first, last)
+            coa_map = np.zeros_like(marginal)
+            fits = locate.calculate_location(eng, marginal, self.lut.node_spacing, sgm=sgm,
+                                             cov_thresh=cov_thresh, norm_out=coa_map)
+            sel = slice(first, last + 1)
+            result = {
+                "uid": uid, "trigger_time": trigger_time,
+                "otime": _shift(trigger_time, offset), "times0": _shift(trigger_time, first / rate - 2 * mw),
+                "first_sample": first, "last_sample": last,
+                "max_coa": series[0][sel], "max_coa_n": series[1][sel],
+                "coord": self.lut.index2coord(series[2][sel], unravel=True),
+                "coa_map": coa_map, "fits": fits, "onset_data": onset_data,
+            }
+            results.append(result)
+            if on_event is not None:
+                on_event(result)
+        return results
+
     def marginal_coalescence(self, data, first_sample, end_sample):
         """
         The marginalised 3-D coalescence map of one event window without the 4-D map: what

@@ -2875,3 +2875,112 @@ def test_continuous_detect_example(lib, oracle, tmp_path):
         a, _, _ = oracle.detect(cases[i].onsets, cases[0].traveltimes, cases[0].fsmp, cases[0].lsmp,
                                 cases[0].available, threads=4)
         np.testing.assert_allclose(coa[i * ns:(i + 1) * ns], np.minimum(a, 21474.0), atol=5.1e-6)
+
+
+def test_locate_compute_mirrors_the_references_loop(lib, oracle):
+    """MigrationScan.locate_compute = QuakeScan._locate_events' behaviour around the path (scan.py:472-545,
+    event.py:239-240, 369-396, 421-439): the window read per trigger, the origin time as the FIRST maximum of
+    the series, events outside the marginal window or without data dropped, the series trimmed to
+    otime -/+ marginal_window and the map to the same samples without the last one, the normalised marginal
+    map -- restated here with explicit time stamps on the oracle's 4-D map."""
+    import datetime as dt
+
+    from quakemigrate_amd import locate, scan
+
+    grid, rows, rate, mw = (20, 18, 12), 8, 50, 1.0
+    n_win = int(4 * mw * rate) + 1
+    base = [synth.make_case("C3", step=s, grid=grid, rows=rows, n_samples=601, n_events=1) for s in (1, 2, 3)]
+    case = base[0]
+    keys = [f"ST{i}_{'P' if i < 4 else 'S'}" for i in range(rows)]
+    full = dict.fromkeys(keys, 1)
+    less = {**full, "ST5_S": 0}
+
+    def window(c, avail, want_peak):
+        """a 4 mw window of case c's onsets whose coalescence peak falls on scanned sample want_peak"""
+        sel = [j for j, key in enumerate(keys) if avail[key] == 1]
+        tt = np.ascontiguousarray(case.traveltimes[..., sel])
+        a, _, _ = oracle.detect(c.onsets[sel], tt, c.fsmp, c.lsmp, len(sel), threads=4)
+        off = int(np.argmax(a)) - want_peak
+        assert 0 <= off and off + n_win <= 601
+        return np.ascontiguousarray(c.onsets[sel][:, off:off + c.fsmp + n_win + c.lsmp]), tt
+
+    t0 = dt.datetime(2024, 5, 17, 10, 0, 0)
+    plan = [("ev_inside", t0, window(base[0], full, 112), full),
+            ("ev_gap", t0 + dt.timedelta(seconds=60), None, None),
+            ("ev_outside", t0 + dt.timedelta(seconds=120), window(base[1], full, 37), full),     # peak 1.26 s early
+            ("ev_edge", t0 + dt.timedelta(seconds=180), window(base[2], less, 51), less),        # 0.98 s early: inside
+            ("ev_on_the_edge", t0 + dt.timedelta(seconds=240), window(base[1], full, 50), full)]  # exactly mw: dropped
+    by_start, seen = {}, []
+    pre, post = case.fsmp / rate, case.lsmp / rate
+    for uid, trig, win, avail in plan:
+        by_start[trig - dt.timedelta(seconds=2 * mw + pre)] = (uid, win, avail)
+
+    class Data:
+        pass
+
+    class Archive:
+        def read_waveform_data(self, w_beg, w_end):
+            uid, win, avail = by_start[w_beg]
+            seen.append((uid, w_beg, w_end))
+            if win is None:
+                raise scan.DataGapException(f"no data for {uid}")
+            d = Data()
+            d.win, d.avail, d.starttime = win, avail, w_beg
+            return d
+
+    class OnsetData:
+        sampling_rate = rate
+
+        def __init__(self, availability):
+            self.availability = availability
+
+    class Onset:
+        def calculate_onsets(self, data):
+            return data.win[0], OnsetData(dict(data.avail))
+
+    class Lut:
+        node_spacing = np.array([0.5, 0.5, 0.5])
+
+        def serve_traveltimes(self, sampling_rate, availability):
+            sel = [j for j, key in enumerate(keys) if availability[key] == 1]
+            return np.ascontiguousarray(case.traveltimes[..., sel])
+
+        def index2coord(self, idx, unravel=True):
+            return np.stack(np.unravel_index(idx, grid), axis=-1) * 0.5
+
+    eng = lib.Engine(0)
+    s = scan.MigrationScan(Lut(), Onset(), pre, post, stage="locate", scan_rate=rate, engine=eng)
+    got_uids = []
+    results = s.locate_compute(Archive(), [(uid, trig) for uid, trig, _, _ in plan], mw,
+                               on_event=lambda r: got_uids.append(r["uid"]))
+    # every trigger's window was read, with the reference's arithmetic (scan.py:497-498)
+    assert [u for u, _, _ in seen] == [p[0] for p in plan]
+    for (uid, w_beg, w_end), (_, trig, _, _) in zip(seen, plan):
+        assert w_beg == trig - dt.timedelta(seconds=2 * mw + pre) and w_end == trig + dt.timedelta(seconds=2 * mw + post)
+    assert got_uids == ["ev_inside", "ev_edge"] == [r["uid"] for r in results]
+    for r in results:
+        uid, trig, (win, tt), avail = next(p for p in plan if p[0] == r["uid"])
+        n_sel = win.shape[0]
+        vol = oracle.c_migrate(win, tt, case.fsmp, case.lsmp, n_sel, threads=4).reshape(grid + (n_win,))
+        a, b, c = oracle.detect(win, tt, case.fsmp, case.lsmp, n_sel, threads=4)
+        # the reference's rule, with time stamps
+        times = [trig - dt.timedelta(seconds=2 * mw) + dt.timedelta(seconds=i / rate) for i in range(n_win)]
+        otime = times[int(np.argmax(a))]
+        assert trig > otime - dt.timedelta(seconds=mw) and trig < otime + dt.timedelta(seconds=mw)
+        keep = [i for i, t in enumerate(times)
+                if otime - dt.timedelta(seconds=mw) <= t <= otime + dt.timedelta(seconds=mw)]
+        assert r["otime"] == otime and r["times0"] == times[keep[0]]
+        assert (r["first_sample"], r["last_sample"]) == (keep[0], keep[-1])
+        np.testing.assert_allclose(r["max_coa"], a[keep[0]:keep[-1] + 1], rtol=RTOL)
+        np.testing.assert_allclose(r["max_coa_n"], b[keep[0]:keep[-1] + 1], rtol=RTOL)
+        assert np.array_equal(r["coord"], np.stack(np.unravel_index(c[keep[0]:keep[-1] + 1], grid), axis=-1) * 0.5)
+        marginal = vol[..., keep[0]:keep[-1]].sum(-1)                # (event.py:433-435: without the last sample)
+        want_map = marginal / np.nanmax(marginal)
+        np.testing.assert_allclose(r["coa_map"], want_map, rtol=1e-11)
+        want_fits = locate.calculate_location(eng, marginal, Lut.node_spacing)
+        np.testing.assert_allclose(r["fits"].spline, want_fits.spline, atol=1e-6)
+        np.testing.assert_allclose(r["fits"].gaussian, want_fits.gaussian, atol=1e-6)
+        np.testing.assert_allclose(r["fits"].covariance, want_fits.covariance, atol=1e-6)
+        assert np.abs(np.asarray(r["fits"].spline) - np.unravel_index(int(np.argmax(want_map)), grid)).max() <= 1.0
+    assert eng.get("table_misses") == 2
+    eng.close()
