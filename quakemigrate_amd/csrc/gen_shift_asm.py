@@ -275,6 +275,8 @@ def window_address(e, hdr):
 def issue_window(e, q, hdr):
     """block form (prologue only): reads of the row whose header is s[hdr], s[hdr+1] into WIN[q]"""
     window_address(e, hdr)
+    if "noreads" in EXP:         # (timing experiment: the loop without its window reads)
+        return
     if CONTIG:
         for line in contig_base_reads(WIN[q]):
             e(line)
