@@ -240,6 +240,15 @@ class Emitter:
 
 def quad_reads(win, m):
     plane_b = f"v{VADDRB} offset:{16 * m}" if FAR else f"v{VADDR} offset:{PLANE + 16 * m}"
+    if "readsnone" in EXP:       # timing experiments (wrong results): the branches without the reads / plane A
+        return []                # only / every 16-byte read as two 8-byte ones
+    if "readsa" in EXP:
+        return [f"ds_read_b128 v[{win + 8 * m}:{win + 8 * m + 3}], v{VADDR} offset:{16 * m}"]
+    if "readsb64" in EXP and not FAR:
+        return [f"ds_read_b64 v[{win + 8 * m}:{win + 8 * m + 1}], v{VADDR} offset:{16 * m}",
+                f"ds_read_b64 v[{win + 8 * m + 2}:{win + 8 * m + 3}], v{VADDR} offset:{16 * m + 8}",
+                f"ds_read_b64 v[{win + 8 * m + 4}:{win + 8 * m + 5}], v{VADDR} offset:{PLANE + 16 * m}",
+                f"ds_read_b64 v[{win + 8 * m + 6}:{win + 8 * m + 7}], v{VADDR} offset:{PLANE + 16 * m + 8}"]
     return [f"ds_read_b128 v[{win + 8 * m}:{win + 8 * m + 3}], v{VADDR} offset:{16 * m}",
             f"ds_read_b128 v[{win + 8 * m + 4}:{win + 8 * m + 7}], {plane_b}"]
 
