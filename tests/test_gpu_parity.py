@@ -2984,3 +2984,26 @@ def test_locate_compute_mirrors_the_references_loop(lib, oracle):
         assert np.abs(np.asarray(r["fits"].spline) - np.unravel_index(int(np.argmax(want_map)), grid)).max() <= 1.0
     assert eng.get("table_misses") == 2
     eng.close()
+
+
+def test_locate_events_example(lib):
+    """examples/locate_events.py: the reference's locate loop with plugin objects on the default engine: every
+    synthetic event is located at its injected node and origin sample."""
+    import importlib.util
+
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("locate_events", ROOT / "examples" / "locate_events.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    located, truth, record_start, rate = mod.run()
+    assert [r["uid"] for r in located] == ["event_0", "event_1", "event_3", "event_4"]     # (event_2: no data)
+    for r in located:
+        k = int(r["uid"].split("_")[1])
+        (node, t0), start = truth[k], record_start[k]
+        assert abs((r["otime"] - start).total_seconds() * rate - t0) <= 1
+        # (depth is the poorly resolved axis of a surface network; the Gaussian fit's window is cut by the
+        # grid's edge for events near it)
+        assert np.abs(np.asarray(r["fits"].spline) - np.asarray(node)).max() <= 2.0
+        assert np.abs(np.asarray(r["fits"].gaussian) - np.asarray(node)).max() <= 4.0
+        assert r["last_sample"] - r["first_sample"] == 2 * rate
