@@ -151,6 +151,11 @@ int qm_engine_synchronize(qm_engine *e);
  *                                                wavefront on (max_norm_coa within 1e-15 of the eager one)
  * shift_tail            0 / 1 [1]                a scan's remainder of <= 192 samples as ONE tail tile of
  *                                                64 / 128 / 192 samples; 0 = whole 256-sample tiles only
+ * shift_wide            -1, 0, 1 [-1]            fused detect on WIDE tiles (384 samples, six per lane, 8-wave
+ *                                                workgroups, own brick grid) where the table's windows fit and the
+ *                                                scan holds at least one; 0 = the 256-sample tiles of rounds 3-5.
+ *                                                max_coa / max_coa_idx bit-equal, max_norm_coa within 1e-14 (the
+ *                                                sum over the nodes is formed in another order)
  * shift_rows_direct     0, 1, 2 [1]              tables of > 64 rows (row blocks): 1 = blocks of <= 34 rows,
  *                                                double-buffered LDS, LDS-direct loads; 0 = blocks of <= 64
  *                                                through registers; 2 = two 4-wave workgroups per CU
@@ -165,7 +170,8 @@ int qm_engine_synchronize(qm_engine *e);
  * n_wide_bricks, mean_span; last_kernel (0 chunked, 1 exact-row-count, 2 paired, 3 shift-reuse),
  * last_kernel_j, steps_per_launch (timesteps the last detect_batch put into one launch);
  * shift_ok, shift_brick_nodes, shift_wide_bricks, shift_row_blocks, shift_operands_per_add_x1000,
- * shift_tail_spl; pair_brick_nodes, pair_wide_bricks, pair_tile; screened_steps, fallback_steps,
+ * shift_tail_spl; shift_wide_ok, shift_wide_tiles (of the last launch), shift_wide_brick_nodes,
+ * shift_wide_direct_bricks, shift_wide_operands_per_add_x1000; pair_brick_nodes, pair_wide_bricks, pair_tile; screened_steps, fallback_steps,
  * last_candidates, screen_brick_nodes; tie_refined_steps, tie_pairs and tie_overflow_samples (of the last
  * refined launch);
  * table_hits, table_misses, table_evictions, tables_parked, table_bytes, tables_parked_bytes. */

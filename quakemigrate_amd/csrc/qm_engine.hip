@@ -127,16 +127,7 @@ int launch_pair_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_
 bool pair_built(int S) { return S >= 1 && S <= qm::kPairMaxRows; }
 
 // ---- shift-reuse layout (qm_shift.hpp) ----------------------------------------------------------
-// Own brick grid (e->shg, even brick dimensions: the kernel walks 2x2x2 node groups): the largest
-// shape whose de-interleaved row windows fit 80 KB and whose groups' delay spread fits the
-// register window for (almost) every brick; per-(brick, row) slot records and the record stream.
-int build_shift_tables(qm_engine *e);
-
-void release_shift_tables(qm_engine *e) {
-    PoolReleaseScope one_wait;
-    e->d_shraw.release(); e->d_shmeta.release(); e->d_shtotal.release(); e->d_shfit.release();
-    e->d_shwide.release(); e->d_shstream.release();
-}
+// (the layouts themselves: ShiftLayout, qm_engine.hpp; built by ensure_shift_tables, qm_tables.hip)
 
 // does this launch take the shift-reuse kernel?  Whole 256-sample tiles plus, for what a scan leaves
 // beyond them, one tail tile of 64 / 128 / 192 samples (qm_shift.hpp: shift_work); the kernels
@@ -153,14 +144,32 @@ bool shift_wanted(const qm_engine *e, int n_chunk, bool plain, bool volume, int6
     return n_chunk >= 1;
 }
 
-// samples per lane of the scan's tail tile (0: none -- whole tiles only, the last one pulled back)
-int shift_tail_spl(const qm_engine *e, int n_chunk) {
-    const int rem = n_chunk % qm::kShiftKT;
+// samples per lane of the scan's tail tile (0: none -- whole tiles only, the last one pulled back), for the
+// `rest` samples a scan leaves beyond the tiles in front
+int shift_tail_spl(const qm_engine *e, int rest) {
+    const int rem = rest % qm::kShiftKT;
     if (rem == 0 || rem > 192 || !e->cfg_shift_tail) return 0;
     return (rem + qm::kWave - 1) / qm::kWave;
 }
 
-int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups_direct,
+// Tiles of a fused detect on the wide layout: 384-sample tiles in front; what the scan leaves beyond them runs
+// as ONE tail tile (<= 192 samples), ONE 256-sample tile pulled back over its predecessor (<= 256), or one more
+// wide tile pulled back (qm_shift.hpp: shift_work).
+void shift_wide_tiles(const qm_engine *e, int n_chunk, qm::StackArgs &a) {
+    int wide = n_chunk / qm::kShiftWideKT;
+    const int rest = n_chunk - wide * qm::kShiftWideKT;
+    a.tail_spl = 0;
+    int behind = 0;
+    if (rest > qm::kShiftKT) ++wide;
+    else if (rest > 0) {
+        a.tail_spl = shift_tail_spl(e, rest);
+        behind = 1;
+    }
+    a.wide_tiles = wide;
+    a.ntiles = wide + behind;
+}
+
+int launch_shift_path(qm_engine *e, const ShiftLayout &L, qm::StackArgs &a, int groups_lds, int groups_direct,
                       bool use_lds, bool use_direct, int mode) {
     const bool volume = mode != qm::kShiftDetect;        // (the direct kernel's VOLUME covers the map too)
     if (use_lds) {
@@ -169,50 +178,56 @@ int launch_shift_path(qm_engine *e, qm::StackArgs &a, int groups_lds, int groups
         a.n_list = 0;
         qm::ShiftArgs s{};
         s.a = a;
-        s.smeta = reinterpret_cast<const int4 *>(e->d_shmeta.p);
-        s.stotal = e->d_shtotal.p;
-        s.sfit = e->d_shfit.p;
-        s.stream = reinterpret_cast<const char *>(e->d_shstream.p);
-        s.rows2 = e->shift_rows2;
-        s.nw = e->shift_nw;
-        s.nblk = e->shift_nblk;
-        s.sb = e->shift_sb;
-        s.stage_slots = e->shift_stage_slots;
-        s.stage_reach = e->shift_stage_reach;
+        s.smeta = reinterpret_cast<const int4 *>(L.meta.p);
+        s.stotal = L.total.p;
+        s.sfit = L.fit.p;
+        s.stream = reinterpret_cast<const char *>(L.stream.p);
+        s.wmeta = reinterpret_cast<const int4 *>(L.wmeta.p);
+        s.wtotal = L.wtotal.p;
+        s.wstream = reinterpret_cast<const char *>(L.wstream.p);
+        s.rows2 = L.rows2;
+        s.nw = L.nw;
+        s.nblk = L.nblk;
+        s.sb = L.sb;
+        s.stage_slots = L.stage_slots;
+        s.stage_reach = L.stage_reach;
         // groups a wavefront sees before its running maximum is reset: bricks per workgroup x
         // groups per (brick, wavefront)
-        const int64_t life = ((int64_t)e->shg.nbricks / std::max(1, a.ngroups)) *
-                             std::max(1, e->shg.brick_nodes / 8 / e->shift_nw);
+        const int64_t life = ((int64_t)L.g.nbricks / std::max(1, a.ngroups)) *
+                             std::max(1, L.g.brick_nodes / 8 / L.nw);
         s.lazy = e->cfg_shift_lazy >= 0 ? e->cfg_shift_lazy : (life >= qm::kShiftLazyGroups ? 1 : 0);
-        if (e->shift_nblk > 1 && !e->shift_direct) s.lazy = 0;    // (the register-staged form: eager only)
+        if (L.nblk > 1 && !L.direct) s.lazy = 0;    // (the register-staged form: eager only)
         e->shift_lazy_last = s.lazy;
         e->shift_tail_last = a.tail_spl;
-        const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, e->shift_nw * qm::kWave,
-                                                  qm::shift_lds_bytes(e->shift_nw));
-        const bool rows = e->shift_nblk > 1, big = e->shift_nw == qm::kShiftWaves8;
-        if (rows && e->shift_quad && mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_rows4_volume(s, shape));
-        else if (rows && e->shift_quad) QM_TABLE(qm::launch_shift_rows4(s, shape));
-        else if (rows && e->shift_direct && mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_rows2_volume(s, shape));
-        else if (rows && e->shift_direct) QM_TABLE(qm::launch_shift_rows2(s, shape));
+        e->shift_wide_last = a.wide_tiles;
+        const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, L.nw * qm::kWave,
+                                                  qm::shift_lds_bytes(L.nw));
+        const bool rows = L.nblk > 1, big = L.nw == qm::kShiftWaves8;
+        if (rows && L.quad && mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_rows4_volume(s, shape));
+        else if (rows && L.quad) QM_TABLE(qm::launch_shift_rows4(s, shape));
+        else if (rows && L.direct && mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_rows2_volume(s, shape));
+        else if (rows && L.direct) QM_TABLE(qm::launch_shift_rows2(s, shape));
         else if (rows) QM_TABLE(qm::launch_shift_rows8(s, shape));
         else if (mode == qm::kShiftMarginal && big) QM_TABLE(qm::launch_shift_marginal8(s, shape));
         else if (mode == qm::kShiftMarginal) QM_TABLE(qm::launch_shift_marginal(s, shape));
         else if (mode == qm::kShiftVolume && big) QM_TABLE(qm::launch_shift_volume8(s, shape));
         else if (mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_volume(s, shape));
-        else if (e->shift_nw == qm::kShiftWaves3) QM_TABLE(qm::launch_shift_detect3(s, shape));
+        else if (L.nw == qm::kShiftWaves3) QM_TABLE(qm::launch_shift_detect3(s, shape));
         else if (big) QM_TABLE(qm::launch_shift_detect8(s, shape));
         else QM_TABLE(qm::launch_shift_detect(s, shape));
         e->last_kernel = 3;
-        e->last_j = 4;
+        e->last_j = a.wide_tiles > 0 ? qm::kShiftWideSpl : 4;
         a.set0 += groups_lds;
     }
     if (use_direct) {
         const int threads = 512;
         const size_t publish_bytes = (size_t)3 * (threads / qm::kWave) * qm::kShiftKT * sizeof(double);
         a.ngroups = groups_direct;
-        a.brick_list = e->d_shwide.p;
-        a.n_list = e->n_shwide;
+        a.brick_list = L.list.p;
+        a.n_list = L.n_list;
         a.tail_spl = 0;                                // (its own whole tiles of 256 samples, clamped)
+        a.wide_tiles = 0;
+        a.ntiles = (a.n_chunk + qm::kShiftKT - 1) / qm::kShiftKT;
         if (launch_direct(e, a, 4, volume, groups_direct, threads, publish_bytes)) return 1;
         a.set0 += groups_direct;
     }
@@ -284,13 +299,22 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     bool shift = shift_wanted(e, n_chunk, !accumulate && (volume || marginal || want_scan),
                               volume != nullptr, vol_stride);
     const int shift_mode = marginal ? qm::kShiftMarginal : volume ? qm::kShiftVolume : qm::kShiftDetect;
-    if (shift) {
-        if (ensure_shift_tables(e)) return 1;
+    // Round 6: the fused detect of a scan that holds at least one 384-sample tile runs on the WIDE layout where
+    // the table has one (ShiftLayout, qm_engine.hpp): its own brick grid, the 8-wave shape
+    ShiftLayout *L = &e->sh;
+    if (shift && shift_mode == qm::kShiftDetect && e->cfg_shift_wide != 0 && n_chunk >= qm::kShiftWideKT &&
+        e->cfg_shift_waves == 0 && e->g.n_rows <= qm::kShiftMaxRows) {
+        if (ensure_shift_tables(e, e->shw)) return 1;
+        if (e->shw.ok) L = &e->shw;
+    }
+    const bool wide = L == &e->shw;
+    if (shift && !wide) {
+        if (ensure_shift_tables(e, e->sh)) return 1;
         // the 12-wave shape and the register-staged row blocks are built for the fused detect only,
         // row blocks have no marginal-map flavour; none of the three has tail tiles
-        const bool plain = e->shift_nblk == 1 && e->shift_nw != qm::kShiftWaves3;
-        shift = e->shift_ok && (plain || (shift_mode == qm::kShiftDetect) ||
-                                (shift_mode == qm::kShiftVolume && e->shift_nblk > 1 && e->shift_direct));
+        const bool plain = e->sh.nblk == 1 && e->sh.nw != qm::kShiftWaves3;
+        shift = e->sh.ok && (plain || (shift_mode == qm::kShiftDetect) ||
+                                (shift_mode == qm::kShiftVolume && e->sh.nblk > 1 && e->sh.direct));
         a.tail_spl = (shift && plain) ? shift_tail_spl(e, n_chunk) : 0;
         // a last tile that is pulled back needs a whole tile of scan (and the detect flavours of the
         // kernels without tail tiles keep their former lower bound)
@@ -299,12 +323,13 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
             shift = false;
     }
     if (shift) {
-        a.g = e->shg;
+        a.g = L->g;
         a.rel = nullptr;
         a.brick_meta = nullptr;
         a.brick_total = nullptr;
         a.ntiles = (n_chunk + qm::kShiftKT - 1) / qm::kShiftKT;
         a.cap_doubles = qm::kShiftLdsBytes / 8;
+        if (wide) shift_wide_tiles(e, n_chunk, a);
     } else {
         a.tail_spl = 0;
     }
@@ -327,7 +352,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     }
     if (n_steps > 1) {
         const bool ok = !volume && !marginal && !accumulate && run_if == nullptr && want_scan &&
-                        (!shift || (e->shift_nblk == 1 && e->shift_nw != qm::kShiftWaves3));
+                        (!shift || (L->nblk == 1 && L->nw != qm::kShiftWaves3));
         if (batched) *batched = ok;
         if (!ok) return batched ? 0 : fail("run_stack: this launch cannot hold several timesteps");
         a.n_steps = n_steps;
@@ -344,13 +369,13 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         a.marginal = e->d_marg.p;
         e->marg_tiles = a.ntiles;
     }
-    const int n_wide_now = shift ? e->n_shwide : jp > 0 ? e->n_pwide : e->n_wide;
-    const int nbricks_now = shift ? e->shg.nbricks : jp > 0 ? e->pg.nbricks : e->g.nbricks;
+    const int n_wide_now = shift ? L->n_list : jp > 0 ? e->n_pwide : e->n_wide;
+    const int nbricks_now = shift ? L->g.nbricks : jp > 0 ? e->pg.nbricks : e->g.nbricks;
     const bool use_direct = e->cfg_force_direct || n_wide_now > 0;
     const bool use_lds = !e->cfg_force_direct && n_wide_now < nbricks_now;
     const int threads = shift ? 512 : jp > 0 ? 1024 : e->cfg_waves * qm::kWave;   // (direct launch)
     const int lds_blocks_per_cu =
-        shift ? (e->shift_nw == qm::kShiftWaves ? 2 : 1) : jp > 0 ? 1
+        shift ? (L->nw == qm::kShiftWaves ? 2 : 1) : jp > 0 ? 1
                : std::max(1, std::min(160 * 1024 / std::max(1, e->cfg_lds_bytes), 2048 / threads));
     int groups_lds = 0, groups_direct = 0;
     if (use_lds) {
@@ -391,7 +416,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     e->last_groups_lds = groups_lds;
     e->last_groups_direct = groups_direct;
     e->last_list = !use_direct || e->cfg_force_direct ? nullptr
-                   : shift ? e->d_shwide.p : jp > 0 ? e->d_pwide.p : e->d_wide.p;
+                   : shift ? L->list.p : jp > 0 ? e->d_pwide.p : e->d_wide.p;
     e->last_n_list = !use_direct ? 0 : e->cfg_force_direct ? nbricks_now : n_wide_now;
 
     // a conditional launch (the fallback of a screened step) is not part of the timing log: it
@@ -417,7 +442,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
              ? launch_stack_j<JJ, true>(e, a, groups_lds, groups_direct, use_lds, use_direct)  \
                 : launch_stack_j<JJ, false>(e, a, groups_lds, groups_direct, use_lds, use_direct)
     if (shift)
-        rc = launch_shift_path(e, a, groups_lds, groups_direct, use_lds, use_direct, shift_mode);
+        rc = launch_shift_path(e, *L, a, groups_lds, groups_direct, use_lds, use_direct, shift_mode);
     else if (jp == 2)
         rc = volume ? launch_pair_path<2, true>(e, a, groups_lds, groups_direct, use_lds, use_direct)
                     : launch_pair_path<2, false>(e, a, groups_lds, groups_direct, use_lds, use_direct);
@@ -708,13 +733,16 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
         if (v != 0 && v != qm::kShiftWaves && v != qm::kShiftWaves8 && v != qm::kShiftWaves3)
             return fail("shift_waves must be 0 (automatic), 4, 8 or 12");
         e->cfg_shift_waves = (int)v;
-        e->shift_built = false;
+        e->sh.built = false;
     } else if (k == "shift_rows_direct") {
         if (v < 0 || v > 2) return fail("shift_rows_direct must be 0, 1 or 2");
         e->cfg_shift_rows_direct = (int)v;
-        e->shift_built = false;
+        e->sh.built = false;
     } else if (k == "shift_tail") {
         e->cfg_shift_tail = v ? 1 : 0;
+    } else if (k == "shift_wide") {
+        if (v < -1 || v > 1) return fail("shift_wide must be -1 (automatic), 0 (off) or 1");
+        e->cfg_shift_wide = (int)v;
     } else if (k == "tie_rule") {
         if (v != 0 && v != 1) return fail("tie_rule must be 0 (largest sum) or 1 (the reference's exp rule)");
         e->cfg_tie_rule = (int)v;
@@ -771,11 +799,18 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "last_kernel") *v = e->last_kernel;
     else if (k == "last_kernel_j") *v = e->last_j;
     else if (k == "shift") *v = e->cfg_shift;
-    else if (k == "shift_ok") *v = e->shift_built && e->shift_ok ? 1 : 0;
-    else if (k == "shift_waves") *v = e->shift_ok ? e->shift_nw : e->cfg_shift_waves;
+    else if (k == "shift_ok") *v = e->sh.built && e->sh.ok ? 1 : 0;
+    else if (k == "shift_waves") *v = e->sh.ok ? e->sh.nw : e->cfg_shift_waves;
     else if (k == "shift_lazy") *v = e->shift_lazy_last;
     else if (k == "shift_tail") *v = e->cfg_shift_tail;
     else if (k == "shift_tail_spl") *v = e->shift_tail_last;
+    else if (k == "shift_wide") *v = e->cfg_shift_wide;
+    else if (k == "shift_wide_ok") *v = e->shw.built && e->shw.ok ? 1 : 0;
+    else if (k == "shift_wide_tiles") *v = e->shift_wide_last;
+    else if (k == "shift_wide_brick_nodes") *v = e->shw.ok ? e->shw.g.brick_nodes : 0;
+    else if (k == "shift_wide_direct_bricks") *v = e->shw.ok ? e->shw.n_list : 0;
+    else if (k == "shift_wide_operands_per_add_x1000")   // 8-byte LDS operands fetched per add of a wide tile (x 1000)
+        *v = e->shw.ok && e->shw.group_rows > 0 ? (e->shw.wquads * 4 * 1000) / (e->shw.group_rows * 48) : 0;
     else if (k == "steps_per_launch") *v = e->last_batched;
     else if (k == "tie_rule") *v = e->cfg_tie_rule;
     else if (k == "tie_refined_steps") *v = e->tie_refined_steps;
@@ -802,12 +837,12 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
         *v = 0;
         for (const TableSlot &sl : e->slots) *v += sl.used ? (int64_t)sl.state.device_bytes() : 0;
     }
-    else if (k == "shift_row_blocks") *v = e->shift_ok ? e->shift_nblk : 0;
-    else if (k == "shift_brick_nodes") *v = e->shift_ok ? e->shg.brick_nodes : 0;
-    else if (k == "shift_wide_bricks") *v = e->shift_ok ? e->n_shwide : 0;
+    else if (k == "shift_row_blocks") *v = e->sh.ok ? e->sh.nblk : 0;
+    else if (k == "shift_brick_nodes") *v = e->sh.ok ? e->sh.g.brick_nodes : 0;
+    else if (k == "shift_wide_bricks") *v = e->sh.ok ? e->sh.n_list : 0;
     else if (k == "shift_operands_per_add_x1000")   // 8-byte LDS operands fetched per add (x 1000)
-        *v = e->shift_ok && e->shift_group_rows > 0
-                 ? (e->shift_quads * 4 * 1000) / (e->shift_group_rows * 32) : 0;
+        *v = e->sh.ok && e->sh.group_rows > 0
+                 ? (e->sh.quads * 4 * 1000) / (e->sh.group_rows * 32) : 0;
     else if (k == "pair_brick_nodes") *v = e->pair_kt ? e->pg.brick_nodes : 0;
     else if (k == "pair_wide_bricks") *v = e->pair_kt ? e->n_pwide : 0;
     else if (k == "pair_tile") *v = e->pair_ok ? e->pair_kt : 0;

@@ -95,6 +95,39 @@ struct DevBuf {
     }
 };
 
+// One shift-reuse layout of a table (qm_shift.hpp): brick grid with even brick dimensions, the row-window
+// records of every brick, which bricks fit, the record stream dealt over the workgroup's wavefronts.  A table
+// has up to two: `sh`, what rounds 3-5 built (256-sample tiles; any launch kind), and -- round 6 -- `shw` for
+// the fused detect where WIDE tiles fit: the 8-wave shape on its own brick grid, with a second set of records
+// and a second stream for the 384-sample tiles beside those of the 256-sample and tail tiles behind them.
+struct ShiftLayout {
+    int nw = 0;                             // workgroup shape the tables were built for
+    qm::GridDesc g{};
+    DevBuf<int32_t> raw, meta, total, fit, list;   // list: the bricks that do not fit (direct kernel)
+    DevBuf<uint32_t> stream;
+    int n_list = 0, rows2 = 0;
+    int nblk = 1, sb = 0;                   // row blocks (tables of more than 64 rows): blocks, rows per block
+    int stage_slots = 0, stage_reach = 0;   // ... largest row window (slots), furthest sample it holds
+    bool direct = false;                    // ... staged by LDS-direct loads (stack_shift_rows2_kernel)
+    bool quad = false;                      // ... by two 4-wave workgroups per CU (stack_shift_rows4_kernel)
+    bool built = false, ok = false;
+    int64_t quads = 0, group_rows = 0;      // register-window quads fetched / (group, row)s
+    // wide tiles (shw only)
+    bool wide = false;
+    DevBuf<int32_t> wmeta, wtotal;
+    DevBuf<uint32_t> wstream;
+    int64_t wquads = 0;                     // quads fetched by the wide tiles' windows (per 48 adds, not 32)
+
+    void release() {
+        PoolReleaseScope one_wait;
+        raw.release(); meta.release(); total.release(); fit.release(); list.release(); stream.release();
+        wmeta.release(); wtotal.release(); wstream.release();
+    }
+    size_t device_words() const {
+        return raw.n + meta.n + total.n + fit.n + list.n + stream.n + wmeta.n + wtotal.n + wstream.n;
+    }
+};
+
 // Everything that is derived from ONE travel-time table: the table itself, its brick records and
 // window offsets, the layouts of the paired / screened / shift-reuse kernels built from it on first
 // use, and the launch shape the table's layout search picked.  The engine works on the state it
@@ -132,32 +165,20 @@ struct TableState {
     int pair_kt = 0;                        // tile length the paired tables were built for
     bool pair_ok = false;                   // ... and whether (almost) every brick fits
 
-    // shift-reuse layout of the fused float64 detect (qm_shift.hpp): own brick grid, row-window
-    // slots, record stream
-    int shift_nw = 0;                       // workgroup shape the tables were built for
-    qm::GridDesc shg{};
-    DevBuf<int32_t> d_shraw, d_shmeta, d_shtotal, d_shfit, d_shwide;
-    DevBuf<uint32_t> d_shstream;
-    int n_shwide = 0, shift_rows2 = 0;
-    int shift_nblk = 1, shift_sb = 0;       // row blocks (tables of more than 64 rows): blocks, rows per block
-    int shift_stage_slots = 0, shift_stage_reach = 0;   // ... largest row window (slots), furthest sample it holds
-    bool shift_direct = false;              // ... staged by LDS-direct loads (stack_shift_rows2_kernel)
-    bool shift_quad = false;                // ... by two 4-wave workgroups per CU (stack_shift_rows4_kernel)
-    bool shift_built = false, shift_ok = false;
-    int64_t shift_quads = 0, shift_group_rows = 0;   // register-window quads fetched / (group, row)s
+    // shift-reuse layouts (qm_shift.hpp): own brick grids, row-window slots, record streams
+    ShiftLayout sh, shw;
 
     void release_all() {
         PoolReleaseScope one_wait;
         d_lut.release(); d_bmeta.release(); d_btotal.release(); d_wide.release(); d_rel.release();
         d_smeta.release(); d_smeta_raw.release(); d_stotal.release(); d_swide.release(); d_srel.release();
         d_pmeta.release(); d_pmeta_raw.release(); d_ptotal.release(); d_pwide.release(); d_prel.release();
-        d_shraw.release(); d_shmeta.release(); d_shtotal.release(); d_shfit.release();
-        d_shwide.release(); d_shstream.release();
+        sh.release(); shw.release();
     }
     size_t device_bytes() const {
         return (d_lut.n + d_bmeta.n + d_btotal.n + d_wide.n + d_smeta.n + d_smeta_raw.n + d_stotal.n +
-                d_swide.n + d_pmeta.n + d_pmeta_raw.n + d_ptotal.n + d_pwide.n + d_shraw.n + d_shmeta.n +
-                d_shtotal.n + d_shfit.n + d_shwide.n + d_shstream.n) * 4 +
+                d_swide.n + d_pmeta.n + d_pmeta_raw.n + d_ptotal.n + d_pwide.n + sh.device_words() +
+                shw.device_words()) * 4 +
                (d_rel.n + d_srel.n + d_prel.n) * 2;
     }
 };
@@ -217,6 +238,8 @@ struct qm_engine : TableState {
     int cfg_shift_tail = 1;                 // 1: a scan's remainder of <= 192 samples runs as one tail tile of
                                             // 64 / 128 / 192 samples; 0: whole tiles only (round 3)
     int cfg_shift_rows_direct = 1;
+    int cfg_shift_wide = -1;                // fused detect on WIDE tiles (384 samples, six per lane; round 6): -1 where
+                                            // they fit and the scan holds at least one, 0 never, 1 as -1 (explicit)
     int cfg_tie_rule = 0;                   // 0: largest float64 sum, lowest index among equal ones (default);
                                             // 1: the reference's rule on near-ties (qm_ties.hpp)
 
@@ -232,6 +255,7 @@ struct qm_engine : TableState {
     int flags_pending = 0, flags_head = 0;  // not yet folded into the counters
     int shift_lazy_last = 0;                // loop flavour the last shift-reuse launch took
     int shift_tail_last = 0;                // samples per lane of the last launch's tail tile (0: none)
+    int shift_wide_last = 0;                // wide tiles of the last shift-reuse launch
     int last_batched = 1;                   // timesteps the last detect_batch put into one launch
     // which bricks the partial sets of the last stacking launch stand for (qm_ties.hpp)
     qm::GridDesc last_g{};
@@ -303,7 +327,7 @@ int run_j(const qm_engine *e, int n_chunk);
 int plan_wide(qm_engine *e, int J);
 int pair_jp(const qm_engine *e, int n_chunk, bool volume);
 int ensure_pair_tables(qm_engine *e, int jp);
-int ensure_shift_tables(qm_engine *e);
+int ensure_shift_tables(qm_engine *e, ShiftLayout &L);
 bool screen_plan_feasible(const qm_engine *e, int S, const ScreenPlan &p);
 ScreenPlan screen_plan(const qm_engine *e, int S, int n_samples);
 int ensure_screen_tables(qm_engine *e, const ScreenPlan &plan);

@@ -53,6 +53,8 @@ struct StackArgs {
     int ntiles, ngroups;
     int tail_spl;                  // shift-reuse kernels: samples per lane of the scan's tail tile (1..3;
                                    // 0: whole 256-sample tiles only, the last one pulled back)
+    int wide_tiles;                // shift-reuse kernels, round 6: the launch's first tiles are this many WIDE
+                                   // tiles of 384 samples (six per lane, qm_shift.hpp); 256-sample tiles follow
     // K timesteps in one launch (detect-type launches): step k scans onsets + k * step_stride with
     // the same table and geometry and publishes its partial sets at column k * n_chunk of rows that
     // are part_stride long.  The time-tile axis of the grid is n_steps * ntiles long.

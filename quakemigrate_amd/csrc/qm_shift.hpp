@@ -54,6 +54,12 @@ constexpr int kShiftWaves = 4;                          // wavefronts per workgr
 constexpr int kShiftWaves8 = 8;
 constexpr int kShiftWaves3 = 12;
 constexpr int kShiftKT = 256;                           // samples per time tile
+// Round 6, WIDE tiles: six samples per lane, time tile 384.  A register window then feeds 48 adds instead
+// of 32 (the row loop's cost is its LDS reads and per-row bookkeeping), and with a
+// lane stride of 48 bytes 16-byte reads of a CONTIGUOUS row window are conflict-free, so the window may start
+// at any EVEN sample (two-plane layout: a multiple of four).  384-sample windows of ~30 rows need more than
+// 80 KB: the 8-wave workgroup that owns a CU's LDS.
+constexpr int kShiftWideKT = kWave * kShiftWideSpl;
 constexpr int kShiftLdsBytes = 2 * kShiftPlane;         // both planes
 constexpr int kShiftStateBytes = 5 * kShiftStateChunk;  // per wavefront (12-wave shape)
 constexpr int kShiftLdsBytes3 = 2 * kShiftPlane3 + kShiftWaves3 * kShiftStateBytes;
@@ -109,6 +115,11 @@ struct ShiftArgs {
     int sb;                      // rows per block (even; the last block may hold fewer)
     int stage_slots;             // row blocks: the largest slot count of a row window (the loop's staging: <= 127)
     int stage_reach;             // ... and the furthest sample past a tile's first that a window holds
+    // wide tiles (a.wide_tiles > 0: the launch's first tiles hold 384 samples, six per lane): their own row-window
+    // records and stream on the same brick grid and deal; sfit is the verdict for BOTH tile kinds
+    const int4 *wmeta;
+    const int32_t *wtotal;
+    const char *wstream;
 };
 
 // a wavefront that sees at least this many 2x2x2 groups between two resets of its running
@@ -168,16 +179,29 @@ __device__ __forceinline__ unsigned shift_group_delays(const GridDesc &g, const 
     return mask;
 }
 
-__device__ __forceinline__ void shift_window(const int (&d)[8], int &e0, int &nq) {
+// register window of a (group, row): first sample e0 (relative to the brick's row minimum) and quads of four
+// doubles it spans.  wide: six samples per lane from an even sample (kShiftWideSpl), else four from a multiple
+// of four.
+__device__ __forceinline__ void shift_window(const int (&d)[8], int wide, int &e0, int &nq) {
     int dmin = d[0], dmax = d[0];
 #pragma unroll
     for (int n = 1; n < 8; ++n) {
         dmin = d[n] < dmin ? d[n] : dmin;
         dmax = d[n] > dmax ? d[n] : dmax;
     }
-    e0 = dmin & ~3;
-    nq = (dmax - e0 + 4 + 3) / 4;
+    e0 = wide ? dmin & ~1 : dmin & ~3;
+    nq = (dmax - e0 + (wide ? kShiftWideSpl : 4) + 3) / 4;
     nq = nq < 2 ? 2 : nq;
+}
+// samples a lane is ahead of its predecessor / the furthest 4-double slot (exclusive) a lane may touch in a
+// window that starts at sample e0 and fetches `fetched` quads
+__host__ __device__ constexpr int shift_lane_step(int wide) { return wide ? kShiftWideSpl : 4; }
+__host__ __device__ constexpr int shift_slots_touched(int wide, int e0, int fetched) {
+    return (e0 + shift_lane_step(wide) * (kWave - 1) + 4 * fetched + 3) / 4;
+}
+// slots of the all-zero window that the padding row of an odd row count reads
+__host__ __device__ constexpr int shift_zero_slots(int wide) {
+    return wide ? shift_slots_touched(1, 0, kShiftNqMin) : kWave + kShiftNqMin;
 }
 
 #ifdef QM_TU_TABLES
@@ -190,7 +214,7 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
                                                          int32_t *__restrict__ stotal,
                                                          int32_t *__restrict__ sfit,
                                                          unsigned long long *__restrict__ tally,
-                                                         int plane_bytes, int nblk, int sb) {
+                                                         int plane_bytes, int nblk, int sb, int wide) {
     // tally[0] += quads the loop fetches, tally[1] += (group, row) pairs: operands per add; tally[2] = the
     // largest slot count of a row window, tally[3] = the furthest window sample past a tile's first one (what
     // the row-block kernels need to know before they let the row loop stage: ShiftArgs::stage_slots / _reach)
@@ -213,11 +237,11 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
         int d[8], e0, nq;
         shift_group_delays(g, lut, x0, y0, z0, vx, vy, vz, gx, gy, gz, r0 + r,
                            meta_raw[(int64_t)b * g.n_rows + r0 + r].x, d);
-        shift_window(d, e0, nq);
+        shift_window(d, wide, e0, nq);
         if (nq > kShiftNqMax) atomicOr(&overflow, 1);
         const int fetched = nq > kShiftNqMin ? nq : kShiftNqMin;
         quads += (unsigned)fetched;
-        atomicMax(&need[r], e0 / 4 + 63 + fetched);
+        atomicMax(&need[r], shift_slots_touched(wide, e0, fetched));
     }
     atomicAdd(&tally[0], (unsigned long long)quads);
     __syncthreads();
@@ -233,7 +257,8 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
             atomicMax(&tally[3], (unsigned long long)(reach > 0 ? reach : 0));
         }
         stotal[vb] = run;
-        const int zero_row = (S & 1) ? 64 + kShiftNqMin : 0;   // all-zero window of the padding row
+        const int zero_row = (S & 1) ? shift_zero_slots(wide) : 0;   // all-zero window of the padding row
+        // (two planes of 16-byte slots; wide tiles: ONE contiguous region of 32-byte slots, plane_bytes = half of it)
         sfit[vb] = (!overflow && (int64_t)(run + zero_row) * 16 <= plane_bytes) ? 1 : 0;
     }
 }
@@ -243,7 +268,7 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
                                                            const int4 *__restrict__ smeta,
                                                            const int32_t *__restrict__ stotal,
                                                            const int32_t *__restrict__ sfit, int rows2max,
-                                                           int nw, int nblk, int sb, int packed,
+                                                           int nw, int nblk, int sb, int packed, int wide,
                                                            uint32_t *__restrict__ stream) {
     extern __shared__ uint2 hdr[];                      // [group j][row] (LDS address, quads)
     // (row blocks: workgroup vb = (brick, block); sfit is per brick -- all of its blocks fit)
@@ -271,7 +296,7 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
         const int4 m = smeta[(int64_t)vb * sb + r];
         int d[8], e0, nq;
         const unsigned mask = shift_group_delays(g, lut, x0, y0, z0, vx, vy, vz, gx, gy, gz, r0 + r, m.x, d);
-        shift_window(d, e0, nq);
+        shift_window(d, wide, e0, nq);
         if (packed) {                                   // the eight register indices (< 48) as bytes
             uint32_t lo = 0, hi = 0;
             for (int n = 0; n < 4; ++n) {
@@ -283,7 +308,9 @@ __global__ __launch_bounds__(256) void shift_stream_kernel(GridDesc g, const int
         } else {
             for (int n = 0; n < 8; ++n) rec[n] = 2u * (unsigned)(d[n] - e0);
         }
-        hdr[j * rows2 + r] = make_uint2(16u * (unsigned)(m.z + e0 / 4), (unsigned)nq);
+        // (the loops of contiguous windows double this: byte 32 z + 8 e0 -- wide tiles: e0 is even, not a
+        // multiple of four)
+        hdr[j * rows2 + r] = make_uint2(16u * (unsigned)m.z + 4u * (unsigned)e0, (unsigned)nq);
         if (r == 0) {
             rec[shift_rec_base(packed)] = (uint32_t)(((int64_t)(x0 + 2 * gx) * g.ny + (y0 + 2 * gy)) * g.nz + (z0 + 2 * gz));
             rec[shift_rec_base(packed) + 1] = mask;
@@ -325,6 +352,9 @@ template <int NW, int RB = (NW == 12 ? 3 : 8), int U = 6, bool CONTIG = false, i
 __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *win, int vb, int row0,
                                                     int S, int sb, int wave, int lane, int t_first) {
     const StackArgs &a = s.a;
+    constexpr bool kWide = KT == kShiftWideKT;
+    const int4 *const smeta = kWide ? s.wmeta : s.smeta;
+    const int32_t *const stotal = kWide ? s.wtotal : s.stotal;
     // A wavefront stages rows wave, wave + NW, ...: the loads of ALL its rows (up to RB x U x 64
     // samples) are issued before the first LDS store, so the brick's staging costs one round trip
     // to L2 instead of one per row (while a workgroup stages, its SIMDs' other wavefronts run at
@@ -342,7 +372,7 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
             const int r = r0 + k * NW;
-            m[k] = r < S ? s.smeta[(int64_t)vb * sb + r] : make_int4(0, 0, 0, 0);
+            m[k] = r < S ? smeta[(int64_t)vb * sb + r] : make_int4(0, 0, 0, 0);
             const int len = m[k].y + KT;                           // samples the brick can touch
             const int first = m[k].x + a.fsmp + a.sample0 + t_first;   // index inside the row
             const int room = a.T - first;
@@ -374,8 +404,61 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
         }
     }
     if ((S & 1) && wave == 0) {                                    // the padding row's zero window
-        const int z = s.stotal[vb];
-        for (int u = lane; u < 4 * (64 + kShiftNqMin); u += kWave) win[where(z, u)] = 0.0;
+        const int z = stotal[vb];
+        for (int u = lane; u < 4 * shift_zero_slots(kWide); u += kWave) win[where(z, u)] = 0.0;
+    }
+}
+
+// Wide tiles: the contiguous row windows of brick b by LDS-DIRECT loads (global_load_lds_dwordx4: 16 bytes per
+// lane from global memory to LDS at M0 + 16 lane, no registers -- the group loop leaves the compiler 48 VGPRs,
+// and a staging through registers spilled the wavefront's running state around every brick).  A wavefront
+// stages rows wave, wave + NW, ...; everything about a row is wave-uniform except the lane's 16 bytes: M0 = the
+// chunk's LDS address, the chunk's global address as the instruction's scalar base, EXEC = the chunk's pairs.
+// Samples behind what the brick can touch are whatever follows them in memory (fetched with a window, never
+// added); a row whose window reaches past the onsets' last sample -- only the scan's last tiles at the largest
+// delays -- goes through registers, zero-filled.  The caller waits (vmcnt) before its barrier.
+template <int NW>
+__device__ __forceinline__ void stage_shift_wide(const ShiftArgs &s, double *win, int b, int S, int wave,
+                                                 int lane, int t_first) {
+    const StackArgs &a = s.a;
+    using int4s = int __attribute__((ext_vector_type(4)));
+    const int4s *meta = reinterpret_cast<const int4s *>(s.wmeta + (int64_t)b * S);
+    const unsigned lds_base = (unsigned)(uintptr_t)((lds_f64 *)win);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    for (int r = wave; r < S; r += NW) {
+        const int4s m = meta[__builtin_amdgcn_readfirstlane(r)];          // (min delay, span, first slot, slots)
+        const int first = __builtin_amdgcn_readfirstlane(m.x) + a.fsmp + a.sample0 + t_first;
+        const int total = 4 * __builtin_amdgcn_readfirstlane(m.w);         // doubles, all of them written
+        const int z4 = 4 * __builtin_amdgcn_readfirstlane(m.z);
+        const int room = a.T - first;
+        const double *src = a.onsets + (int64_t)r * a.T + first;
+        if (room >= total) {
+            const unsigned long long sp = (unsigned long long)src;
+            const double *usrc = (const double *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sp >> 32)) << 32) |
+                                                  (unsigned)__builtin_amdgcn_readfirstlane((int)sp));
+            for (int c = 0; c < total; c += 2 * kWave) {
+                const int pairs = (total - c) / 2 < kWave ? (total - c) / 2 : kWave;
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "s_lshr_b64 exec, -1, %[sh]\n\t"
+                             "s_mov_b32 m0, %[ma]\n\t"
+                             "s_nop 0\n\t"
+                             "global_load_lds_dwordx4 %[vo], %[src]\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sv] "=&s"(saved)
+                             : [sh] "s"(__builtin_amdgcn_readfirstlane(kWave - pairs)),
+                               [ma] "s"(__builtin_amdgcn_readfirstlane((int)(lds_base + 8u * (unsigned)(z4 + c)))),
+                               [vo] "v"(lane16), [src] "s"(usrc + c)
+                             : "memory", "m0");
+            }
+        } else {
+            const int len = __builtin_amdgcn_readfirstlane(m.y) + kShiftWideKT;
+            for (int u = lane; u < total; u += kWave) win[z4 + u] = (u < len && u < room) ? src[u] : 0.0;
+        }
+    }
+    if ((S & 1) && wave == 0) {                                    // the padding row's zero window
+        const int z4 = 4 * s.wtotal[b];
+        for (int u = lane; u < 4 * shift_zero_slots(1); u += kWave) win[z4 + u] = 0.0;
     }
 }
 
@@ -386,17 +469,28 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
 // loop flavour (gen_shift_asm.py) -- or (a.tail_spl = 0: a remainder of more than 192 samples, and the
 // kernels without tail flavours) a last whole tile pulled back so that it ends with the scan (it
 // overlaps its predecessor: same arithmetic, same bits).
+// Round 6: the launch's first a.wide_tiles tiles are WIDE (384 samples, six per lane; the last of them pulled
+// back if the scan ends inside it), the 256-sample tiles and the tail tile follow behind them.
 struct ShiftWork {
-    int tile, group, t_first, spl;
+    int tile, group, spl;
+    int t_own;                   // first sample the tile is there for
+    int t_first;                 // first sample it computes (< t_own: pulled back over its predecessor)
     bool run;
 };
 __device__ __forceinline__ ShiftWork shift_work(const StackArgs &a) {
     ShiftWork w;
     stack_tile_group(a, w.tile, w.group);
     w.run = w.group < a.ngroups && !(a.run_if != nullptr && *a.run_if == 0);
+    if (w.tile < a.wide_tiles) {
+        w.spl = kShiftWideSpl;
+        w.t_own = w.tile * kShiftWideKT;
+        w.t_first = w.t_own + kShiftWideKT > a.n_chunk ? a.n_chunk - kShiftWideKT : w.t_own;
+        return w;
+    }
     w.spl = (a.tail_spl > 0 && w.tile == a.ntiles - 1) ? a.tail_spl : 4;
-    w.t_first = (w.spl == 4 && (w.tile + 1) * kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT)
-                    ? a.n_chunk - kShiftKT : w.tile * kShiftKT;
+    w.t_own = a.wide_tiles * kShiftWideKT + (w.tile - a.wide_tiles) * kShiftKT;
+    w.t_first = (w.spl == 4 && w.t_own + kShiftKT > a.n_chunk && a.n_chunk >= kShiftKT)
+                    ? a.n_chunk - kShiftKT : w.t_own;
     return w;
 }
 // a wavefront's running (max z, sum of 2^z, first index) of its J samples per lane
@@ -451,13 +545,19 @@ __device__ __forceinline__ void shift_publish(const StackArgs &a, double *win, c
 }
 
 // One (time tile, brick group) of a launch: J samples per lane (4: a whole tile on the two-plane
-// layout; 1..3: the scan's tail tile on the contiguous layout).
-template <int MODE, int NW, int J>
+// layout; 1..3: the scan's tail tile on the contiguous layout; 6: a wide tile, contiguous layout, fused
+// detect in the 8-wave shape only).
+// (WIDE_LAZY: the wide tile's loop flavour, chosen outside the brick loop -- with both flavours' asm statements
+// in one loop the compiler shuffled the 30 registers of running state between their operand assignments and
+// spilled them around every brick)
+template <int MODE, int NW, int J, bool WIDE_LAZY = false>
 __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, const ShiftWork &work,
                                            int lane, int wave) {
     constexpr bool kLdsState = NW == kShiftWaves3;
-    constexpr bool kTail = J < 4;
+    constexpr bool kWide = J == kShiftWideSpl;
+    constexpr bool kTail = J != 4;                      // (contiguous row windows)
     static_assert(!(kTail && kLdsState), "the 12-wave shape has no tail flavours");
+    static_assert(!kWide || (MODE == kShiftDetect && NW == kShiftWaves8), "wide tiles: fused detect, 8 waves");
     const StackArgs &a = s.a;
     const GridDesc &g = a.g;
     const int tile = work.tile, group = work.group, t_first = work.t_first;
@@ -465,7 +565,7 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
     const unsigned lane_addr = lds_base + (unsigned)lane * (kTail ? 8u * J : 16u);
     // volume, whole tiles: lanes of a pulled-back tile whose four samples its predecessor stores are
     // masked off at the stores (a lane that straddles the seam stores its four: same bits)
-    const int seam = tile * kShiftKT - t_first;                    // samples of overlap, 0 .. 255
+    const int seam = work.t_own - t_first;                         // samples of overlap, 0 .. 255
     const unsigned long long store_lanes = ~0ull << (seam / 4);
     // volume, tail tiles: per sample slot the lanes whose sample lies inside the scan
     unsigned long long slot_lanes[J];
@@ -476,7 +576,7 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
     for (int k = 0; k < J; ++k) {
         const int t = t_first + J * lane + k;
         slot_lanes[k] = __builtin_amdgcn_ballot_w64(t < a.n_chunk);
-        weight[k] = (t >= tile * kShiftKT && t >= a.m0 && t < a.m1 && t < a.n_chunk) ? 1.0 : 0.0;
+        weight[k] = (t >= work.t_own && t >= a.m0 && t < a.m1 && t < a.n_chunk) ? 1.0 : 0.0;
     }
     // marginal map, whole groups: the eight nodes' shares are summed over the wavefront together
     // (gen_shift_asm.py, marginal_butterfly); lane l ends with the total of node 4 b2 + 2 b0 + b1 of
@@ -528,8 +628,13 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
         }
 #else
         __syncthreads();                              // previous brick fully consumed
-        stage_shift_windows<NW, (NW == 12 ? 3 : 8), 6, kTail, kWave * J>(s, win, b, 0, g.n_rows, g.n_rows, wave,
-                                                                         lane, t_first);
+        if constexpr (kWide) {
+            stage_shift_wide<NW>(s, win, b, g.n_rows, wave, lane, t_first);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            stage_shift_windows<NW, (NW == 12 ? 3 : 8), 6, kTail, kWave * J>(s, win, b, 0, g.n_rows, g.n_rows, wave,
+                                                                             lane, t_first);
+        }
         __syncthreads();
 #endif
         int x0, y0, z0, vx, vy, vz, cx, cy, cz;
@@ -537,12 +642,13 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
         const int nvg = cx * cy * cz;
         const int mine = (nvg - wave + NW - 1) / NW;                       // groups of this wave
         if (mine <= 0) continue;
-        const char *run = s.stream + shift_run_record(b, wave, 0, NW, 1, rpw) * kShiftRec;
+        const char *const stream = kWide ? s.wstream : s.stream;
+        const char *run = stream + shift_run_record(b, wave, 0, NW, 1, rpw) * kShiftRec;
         // this wavefront's next run (its next brick that runs here; none: this one again, harmless):
         // the loop pulls its head into L2 (gen_shift_asm.py: NEXT_RUN)
         int nb = b + a.ngroups;
         while (nb < g.nbricks && !s.sfit[nb]) nb += a.ngroups;
-        const char *next_run = s.stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, 1, rpw) * kShiftRec;
+        const char *next_run = stream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, 1, rpw) * kShiftRec;
         const unsigned next_off = (unsigned)lane * 64u;
         const void *next_meta = s.smeta + (int64_t)(nb < g.nbricks ? nb : b) * g.n_rows;
         (void)next_meta;
@@ -562,7 +668,13 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
         else                                                                                          \
             shift_tail##JJ##_detect(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz,         \
                                     a.z_scale, c)
-        if constexpr (J == 1) { QM_TAIL_CALL(1); }
+        if constexpr (kWide && WIDE_LAZY)
+            shift_wide_detect_lazy(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz,
+                                   a.z_scale, c);
+        else if constexpr (kWide)
+            shift_wide_detect(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz,
+                              a.z_scale, c);
+        else if constexpr (J == 1) { QM_TAIL_CALL(1); }
         else if constexpr (J == 2) { QM_TAIL_CALL(2); }
         else if constexpr (J == 3) { QM_TAIL_CALL(3); }
 #undef QM_TAIL_CALL
@@ -617,6 +729,12 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
     if constexpr (MODE == kShiftDetect) s.a = step_view(s.a);   // (several timesteps per launch: this workgroup's)
     const ShiftWork work = shift_work(s.a);
     if (!work.run) return;
+    if constexpr (MODE == kShiftDetect && NW == kShiftWaves8) {
+        if (work.spl == kShiftWideSpl) {
+            if (s.lazy) return shift_tile<MODE, NW, kShiftWideSpl, true>(s, win, work, lane, wave);
+            return shift_tile<MODE, NW, kShiftWideSpl, false>(s, win, work, lane, wave);
+        }
+    }
     if constexpr (NW != kShiftWaves3) {
         if (work.spl == 3) return shift_tile<MODE, NW, 3>(s, win, work, lane, wave);
         if (work.spl == 2) return shift_tile<MODE, NW, 2>(s, win, work, lane, wave);

@@ -160,43 +160,41 @@ int ensure_pair_tables(qm_engine *e, int jp) {
 }
 
 // ---- shift-reuse layout (qm_shift.hpp) ----------------------------------------------------------
-// Own brick grid (e->shg, even brick dimensions: the kernel walks 2x2x2 node groups): the largest
+// Own brick grid (L.g, even brick dimensions: the kernel walks 2x2x2 node groups): the largest
 // shape whose de-interleaved row windows fit 80 KB and whose groups' delay spread fits the
 // register window for (almost) every brick; per-(brick, row) slot records and the record stream.
-int build_shift_tables(qm_engine *e);
+// e->shw (round 6): the same for the 8-wave shape with WIDE tiles in front -- both kinds of records and
+// streams on one brick grid, a brick runs there if the windows of both tile kinds fit.
+static int build_shift_tables(qm_engine *e, ShiftLayout &L, bool wide);
 
-void release_shift_tables(qm_engine *e) {
-    PoolReleaseScope one_wait;
-    e->d_shraw.release(); e->d_shmeta.release(); e->d_shtotal.release(); e->d_shfit.release();
-    e->d_shwide.release(); e->d_shstream.release();
-}
-
-// Outcome per resident table: the layout is built (shift_ok), or the table does not qualify, or the
-// tables could not be built -- most likely no memory for the record stream (8 S bytes per node, twice
-// the table): that, too, is "does not qualify": the buffers are released, the error is dropped and
+// Outcome per resident table: the layout is built (L.ok), or the table does not qualify, or the
+// tables could not be built -- most likely no memory for the record stream (4 S bytes per node, the
+// table's size): that, too, is "does not qualify": the buffers are released, the error is dropped and
 // the same step runs on the other kernels.
-int ensure_shift_tables(qm_engine *e) {
-    if (e->shift_built) return 0;
-    e->shift_ok = false;
-    const int rc = build_shift_tables(e);
-    if (rc != 0 || !e->shift_ok) {
-        e->shift_ok = false;
-        release_shift_tables(e);
+int ensure_shift_tables(qm_engine *e, ShiftLayout &L) {
+    if (L.built) return 0;
+    L.ok = false;
+    const int rc = build_shift_tables(e, L, &L == &e->shw);
+    if (rc != 0 || !L.ok) {
+        L.ok = false;
+        L.release();
         if (rc != 0) {
             (void)hipGetLastError();                    // (an allocation failure is not sticky)
             clear_error();
         }
     }
-    e->shift_built = true;
+    L.built = true;
     return 0;
 }
 
-int build_shift_tables(qm_engine *e) {
+static int build_shift_tables(qm_engine *e, ShiftLayout &L, bool wide) {
     const int S = e->g.n_rows;
+    L.wide = wide;
     // More rows than a CU's LDS holds windows for: row blocks (stack_shift_rows_kernel) -- bricks of
     // 4x4x4 nodes = one 2x2x2 group per wavefront of the 8-wave workgroup, whose accumulators stay
     // in registers while the rows are staged in nblk blocks of sb <= 64 rows.
     const bool blocks = S > qm::kShiftMaxRows;
+    if (wide && blocks) return 0;                       // (wide tiles: all rows of a brick in LDS at once)
     // two forms (qm_shift.hpp): blocks of <= 34 rows staged by LDS-direct loads into the idle half of
     // a double-buffered LDS (default), or blocks of <= 64 staged through registers between two barriers
     // (that one only from 97 rows on: at 65-96 two blocks of <= 48 rows stage as often as they
@@ -222,9 +220,14 @@ int build_shift_tables(qm_engine *e) {
     static const int kShapes4[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4}, {2, 4, 4}};
     static const int kShapes8[][3] = {{8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4}, {4, 4, 4}};
     static const int kShapes12[][3] = {{8, 8, 12}, {8, 8, 6}, {4, 8, 6}, {4, 4, 6}, {2, 4, 6}};
+    // (wide tiles, 8 waves: 8x8x16 gives a wavefront sixteen groups per brick, as 8x8x8 does on four waves)
+    static const int kShapesWide[][3] = {{8, 8, 16}, {8, 8, 8}, {4, 8, 8}, {4, 4, 8}, {4, 4, 4}};
     int candidates[2] = {qm::kShiftWaves, qm::kShiftWaves8};
     int n_candidates = 2;
-    if (e->cfg_shift_waves != 0) {
+    if (wide) {
+        candidates[0] = qm::kShiftWaves8;
+        n_candidates = 1;
+    } else if (e->cfg_shift_waves != 0) {
         candidates[0] = e->cfg_shift_waves;
         n_candidates = 1;
     } else if (blocks && quad) {
@@ -240,13 +243,13 @@ int build_shift_tables(qm_engine *e) {
     static const int kShapesBlocks4[][3] = {{4, 4, 2}};
     int nw = candidates[0];
     qm::GridDesc g = e->g;
-    std::vector<int32_t> fit, wide;
+    std::vector<int32_t> fit, fitw, list;
     bool ok = false;
     auto even_up = [](int v) { return v + (v & 1); };
     for (int cand = 0; cand < n_candidates && !ok; ++cand) {
     nw = candidates[cand];
-    const int (*kShapes)[3] = blocks ? (quad ? kShapesBlocks4 : kShapesBlocks) : nw == qm::kShiftWaves3 ? kShapes12
-                              : nw == qm::kShiftWaves8 ? kShapes8 : kShapes4;
+    const int (*kShapes)[3] = blocks ? (quad ? kShapesBlocks4 : kShapesBlocks) : wide ? kShapesWide
+                              : nw == qm::kShiftWaves3 ? kShapes12 : nw == qm::kShiftWaves8 ? kShapes8 : kShapes4;
     for (int s = 0; s < n_shapes; ++s) {
         g = e->g;
         g.bx = std::min(even_up(fixed ? e->cfg_bx : kShapes[s][0]), even_up(g.nx));
@@ -259,36 +262,52 @@ int build_shift_tables(qm_engine *e) {
         g.brick_nodes = g.bx * g.by * g.bz;
         const size_t br = (size_t)g.nbricks * S;
         const size_t nvb = (size_t)g.nbricks * nblk;               // (brick, row block) pairs
-        // (d_shmeta: + 4 KB of slack -- the row-block loops prefetch that much metadata ahead)
-        if (e->d_shraw.ensure(4 * br) || e->d_shmeta.ensure(4 * nvb * sb + 1024) ||
-            e->d_shtotal.ensure(nvb) || e->d_shfit.ensure(nvb) || e->d_scalar.ensure(12))
+        // (meta: + 4 KB of slack -- the row-block loops prefetch that much metadata ahead)
+        if (L.raw.ensure(4 * br) || L.meta.ensure(4 * nvb * sb + 1024) ||
+            L.total.ensure(nvb) || L.fit.ensure(nvb) || e->d_scalar.ensure(12))
             return 1;
+        if (wide && (L.wmeta.ensure(4 * nvb * sb + 1024) || L.wtotal.ensure(nvb) || e->d_work.ensure(nvb))) return 1;
         QM_HIP(hipMemsetAsync(e->d_scalar.p, 0, 12 * sizeof(int32_t), e->stream));
         hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
-                           e->d_lut.p, reinterpret_cast<int4 *>(e->d_shraw.p), e->d_scalar.p);
+                           e->d_lut.p, reinterpret_cast<int4 *>(L.raw.p), e->d_scalar.p);
+        unsigned long long *const tally_d = reinterpret_cast<unsigned long long *>(e->d_scalar.p + 4);
         hipLaunchKernelGGL(qm::shift_need_kernel, dim3((unsigned)nvb), dim3(256), 0, e->stream, g,
-                           e->d_lut.p, reinterpret_cast<const int4 *>(e->d_shraw.p),
-                           reinterpret_cast<int4 *>(e->d_shmeta.p), e->d_shtotal.p, e->d_shfit.p,
-                           reinterpret_cast<unsigned long long *>(e->d_scalar.p + 4),
-                           blocks && direct ? qm::kShiftPlane : qm::shift_plane(nw), nblk, sb);
+                           e->d_lut.p, reinterpret_cast<const int4 *>(L.raw.p),
+                           reinterpret_cast<int4 *>(L.meta.p), L.total.p, L.fit.p, tally_d,
+                           blocks && direct ? qm::kShiftPlane : qm::shift_plane(nw), nblk, sb, 0);
         QM_HIP(hipGetLastError());
         fit.resize(nvb);
         unsigned long long tally[4] = {0, 0, 0, 0};
-        QM_HIP(copy_back(fit.data(), e->d_shfit.p, nvb * sizeof(int32_t), e->stream));
-        QM_HIP(copy_back(tally, e->d_scalar.p + 4, sizeof(tally), e->stream));
+        QM_HIP(copy_back(fit.data(), L.fit.p, nvb * sizeof(int32_t), e->stream));
+        QM_HIP(copy_back(tally, tally_d, sizeof(tally), e->stream));
         QM_HIP(hipStreamSynchronize(e->stream));
-        e->shift_quads = (int64_t)tally[0];
-        e->shift_group_rows = (int64_t)tally[1];
-        e->shift_stage_slots = (int)std::min<unsigned long long>(tally[2], 1u << 30);
-        e->shift_stage_reach = (int)std::min<unsigned long long>(tally[3], 1u << 30);
-        wide.clear();
+        L.quads = (int64_t)tally[0];
+        L.group_rows = (int64_t)tally[1];
+        L.stage_slots = (int)std::min<unsigned long long>(tally[2], 1u << 30);
+        L.stage_reach = (int)std::min<unsigned long long>(tally[3], 1u << 30);
+        if (wide) {
+            // the wide tiles' row windows: 384 + span samples in ONE contiguous region (slots of 32 bytes)
+            QM_HIP(hipMemsetAsync(tally_d, 0, sizeof(tally), e->stream));
+            hipLaunchKernelGGL(qm::shift_need_kernel, dim3((unsigned)nvb), dim3(256), 0, e->stream, g,
+                               e->d_lut.p, reinterpret_cast<const int4 *>(L.raw.p),
+                               reinterpret_cast<int4 *>(L.wmeta.p), L.wtotal.p, e->d_work.p, tally_d,
+                               qm::kShiftLdsBytes8 / 2, nblk, sb, 1);
+            QM_HIP(hipGetLastError());
+            fitw.resize(nvb);
+            QM_HIP(copy_back(fitw.data(), e->d_work.p, nvb * sizeof(int32_t), e->stream));
+            QM_HIP(copy_back(tally, tally_d, sizeof(tally), e->stream));
+            QM_HIP(hipStreamSynchronize(e->stream));
+            L.wquads = (int64_t)tally[0];
+            for (size_t i = 0; i < nvb; ++i) fit[i] &= fitw[i];
+        }
+        list.clear();
         for (int b = 0; b < g.nbricks; ++b) {                      // a brick fits if all its blocks do
             int all = 1;
             for (int k = 0; k < nblk; ++k) all &= fit[(size_t)b * nblk + k];
             fit[b] = all;
-            if (!all) wide.push_back(b);
+            if (!all) list.push_back(b);
         }
-        ok = fixed ? (int)wide.size() < g.nbricks : (int64_t)wide.size() * 200 <= g.nbricks;
+        ok = fixed ? (int)list.size() < g.nbricks : (int64_t)list.size() * 200 <= g.nbricks;
         if (ok) break;
     }
     }
@@ -296,34 +315,42 @@ int build_shift_tables(qm_engine *e) {
     const int rows2 = sb + (sb & 1);
     const int64_t words = (int64_t)g.nbricks * nw * nblk * qm::shift_recs_per_wave(g, rows2, nw) *
                           (qm::shift_rec_bytes(blocks) / 4);
-    if (blocks)                                          // per-brick verdicts for the kernels
-        QM_HIP(copy_in(e->d_shfit.p, fit.data(), (size_t)g.nbricks * sizeof(int32_t), e->stream));
+    if (blocks || wide)                                  // per-brick verdicts for the kernels
+        QM_HIP(copy_in(L.fit.p, fit.data(), (size_t)g.nbricks * sizeof(int32_t), e->stream));
     // (+ slack: the loop loads one record past a wavefront's run and touches the line 16 records
     // ahead with its L2 prefetch -- after the last run of the last brick that is past the stream)
-    if (e->d_shstream.ensure((size_t)words + 4096)) return 1;
+    if (L.stream.ensure((size_t)words + 4096)) return 1;
+    if (wide && L.wstream.ensure((size_t)words + 4096)) return 1;
     const size_t hdr_bytes = (size_t)qm::shift_groups_per_brick(g) * rows2 * sizeof(uint2);
     QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(qm::shift_stream_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_bytes));
     hipLaunchKernelGGL(qm::shift_stream_kernel, dim3((unsigned)((size_t)g.nbricks * nblk)), dim3(256),
                        hdr_bytes, e->stream, g, e->d_lut.p,
-                       reinterpret_cast<const int4 *>(e->d_shmeta.p), e->d_shtotal.p, e->d_shfit.p,
-                       rows2, nw, nblk, sb, qm::shift_packed(blocks) ? 1 : 0, e->d_shstream.p);
+                       reinterpret_cast<const int4 *>(L.meta.p), L.total.p, L.fit.p,
+                       rows2, nw, nblk, sb, qm::shift_packed(blocks) ? 1 : 0, 0, L.stream.p);
     QM_HIP(hipGetLastError());
-    e->n_shwide = (int)wide.size();
-    if (e->n_shwide) {
-        if (e->d_shwide.ensure(wide.size())) return 1;
-        QM_HIP(copy_in(e->d_shwide.p, wide.data(), wide.size() * sizeof(int32_t), e->stream));
+    if (wide) {
+        hipLaunchKernelGGL(qm::shift_stream_kernel, dim3((unsigned)((size_t)g.nbricks * nblk)), dim3(256),
+                           hdr_bytes, e->stream, g, e->d_lut.p,
+                           reinterpret_cast<const int4 *>(L.wmeta.p), L.wtotal.p, L.fit.p,
+                           rows2, nw, nblk, sb, qm::shift_packed(false) ? 1 : 0, 1, L.wstream.p);
+        QM_HIP(hipGetLastError());
     }
-    QM_HIP(hipStreamSynchronize(e->stream));           // `wide` is a stack-lifetime buffer
-    e->d_shraw.release();
-    e->shg = g;
-    e->shift_rows2 = rows2;
-    e->shift_nw = nw;
-    e->shift_nblk = nblk;
-    e->shift_sb = sb;
-    e->shift_direct = blocks && direct;
-    e->shift_quad = blocks && quad;
-    e->shift_ok = true;
+    L.n_list = (int)list.size();
+    if (L.n_list) {
+        if (L.list.ensure(list.size())) return 1;
+        QM_HIP(copy_in(L.list.p, list.data(), list.size() * sizeof(int32_t), e->stream));
+    }
+    QM_HIP(hipStreamSynchronize(e->stream));           // `list` is a stack-lifetime buffer
+    L.raw.release();
+    L.g = g;
+    L.rows2 = rows2;
+    L.nw = nw;
+    L.nblk = nblk;
+    L.sb = sb;
+    L.direct = blocks && direct;
+    L.quad = blocks && quad;
+    L.ok = true;
     return 0;
 }
 
@@ -574,8 +601,8 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     e->plan_j = -1;
     e->screen_kt = 0;
     e->pair_kt = 0;
-    e->shift_built = false;
-    e->shift_ok = false;
+    e->sh.built = e->sh.ok = false;
+    e->shw.built = e->shw.ok = false;
     e->have_lut = true;
     return plan_wide(e, eff_j(e));
 }
@@ -640,7 +667,8 @@ int qm_engine_table_select(qm_engine *e, uint64_t key, int32_t capacity, int32_t
     } else if (e->have_lut) {
         // nothing may be parked: keep the buffers for the next table (load_lut reuses allocations)
         e->have_lut = false;
-        e->shift_built = e->shift_ok = false;
+        e->sh.built = e->sh.ok = false;
+        e->shw.built = e->shw.ok = false;
         e->pair_kt = 0;
         e->screen_kt = 0;
         e->plan_j = -1;

@@ -1658,6 +1658,114 @@ def test_shift_kernel_equals_round2_kernels_and_oracle(lib, oracle, recipe, grid
         np.testing.assert_allclose(r["shift"][1], r["round2"][1], rtol=NORM)
 
 
+# ---- round 6: WIDE tiles (384 samples, six per lane; qm_shift.hpp) --------
+WIDE_SHAPES = [  # recipe, grid, rows, scanned samples, expected (wide tiles, tail samples per lane, tiles)
+    ("C3", (40, 33, 21), 30, 1000, (2, 0, 3)),   # 2 wide + 232: a 256-sample tile pulled back behind them
+    ("C3", (17, 16, 33), 30, 384, (1, 0, 1)),    # exactly one wide tile; bricks of 8 x 8 x 16
+    ("C3", (16, 18, 16), 29, 500, (1, 2, 2)),    # odd row count (padding row); 116 left: tail tile, 2 per lane
+    ("C3", (9, 10, 33), 1, 800, (2, 1, 3)),      # one row; 32 left: tail tile, 1 per lane
+    ("C3", (12, 13, 8), 2, 1100, (3, 0, 3)),     # 332 left: a third wide tile pulled back by 52 samples
+    ("C1", (23, 20, 19), 24, 625, (1, 0, 2)),    # the Icequake timestep: 384 + a pulled-back 256
+    ("C3", (3, 2, 70), 31, 960, (2, 3, 3)),      # a grid thinner than a brick; 192 left: tail tile, 3 per lane
+    ("C3", (25, 24, 10), 36, 450, (1, 2, 2)),    # 36 rows; 66 left: tail tile, 2 per lane
+    ("C4", (20, 21, 22), 44, 770, (2, 1, 3)),    # 44 rows; a tail of 2 samples
+    ("C3", (18, 17, 12), 34, 1536, (4, 0, 4)),   # whole wide tiles only
+    ("C4", (14, 15, 12), 37, 389, (1, 1, 2)),    # padding row + a 5-sample tail
+]
+
+
+@pytest.mark.parametrize("recipe,grid,rows,ns,tiles", WIDE_SHAPES)
+def test_shift_wide_tiles_equal_the_256_sample_tiles_and_oracle(lib, oracle, recipe, grid, rows, ns, tiles):
+    """Six samples per lane change how many adds a register window feeds, not what is added: the same
+    operands in the same row order (migratelib.c:54-59) -- maxima and indices are the bits of the
+    256-sample tiles and of the round-2 kernels, the oracle's argmax; max_norm_coa within 1e-13 (the
+    sum over the nodes is formed over another brick grid)."""
+    case = synth.make_case(recipe, step=1, grid=grid, rows=rows, n_samples=ns)
+    lon = oracle.log_onsets(case.onsets)
+    want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available,
+                         threads=4)
+    narrow = lib.Engine(0, shift_wide=0)
+    narrow.load_lut(case.traveltimes)
+    ref = narrow.detect(lon, case.fsmp, case.lsmp, case.available)
+    assert narrow.get("last_kernel") == 3 and narrow.get("shift_wide_tiles") == 0
+    narrow.close()
+    for lazy in (0, 1):
+        eng = lib.Engine(0, shift_wide=1, shift_lazy=lazy)
+        eng.load_lut(case.traveltimes)
+        got = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+        assert eng.get("last_kernel") == 3 and eng.get("last_kernel_j") == 6, "the wide tiles did not run"
+        assert eng.get("shift_wide_ok") == 1 and eng.get("shift_lazy") == lazy
+        assert (eng.get("shift_wide_tiles"), eng.get("shift_tail_spl")) == tiles[:2]
+        assert eng.get("shift_wide_direct_bricks") == 0
+        eng.close()
+        _assert_series(got, want)
+        assert np.array_equal(got[2], ref[2])
+        assert np.array_equal(got[0], ref[0])                           # same bits
+        np.testing.assert_allclose(got[1], ref[1], rtol=1e-13)
+
+
+def test_shift_wide_tiles_ties_nan_batches_and_shards(lib, oracle):
+    """What the other shift-reuse flavours are held to, on wide tiles: exact ties resolve to the lowest
+    flat index, a NaN onset poisons its own samples only, K timesteps per launch give each step's own
+    bits, and partial sets of x-plane shards (node offsets) fold to the unsharded result."""
+    case = synth.make_case("C3", step=2, grid=(24, 20, 18), rows=30, n_samples=900)
+    lon = oracle.log_onsets(case.onsets)
+    want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available, threads=4)
+    eng = lib.Engine(0, shift_wide=1)
+    eng.load_lut(case.traveltimes)
+    got = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+    assert eng.get("last_kernel_j") == 6
+    _assert_series(got, want)
+    # K steps per launch
+    steps = [oracle.log_onsets(synth.make_case("C3", step=k, grid=(24, 20, 18), rows=30, n_samples=900,
+                                               table=False).onsets) for k in range(3)]
+    batch = eng.detect_batch(np.stack(steps), case.fsmp, case.lsmp, case.available)
+    assert eng.get("steps_per_launch") == 3 and eng.get("last_kernel_j") == 6
+    for k in range(3):
+        one = eng.detect(steps[k], case.fsmp, case.lsmp, case.available)
+        for i in range(3):
+            assert np.array_equal(batch[i][k], one[i]), (k, i)
+    # NaN onsets: the samples that see them, and only those
+    bad = lon.copy()
+    bad[3, case.fsmp + 500] = np.nan
+    a, b, c = eng.detect(bad, case.fsmp, case.lsmp, case.available)
+    tt = np.maximum(case.traveltimes.reshape(-1, 30)[:, 3], 0)
+    hit = np.zeros(900, bool)
+    for d in np.unique(tt):
+        if 0 <= 500 - d < 900:
+            hit[500 - d] = True
+    assert np.isnan(b[hit]).all() and not np.isnan(b[~hit]).any()
+    assert np.array_equal(c[~hit], got[2][~hit]) and np.array_equal(a[~hit], got[0][~hit])
+    eng.close()
+    # exact ties: every node pair of a mirrored table stacks the same sums
+    tt = case.traveltimes.copy()
+    tt[12:] = tt[11::-1]
+    want_t = oracle.detect(case.onsets, tt, case.fsmp, case.lsmp, case.available, threads=4)
+    eng = lib.Engine(0, shift_wide=1)
+    eng.load_lut(tt)
+    got_t = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+    assert eng.get("last_kernel_j") == 6
+    eng.close()
+    _assert_series(got_t, want_t)
+    assert (got_t[2] < 12 * 20 * 18).all()
+    # shards: two x-plane slabs (node offsets), their partial sets folded on the device
+    import torch
+
+    ns = case.n_samples
+    pmax = torch.empty((2, ns), dtype=torch.float64, device="cuda")
+    psum = torch.empty((2, ns), dtype=torch.float64, device="cuda")
+    pidx = torch.empty((2, ns), dtype=torch.int64, device="cuda")
+    sh = lib.Engine(0, shift_wide=1)
+    for r, (x0, x1) in enumerate(((0, 11), (11, 24))):
+        sh.load_lut(np.ascontiguousarray(case.traveltimes[x0:x1]), node_offset=x0 * 20 * 18)
+        sh.detect_partial(lon, case.fsmp, case.lsmp, case.available, (pmax[r], pidx[r], psum[r]))
+        assert sh.get("last_kernel_j") == 6
+    sh.synchronize()
+    folded = sh.finalize(pmax, pidx, psum, 2, ns, case.n_nodes_total)
+    sh.close()
+    _assert_series(folded, want)
+
+
 @pytest.mark.parametrize("recipe,grid,rows,ns", [SHIFT_SHAPES[0], SHIFT_SHAPES[1], SHIFT_SHAPES[4],
                                                  SHIFT_SHAPES[9], SHIFT_SHAPES[10]])
 def test_shift_kernel_volume_variant_both_workgroup_shapes(lib, oracle, recipe, grid, rows, ns):

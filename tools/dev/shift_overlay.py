@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Development overlay of the shift-reuse loop generator (quakemigrate_amd/csrc/gen_shift_asm.py).
+
+The product generator reads nothing from the environment.  For an A/B build of a
+variant this script imports it, sets module constants named on the command line and prints the file:
+
+    python tools/dev/shift_overlay.py PF_AHEAD=32 WIDE_SLOTTED=0 > build_variants/shift_asm_x.inc
+
+tools/shift_variants.sh builds a library per variant around such a file; nothing of it reaches
+`__graft_entry__.build()`, which regenerates the committed qm_shift_asm.inc from the product constants
+and ignores the environment."""
+import importlib.util
+import pathlib
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parents[2]
+
+
+def main(argv):
+    spec = importlib.util.spec_from_file_location("gen_shift_asm", ROOT / "quakemigrate_amd" / "csrc" / "gen_shift_asm.py")
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    for item in argv:
+        name, _, value = item.partition("=")
+        if not hasattr(gen, name):
+            raise SystemExit(f"shift_overlay: the generator has no constant {name}")
+        old = getattr(gen, name)
+        setattr(gen, name, type(old)(int(value)) if isinstance(old, (bool, int)) else type(old)(value))
+    gen.WMAX = 4 * gen.NQMAX
+    gen.main()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,6 +1,7 @@
 #!/bin/bash
-# library variants that differ in the generated shift-reuse loop (gen_shift_asm.py knobs) or in
-# -D defines of qm_launch_shift.hip.  usage: tools/shift_variants.sh name[:ENV=VAL;ENV=VAL][@-DX=1 ...] ...
+# library variants that differ in the generated shift-reuse loop (constants of gen_shift_asm.py, set through
+# tools/dev/shift_overlay.py) or in -D defines of qm_launch_shift.hip.
+# usage: tools/shift_variants.sh name[:CONST=VAL;CONST=VAL][@-DX=1 ...] ...
 # result: build_variants/libqmhip_<name>.so (the other objects are the in-tree build's)
 cd "$(dirname "$0")/.."
 C=quakemigrate_amd/csrc
@@ -9,7 +10,7 @@ for spec in "$@"; do
   defs=""; [[ "$spec" == *@* ]] && defs="${spec#*@}" && spec="${spec%%@*}"
   name=${spec%%:*}; envs=""; [ "$spec" != "$name" ] && envs=$(echo "${spec#*:}" | tr ';' ' ')
   inc=$PWD/build_variants/shift_asm_$name.inc
-  env $envs python $C/gen_shift_asm.py > $inc || exit 1
+  python tools/dev/shift_overlay.py $envs > $inc || exit 1
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DQM_SHIFT_ASM_INC="\"$inc\"" $defs -c $C/qm_launch_shift.hip \
       -o build_variants/qm_launch_shift_$name.o 2>&1 | grep -E "error|Spill" 
   objs=$(ls $C/build/*.o | grep -v qm_launch_shift)
