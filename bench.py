@@ -494,7 +494,9 @@ def main():
     shift_kernel = eng.get("last_kernel") == 3
     # 8-byte LDS operands fetched per add: 1 for the round-2 kernels; the shift-reuse kernel shares
     # a register window between the 8 nodes of a group (measured on the resident table)
-    per_add = eng.get("shift_operands_per_add_x1000") / 1000.0 if shift_kernel else 1.0
+    wide_tiles = eng.get("shift_wide_tiles") if shift_kernel else 0
+    per_add = (eng.get("shift_wide_operands_per_add_x1000" if wide_tiles else "shift_operands_per_add_x1000") / 1000.0
+               if shift_kernel else 1.0)
     exp_ops = EXP_FP64_OPS_LAZY if shift_kernel and eng.get("shift_lazy") == 1 else EXP_FP64_OPS
     chip = onchip(screened, local_ns, S, kern_s, per_add, exp_ops)
     valu_key = "int32_valu" if screened else "fp64_valu"
@@ -548,7 +550,17 @@ def main():
                                   waves=eng.get("waves"))},
         "kernel": {"name": kname, "avg_ms": kern_launch_s * 1e3,
                    "avg_ms_per_step": kern_s * 1e3, "steps_per_launch": steps_per_launch,
-                   "launches": kern_calls, "timing": "HIP events on the launch stream"},
+                   "launches": kern_calls, "timing": "HIP events on the launch stream",
+                   # shift-reuse kernel: how the scan was tiled (wide = 384-sample tiles, six samples per lane,
+                   # round 6; behind them 256-sample tiles and / or one tail tile) and on which brick shape
+                   "tiles": ({"wide_384": wide_tiles, "tail_samples_per_lane": eng.get("shift_tail_spl"),
+                              "samples_per_lane": eng.get("last_kernel_j"),
+                              "brick_nodes": eng.get("shift_wide_brick_nodes" if wide_tiles else "shift_brick_nodes"),
+                              "lazy_argmax": eng.get("shift_lazy"),
+                              "lds_operands_per_add": per_add} if shift_kernel else None)},
+        # what the library was built from (generator constants + source digest; "overlay=none; defines=none" =
+        # the product build, include/qmhip.h: qm_build_info)
+        "build_info": lib.build_info(),
         "roofline": {"bound": bind, "achieved": chip[bind]["achieved"], "peak": chip[bind]["peak"],
                      "unit": chip[bind]["unit"], "frac": chip[bind]["frac"],
                      # HBM bytes per launch (fetch + write) from the stored PMC passes over this

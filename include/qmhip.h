@@ -90,8 +90,12 @@ typedef struct qm_engine qm_engine;
 const char *qm_last_error(void);
 /* number of HIP devices visible, or -1 */
 int qm_device_count(void);
+/* What the library was built from: the constants and source digest of the generated shift-reuse loops and
+ * the development defines of the kernels' unit ("overlay=none", "defines=none" in the product build;
+ * tools/shift_variants.sh makes the others).  bench.py prints it, the GPU suite asserts it. */
+const char *qm_build_info(void);
 /* Device memory released by engines (destroyed engines, replaced tables) is parked in the process
- * and reused by the next request of its size (up to 8 GB stay parked); this returns all of it to
+ * and reused by the next request of its size (up to QM_HIP_POOL_KEEP_MB, default 2 GB, stay parked per device); this returns all of it to
  * the driver.  Always 0. */
 int qm_release_cached_memory(void);
 

@@ -56,6 +56,8 @@ for _f in (qmlib.overlapping_sta_lta, qmlib.centred_sta_lta,
 _vp = ctypes.c_void_p
 qmlib.qm_last_error.restype = ctypes.c_char_p
 qmlib.qm_device_count.restype = ctypes.c_int
+qmlib.qm_build_info.restype = ctypes.c_char_p
+qmlib.qm_build_info.argtypes = []
 qmlib.qm_compat_status.restype = ctypes.c_int
 qmlib.qm_table_hash.restype = None
 qmlib.qm_table_hash.argtypes = [ctypes.c_void_p, c_int64, ctypes.POINTER(ctypes.c_uint64),
@@ -139,6 +141,12 @@ def _check(rc):
 
 def _host(a):
     return a.ctypes.data_as(_vp)
+
+
+def build_info():
+    """What the loaded library was built from (include/qmhip.h: qm_build_info): the generated shift-reuse
+    loops' constants and generator digest, overlay and development defines ("none" in the product build)."""
+    return qmlib.qm_build_info().decode()
 
 
 class Engine:

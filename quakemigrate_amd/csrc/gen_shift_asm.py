@@ -102,6 +102,7 @@ PLANE8 = 81856           # ... for the 8-wave workgroup that owns a CU's whole L
 STATE_CHUNK = 1024       # running state in LDS: 5 chunks of 64 lanes x 16 bytes per wavefront
 VB_BLOCK = 80            # first hard VGPR of the row-block flavour
 VB_WIDE = 48             # ... of the wide flavours (SPL = 6: 30 VGPRs of running state below it)
+NQMIN_WIDE = 4           # quads a wide tile's window fetches unconditionally (6: no conditional reads at all)
 BUTTERFLY = True         # marginal map: the eight nodes of a whole group summed over the wavefront together
 VOLUME_DEGREE = 10       # 2^f of stored values (qm_kernels.hpp: QM_EXP2_DEGREE_VOLUME)
 MARGINAL_DEGREE = 8      # 2^f of the marginalised map's terms: the polynomial of the running sums (7.8e-13), every
@@ -257,7 +258,7 @@ def contig_reads(win, m):
 def contig_base_reads(win):
     if SPL == 6:
         return [f"ds_read_b128 v[{win + 4 * p}:{win + 4 * p + 3}], v{VADDR} offset:{16 * p}"
-                for p in range(2 * NQMIN)]
+                for p in range(2 * NQMIN_WIDE)]
     if SPL == 2:
         return [f"ds_read_b128 v[{win + 4 * p}:{win + 4 * p + 3}], v{VADDR} offset:{16 * p}"
                 for p in range(2 * NQMIN - 1)]
@@ -286,7 +287,7 @@ def issue_window(e, q, hdr):
             for line in quad_reads(WIN[q], m):
                 e(line)
     done = e.label("rd")
-    for m in range(NQMIN, NQMAX):
+    for m in range(NQMIN_WIDE if SPL == 6 else NQMIN, NQMAX):
         e(f"s_cmp_le_u32 s{hdr + 1}, {m}")
         e(f"s_cbranch_scc1 {done}")
         for line in (contig_reads(WIN[q], m) if CONTIG else quad_reads(WIN[q], m)):
@@ -385,7 +386,10 @@ def stage_record(e):
 def row_iter(e, p, first):
     """row of parity p: its record is in BUF[p], its window in WIN[p].  The next row's window is
     requested before this row's adds (a block of reads at the row's start: spread between the adds,
-    the late ones land after the next row's wait -- measured slower, tools/micro results r03a)."""
+    the late ones land after the next row's wait -- measured slower, tools/micro results r03a; round 6, wide
+    flavours, ONE read behind each of the row's first ten adds, the last of them thirty adds before the row's
+    end: 42.54 against 42.49 ms at C3, profiles/r06_ab_runs.txt -- a read costs the SIMD its four cycles
+    wherever it is issued)."""
     q = 1 - p
     hdr = BUF[p] + R_HDR
     e("s_waitcnt lgkmcnt(0)")                                  # both have landed
@@ -980,9 +984,26 @@ def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False,
     print("}")
 
 
+OVERLAY = "none"         # (tools/dev/shift_overlay.py says here what it changed)
+
+
+def build_info():
+    """what this file was generated from: the constants and a digest of the generator's source (the library
+    hands it out through qm_build_info(); bench.py prints it, a GPU test asserts it is the product's)"""
+    import hashlib
+    import pathlib
+    consts = " ".join(f"{k}={int(globals()[k])}" for k in (
+        "NQMAX", "NQMIN", "NQMIN_WIDE", "PF_AHEAD", "PF_EVERY", "NEXT_RUN", "NEXT_META", "STAGE_IN_LOOP",
+        "PACKED_GROUPS", "PACKED_BLOCKS", "PACKED_SHIFT64", "BUTTERFLY", "VOLUME_DEGREE",
+        "MARGINAL_DEGREE", "VB_BLOCK", "VB_WIDE"))
+    digest = hashlib.sha256(pathlib.Path(__file__).read_bytes()).hexdigest()[:16]
+    return f"{consts}; generator={digest}; overlay={OVERLAY}"
+
+
 def main():
     print("// GENERATED by gen_shift_asm.py -- do not edit.  See that file for the schedule and the")
     print("// stream format.")
+    print(f'constexpr char kShiftGenInfo[] = "{build_info()}";')
     configure(False)
     print(f"constexpr int kShiftNqMax = {NQMAX};          // quads (4 samples) a register window holds")
     print(f"constexpr int kShiftNqMin = {NQMIN};          // quads fetched unconditionally")
@@ -994,6 +1015,7 @@ def main():
     print(f"constexpr bool kShiftPackedBlocks = {'true' if PACKED_BLOCKS else 'false'};   // ... of the row-block loops")
     print(f"constexpr int kShiftBlockVgprs = {VB_BLOCK};   // row-block flavour: the compiler's own code stays below")
     print("constexpr int kShiftWideSpl = 6;          // samples per lane of the wide tiles (time tile 384)")
+    print(f"constexpr int kShiftNqMinWide = {NQMIN_WIDE};      // quads a wide tile's window fetches unconditionally")
     print(f"constexpr bool kShiftStageInLoop = {'true' if STAGE_IN_LOOP else 'false'};   // row blocks: the next block's staging issued by the row loop")
     print(f"constexpr int kShiftVolumeDegree = {VOLUME_DEGREE};   // 2^f polynomial of the volume-writing flavours")
     print(f"constexpr int kShiftMarginalDegree = {MARGINAL_DEGREE};   // 2^f polynomial of the marginal-map flavours")

@@ -301,8 +301,16 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     const int shift_mode = marginal ? qm::kShiftMarginal : volume ? qm::kShiftVolume : qm::kShiftDetect;
     // Round 6: the fused detect of a scan that holds at least one 384-sample tile runs on the WIDE layout where
     // the table has one (ShiftLayout, qm_engine.hpp): its own brick grid, the 8-wave shape
+    // (automatic: only where one timestep is at least eight rounds of one-brick workgroups over the CUs and holds
+    // four wide tiles -- the Icequake-sized C1, 288 bricks x 2 tiles, runs 0.49 ms on the wide layout and 0.42 on
+    // the other, C3's 401-sample locate window 5.4 against 4.0: one wide tile and a short tail tile side by side
+    // leave the CUs with the short one idle; the count is the single step's, so that a step's bits do not depend
+    // on how many share its launch)
     ShiftLayout *L = &e->sh;
+    const int64_t wide_work = (int64_t)((e->g.nx + 7) / 8) * ((e->g.ny + 7) / 8) * ((e->g.nz + 15) / 16) *
+                              ((n_chunk + qm::kShiftWideKT - 1) / qm::kShiftWideKT);
     if (shift && shift_mode == qm::kShiftDetect && e->cfg_shift_wide != 0 && n_chunk >= qm::kShiftWideKT &&
+        (e->cfg_shift_wide == 1 || (wide_work >= 8 * (int64_t)e->n_cu && n_chunk >= 4 * qm::kShiftWideKT)) &&
         e->cfg_shift_waves == 0 && e->g.n_rows <= qm::kShiftMaxRows) {
         if (ensure_shift_tables(e, e->shw)) return 1;
         if (e->shw.ok) L = &e->shw;
@@ -386,6 +394,18 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         // workgroup's fixed costs weigh more than the grid's tail, three rounds instead of twelve:
         // E2 0.418 -> 0.394 ms, profiles/r04_rounds_sweep.txt)
         int rounds = (!shift && jp == 0 && !e->user_rounds && e->g.brick_nodes <= 64) ? 3 : 0;
+        // (the wide layout's 8-wave workgroups, one per CU: FEW, long workgroups -- C3 41.7 / 42.1 / 42.3 / 42.6 ms
+        // at 1 / 4 / 8 / 12 rounds, where the 4-wave shape runs 50.1 / 46.5 / 45.7 at 4 / 8 / 12,
+        // profiles/r06_ab_runs.txt: the fewest rounds that leave no slot idle, 0.2 % charged per round)
+        if (shift && wide && !e->user_rounds) {
+            double best = 1e300;
+            for (int r = 1; r <= e->cfg_rounds; ++r) {
+                const int g = auto_groups(e, a.ntiles, nbricks_now, lds_blocks_per_cu, r);
+                const double busy = (double)a.ntiles * g / ((double)r * e->n_cu * lds_blocks_per_cu);
+                const double cost = (1.0 - std::min(1.0, busy)) + 0.002 * r;
+                if (cost < best - 1e-9) { best = cost; rounds = r; }
+            }
+        }
         // (tie_rule = 1 stacks one SET of bricks again per sample, qm_ties.hpp: eight times as many,
         // smaller sets -- the refinement's cost falls with the set size, the stacking launch loses ~1 %)
         groups_lds = e->cfg_groups > 0 ? std::min(e->cfg_groups, nbricks_now)
@@ -800,7 +820,8 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "last_kernel_j") *v = e->last_j;
     else if (k == "shift") *v = e->cfg_shift;
     else if (k == "shift_ok") *v = e->sh.built && e->sh.ok ? 1 : 0;
-    else if (k == "shift_waves") *v = e->sh.ok ? e->sh.nw : e->cfg_shift_waves;
+    else if (k == "shift_waves")                        // (of the layout the last shift-reuse launch ran on)
+        *v = e->shift_wide_last > 0 && e->shw.ok ? e->shw.nw : e->sh.ok ? e->sh.nw : e->cfg_shift_waves;
     else if (k == "shift_lazy") *v = e->shift_lazy_last;
     else if (k == "shift_tail") *v = e->cfg_shift_tail;
     else if (k == "shift_tail_spl") *v = e->shift_tail_last;

@@ -5,6 +5,28 @@
 #include "qm_shift.hpp"
 
 namespace qm {
+// development defines this unit was compiled with (timing experiments, staging variants: tools/shift_variants.sh);
+// the product build has none -- qm_build_info() hands the list out
+const char *shift_unit_defines() {
+    static const char text[] = ""
+#ifdef QM_SHIFT_EXP_NOSTAGE
+        "QM_SHIFT_EXP_NOSTAGE "
+#endif
+#ifdef QM_ROWS_EXP_NOSTAGE
+        "QM_ROWS_EXP_NOSTAGE "
+#endif
+#ifdef QM_ROWS_EXP_NOBARRIER
+        "QM_ROWS_EXP_NOBARRIER "
+#endif
+#ifdef QM_ROWS_STAGE_SLOW
+        "QM_ROWS_STAGE_SLOW "
+#endif
+#ifdef QM_SHIFT_DEPHASE
+        "QM_SHIFT_DEPHASE "
+#endif
+        ;
+    return sizeof(text) > 1 ? text : "none";
+}
 hipError_t launch_shift_detect(const ShiftArgs &a, const LaunchShape &s) {
     return launch_with_lds(&stack_shift_kernel<kShiftDetect, kShiftWaves>, a, s);
 }

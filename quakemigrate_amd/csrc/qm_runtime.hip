@@ -420,4 +420,13 @@ int qm_device_count(void) {
     return n;
 }
 
+// What the library was built from: the constants and source digest of the generated
+// shift-reuse loops (gen_shift_asm.py: build_info) and the development defines the kernels' unit was compiled
+// with.  The product build reads "overlay=none" and "defines=none".
+const char *qm_build_info(void) {
+    static const std::string info = std::string("shift loops: ") + qm::kShiftGenInfo + "; defines=" +
+                                    qm::shift_unit_defines();
+    return info.c_str();
+}
+
 }  // extern "C"

@@ -135,7 +135,8 @@ constexpr int kShiftMarginal = 2;   // the marginalised map: per (tile, node) th
                                     // samples inside [m0, m1) -> a.marginal[tile][node]
 
 struct LaunchShape;
-hipError_t launch_shift_detect(const ShiftArgs &a, const LaunchShape &s);   // qm_launch_shift.hip
+const char *shift_unit_defines();                                           // qm_launch_shift.hip
+hipError_t launch_shift_detect(const ShiftArgs &a, const LaunchShape &s);
 hipError_t launch_shift_volume(const ShiftArgs &a, const LaunchShape &s);
 hipError_t launch_shift_marginal(const ShiftArgs &a, const LaunchShape &s);
 hipError_t launch_shift_marginal8(const ShiftArgs &a, const LaunchShape &s);
@@ -200,8 +201,9 @@ __host__ __device__ constexpr int shift_slots_touched(int wide, int e0, int fetc
     return (e0 + shift_lane_step(wide) * (kWave - 1) + 4 * fetched + 3) / 4;
 }
 // slots of the all-zero window that the padding row of an odd row count reads
+__host__ __device__ constexpr int shift_nq_min(int wide) { return wide ? kShiftNqMinWide : kShiftNqMin; }
 __host__ __device__ constexpr int shift_zero_slots(int wide) {
-    return wide ? shift_slots_touched(1, 0, kShiftNqMin) : kWave + kShiftNqMin;
+    return wide ? shift_slots_touched(1, 0, kShiftNqMinWide) : kWave + kShiftNqMin;
 }
 
 #ifdef QM_TU_TABLES
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void shift_need_kernel(GridDesc g, const int32
                            meta_raw[(int64_t)b * g.n_rows + r0 + r].x, d);
         shift_window(d, wide, e0, nq);
         if (nq > kShiftNqMax) atomicOr(&overflow, 1);
-        const int fetched = nq > kShiftNqMin ? nq : kShiftNqMin;
+        const int fetched = nq > shift_nq_min(wide) ? nq : shift_nq_min(wide);
         quads += (unsigned)fetched;
         atomicMax(&need[r], shift_slots_touched(wide, e0, fetched));
     }
@@ -623,7 +625,12 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
 #ifdef QM_SHIFT_EXP_NOSTAGE                            // timing experiment (wrong results): the first
                                                       // brick's windows for all, no barriers
         if (b == group) {
-            stage_shift_windows<NW>(s, win, b, 0, g.n_rows, g.n_rows, wave, lane, t_first);
+            if constexpr (kWide) {
+                stage_shift_wide<NW>(s, win, b, g.n_rows, wave, lane, t_first);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                stage_shift_windows<NW>(s, win, b, 0, g.n_rows, g.n_rows, wave, lane, t_first);
+            }
             __syncthreads();
         }
 #else

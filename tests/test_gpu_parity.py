@@ -439,6 +439,22 @@ def test_full_size_configs_chunk_oracle_and_properties(lib, oracle, name, nk):
     assert eng.get("n_wide_bricks") == 0
     got = eng.detect(lon, case.fsmp, case.lsmp, case.available)
     ns = case.n_samples
+    # which kernel family ran (a silent fallback to the round-2 kernels would keep everything below green):
+    # C3 = the shift-reuse kernel on WIDE tiles (15 of 384 samples + a pulled-back 256), C2 (incoherent for it:
+    # 1 km nodes) = the exact-row-count kernel
+    if name == "C3":
+        assert (eng.get("last_kernel"), eng.get("last_kernel_j"), eng.get("shift_wide_tiles")) == (3, 6, 15)
+        assert eng.get("shift_wide_direct_bricks") == 0 and eng.get("shift_tail_spl") == 0
+        # ... and the 256-sample tiles of rounds 3-5 on the same step: maxima and indices bit for bit
+        narrow = lib.Engine(0, shift_wide=0)
+        narrow.load_lut(case.traveltimes)
+        ref = narrow.detect(lon, case.fsmp, case.lsmp, case.available)
+        assert (narrow.get("last_kernel"), narrow.get("last_kernel_j"), narrow.get("shift_waves")) == (3, 4, 4)
+        narrow.close()
+        assert np.array_equal(ref[2], got[2]) and np.array_equal(ref[0], got[0])
+        np.testing.assert_allclose(ref[1], got[1], rtol=1e-13)
+    else:
+        assert eng.get("last_kernel") == 1 and eng.get("shift_wide_tiles") == 0
     # (a) the injected events are found at their nodes and samples
     for (ijk, t0) in case.event_nodes:
         assert got[2][t0] == np.ravel_multi_index(ijk, case.grid)
@@ -508,6 +524,8 @@ def test_c4_slab_of_8_chunk_oracle_and_properties(lib, oracle, rank):
         # normalised by the slab's own node count so that the oracle on the slab is the answer
         got = eng.detect(lon, case.fsmp, case.lsmp, case.available, n_nodes_total=n_local)
         assert (eng.get("screened_steps"), eng.get("fallback_steps")) == (screen, 0)
+        if screen == 0:                                  # the shift-reuse kernel, 8-wave shape (60 rows)
+            assert (eng.get("last_kernel"), eng.get("shift_waves"), eng.get("shift_wide_tiles")) == (3, 8, 0)
         for k0, want in chunks.items():
             local = (got[0][k0:k0 + nk], got[1][k0:k0 + nk], got[2][k0:k0 + nk] - x0 * plane)
             _assert_series(local, want, norm=SCREEN_NORM if screen else NORM)
@@ -555,6 +573,7 @@ def test_c5_streaming_detector_on_the_full_c3_grid(lib, oracle):
                            first.available, depth=3)
     got = sd.run(iter(windows))
     assert len(got) == steps
+    assert (eng.get("last_kernel"), eng.get("last_kernel_j"), eng.get("shift_wide_tiles")) == (3, 6, 15)
     for c, w, g in zip(cases, windows, got):
         want = eng.detect(w, c.fsmp, c.lsmp, c.available)
         for a, b in zip(g, want):
@@ -603,6 +622,8 @@ def test_c3_locate_window_materialised_volume_against_oracle(lib, oracle):
            torch.full((ns,), -1, dtype=torch.int64, device="cuda"))
     eng.migrate(d_lon, case.fsmp, case.lsmp, S, vol, scan_out=out)
     torch.cuda.synchronize()
+    # the shift-reuse kernel's volume flavour, 4-wave shape: a 256-sample tile + a tail tile of 145 (3 per lane)
+    assert (eng.get("last_kernel"), eng.get("shift_waves"), eng.get("shift_tail_spl")) == (3, 4, 3)
     got = tuple(o.cpu().numpy() for o in out)
     want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, S,
                          threads=os.cpu_count(), max_bytes=6 << 30)
@@ -629,6 +650,7 @@ def test_c3_locate_window_materialised_volume_against_oracle(lib, oracle):
     cmap = torch.empty(n, dtype=torch.float64, device="cuda")
     eng.marginal_map(d_lon, case.fsmp, case.lsmp, S, 100, 301, out=cmap)
     torch.cuda.synchronize()
+    assert (eng.get("last_kernel"), eng.get("shift_tail_spl")) == (3, 3)
     np.testing.assert_allclose(cmap.cpu().numpy(), vol[:, 100:301].sum(dim=1).cpu().numpy(),
                                rtol=1e-12)
     fused = eng.detect(d_lon, case.fsmp, case.lsmp, S,

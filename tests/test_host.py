@@ -292,6 +292,98 @@ def test_exchange_partials_world_size_2_gloo(oracle, tmp_path):
         np.testing.assert_allclose(got["marg"], vol[..., 40:150].sum(axis=-1), rtol=1e-13)
 
 
+def _worker_columns(rank, world, port, tmp, grid, rows, ns, tag):
+    """One rank of a column-partitioned detect on CPU: every box's partial set from the oracle, the packed
+    all-gather + fold and the three-all-reduce form (quakemigrate_amd.distributed) -- SURVEY section 8e."""
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, str(ROOT))
+    from oracle import qm_oracle
+    from quakemigrate_amd import distributed as qd
+    from quakemigrate_amd import synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = synth.make_case("C3", step=4, grid=grid, rows=rows, n_samples=ns)
+    n_total = int(np.prod(grid))
+    c0, c1 = qd.shard_columns(grid[0], grid[1], world, rank)
+    boxes = qd.column_boxes(c0, c1, grid[1])
+    assert len(boxes) <= qd.MAX_BOXES
+    assert sum((b[1] - b[0]) * (b[3] - b[2]) for b in boxes) == c1 - c0
+    packed = torch.empty((qd.MAX_BOXES, 3, ns), dtype=torch.float64)
+    packed[:, 0] = float("-inf")
+    packed[:, 1].view(torch.int64).fill_(qd.INT64_MAX)
+    packed[:, 2] = 0.0
+    for k, (bx0, bx1, by0, by1) in enumerate(boxes):
+        box_tt = np.ascontiguousarray(full.traveltimes[bx0:bx1, by0:by1])
+        bvol = qm_oracle.c_migrate(full.onsets, box_tt, full.fsmp, full.lsmp, full.available, threads=1)
+        bvol = bvol.reshape(-1, ns)
+        bi = np.argmax(bvol, axis=0)
+        # local flat index inside the box -> flat index of the full grid
+        lx, rem = np.divmod(bi, (by1 - by0) * grid[2])
+        ly, lz = np.divmod(rem, grid[2])
+        gidx = ((bx0 + lx) * grid[1] + (by0 + ly)) * grid[2] + lz
+        packed[k, 0] = torch.from_numpy(np.log2(bvol[bi, np.arange(ns)]))
+        packed[k, 1].view(torch.int64).copy_(torch.from_numpy(gidx.astype(np.int64)))
+        packed[k, 2] = torch.from_numpy(bvol.sum(axis=0))
+    gathered = torch.empty((world, qd.MAX_BOXES, 3, ns), dtype=torch.float64)
+    qd.all_gather_packed(packed, gathered)
+    a, b, c = qd.combine_packed_torch(gathered.view(world * qd.MAX_BOXES, 3, -1), n_total)
+    # the all-reduce form on the rank's own fold of its boxes (a rank without columns brings the neutral set)
+    own = packed.view(1, qd.MAX_BOXES, 3, ns)
+    pm, order = own[0, :, 0].max(dim=0)
+    ties = own[0, :, 0] == pm
+    pi = torch.where(ties, own[0, :, 1].view(torch.int64), torch.full((1,), qd.INT64_MAX)).min(dim=0).values
+    ps = own[0, :, 2].sum(dim=0)
+    ra, rb, rc = qd.exchange_partials(pm.contiguous(), pi.contiguous(), ps.contiguous(), n_total)
+    assert torch.equal(rc, c) and torch.equal(ra, a)
+    assert torch.allclose(rb, b, rtol=1e-14, atol=0)
+    np.savez(pathlib.Path(tmp) / f"{tag}{rank}.npz", a=a.numpy(), b=b.numpy(), c=c.numpy(),
+             boxes=np.array([len(boxes), c1 - c0]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,grid,tag", [(8, (201, 201, 2), "c3columns"), (9, (2, 4, 3), "degenerate")])
+def test_column_partition_fold_at_world_8_gloo(oracle, tmp_path, world, grid, tag):
+    """The first 8-GPU run must not be the first time the world-8 arithmetic executes:
+    C3's real column partition -- 201 x 201 columns over 8 ranks = 5051 / 5050 each, one to three boxes per
+    rank -- with every box's partial from the oracle, folded by the packed all-gather and by the all-reduce
+    form, against the oracle's one-shot series (index and maximum exact, normalised value to 1e-14); and nine
+    ranks on eight columns: one rank holds nothing."""
+    import torch.multiprocessing as mp
+
+    from quakemigrate_amd import distributed as qd
+    from quakemigrate_amd import synth
+
+    rows, ns = 3, 48
+    port = _free_port()
+    mp.spawn(_worker_columns, args=(world, port, str(tmp_path), grid, rows, ns, tag), nprocs=world, join=True)
+    case = synth.make_case("C3", step=4, grid=grid, rows=rows, n_samples=ns)
+    vol = oracle.c_migrate(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available, threads=4)
+    vol = vol.reshape(-1, ns)
+    idx = np.argmax(vol, axis=0)
+    top = vol[idx, np.arange(ns)]
+    counts = []
+    for rank in range(world):
+        got = np.load(tmp_path / f"{tag}{rank}.npz")
+        assert np.array_equal(got["c"], idx), rank
+        np.testing.assert_allclose(got["a"], top, rtol=4e-16)                 # (2^log2 of the exact maximum)
+        # (against the sum over the nodes in extended precision: float64 sums of 8e4 terms in two different
+        # orders differ by 3e-14 from each other)
+        exact = np.asarray(vol.astype(np.longdouble).sum(axis=0), dtype=np.float64)
+        np.testing.assert_allclose(got["b"], top * vol.shape[0] / exact, rtol=1e-14)
+        counts.append(tuple(int(v) for v in got["boxes"]))
+    columns = [c for _, c in counts]
+    assert sum(columns) == grid[0] * grid[1] and max(columns) - min(columns) <= 1
+    if tag == "c3columns":
+        assert sorted(set(columns)) == [5050, 5051] and all(1 <= n <= 3 for n, _ in counts)
+        assert {n for n, _ in counts} >= {2, 3}                              # partitions with several boxes occur
+    else:
+        assert columns.count(0) == 1 and [n for n, c in counts if c == 0] == [0]
+
+
 def test_cubic_rbf_algebra_is_scipys_rbf():
     """locate._cubic_rbf_weights / _cubic_rbf_on_grid (what Engine.rbf_peak evaluates on the GPU)
     against scipy.interpolate.Rbf(function="cubic") called the way _splineloc calls it
@@ -412,16 +504,42 @@ def test_fixed_point_screening_bounds_hold_on_cpu():
 
 
 
-def test_generated_shift_loop_is_current():
-    """qm_shift_asm.inc is generated (gen_shift_asm.py) and committed: the two must agree."""
+def test_generated_shift_loop_is_current_whatever_the_environment_holds():
+    """qm_shift_asm.inc is generated (gen_shift_asm.py) and committed: the two must agree -- and the product
+    generator reads NOTHING from the environment (a stray QM_SHIFT_EXP=noreads used to
+    yield a library that built, passed this test and was wrong).  Variants come from tools/dev/shift_overlay.py
+    only, and say so in the file they write."""
     import subprocess
     import sys
 
     csrc = ROOT / "quakemigrate_amd" / "csrc"
-    gen = subprocess.check_output([sys.executable, str(csrc / "gen_shift_asm.py")], text=True,
-                                  env={k: v for k, v in __import__("os").environ.items()
-                                       if not k.startswith("QM_SHIFT_")})
+    hostile = dict(os.environ, QM_SHIFT_EXP="noreads,nowait", QM_SHIFT_NQMIN="6", QM_SHIFT_PF="0",
+                   QM_SHIFT_PACKED="0", QM_SHIFT_STAGE_IN_LOOP="0", QM_SHIFT_VB="40", QM_DEV_VARIANT="1")
+    gen = subprocess.check_output([sys.executable, str(csrc / "gen_shift_asm.py")], text=True, env=hostile)
     assert gen == (csrc / "qm_shift_asm.inc").read_text()
+    assert "os.environ" not in (csrc / "gen_shift_asm.py").read_text()
+    variant = subprocess.check_output([sys.executable, str(ROOT / "tools" / "dev" / "shift_overlay.py"),
+                                       "PF_AHEAD=32"], text=True)
+    assert variant != gen and "overlay=PF_AHEAD=32" in variant and "overlay=none" in gen
+
+
+def test_library_exports_only_the_c_abi_and_says_what_it_was_built_from(built):
+    """`nm -D`: the symbols include/qmhip.h declares and nothing else (csrc/qmhip.map; the kernels' host stubs
+    and the engine's C++ internals used to be visible beside them); qm_build_info() names the product
+    generator's constants, the digest of its source, no overlay, no development defines."""
+    import hashlib
+    import subprocess
+
+    csrc = ROOT / "quakemigrate_amd" / "csrc"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", str(csrc / "libqmhip.so")], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == _declared_functions(), sorted(set(exported) ^ set(_declared_functions()))
+    lib = ctypes.CDLL(str(csrc / "libqmhip.so"))
+    lib.qm_build_info.restype = ctypes.c_char_p
+    info = lib.qm_build_info().decode()
+    digest = hashlib.sha256((csrc / "gen_shift_asm.py").read_bytes()).hexdigest()[:16]
+    assert f"generator={digest}" in info and "overlay=none" in info and info.endswith("defines=none"), info
+    assert "NQMAX=6 NQMIN=4" in info and "PF_AHEAD=16" in info
 
 
 def test_headline_kernels_stay_in_registers(tmp_path):

@@ -6,6 +6,10 @@ variant this script imports it, sets module constants named on the command line 
 
     python tools/dev/shift_overlay.py PF_AHEAD=32 WIDE_SLOTTED=0 > build_variants/shift_asm_x.inc
 
+Timing experiments (WRONG RESULTS by construction -- what a component of the loop costs in situ):
+`DROP=<regex>` leaves out every emitted instruction that matches, `ONLY=<name regex>` restricts that to the
+flavours whose function name matches, e.g. DROP='ds_read_b128' ONLY='shift_wide'.
+
 tools/shift_variants.sh builds a library per variant around such a file; nothing of it reaches
 `__graft_entry__.build()`, which regenerates the committed qm_shift_asm.inc from the product constants
 and ignores the environment."""
@@ -20,6 +24,29 @@ def main(argv):
     spec = importlib.util.spec_from_file_location("gen_shift_asm", ROOT / "quakemigrate_amd" / "csrc" / "gen_shift_asm.py")
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
+    import re
+
+    drop = only = None
+    for item in list(argv):
+        name, _, value = item.partition("=")
+        if name in ("DROP", "ONLY"):
+            argv.remove(item)
+            if name == "DROP":
+                drop = re.compile(value)
+            else:
+                only = re.compile(value)
+    if drop is not None:
+        emit = gen.emit
+        plain = gen.Emitter.__call__
+
+        def emit_filtered(degree, volume, lds_state, far, lazy, block, name, *rest, **kw):
+            active = only is None or only.search(name)
+            gen.Emitter.__call__ = (lambda self, text: None if drop.search(text) else plain(self, text)) if active else plain
+            try:
+                emit(degree, volume, lds_state, far, lazy, block, name, *rest, **kw)
+            finally:
+                gen.Emitter.__call__ = plain
+        gen.emit = emit_filtered
     for item in argv:
         name, _, value = item.partition("=")
         if not hasattr(gen, name):
@@ -27,6 +54,7 @@ def main(argv):
         old = getattr(gen, name)
         setattr(gen, name, type(old)(int(value)) if isinstance(old, (bool, int)) else type(old)(value))
     gen.WMAX = 4 * gen.NQMAX
+    gen.OVERLAY = ",".join(sys.argv[1:]).replace('"', "'").replace("\\", "/") or "none"
     gen.main()
 
 
