@@ -98,6 +98,8 @@ def parse():
                     help="skip the availability-change leg (table_switch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--engine", default="{}", help="json dict of engine tunables")
+    ap.add_argument("--no-materialise-full", action="store_true",
+                    help="skip the literal BASELINE configs[2] leg (roofline_materialised_full)")
     ap.add_argument("--materialise-full", action="store_true",
                     help="also run configs[2] literally: the whole n_samples volume (196 GB at "
                          "C3) written to HBM with the scan outputs (needs the memory)")
@@ -784,7 +786,21 @@ def main():
         sw.close()
         del tt_a, tt_b
 
-    if args.materialise_full and world == 1 and not streaming:
+    # ---- BASELINE configs[2] literally: the whole n_samples volume of the step written to HBM with its scan
+    # (SURVEY 8d figure 1 on the configuration itself: 196 GB at C3).  Part of the default line since round 6
+    # (VERDICT r05 item 3), skipped -- and said so -- where the GPU has not the memory free.
+    full_bytes = 8.0 * n_local * ns
+    free_bytes = torch.cuda.mem_get_info(dev)[0] if world == 1 else 0
+    want_full = (args.materialise_full or (cfg_name == "C3" and not args.no_materialise_full)) and \
+        world == 1 and not streaming and part_world == 1
+    if want_full and free_bytes < full_bytes + (4 << 30):
+        lib.release_cached_memory() if hasattr(lib, "release_cached_memory") else None
+        torch.cuda.empty_cache()
+        free_bytes = torch.cuda.mem_get_info(dev)[0]
+    if want_full and free_bytes < full_bytes + (4 << 30):
+        result["roofline_materialised_full"] = {"skipped": f"{full_bytes / 1e9:.0f} GB volume, "
+                                                           f"{free_bytes / 1e9:.0f} GB of HBM free"}
+    elif want_full:
         vol = torch.empty((n_local, ns), dtype=torch.float64, device=dev)
         o3 = tuple(torch.empty(ns, dtype=d, device=dev)
                    for d in (torch.float64, torch.float64, torch.int64))
@@ -798,10 +814,13 @@ def main():
         eng.config("log_timing", 0)
         sec = ms / 1e3 / calls
         b_full = 8.0 * n_local * ns + b_fused
+        k_full = stack_kernel_name(eng, S, volume=True)
+        tiles_full = {"wide_384": eng.get("shift_wide_tiles"), "tail_samples_per_lane": eng.get("shift_tail_spl")}
         eng.detect(onsets_dev[0], case.fsmp, case.lsmp, case.available, n_nodes_total=n_total,
                    out=out)
         torch.cuda.synchronize()
         result["roofline_materialised_full"] = {
+            "kernel": k_full, "tiles": tiles_full,
             "bound": "hbm", "achieved": b_full / sec / 1e9, "peak": HBM_PEAK / 1e9,
             "unit": "GB/s", "frac": b_full / sec / HBM_PEAK, "avg_ms": sec * 1e3,
             "node_samples_per_s": n_local * ns / sec,

@@ -1044,6 +1044,11 @@ def main():
     # sample: 48 adds per register window instead of 32, 0.19 instead of 0.28 LDS reads per add at C3
     emit(8, False, False, False, False, False, "shift_wide_detect", 6, True)
     emit(8, False, False, False, True, False, "shift_wide_detect_lazy", 6, True)
+    # (a volume-writing wide flavour -- three 16-byte stores per node at a lane stride of 48 bytes -- was built,
+    # bit-equal, and measured: the whole 6000-sample C3 volume in 110 ms against 62 on the 256-sample tiles,
+    # whose two stores at a stride of 32 bytes complete a 64-byte line from two lanes; here a store instruction
+    # touches 48 lines to write 16: 1.5 x the write requests per sample.  Volume launches keep the 256-sample
+    # tiles; profiles/r06_ab_runs.txt)
 
 
 if __name__ == "__main__":

@@ -397,7 +397,10 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         // (the wide layout's 8-wave workgroups, one per CU: FEW, long workgroups -- C3 41.7 / 42.1 / 42.3 / 42.6 ms
         // at 1 / 4 / 8 / 12 rounds, where the 4-wave shape runs 50.1 / 46.5 / 45.7 at 4 / 8 / 12,
         // profiles/r06_ab_runs.txt: the fewest rounds that leave no slot idle, 0.2 % charged per round)
-        if (shift && wide && !e->user_rounds) {
+        // (the 8-wave shape of 33-64 rows likewise: a C4 slab, 47 tiles, 170.2 ms at 12 rounds = 64 groups, 168.6 at
+        // 16 groups = 2.94 rounds, 181.5 at 40 groups = 7.3 rounds: what the count must avoid is a last round that is
+        // mostly empty)
+        if (shift && (wide || (L->nw == qm::kShiftWaves8 && L->nblk == 1)) && !e->user_rounds) {
             double best = 1e300;
             for (int r = 1; r <= e->cfg_rounds; ++r) {
                 const int g = auto_groups(e, a.ntiles, nbricks_now, lds_blocks_per_cu, r);

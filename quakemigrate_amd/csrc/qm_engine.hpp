@@ -136,6 +136,8 @@ struct ShiftLayout {
 // lut.py:529-537 -- costs a rebuild only the first time that table is seen.
 struct TableState {
     bool have_lut = false;
+    uint64_t serial = 0;            // identity of the loaded table (process-unique; travels with the state
+                                    // through qm_engine_table_select): what a qm_stream checks before a launch
     qm::GridDesc g{};
     int64_t n_nodes = 0;
     int64_t node_offset = 0;

@@ -567,7 +567,7 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
     const unsigned lane_addr = lds_base + (unsigned)lane * (kTail ? 8u * J : 16u);
     // volume, whole tiles: lanes of a pulled-back tile whose four samples its predecessor stores are
     // masked off at the stores (a lane that straddles the seam stores its four: same bits)
-    const int seam = work.t_own - t_first;                         // samples of overlap, 0 .. 255
+    const int seam = work.t_own - t_first;                         // samples of overlap, 0 .. 64 J - 1
     const unsigned long long store_lanes = ~0ull << (seam / 4);
     // volume, tail tiles: per sample slot the lanes whose sample lies inside the scan
     unsigned long long slot_lanes[J];

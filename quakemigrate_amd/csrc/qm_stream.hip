@@ -28,6 +28,7 @@ struct qm_stream {
     qm_engine *e = nullptr;
     int n_rows = 0, T = 0, fsmp = 0, lsmp = 0, available = 0, ns = 0, K = 1, depth = 2;
     int64_t n_nodes_total = 0;
+    uint64_t table_serial = 0;          // the table the stream was made on (TableState::serial)
     hipStream_t copy_stream = nullptr;
     struct Slot {
         double *h_on = nullptr;         // pinned [K][n_rows][T]
@@ -83,9 +84,13 @@ int launch_slot(qm_stream *s) {
     qm_engine *e = s->e;
     qm_stream::Slot &sl = s->slots[s->fill_slot];
     const int n = s->fill_n;
-    if (!e->have_lut || e->g.n_rows != s->n_rows)
-        return fail("qm_stream: the engine's resident table changed under the stream (%d rows, the stream "
-                    "was made for %d)", e->have_lut ? e->g.n_rows : 0, s->n_rows);
+    // (not the row count alone -- another table of the same shape, e.g. a table_select switch or a
+    // foreign load on the shared default engine, would be stacked and normalised as if it were the stream's)
+    if (!e->have_lut || e->serial != s->table_serial || e->g.n_rows != s->n_rows)
+        return fail("qm_stream: the engine's resident table changed under the stream (table #%llu with %d rows, "
+                    "the stream was made on #%llu with %d): select the stream's table again, then push or flush",
+                    (unsigned long long)(e->have_lut ? e->serial : 0), e->have_lut ? e->g.n_rows : 0,
+                    (unsigned long long)s->table_serial, s->n_rows);
     const size_t kns = (size_t)s->K * s->ns;
     QM_HIP(hipMemcpyAsync(sl.d_on, sl.h_on, (size_t)n * step_in(s) * sizeof(double), hipMemcpyHostToDevice,
                           s->copy_stream));
@@ -138,6 +143,7 @@ int qm_stream_create(qm_engine *e, int32_t t_samples, int32_t fsmp, int32_t lsmp
     qm_stream *s = new qm_stream();
     s->e = e;
     s->n_rows = e->g.n_rows;
+    s->table_serial = e->serial;
     s->T = t_samples; s->fsmp = fsmp; s->lsmp = lsmp; s->available = available; s->ns = ns;
     s->K = steps_per_launch; s->depth = depth;
     s->n_nodes_total = n_nodes_total > 0 ? n_nodes_total : e->n_nodes;
@@ -179,6 +185,12 @@ void qm_stream_destroy(qm_stream *s) {
 int qm_stream_push(qm_stream *s, const double *log_onsets) {
     if (!log_onsets) return fail("qm_stream_push: NULL argument");
     if (alive(s, "qm_stream_push")) return 1;
+    DeviceGuard guard(s->e->device);
+    // A full slot whose launch FAILED (the table changed under the stream, no memory, a refused step) is still
+    // waiting to go out: it goes first, or this call fails as that one did -- never a copy past the slot's
+    // K timesteps (the next push used to write one timestep behind the pinned buffer and launch
+    // K + 1 of them).
+    if (s->fill_n >= s->K && launch_slot(s)) return 1;
     qm_stream::Slot &sl = s->slots[s->fill_slot];
     if (s->fill_n == 0 && sl.in_flight) {
         (void)fail("qm_stream_push: all %d slots hold results that have not been popped", s->depth);
@@ -187,7 +199,6 @@ int qm_stream_push(qm_stream *s, const double *log_onsets) {
     // (the slot's previous H2D has finished: its launch's results were popped)
     host_copy(sl.h_on + (size_t)s->fill_n * step_in(s), log_onsets, step_in(s) * sizeof(double));
     if (++s->fill_n < s->K) return 0;
-    DeviceGuard guard(s->e->device);
     return launch_slot(s);
 }
 

@@ -604,6 +604,8 @@ int qm_engine_load_lut(qm_engine *e, const int32_t *lut, int lut_on_device, int3
     e->sh.built = e->sh.ok = false;
     e->shw.built = e->shw.ok = false;
     e->have_lut = true;
+    static std::atomic<uint64_t> next_serial{1};
+    e->serial = next_serial.fetch_add(1);
     return plan_wide(e, eff_j(e));
 }
 

@@ -82,6 +82,13 @@ class DataAvailabilityException(_NoDataException):
 _NO_DATA = ("ArchiveEmptyException", "DataGapException", "DataAvailabilityException")
 
 
+def _is_no_data(exc):
+    """The reference catches util.ArchiveEmptyException / DataGapException / DataAvailabilityException AND their
+    subclasses (scan.py:449-458); its exception objects are recognised by the names in the raised class's MRO
+    (obspy-free: the reference's util module is not imported here)."""
+    return any(cls.__name__ in _NO_DATA for cls in type(exc).__mro__)
+
+
 def _shift(t, seconds):
     """``t + seconds`` for obspy ``UTCDateTime`` (adds floats) and ``datetime`` alike."""
     try:
@@ -291,8 +298,6 @@ class MigrationScan:
         """
         from collections import deque
 
-        from quakemigrate_amd.stream import StreamingDetector
-
         if self.stage != "detect":
             raise ValueError("continuous_compute is the detect stage's loop")
         ucf = getattr(self.lut, "unit_conversion_factor", 1.0)
@@ -314,6 +319,42 @@ class MigrationScan:
                 while pending:
                     emit(min(state["stream"].k, len(pending)))
 
+        # (what the pipeline holds when anything else goes wrong mid-run is sunk before the error travels on: the
+        # reference has appended every timestep it computed, scan.py:434-448)
+        try:
+            self._continuous_steps(archive, starttime, timestep, scan_rate, n_steps, sink, ucf, rows, pending,
+                                   state, emit, drain, steps_per_launch, depth)
+        except BaseException:
+            try:
+                drain()
+            except Exception:  # noqa: BLE001  (the first error is the one to report)
+                pass
+            raise
+        finally:
+            if state["stream"] is not None:
+                state["stream"].close()
+            self._restore_screen(state.get("engine"), state.get("screen_before"))
+        if not getattr(sink, "written", False):
+            sink.write()
+        columns = next((list(r) for r in rows if r is not None), [])
+        return [r if r is not None else dict.fromkeys(columns, 0) for r in rows]
+
+    def _apply_screen(self, eng):
+        """MigrationScan.screen on the engine for the calls that follow (as _compute does per step); returns what
+        to restore."""
+        previous = eng.get("screen")
+        if self.screen is not None:
+            eng.config("screen", 1 if self.screen else 0)
+        return previous
+
+    def _restore_screen(self, eng, previous):
+        if eng is not None and previous is not None and self.screen is not None:
+            eng.config("screen", previous)
+
+    def _continuous_steps(self, archive, starttime, timestep, scan_rate, n_steps, sink, ucf, rows, pending, state,
+                          emit, drain, steps_per_launch, depth):
+        from quakemigrate_amd.stream import StreamingDetector
+
         for i in range(n_steps):
             w_beg = _shift(_shift(starttime, timestep * i), -self.pre_pad)
             w_end = _shift(_shift(starttime, timestep * (i + 1) - 1 / scan_rate), self.post_pad)
@@ -322,7 +363,7 @@ class MigrationScan:
                 data = archive.read_waveform_data(w_beg, w_end)
                 onsets, onset_data = self.onset.calculate_onsets(data)
             except Exception as e:  # noqa: BLE001
-                if type(e).__name__ not in _NO_DATA:
+                if not _is_no_data(e):
                     raise
                 drain()
                 sink.empty(starttime, timestep, i, getattr(e, "msg", str(e)), ucf)
@@ -333,6 +374,8 @@ class MigrationScan:
             if (onset_data.sampling_rate, tuple(onset_data.availability.items())) != self._resident_key:
                 drain()
             eng = self._ensure_table(onset_data.sampling_rate, onset_data.availability)
+            if state.get("engine") is None:              # (the scan's `screen` holds for the whole run)
+                state["engine"], state["screen_before"] = eng, self._apply_screen(eng)
             fsmp = time2sample(self.pre_pad, onset_data.sampling_rate)
             lsmp = time2sample(self.post_pad, onset_data.sampling_rate)
             avail = int(np.sum([value for _, value in onset_data.availability.items()]))
@@ -358,12 +401,6 @@ class MigrationScan:
             pending.append((_shift(data.starttime, self.pre_pad), onset_data))
             rows.append(dict(onset_data.availability))
         drain()
-        if state["stream"] is not None:
-            state["stream"].close()
-        if not getattr(sink, "written", False):
-            sink.write()
-        columns = next((list(r) for r in rows if r is not None), [])
-        return [r if r is not None else dict.fromkeys(columns, 0) for r in rows]
 
     def locate_compute(self, archive, triggers, marginal_window, sgm=0.8, cov_thresh=0.90, on_event=None):
         """
@@ -406,7 +443,7 @@ class MigrationScan:
                 data = archive.read_waveform_data(w_beg, w_end)
                 onsets, onset_data = self.onset.calculate_onsets(data)
             except Exception as e:  # noqa: BLE001
-                if type(e).__name__ not in _NO_DATA:
+                if not _is_no_data(e):
                     raise
                 logging.info(getattr(e, "msg", str(e)))
                 continue
@@ -422,8 +459,18 @@ class MigrationScan:
                                  f"{n_onsets}:{eng.n_rows}")
             if onsets.size < n_samples + fsmp:
                 raise ValueError("Data array smaller than coalescence array.")
+            # times[i] below takes the first scanned sample for trigger - 2 mw (event.py:412-420): the window read
+            # must hold exactly 4 mw rate + 1 samples (the reference fails on the DataFrame's length otherwise)
+            if n_samples != int(round(4 * mw * rate)) + 1:
+                raise ValueError(f"Event {uid}: {n_samples} scanned samples where 4 * marginal_window * rate + 1 = "
+                                 f"{int(round(4 * mw * rate)) + 1} are expected (pre_pad / post_pad / the archive's "
+                                 "window do not match the marginal window)")
             series = (np.zeros(n_samples), np.zeros(n_samples), np.zeros(n_samples, dtype=np.int64))
-            eng.detect(onsets, fsmp, lsmp, avail, out=series)                          # pass 1: the origin time
+            screen_before = self._apply_screen(eng)
+            try:
+                eng.detect(onsets, fsmp, lsmp, avail, out=series)                      # pass 1: the origin time
+            finally:
+                self._restore_screen(eng, screen_before)
             i_max = int(np.nanargmax(series[0]))                                       # idxmax: the first maximum
             # times[i] = trigger_time - 2 mw + i / rate (event.py:412-420)
             offset = i_max / rate - 2 * mw                                             # otime - trigger_time
@@ -433,6 +480,9 @@ class MigrationScan:
             eps = 1e-6                                                                 # (time stamps are whole ns)
             first = max(0, int(np.ceil(i_max - mw * rate - eps)))
             last = min(n_samples - 1, int(np.floor(i_max + mw * rate + eps)))
+            if last <= first:
+                raise ValueError(f"Event {uid}: the marginal window holds no sample interval (marginal_window "
+                                 f"{mw} s at {rate} Hz: samples {first}..{last})")
             marginal = eng.marginal_map(onsets, fsmp, lsmp, avail, first, last)        # pass 2: samples [first, last)
             coa_map = np.zeros_like(marginal)
             fits = locate.calculate_location(eng, marginal, self.lut.node_spacing, sgm=sgm,

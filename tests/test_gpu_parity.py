@@ -662,6 +662,59 @@ def test_c3_locate_window_materialised_volume_against_oracle(lib, oracle):
     eng.close()
 
 
+def test_c3_whole_step_materialised_volume_sampled_rows_against_oracle(lib, oracle):
+    """BASELINE configs[2] LITERALLY: the 201x201x101 x 30 rows x 6000-sample volume of one step (196 GB) written
+    on the device with its scan (core/lib.py:99-123; what bench.py's roofline_materialised_full times).  3000
+    sampled node rows, the rows of the scan's argmax nodes and the grid's corners against the oracle's volume;
+    the scan series against the fused detect's bits and, on chunks, the oracle's; nothing left unwritten in the
+    sampled rows.  Skipped where the GPU has not 200 GB free."""
+    import torch
+
+    case = synth.make_case("C3", step=0)
+    S, ns, n = case.available, case.n_samples, case.n_nodes_total
+    need = 8 * n * ns + (6 << 30)
+    lib.release_cached_memory()
+    torch.cuda.empty_cache()
+    if torch.cuda.mem_get_info(0)[0] < need:
+        pytest.skip(f"{need / 1e9:.0f} GB of HBM needed, {torch.cuda.mem_get_info(0)[0] / 1e9:.0f} free")
+    lon = oracle.log_onsets(case.onsets)
+    eng = lib.Engine(0)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.load_lut(case.traveltimes)
+    d_lon = torch.from_numpy(lon).cuda()
+    vol = torch.empty((n, ns), dtype=torch.float64, device="cuda")
+    rng = np.random.default_rng(6000)
+    probe = np.unique(np.concatenate([rng.choice(n, size=3000, replace=False), [0, n - 1, 100, 101 * 201 - 1]]))
+    vol[torch.from_numpy(probe).cuda()] = float("nan")          # (the rows that will be compared start unwritten)
+    out = tuple(torch.empty(ns, dtype=d, device="cuda") for d in (torch.float64, torch.float64, torch.int64))
+    eng.migrate(d_lon, case.fsmp, case.lsmp, S, vol, scan_out=out)
+    torch.cuda.synchronize()
+    assert (eng.get("last_kernel"), eng.get("shift_waves"), eng.get("shift_wide_tiles")) == (3, 4, 0)
+    got = tuple(o.cpu().numpy() for o in out)
+    fused = eng.detect(d_lon, case.fsmp, case.lsmp, S, out=tuple(torch.empty_like(o) for o in out))
+    torch.cuda.synchronize()
+    assert np.array_equal(fused[2].cpu().numpy(), got[2]) and np.array_equal(fused[0].cpu().numpy(), got[0])
+    np.testing.assert_allclose(fused[1].cpu().numpy(), got[1], rtol=1e-13)
+    nk = 24
+    for k0 in (0, case.event_nodes[0][1] - nk // 2, ns - nk):
+        _assert_series(tuple(g[k0:k0 + nk] for g in got), _oracle_chunk(oracle, case, k0, nk))
+    nodes = np.unique(np.concatenate([probe, got[2][:: ns // 40]]))
+    rows = vol[torch.from_numpy(nodes).cuda()].cpu().numpy()
+    assert not np.isnan(rows).any()
+    sub = np.ascontiguousarray(case.traveltimes.reshape(-1, S)[nodes].reshape(-1, 1, 1, S))
+    ref_rows = oracle.c_migrate(case.onsets, sub, case.fsmp, case.lsmp, S, threads=8).reshape(len(nodes), ns)
+    np.testing.assert_allclose(rows, ref_rows, rtol=RTOL)
+    np.testing.assert_allclose(rows, ref_rows, rtol=TIGHT)
+    # the stored maxima are the scan's: find_max_coa over the sampled argmax rows reproduces max_coa there
+    for t in range(0, ns, ns // 40):
+        r = int(np.searchsorted(nodes, got[2][t]))
+        np.testing.assert_allclose(rows[r, t], got[0][t], rtol=TIGHT)
+    del vol
+    eng.close()
+    lib.release_cached_memory()
+    torch.cuda.empty_cache()
+
+
 def test_migration_scan_compute_mirrors_reference_glue(lib, oracle):
     """MigrationScan._compute with duck-typed LUT / onset plugins, both stages."""
     from quakemigrate_amd import scan
@@ -2795,6 +2848,31 @@ def test_native_stream_push_pop_semantics(lib, oracle):
         assert all(np.array_equal(x, y) for x, y in zip(g, w))
     with pytest.raises(ValueError):
         sd.push(wins[0][:, :-1])
+    # a launch that FAILS (another table of the same shape became resident under the stream) leaves
+    # its full slot waiting; the caller selects the stream's table again and goes on -- nothing is copied past
+    # the slot's K timesteps, no timestep is lost or doubled
+    keyed = lib.Engine(0)
+    assert not keyed.select_table("A")
+    keyed.load_lut(c0.traveltimes)
+    sk = StreamingDetector(keyed, c0.available, wins[0].shape[1], c0.fsmp, c0.lsmp, c0.available, depth=2,
+                           steps_per_launch=3)
+    assert sk.push(wins[0]) and sk.push(wins[1])
+    assert not keyed.select_table("B")
+    keyed.load_lut(np.ascontiguousarray(c0.traveltimes[::-1]))     # same shape and row count, other delays
+    with pytest.raises(lib.QMHipError, match="changed under the stream"):
+        sk.push(wins[2])                                   # fills the slot; its launch is refused
+    with pytest.raises(lib.QMHipError, match="changed under the stream"):
+        sk.push(wins[3])                                   # still refused: nothing copied, nothing launched
+    assert sk.pending() == (0, 3)
+    assert keyed.select_table("A")                         # the stream's table again (a pointer swap)
+    assert sk.push(wins[3]) and sk.push(wins[4])           # the waiting launch goes out first
+    assert sk.pending() == (3, 2)
+    sk.flush()
+    out = sk.pop(5)
+    for j in range(5):
+        assert all(np.array_equal(x[j], y) for x, y in zip(out, single[j]))
+    sk.close()
+    keyed.close()
     eng.close()                                            # the stream is orphaned, not dangling
     with pytest.raises(lib.QMHipError):
         sd.push(wins[0])
