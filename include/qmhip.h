@@ -160,6 +160,9 @@ int qm_engine_synchronize(qm_engine *e);
  *                                                scan holds at least one; 0 = the 256-sample tiles of rounds 3-5.
  *                                                max_coa / max_coa_idx bit-equal, max_norm_coa within 1e-14 (the
  *                                                sum over the nodes is formed in another order)
+ * shift_wide_rows       0, 1, 2 [1]              wide tiles on ROW BLOCKS (4x4x4 bricks, blocks of <= 20 rows through a
+ *                                                double-buffered LDS) where the 384-sample windows of all rows do not
+ *                                                fit a CU's LDS (BASELINE configs[3]: 60 rows); 0 = never, 2 = always
  * shift_rows_direct     0, 1, 2 [1]              tables of > 64 rows (row blocks): 1 = blocks of <= 34 rows,
  *                                                double-buffered LDS, LDS-direct loads; 0 = blocks of <= 64
  *                                                through registers; 2 = two 4-wave workgroups per CU
@@ -175,7 +178,7 @@ int qm_engine_synchronize(qm_engine *e);
  * last_kernel_j, steps_per_launch (timesteps the last detect_batch put into one launch);
  * shift_ok, shift_brick_nodes, shift_wide_bricks, shift_row_blocks, shift_operands_per_add_x1000,
  * shift_tail_spl; shift_wide_ok, shift_wide_tiles (of the last launch), shift_wide_brick_nodes,
- * shift_wide_direct_bricks, shift_wide_operands_per_add_x1000; pair_brick_nodes, pair_wide_bricks, pair_tile; screened_steps, fallback_steps,
+ * shift_wide_direct_bricks, shift_wide_row_blocks, shift_wide_operands_per_add_x1000; pair_brick_nodes, pair_wide_bricks, pair_tile; screened_steps, fallback_steps,
  * last_candidates, screen_brick_nodes; tie_refined_steps, tie_pairs and tie_overflow_samples (of the last
  * refined launch);
  * table_hits, table_misses, table_evictions, tables_parked, table_bytes, tables_parked_bytes. */

@@ -26,11 +26,28 @@ ROW_BLOCK_KERNELS = ("_ZN2qm23stack_shift_rows_kernelILi8EEEvNS_9ShiftArgsE",
                      "_ZN2qm24stack_shift_rows4_kernelILb1EEEvNS_9ShiftArgsE")
 
 
-def first_hard_register(inc_text):
-    return int(re.search(r"kShiftBlockVgprs = (\d+);", inc_text).group(1))
+# round 6: the row-block kernel of the WIDE tiles -- 96 accumulators from v56 up (kShiftWideBlockVgprs,
+# amdgpu_waves_per_eu(9, 9))
+WIDE_ROW_BLOCK_KERNELS = ("_ZN2qm28stack_shift_wide_rows_kernelENS_9ShiftArgsE",)
 
 
-def check(sasm, first_hard, kernels=ROW_BLOCK_KERNELS):
+def first_hard_register(inc_text, wide=False):
+    name = "kShiftWideBlockVgprs" if wide else "kShiftBlockVgprs"
+    return int(re.search(name + r" = (\d+);", inc_text).group(1))
+
+
+def check_all(sasm, inc_text):
+    """both families against their own first hard register.  What has to survive between two calls is the
+    ACCUMULATORS: from the first hard register up in the 4-sample kernels (everything above is the loop's), the
+    96 registers from kShiftWideBlockVgprs in the wide kernel -- its loop names every register up to v255, and the
+    compiler may park a value in one of the two or three the eager flavour leaves unnamed (windows, addresses and
+    constants are made anew by every call's prologue)."""
+    wide_first = first_hard_register(inc_text, wide=True)
+    return (check(sasm, first_hard_register(inc_text)) +
+            check(sasm, wide_first, WIDE_ROW_BLOCK_KERNELS, last=wide_first + 96))
+
+
+def check(sasm, first_hard, kernels=ROW_BLOCK_KERNELS, last=1 << 20):
     """Raises AssertionError naming the offending line; returns the number of compiler
     instructions with VGPR operands that were checked."""
     total = 0
@@ -49,7 +66,7 @@ def check(sasm, first_hard, kernels=ROW_BLOCK_KERNELS):
             code = line.split(";")[0]
             regs = [int(x) for x in re.findall(r"\bv(\d+)\b", code)]
             regs += [int(b) for _, b in re.findall(r"\bv\[(\d+):(\d+)\]", code)]
-            assert all(r < first_hard for r in regs), \
+            assert all(r < first_hard or r >= last for r in regs), \
                 f"{symbol}: compiler code touches a register >= v{first_hard}: {line.strip()}"
             checked += bool(regs)
         assert checked > 100, (symbol, checked)
@@ -60,5 +77,5 @@ def check(sasm, first_hard, kernels=ROW_BLOCK_KERNELS):
 if __name__ == "__main__":
     here = pathlib.Path(__file__).resolve().parent
     inc = pathlib.Path(sys.argv[2]) if len(sys.argv) > 2 else here / "qm_shift_asm.inc"
-    n = check(pathlib.Path(sys.argv[1]).read_text(), first_hard_register(inc.read_text()))
+    n = check_all(pathlib.Path(sys.argv[1]).read_text(), inc.read_text())
     print(f"row-block kernels: {n} compiler instructions checked, none touches the asm's registers")

@@ -102,6 +102,8 @@ PLANE8 = 81856           # ... for the 8-wave workgroup that owns a CU's whole L
 STATE_CHUNK = 1024       # running state in LDS: 5 chunks of 64 lanes x 16 bytes per wavefront
 VB_BLOCK = 80            # first hard VGPR of the row-block flavour
 VB_WIDE = 48             # ... of the wide flavours (SPL = 6: 30 VGPRs of running state below it)
+VB_WIDE_BLOCK = 56       # ... of the wide row-block flavour (accumulators kept across calls: the compiler's code
+                         # between them stays below -- amdgpu_waves_per_eu(9, 9), checked in the ISA at every build)
 NQMIN_WIDE = 4           # quads a wide tile's window fetches unconditionally (6: no conditional reads at all)
 BUTTERFLY = True         # marginal map: the eight nodes of a whole group summed over the wavefront together
 VOLUME_DEGREE = 10       # 2^f of stored values (qm_kernels.hpp: QM_EXP2_DEGREE_VOLUME)
@@ -124,7 +126,7 @@ def configure(lds_state, far=False, lazy=False, block=False, spl=4, contig=False
     MARGINAL = marginal      # the marginalised map instead of the volume
     wide = spl == 6
     assert (1 <= spl <= 4 or wide) and (contig or spl == 4)
-    assert not (contig and (far or lds_state or block)) and not (contig and lazy and not wide)
+    assert not (contig and (far or lds_state)) and not (contig and (lazy or block) and not wide)
     assert not (wide and marginal)
     AS = 2 * spl if wide else 8      # VGPRs between the accumulators of consecutive nodes
     LDS_STATE = lds_state
@@ -133,7 +135,7 @@ def configure(lds_state, far=False, lazy=False, block=False, spl=4, contig=False
     PLANE = PLANE3 if lds_state else PLANE8 if far else PLANE2
     # first hard VGPR (row-block flavour: the accumulators must survive the compiler's code between
     # two calls, which therefore has to stay below VB -- tests/test_host.py checks the ISA)
-    VB = 4 if lds_state else VB_BLOCK if block else VB_WIDE if wide else 32
+    VB = 4 if lds_state else VB_WIDE_BLOCK if block and wide else VB_BLOCK if block else VB_WIDE if wide else 32
     ACC = VB                 # acc[g][k] = v[ACC + AS g + 2 k : +1]
     WIN = [ACC + 8 * AS, ACC + 8 * AS + 2 * WMAX]
     VADDR = WIN[1] + 2 * WMAX
@@ -168,7 +170,12 @@ def configure(lds_state, far=False, lazy=False, block=False, spl=4, contig=False
     VZERO = VPF + 1
     VMAG = (VZERO + 2) & ~1      # 1.5 * 2^52 as a VGPR pair (lazy flavour: z is folded into FMAs)
     VEND = VMAG + 2 if lazy else VZERO + 1
-    if wide:
+    if wide and block:
+        # (one group per call: no next group's window is on its way into window 0 while the epilogue runs)
+        GIDX = WIN[0]
+        KI = WIN[0] + SPL
+        assert VEND <= 256
+    elif wide:
         GIDX = VEND
         KI = VEND + SPL
         VEND = KI + 1
@@ -342,6 +349,34 @@ def stage_step(e):
     m, t = SG_META, SG_T
     e(f"s_cmp_ge_u32 s{SG_ROW}, %[stgn]")
     e(f"s_cbranch_scc1 {skip}")
+    if CONTIG:
+        # wide tiles: ONE contiguous window per row, slots of 32 bytes: pairs 0-191 (384 samples: every window
+        # holds them) are three full loads, the rest (up to 62 pairs: the kernel hands rows over only while no
+        # window holds more than 127 slots) a fourth under EXEC; the instruction offset moves the global and the
+        # LDS address together, so M0 is set once
+        e(f"s_mul_i32 s{SG_SRC}, s{SG_ROW}, %[stgt8]")
+        e(f"s_mul_hi_u32 s{SG_SRC + 1}, s{SG_ROW}, %[stgt8]")
+        e(f"s_ashr_i32 s{t + 1}, s{m}, 31")
+        e(f"s_mov_b32 s{t}, s{m}")
+        e(f"s_lshl_b64 {s2(t)}, {s2(t)}, 3")
+        e(f"s_add_u32 s{SG_SRC}, s{SG_SRC}, s{t}")
+        e(f"s_addc_u32 s{SG_SRC + 1}, s{SG_SRC + 1}, s{t + 1}")
+        e(f"s_add_u32 s{SG_SRC}, s{SG_SRC}, %[stglo]")
+        e(f"s_addc_u32 s{SG_SRC + 1}, s{SG_SRC + 1}, %[stghi]")
+        e(f"s_lshl_b32 s{SG_LDS}, s{m + 2}, 5")
+        e(f"s_add_u32 m0, s{SG_LDS}, %[stglds]")
+        e("s_nop 0")
+        for c in range(3):
+            e(f"global_load_lds_dwordx4 %[lane32], {s2(SG_SRC)}" + (f" offset:{1024 * c}" if c else ""))
+        e(f"s_lshl_b32 s{t}, s{m + 3}, 1")                          # pairs of the window
+        e(f"s_sub_u32 s{t}, s{t}, 192")
+        e(f"s_bfm_b64 exec, s{t}, 0")
+        e(f"global_load_lds_dwordx4 %[lane32], {s2(SG_SRC)} offset:3072")
+        e("s_mov_b64 exec, -1")
+        e(f"s_mov_b32 s{SG_AFTER}, 0")
+        e(f"s_add_u32 s{SG_ROW}, s{SG_ROW}, %[stgstride]")
+        e(f"{skip}:")
+        return
     e(f"s_mul_i32 s{SG_SRC}, s{SG_ROW}, %[stgt8]")              # row * bytes per onset row (64 bits)
     e(f"s_mul_hi_u32 s{SG_SRC + 1}, s{SG_ROW}, %[stgt8]")
     e(f"s_ashr_i32 s{t + 1}, s{m}, 31")                         # + 8 * (the window's first sample)
@@ -643,6 +678,10 @@ def marginal_butterfly(e):
 
 def epilogue(e, degree, volume):
     e("s_set_gpr_idx_off")
+    if BLOCK and SPL == 6:
+        # (the group's indices live in window 0 here: what the block's last row has requested into it -- the
+        # harmless window behind the run's end -- must have landed first)
+        e("s_waitcnt lgkmcnt(0)")
     # Group-level running maximum (nodes of a group are visited in ascending flat index: strict >).
     # A whole group (all eight nodes inside the grid, the common case) takes the first node's z
     # as the starting maximum; a group cut by the grid's edge starts from (-inf, none) and skips
@@ -995,7 +1034,7 @@ def build_info():
     consts = " ".join(f"{k}={int(globals()[k])}" for k in (
         "NQMAX", "NQMIN", "NQMIN_WIDE", "PF_AHEAD", "PF_EVERY", "NEXT_RUN", "NEXT_META", "STAGE_IN_LOOP",
         "PACKED_GROUPS", "PACKED_BLOCKS", "PACKED_SHIFT64", "BUTTERFLY", "VOLUME_DEGREE",
-        "MARGINAL_DEGREE", "VB_BLOCK", "VB_WIDE"))
+        "MARGINAL_DEGREE", "VB_BLOCK", "VB_WIDE", "VB_WIDE_BLOCK"))
     digest = hashlib.sha256(pathlib.Path(__file__).read_bytes()).hexdigest()[:16]
     return f"{consts}; generator={digest}; overlay={OVERLAY}"
 
@@ -1015,6 +1054,7 @@ def main():
     print(f"constexpr bool kShiftPackedBlocks = {'true' if PACKED_BLOCKS else 'false'};   // ... of the row-block loops")
     print(f"constexpr int kShiftBlockVgprs = {VB_BLOCK};   // row-block flavour: the compiler's own code stays below")
     print("constexpr int kShiftWideSpl = 6;          // samples per lane of the wide tiles (time tile 384)")
+    print(f"constexpr int kShiftWideBlockVgprs = {VB_WIDE_BLOCK};   // wide row-block flavour: the compiler's own code stays below")
     print(f"constexpr int kShiftNqMinWide = {NQMIN_WIDE};      // quads a wide tile's window fetches unconditionally")
     print(f"constexpr bool kShiftStageInLoop = {'true' if STAGE_IN_LOOP else 'false'};   // row blocks: the next block's staging issued by the row loop")
     print(f"constexpr int kShiftVolumeDegree = {VOLUME_DEGREE};   // 2^f polynomial of the volume-writing flavours")
@@ -1044,6 +1084,10 @@ def main():
     # sample: 48 adds per register window instead of 32, 0.19 instead of 0.28 LDS reads per add at C3
     emit(8, False, False, False, False, False, "shift_wide_detect", 6, True)
     emit(8, False, False, False, True, False, "shift_wide_detect_lazy", 6, True)
+    # ... and on ROW BLOCKS (tables whose 384-sample windows do not fit a CU's LDS all at once: 33 rows and up):
+    # one group per wavefront, blocks of <= 20 rows through a double-buffered LDS, staged by the loop itself
+    emit(8, False, False, False, False, True, "shift_wide_rows", 6, True)
+    emit(8, False, False, False, True, True, "shift_wide_rows_lazy", 6, True)
     # (a volume-writing wide flavour -- three 16-byte stores per node at a lane stride of 48 bytes -- was built,
     # bit-equal, and measured: the whole 6000-sample C3 volume in 110 ms against 62 on the 256-sample tiles,
     # whose two stores at a stride of 32 bytes complete a 64-byte line from two lanes; here a store instruction

@@ -155,12 +155,12 @@ int shift_tail_spl(const qm_engine *e, int rest) {
 // Tiles of a fused detect on the wide layout: 384-sample tiles in front; what the scan leaves beyond them runs
 // as ONE tail tile (<= 192 samples), ONE 256-sample tile pulled back over its predecessor (<= 256), or one more
 // wide tile pulled back (qm_shift.hpp: shift_work).
-void shift_wide_tiles(const qm_engine *e, int n_chunk, qm::StackArgs &a) {
+void shift_wide_tiles(const qm_engine *e, int n_chunk, bool only_wide, qm::StackArgs &a) {
     int wide = n_chunk / qm::kShiftWideKT;
     const int rest = n_chunk - wide * qm::kShiftWideKT;
     a.tail_spl = 0;
     int behind = 0;
-    if (rest > qm::kShiftKT) ++wide;
+    if (rest > qm::kShiftKT || (only_wide && rest > 0)) ++wide;      // (row blocks: no other tile kinds)
     else if (rest > 0) {
         a.tail_spl = shift_tail_spl(e, rest);
         behind = 1;
@@ -203,7 +203,8 @@ int launch_shift_path(qm_engine *e, const ShiftLayout &L, qm::StackArgs &a, int 
         const qm::LaunchShape shape = stack_shape(e, a, a.ngroups, L.nw * qm::kWave,
                                                   qm::shift_lds_bytes(L.nw));
         const bool rows = L.nblk > 1, big = L.nw == qm::kShiftWaves8;
-        if (rows && L.quad && mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_rows4_volume(s, shape));
+        if (L.wide && L.direct) QM_TABLE(qm::launch_shift_wide_rows(s, shape));   // (also a single block)
+        else if (rows && L.quad && mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_rows4_volume(s, shape));
         else if (rows && L.quad) QM_TABLE(qm::launch_shift_rows4(s, shape));
         else if (rows && L.direct && mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_rows2_volume(s, shape));
         else if (rows && L.direct) QM_TABLE(qm::launch_shift_rows2(s, shape));
@@ -310,8 +311,10 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     const int64_t wide_work = (int64_t)((e->g.nx + 7) / 8) * ((e->g.ny + 7) / 8) * ((e->g.nz + 15) / 16) *
                               ((n_chunk + qm::kShiftWideKT - 1) / qm::kShiftWideKT);
     if (shift && shift_mode == qm::kShiftDetect && e->cfg_shift_wide != 0 && n_chunk >= qm::kShiftWideKT &&
-        (e->cfg_shift_wide == 1 || (wide_work >= 8 * (int64_t)e->n_cu && n_chunk >= 4 * qm::kShiftWideKT)) &&
-        e->cfg_shift_waves == 0 && e->g.n_rows <= qm::kShiftMaxRows) {
+        (e->cfg_shift_wide == 1 || (wide_work >= 8 * (int64_t)e->n_cu && n_chunk >= 4 * qm::kShiftWideKT &&
+                                    std::min(e->g.nx, std::min(e->g.ny, e->g.nz)) >= 8)) &&   // (thin boxes of a
+                                    // rank's column partition: their 8 x 8 x 16 bricks would be mostly empty)
+        e->cfg_shift_waves == 0) {
         if (ensure_shift_tables(e, e->shw)) return 1;
         if (e->shw.ok) L = &e->shw;
     }
@@ -337,7 +340,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         a.brick_total = nullptr;
         a.ntiles = (n_chunk + qm::kShiftKT - 1) / qm::kShiftKT;
         a.cap_doubles = qm::kShiftLdsBytes / 8;
-        if (wide) shift_wide_tiles(e, n_chunk, a);
+        if (wide) shift_wide_tiles(e, n_chunk, L->direct, a);        // (direct: the wide layout's row-block form)
     } else {
         a.tail_spl = 0;
     }
@@ -360,7 +363,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     }
     if (n_steps > 1) {
         const bool ok = !volume && !marginal && !accumulate && run_if == nullptr && want_scan &&
-                        (!shift || (L->nblk == 1 && L->nw != qm::kShiftWaves3));
+                        (!shift || (L->nblk == 1 && L->nw != qm::kShiftWaves3 && !(L->wide && L->direct)));
         if (batched) *batched = ok;
         if (!ok) return batched ? 0 : fail("run_stack: this launch cannot hold several timesteps");
         a.n_steps = n_steps;
@@ -766,6 +769,10 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
     } else if (k == "shift_wide") {
         if (v < -1 || v > 1) return fail("shift_wide must be -1 (automatic), 0 (off) or 1");
         e->cfg_shift_wide = (int)v;
+    } else if (k == "shift_wide_rows") {
+        if (v < 0 || v > 2) return fail("shift_wide_rows must be 0 (never), 1 (where all rows do not fit) or 2 (always)");
+        e->cfg_shift_wide_rows = (int)v;
+        e->shw.built = false;
     } else if (k == "tie_rule") {
         if (v != 0 && v != 1) return fail("tie_rule must be 0 (largest sum) or 1 (the reference's exp rule)");
         e->cfg_tie_rule = (int)v;
@@ -830,6 +837,8 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
     else if (k == "shift_tail_spl") *v = e->shift_tail_last;
     else if (k == "shift_wide") *v = e->cfg_shift_wide;
     else if (k == "shift_wide_ok") *v = e->shw.built && e->shw.ok ? 1 : 0;
+    else if (k == "shift_wide_rows") *v = e->cfg_shift_wide_rows;
+    else if (k == "shift_wide_row_blocks") *v = e->shw.ok ? e->shw.nblk : 0;
     else if (k == "shift_wide_tiles") *v = e->shift_wide_last;
     else if (k == "shift_wide_brick_nodes") *v = e->shw.ok ? e->shw.g.brick_nodes : 0;
     else if (k == "shift_wide_direct_bricks") *v = e->shw.ok ? e->shw.n_list : 0;

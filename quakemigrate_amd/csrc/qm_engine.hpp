@@ -242,6 +242,8 @@ struct qm_engine : TableState {
     int cfg_shift_rows_direct = 1;
     int cfg_shift_wide = -1;                // fused detect on WIDE tiles (384 samples, six per lane; round 6): -1 where
                                             // they fit and the scan holds at least one, 0 never, 1 as -1 (explicit)
+    int cfg_shift_wide_rows = 1;            // ... on ROW BLOCKS where the windows of all rows do not fit (0: never,
+                                            // 2: row blocks whatever fits -- tests)
     int cfg_tie_rule = 0;                   // 0: largest float64 sum, lowest index among equal ones (default);
                                             // 1: the reference's rule on near-ties (qm_ties.hpp)
 

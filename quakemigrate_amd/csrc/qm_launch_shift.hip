@@ -60,6 +60,9 @@ hipError_t launch_shift_rows4(const ShiftArgs &a, const LaunchShape &s) {
 hipError_t launch_shift_rows4_volume(const ShiftArgs &a, const LaunchShape &s) {
     return launch_with_lds(&stack_shift_rows4_kernel<true>, a, s);
 }
+hipError_t launch_shift_wide_rows(const ShiftArgs &a, const LaunchShape &s) {
+    return launch_with_lds(&stack_shift_wide_rows_kernel, a, s);
+}
 hipError_t launch_shift_detect3(const ShiftArgs &a, const LaunchShape &s) {
     return launch_with_lds(&stack_shift_kernel<kShiftDetect, kShiftWaves3>, a, s);
 }

@@ -73,6 +73,8 @@ __host__ __device__ constexpr int shift_lds_bytes(int nw) {
     return nw == kShiftWaves3 ? kShiftLdsBytes3 : nw == kShiftWaves8 ? kShiftLdsBytes8 : kShiftLdsBytes;
 }
 constexpr int kShiftMaxRows = 64;                       // table rows the stream builder handles
+constexpr int kShiftHalfBytes = 80 * 1024;              // row blocks, double-buffered: one half of a CU's LDS
+static_assert(2 * kShiftPlane <= kShiftHalfBytes, "a half holds both planes");
 static_assert(QM_EXP2_DEGREE_SUM == 8 && QM_EXP2_DEGREE_VOLUME == kShiftVolumeDegree,
               "the generated loops carry the degree-8 (detect) 2^f and the stored values' degree");
 
@@ -148,6 +150,7 @@ hipError_t launch_shift_rows2(const ShiftArgs &a, const LaunchShape &s);    // .
 hipError_t launch_shift_rows2_volume(const ShiftArgs &a, const LaunchShape &s);
 hipError_t launch_shift_rows4(const ShiftArgs &a, const LaunchShape &s);    // ... two 4-wave workgroups per CU
 hipError_t launch_shift_rows4_volume(const ShiftArgs &a, const LaunchShape &s);
+hipError_t launch_shift_wide_rows(const ShiftArgs &a, const LaunchShape &s);    // row blocks on wide tiles
 
 // valid 2x2x2 groups of a brick form a box [0,cx) x [0,cy) x [0,cz) in group coordinates
 __device__ __forceinline__ void shift_group_box(const GridDesc &g, int b, int &x0, int &y0, int &z0,
@@ -419,12 +422,13 @@ __device__ __forceinline__ void stage_shift_windows(const ShiftArgs &s, double *
 // Samples behind what the brick can touch are whatever follows them in memory (fetched with a window, never
 // added); a row whose window reaches past the onsets' last sample -- only the scan's last tiles at the largest
 // delays -- goes through registers, zero-filled.  The caller waits (vmcnt) before its barrier.
+// (row blocks: vb = (brick, block), the block's S rows start at table row row0, metadata sb rows apart)
 template <int NW>
-__device__ __forceinline__ void stage_shift_wide(const ShiftArgs &s, double *win, int b, int S, int wave,
-                                                 int lane, int t_first) {
+__device__ __forceinline__ void stage_shift_wide(const ShiftArgs &s, double *win, int vb, int S, int wave,
+                                                 int lane, int t_first, int row0 = 0, int sb = 0) {
     const StackArgs &a = s.a;
     using int4s = int __attribute__((ext_vector_type(4)));
-    const int4s *meta = reinterpret_cast<const int4s *>(s.wmeta + (int64_t)b * S);
+    const int4s *meta = reinterpret_cast<const int4s *>(s.wmeta + (int64_t)vb * (sb ? sb : S));
     const unsigned lds_base = (unsigned)(uintptr_t)((lds_f64 *)win);
     const unsigned lane16 = (unsigned)lane * 16u;
     for (int r = wave; r < S; r += NW) {
@@ -433,7 +437,7 @@ __device__ __forceinline__ void stage_shift_wide(const ShiftArgs &s, double *win
         const int total = 4 * __builtin_amdgcn_readfirstlane(m.w);         // doubles, all of them written
         const int z4 = 4 * __builtin_amdgcn_readfirstlane(m.z);
         const int room = a.T - first;
-        const double *src = a.onsets + (int64_t)r * a.T + first;
+        const double *src = a.onsets + (int64_t)(row0 + r) * a.T + first;
         if (room >= total) {
             const unsigned long long sp = (unsigned long long)src;
             const double *usrc = (const double *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sp >> 32)) << 32) |
@@ -459,7 +463,7 @@ __device__ __forceinline__ void stage_shift_wide(const ShiftArgs &s, double *win
         }
     }
     if ((S & 1) && wave == 0) {                                    // the padding row's zero window
-        const int z4 = 4 * s.wtotal[b];
+        const int z4 = 4 * s.wtotal[vb];
         for (int u = lane; u < 4 * shift_zero_slots(1); u += kWave) win[z4 + u] = 0.0;
     }
 }
@@ -765,7 +769,8 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
 // next one's -- two steps ahead in the workgroup's sequence (brick b: blocks 0 .. nblk-1, then its next
 // brick nb) --, for the generated loop's prefetch.  A hint: past the end it points at this brick's own.
 __device__ __forceinline__ const void *shift_meta_ahead(const ShiftArgs &s, const GridDesc &g, int b, int nb,
-                                                        int k) {
+                                                        int k, const int4 *smeta = nullptr) {
+    if (smeta == nullptr) smeta = s.smeta;
     int pb = b, pk = k + 2;
     if (pk >= s.nblk) {
         pb = nb;
@@ -776,7 +781,7 @@ __device__ __forceinline__ const void *shift_meta_ahead(const ShiftArgs &s, cons
         }
     }
     if (pb >= g.nbricks) pb = b, pk = 0;
-    return s.smeta + ((int64_t)pb * s.nblk + pk) * s.sb;
+    return smeta + ((int64_t)pb * s.nblk + pk) * s.sb;
 }
 
 #ifndef QM_ROWS_RB               // rows in flight per wavefront and staging pass, 64-sample chunks per row
@@ -848,8 +853,6 @@ void stack_shift_rows_kernel(ShiftArgs s) {
 // samples (4s, 4s+1), of plane B (4s+2, 4s+3): one instruction per plane and 64 slots.  One
 // barrier per block.  (Window slots past the row's end are left as they are: the loop fetches them
 // with the quads but never adds them.)
-constexpr int kShiftHalfBytes = 80 * 1024;
-static_assert(2 * kShiftPlane <= kShiftHalfBytes, "a half holds both planes");
 
 // the all-zero window of the padding row of a block with an odd row count
 __device__ __forceinline__ void stage_shift_zero_row(const ShiftArgs &s, double *half, int vb, int S, int wave,
@@ -1075,6 +1078,112 @@ void stack_shift_rows2_kernel(ShiftArgs s) {
     // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
     shift_publish<NW>(a, win, vmax, vsum, vidx, wave, lane, group, t_first);
 }
+// Row blocks on WIDE tiles (round 6): the double-buffered form above with six samples per lane -- for tables
+// whose 384-sample row windows do not fit a CU's LDS all at once (from ~36 rows of C3's geometry on; BASELINE
+// configs[3]: 60 rows).  Bricks of 4x4x4 nodes, one 2x2x2 group per wavefront with its 48 accumulators (96
+// VGPRs) in the generated loop's hard registers across the calls; blocks of <= 20 rows in halves of 80 KB,
+// contiguous row windows, the next block staged by the row loop itself (one LDS address per row, four loads:
+// gen_shift_asm.py, stage_step) or -- where a window reaches past the onsets' rows -- by stage_shift_wide.
+// The compiler's own code between two calls stays below kShiftWideBlockVgprs (amdgpu_waves_per_eu(9, 9): 56
+// registers; csrc/check_shift_isa.py walks the ISA at every build).  Fused detect only; whole wide tiles, the
+// last one pulled back over its predecessor.
+// (LAZY: the loop flavour, chosen outside the block loop -- both flavours' asm statements in one loop make the
+// compiler shuffle and spill the running state around every call, see shift_tile)
+template <bool LAZY>
+__device__ __forceinline__ void shift_wide_rows_body(const ShiftArgs &s, double *win) {
+    constexpr int NW = kShiftWaves8, J = kShiftWideSpl;
+    const StackArgs &a = s.a;
+    const GridDesc &g = a.g;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const ShiftWork work = shift_work(a);
+    if (!work.run) return;
+    const int group = work.group, t_first = work.t_first;
+    const unsigned lane_addr = (unsigned)(uintptr_t)((lds_f64 *)win) + (unsigned)lane * (8u * J);
+
+    double vmax[J], vsum[J];
+    int vidx[J];
+    shift_reset<J>(vmax, vsum, vidx);
+    constexpr int D = Exp2Degree<false>::value;
+    double c[D + 1];
+#pragma unroll
+    for (int i = 0; i <= D; ++i) c[i] = exp2_coeff<D>(i);
+
+    const int rows2max = s.sb + (s.sb & 1);
+    const int64_t rpw = shift_recs_per_wave(g, rows2max, NW);
+    auto rows_of = [&](int k) { return g.n_rows - k * s.sb < s.sb ? g.n_rows - k * s.sb : s.sb; };
+    const int tile_room = a.T - (a.fsmp + a.sample0 + t_first);
+    const bool in_loop = s.stage_slots <= 127 && tile_room >= s.stage_reach && a.T < (1 << 28);
+    int b = group;
+    while (b < g.nbricks && !s.sfit[b]) b += a.ngroups;            // (others: the direct kernel's job)
+    int cur = 0;                                                   // half the current block lies in
+    if (b < g.nbricks) stage_shift_wide<NW>(s, win, b * s.nblk, rows_of(0), wave, lane, t_first, 0, s.sb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    while (b < g.nbricks) {
+        int nb = b + a.ngroups;
+        while (nb < g.nbricks && !s.sfit[nb]) nb += a.ngroups;
+        int x0, y0, z0, vx, vy, vz, cx, cy, cz;
+        shift_group_box(g, b, x0, y0, z0, vx, vy, vz, cx, cy, cz);
+        const bool mine = wave < cx * cy * cz;                     // one group per wavefront
+        const char *next_run =
+            s.wstream + shift_run_record(nb < g.nbricks ? nb : b, wave, 0, NW, s.nblk, rpw) * kShiftRecBlocks;
+        for (int k = 0; k < s.nblk; ++k) {
+            const void *next_meta = shift_meta_ahead(s, g, b, nb, k, s.wmeta);
+            double *idle = win + (cur ^ 1) * (kShiftHalfBytes / 8);
+            const bool follows = k + 1 < s.nblk || nb < g.nbricks;
+            const int vbn = k + 1 < s.nblk ? b * s.nblk + k + 1 : nb * s.nblk;
+            const int kn = k + 1 < s.nblk ? k + 1 : 0;
+            ShiftStageNext stage{};
+            stage.meta = s.wmeta;
+            if (follows && in_loop && mine) {
+                if ((rows_of(kn) & 1) && wave == 0) {              // the padding row's zero window
+                    const int z4 = 4 * s.wtotal[vbn];
+                    for (int u = lane; u < 4 * shift_zero_slots(1); u += kWave) idle[z4 + u] = 0.0;
+                }
+                stage.meta = s.wmeta + (int64_t)vbn * s.sb;
+                stage.rows = rows_of(kn);
+                stage.first_row = wave;
+                stage.stride = NW;
+                stage.src = a.onsets + (int64_t)kn * s.sb * a.T + a.fsmp + a.sample0 + t_first;
+                stage.row_bytes = (unsigned)a.T * 8u;
+                stage.lds = (unsigned)(uintptr_t)((lds_f64 *)idle);
+                stage.lane32 = (unsigned)lane * 16u;               // (16 bytes per lane and load)
+            } else if (follows) {
+                stage_shift_wide<NW>(s, idle, vbn, rows_of(kn), wave, lane, t_first, kn * s.sb, s.sb);
+            }
+            if (mine) {
+                const char *run = s.wstream + shift_run_record(b, wave, k, NW, s.nblk, rpw) * kShiftRecBlocks;
+                const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(
+                    (int)((k == 0 ? 1u : 0u) | (k == s.nblk - 1 ? 2u : 0u)));
+                if constexpr (LAZY)
+                    shift_wide_rows_lazy(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
+                                         (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes), stage,
+                                         g.nz, g.ny * g.nz, a.z_scale, c);
+                else
+                    shift_wide_rows(vmax, vsum, vidx, run, flags, next_run, (unsigned)lane * 64u, next_meta,
+                                    (rows_of(k) + 1) / 2, lane_addr + (unsigned)(cur * kShiftHalfBytes), stage,
+                                    g.nz, g.ny * g.nz, a.z_scale, c);
+            }
+            if (!mine) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            cur ^= 1;
+        }
+        b = nb;
+    }
+    if (!a.want_scan) return;
+    // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
+    shift_publish<NW, J>(a, win, vmax, vsum, vidx, wave, lane, group, t_first);
+}
+
+__global__ __attribute__((amdgpu_flat_work_group_size(kShiftWaves8 * kWave, kShiftWaves8 * kWave),
+                          amdgpu_waves_per_eu(9, 9)))
+void stack_shift_wide_rows_kernel(ShiftArgs s) {
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    if (s.lazy) shift_wide_rows_body<true>(s, win);
+    else shift_wide_rows_body<false>(s, win);
+}
+
 // Row blocks, third form (round 4): TWO 4-wave workgroups per CU, 80 KB each -- the shape of the
 // tables of up to ~32 rows, for the same reason: the two wavefronts of a SIMD then belong to
 // different workgroups and are in different phases, so one's block boundary (the barrier, the

@@ -165,7 +165,7 @@ int ensure_pair_tables(qm_engine *e, int jp) {
 // register window for (almost) every brick; per-(brick, row) slot records and the record stream.
 // e->shw (round 6): the same for the 8-wave shape with WIDE tiles in front -- both kinds of records and
 // streams on one brick grid, a brick runs there if the windows of both tile kinds fit.
-static int build_shift_tables(qm_engine *e, ShiftLayout &L, bool wide);
+static int build_shift_tables(qm_engine *e, ShiftLayout &L, bool wide, bool wide_blocks);
 
 // Outcome per resident table: the layout is built (L.ok), or the table does not qualify, or the
 // tables could not be built -- most likely no memory for the record stream (4 S bytes per node, the
@@ -174,7 +174,16 @@ static int build_shift_tables(qm_engine *e, ShiftLayout &L, bool wide);
 int ensure_shift_tables(qm_engine *e, ShiftLayout &L) {
     if (L.built) return 0;
     L.ok = false;
-    const int rc = build_shift_tables(e, L, &L == &e->shw);
+    const bool wide = &L == &e->shw;
+    int rc = wide && e->cfg_shift_wide_rows == 2 ? 0 : build_shift_tables(e, L, wide, false);
+    // (the wide layout: all rows of a brick in LDS where that fits -- up to ~36 rows of C3's geometry; beyond 64
+    // rows, where the 256-sample tiles run on row blocks too, row blocks of <= 20 rows on 4x4x4 bricks: a C3 grid
+    // x 128 rows x 1536 samples 44.0 ms against 48.6.  In between -- BASELINE configs[3]: 60 rows -- the row-block
+    // form LOSES to the 8-wave kernel that holds all rows' 256-sample windows (a C4 slab 177.3 against 168.2 ms,
+    // C3 x 60 rows 22.3 against 21.2, profiles/r06_ab_runs.txt): only on request there, shift_wide_rows = 2)
+    if (wide && rc == 0 && !L.ok && e->cfg_shift_wide_rows != 0 &&
+        (e->g.n_rows > qm::kShiftMaxRows || e->cfg_shift_wide_rows == 2))
+        rc = build_shift_tables(e, L, true, true);
     if (rc != 0 || !L.ok) {
         L.ok = false;
         L.release();
@@ -187,28 +196,31 @@ int ensure_shift_tables(qm_engine *e, ShiftLayout &L) {
     return 0;
 }
 
-static int build_shift_tables(qm_engine *e, ShiftLayout &L, bool wide) {
+static int build_shift_tables(qm_engine *e, ShiftLayout &L, bool wide, bool wide_blocks) {
     const int S = e->g.n_rows;
     L.wide = wide;
     // More rows than a CU's LDS holds windows for: row blocks (stack_shift_rows_kernel) -- bricks of
     // 4x4x4 nodes = one 2x2x2 group per wavefront of the 8-wave workgroup, whose accumulators stay
     // in registers while the rows are staged in nblk blocks of sb <= 64 rows.
-    const bool blocks = S > qm::kShiftMaxRows;
-    if (wide && blocks) return 0;                       // (wide tiles: all rows of a brick in LDS at once)
+    const bool blocks = wide ? wide_blocks : S > qm::kShiftMaxRows;
+    if (wide && !blocks && S > qm::kShiftMaxRows) return 0;        // (all rows of a brick in LDS at once)
+    if (wide && blocks && (S < 2 || e->cfg_bx > 0)) return 0;
     // two forms (qm_shift.hpp): blocks of <= 34 rows staged by LDS-direct loads into the idle half of
     // a double-buffered LDS (default), or blocks of <= 64 staged through registers between two barriers
     // (that one only from 97 rows on: at 65-96 two blocks of <= 48 rows stage as often as they
     // compute and the chunked kernel with its 8x8x8 bricks is 4-5 % faster, profiles/r03_ab_runs.txt)
     // (round 4, form 2: the LDS-direct staging with TWO 4-wave workgroups per CU on bricks of 4x4x2
     // nodes, single-buffered -- stack_shift_rows4_kernel)
-    const int form = e->cfg_shift_rows_direct;          // 0 registers, 1 double-buffered 8 waves, 2 two x 4 waves
+    // (wide tiles: the double-buffered 8-wave form only, blocks of <= 20 rows -- 20 x (384 + span) samples in
+    // each 80 KB half)
+    const int form = wide ? 1 : e->cfg_shift_rows_direct;   // 0 registers, 1 double-buffered 8 waves, 2 two x 4 waves
     const bool direct = form != 0;
     const bool quad = form == 2;
     if (blocks && !direct && S <= 96 && e->cfg_shift != 1) return 0;
-    const int block_rows = direct ? 34 : qm::kShiftMaxRows;
+    const int block_rows = wide ? 20 : direct ? 34 : qm::kShiftMaxRows;
     const int nblk = blocks ? (S + block_rows - 1) / block_rows : 1;
     const int sb = blocks ? ((S + nblk - 1) / nblk + 1) / 2 * 2 : S;
-    if (S > 1024 || (blocks && e->cfg_shift_waves != 0 &&
+    if (S > 1024 || (blocks && !wide && e->cfg_shift_waves != 0 &&
                      e->cfg_shift_waves != (quad ? qm::kShiftWaves : qm::kShiftWaves8)))
         return 0;
     // a grid one node thick has half-empty 2x2x2 groups everywhere (e.g. the flat 1 x 1 x N view
@@ -271,33 +283,42 @@ static int build_shift_tables(qm_engine *e, ShiftLayout &L, bool wide) {
         hipLaunchKernelGGL(qm::brick_minmax_kernel, dim3(g.nbricks), dim3(64), 0, e->stream, g,
                            e->d_lut.p, reinterpret_cast<int4 *>(L.raw.p), e->d_scalar.p);
         unsigned long long *const tally_d = reinterpret_cast<unsigned long long *>(e->d_scalar.p + 4);
-        hipLaunchKernelGGL(qm::shift_need_kernel, dim3((unsigned)nvb), dim3(256), 0, e->stream, g,
-                           e->d_lut.p, reinterpret_cast<const int4 *>(L.raw.p),
-                           reinterpret_cast<int4 *>(L.meta.p), L.total.p, L.fit.p, tally_d,
-                           blocks && direct ? qm::kShiftPlane : qm::shift_plane(nw), nblk, sb, 0);
-        QM_HIP(hipGetLastError());
-        fit.resize(nvb);
         unsigned long long tally[4] = {0, 0, 0, 0};
-        QM_HIP(copy_back(fit.data(), L.fit.p, nvb * sizeof(int32_t), e->stream));
-        QM_HIP(copy_back(tally, tally_d, sizeof(tally), e->stream));
-        QM_HIP(hipStreamSynchronize(e->stream));
-        L.quads = (int64_t)tally[0];
-        L.group_rows = (int64_t)tally[1];
-        L.stage_slots = (int)std::min<unsigned long long>(tally[2], 1u << 30);
-        L.stage_reach = (int)std::min<unsigned long long>(tally[3], 1u << 30);
+        fit.assign(nvb, 1);
+        if (!(wide && blocks)) {                          // (wide row blocks: wide tiles only, no 256-sample ones)
+            hipLaunchKernelGGL(qm::shift_need_kernel, dim3((unsigned)nvb), dim3(256), 0, e->stream, g,
+                               e->d_lut.p, reinterpret_cast<const int4 *>(L.raw.p),
+                               reinterpret_cast<int4 *>(L.meta.p), L.total.p, L.fit.p, tally_d,
+                               blocks && direct ? qm::kShiftPlane : qm::shift_plane(nw), nblk, sb, 0);
+            QM_HIP(hipGetLastError());
+            QM_HIP(copy_back(fit.data(), L.fit.p, nvb * sizeof(int32_t), e->stream));
+            QM_HIP(copy_back(tally, tally_d, sizeof(tally), e->stream));
+            QM_HIP(hipStreamSynchronize(e->stream));
+            L.quads = (int64_t)tally[0];
+            L.group_rows = (int64_t)tally[1];
+            L.stage_slots = (int)std::min<unsigned long long>(tally[2], 1u << 30);
+            L.stage_reach = (int)std::min<unsigned long long>(tally[3], 1u << 30);
+        }
         if (wide) {
-            // the wide tiles' row windows: 384 + span samples in ONE contiguous region (slots of 32 bytes)
+            // the wide tiles' row windows: 384 + span samples in ONE contiguous region (slots of 32 bytes): all
+            // 160 KB, or -- row blocks -- one of the two 80 KB halves
             QM_HIP(hipMemsetAsync(tally_d, 0, sizeof(tally), e->stream));
             hipLaunchKernelGGL(qm::shift_need_kernel, dim3((unsigned)nvb), dim3(256), 0, e->stream, g,
                                e->d_lut.p, reinterpret_cast<const int4 *>(L.raw.p),
                                reinterpret_cast<int4 *>(L.wmeta.p), L.wtotal.p, e->d_work.p, tally_d,
-                               qm::kShiftLdsBytes8 / 2, nblk, sb, 1);
+                               blocks ? qm::kShiftPlane : qm::kShiftLdsBytes8 / 2, nblk, sb, 1);   // (a half holds
+                               // 2 x kShiftPlane bytes, as for the two-plane blocks: the launch's 163712 bytes)
             QM_HIP(hipGetLastError());
             fitw.resize(nvb);
             QM_HIP(copy_back(fitw.data(), e->d_work.p, nvb * sizeof(int32_t), e->stream));
             QM_HIP(copy_back(tally, tally_d, sizeof(tally), e->stream));
             QM_HIP(hipStreamSynchronize(e->stream));
             L.wquads = (int64_t)tally[0];
+            if (blocks) {
+                L.group_rows = (int64_t)tally[1];
+                L.stage_slots = (int)std::min<unsigned long long>(tally[2], 1u << 30);
+                L.stage_reach = (int)std::min<unsigned long long>(tally[3], 1u << 30);
+            }
             for (size_t i = 0; i < nvb; ++i) fit[i] &= fitw[i];
         }
         list.clear();
@@ -319,21 +340,23 @@ static int build_shift_tables(qm_engine *e, ShiftLayout &L, bool wide) {
         QM_HIP(copy_in(L.fit.p, fit.data(), (size_t)g.nbricks * sizeof(int32_t), e->stream));
     // (+ slack: the loop loads one record past a wavefront's run and touches the line 16 records
     // ahead with its L2 prefetch -- after the last run of the last brick that is past the stream)
-    if (L.stream.ensure((size_t)words + 4096)) return 1;
+    if (!(wide && blocks) && L.stream.ensure((size_t)words + 4096)) return 1;
     if (wide && L.wstream.ensure((size_t)words + 4096)) return 1;
     const size_t hdr_bytes = (size_t)qm::shift_groups_per_brick(g) * rows2 * sizeof(uint2);
     QM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(qm::shift_stream_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_bytes));
-    hipLaunchKernelGGL(qm::shift_stream_kernel, dim3((unsigned)((size_t)g.nbricks * nblk)), dim3(256),
-                       hdr_bytes, e->stream, g, e->d_lut.p,
-                       reinterpret_cast<const int4 *>(L.meta.p), L.total.p, L.fit.p,
-                       rows2, nw, nblk, sb, qm::shift_packed(blocks) ? 1 : 0, 0, L.stream.p);
-    QM_HIP(hipGetLastError());
+    if (!(wide && blocks)) {
+        hipLaunchKernelGGL(qm::shift_stream_kernel, dim3((unsigned)((size_t)g.nbricks * nblk)), dim3(256),
+                           hdr_bytes, e->stream, g, e->d_lut.p,
+                           reinterpret_cast<const int4 *>(L.meta.p), L.total.p, L.fit.p,
+                           rows2, nw, nblk, sb, qm::shift_packed(blocks) ? 1 : 0, 0, L.stream.p);
+        QM_HIP(hipGetLastError());
+    }
     if (wide) {
         hipLaunchKernelGGL(qm::shift_stream_kernel, dim3((unsigned)((size_t)g.nbricks * nblk)), dim3(256),
                            hdr_bytes, e->stream, g, e->d_lut.p,
                            reinterpret_cast<const int4 *>(L.wmeta.p), L.wtotal.p, L.fit.p,
-                           rows2, nw, nblk, sb, qm::shift_packed(false) ? 1 : 0, 1, L.wstream.p);
+                           rows2, nw, nblk, sb, qm::shift_packed(blocks) ? 1 : 0, 1, L.wstream.p);
         QM_HIP(hipGetLastError());
     }
     L.n_list = (int)list.size();

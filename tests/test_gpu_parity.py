@@ -1779,6 +1779,43 @@ def test_shift_wide_tiles_equal_the_256_sample_tiles_and_oracle(lib, oracle, rec
         np.testing.assert_allclose(got[1], ref[1], rtol=1e-13)
 
 
+@pytest.mark.parametrize("grid,rows,ns,blocks", [
+    ((21, 18, 17), 60, 500, 3),       # BASELINE configs[3]'s row count: three blocks of 20; odd grid dimensions
+    ((16, 16, 12), 41, 1000, 3),      # blocks of 14 14 13 (a padding row); the last tile pulled back
+    ((13, 12, 16), 20, 384, 1),       # one block, one tile
+    ((12, 9, 10), 130, 800, 7),       # beyond 64 rows: seven blocks of 20 .. 10
+    ((9, 14, 8), 2, 450, 1),          # two rows
+    ((6, 5, 4), 67, 385, 4),          # bricks smaller than 4x4x4; a second tile for one sample
+])
+def test_shift_wide_tiles_on_row_blocks(lib, oracle, grid, rows, ns, blocks):
+    """Wide tiles where the 384-sample windows of ALL rows do not fit a CU's LDS (BASELINE configs[3]: 60 rows):
+    one 2x2x2 group per wavefront, its 48 accumulators in registers across the calls, the rows in blocks of <= 20
+    through a double-buffered LDS.  Still one row at a time in ascending order (migratelib.c:54-59): maxima and
+    indices are the bits of the 256-sample tiles (and of the round-2 kernels), the oracle's argmax."""
+    case = synth.make_case("C4" if rows > 30 else "C3", step=1, grid=grid, rows=rows, n_samples=ns)
+    lon = oracle.log_onsets(case.onsets)
+    want = oracle.detect(case.onsets, case.traveltimes, case.fsmp, case.lsmp, case.available, threads=4)
+    narrow = lib.Engine(0, shift_wide=0, shift=1)
+    narrow.load_lut(case.traveltimes)
+    ref = narrow.detect(lon, case.fsmp, case.lsmp, case.available)
+    narrow.close()
+    for lazy in (0, 1):
+        eng = lib.Engine(0, shift_wide=1, shift_wide_rows=2, shift_lazy=lazy)
+        eng.load_lut(case.traveltimes)
+        got = eng.detect(lon, case.fsmp, case.lsmp, case.available)
+        assert (eng.get("last_kernel"), eng.get("last_kernel_j")) == (3, 6), "the wide tiles did not run"
+        assert eng.get("shift_wide_row_blocks") == blocks and eng.get("shift_lazy") == lazy
+        assert eng.get("shift_wide_tiles") == (ns + 383) // 384 and eng.get("shift_wide_direct_bricks") == 0
+        # K timesteps per launch are not taken by the row-block kernels: the call goes step by step, same bits
+        two = eng.detect_batch(np.stack([lon, lon]), case.fsmp, case.lsmp, case.available)
+        eng.close()
+        _assert_series(got, want)
+        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0])
+        np.testing.assert_allclose(got[1], ref[1], rtol=1e-13)
+        for k in range(2):
+            assert all(np.array_equal(two[i][k], got[i]) for i in range(3))
+
+
 def test_shift_wide_tiles_ties_nan_batches_and_shards(lib, oracle):
     """What the other shift-reuse flavours are held to, on wide tiles: exact ties resolve to the lowest
     flat index, a NaN onset poisons its own samples only, K timesteps per launch give each step's own

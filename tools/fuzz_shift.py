@@ -9,7 +9,8 @@ group counts: the automatic engine against Engine(shift=0) (maxima bit for bit, 
 oracle; every fourth trial also the volume-writing variant against the oracle's volume, every third
 the marginalised map of a random window against the time sum of that volume, every fifth a batch of
 two or three timesteps in one launch against the steps one by one, every seventh the opt-in tie_rule = 1
-against the oracle's restatement of the reference's exp rule.
+against the oracle's restatement of the reference's exp rule.  Round 6: three trials in ten scan 384-2100
+samples, and half of all trials ask for the WIDE tiles (six samples per lane) wherever the scan holds one.
 On a mismatch the trial's diagnosis is printed before the assertion (which kernel, which nodes and
 samples, whether a second run moves): the round-4 GPU-sharing study started from these lines.
 usage: fuzz_shift.py [trials] [seed]      (QM_FUZZ_ONLY=trial [QM_FUZZ_REPEAT=n]: that trial of the seed only)"""
@@ -24,7 +25,7 @@ from quakemigrate_amd.core import lib  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-used = wide = blocks = 0
+used = wide = blocks = six = 0
 repeat = int(os.environ.get("QM_FUZZ_REPEAT", "1"))    # (with QM_FUZZ_ONLY: the trial's engine sequence this many times)
 for trial in range(trials):
     grid = tuple(int(v) for v in rng.integers(2, 34, size=3))
@@ -32,6 +33,8 @@ for trial in range(trials):
         grid = (grid[0], grid[1], max(2, 12000 // (grid[0] * grid[1])))
     S = int(rng.integers(1, 65)) if rng.random() < 0.8 else int(rng.integers(65, 201))   # (row blocks)
     ns = int(rng.integers(1, 900)) if rng.random() < 0.7 else int(rng.integers(192, 900))
+    if rng.random() < 0.3:              # (round 6: scans that hold one to five WIDE tiles of 384 samples)
+        ns = int(rng.integers(384, 2100))
     fsmp, lsmp = int(rng.integers(0, 30)), int(rng.integers(30, 160))
     # coherent table: distance-like delays from random "stations", steepness up to ~7 samples per node, a fifth of the rows up to 30
     ijk = np.stack(np.indices(grid), axis=-1).astype(np.float64)
@@ -52,7 +55,10 @@ for trial in range(trials):
     avail = int(2 ** rng.integers(0, 5)) if trial % 2 else int(rng.integers(1, S + 1))
     cfg = dict(groups=int(rng.choice([0, 1, 3, 9])), shift_lazy=int(rng.integers(-1, 2)),
                shift=1 if 64 < S <= 96 else -1, shift_rows_direct=int(rng.integers(0, 3)),
-               shift_tail=int(rng.integers(0, 2)))
+               shift_tail=int(rng.integers(0, 2)),
+               # (round 6: the fused detect on wide tiles where the table has that layout -- forced on small grids,
+               # where the automatic rule would not take it)
+               shift_wide=int(rng.choice([1, 1, 0, -1])))
     if os.environ.get("QM_FUZZ_ONLY") and trial != int(os.environ["QM_FUZZ_ONLY"]):
         # (replay one trial of a seed: the random stream has to advance as in the full run, including
         # the draws the skipped checks would have made)
@@ -92,6 +98,7 @@ for trial in range(trials):
             res_first = res[tag]
             if tag == "shift":
                 kern, nwide = eng.get("last_kernel"), eng.get("shift_wide_bricks")
+                six_now = kern == 3 and eng.get("shift_wide_tiles") > 0
                 if trial % 4 == 0:
                     vol = np.zeros(grid + (ns,))
                     series = (np.zeros(ns), np.zeros(ns), np.zeros(ns, dtype=np.int64))
@@ -142,6 +149,7 @@ for trial in range(trials):
         used += kern == 3
         blocks += kern == 3 and S > 64
         wide += kern == 3 and nwide > 0
+        six += six_now
         a, b, c = res["shift"]
         if not (np.array_equal(c, want[2]) and np.array_equal(c, res["round2"][2]) and np.array_equal(a, res["round2"][0])):
             badt = np.flatnonzero((c != want[2]) | (a != res["round2"][0]) | (c != res["round2"][2]))
@@ -161,5 +169,5 @@ for trial in range(trials):
         np.testing.assert_allclose(a, want[0], rtol=1e-13)
         np.testing.assert_allclose(b, want[1], rtol=2e-12)   # degree-8 2^f: truncation 7.8e-13 + rounding
         np.testing.assert_allclose(b, res["round2"][1], rtol=2e-12)
-print(f"{trials} trials ok; shift kernel used in {used} ({blocks} of them on row blocks), of which {wide} with "
-      f"bricks on the direct kernel")
+print(f"{trials} trials ok; shift kernel used in {used} ({blocks} of them on row blocks, {six} on wide tiles), of "
+      f"which {wide} with bricks on the direct kernel")

@@ -39,8 +39,9 @@ fi
 if has bench; then
   python bench.py --steps 20 --warmup 3 > $OUT/bench_C3.json 2> $OUT/bench.err; tail -3 $OUT/bench.err
   Q="--no-cpu-baseline --no-screened --no-copies --no-table-switch"
-  python bench.py --steps 20 --warmup 3 --engine '{"shift_tail": 0}' $Q > $OUT/bench_C3_round3_tiles.json 2>> $OUT/bench.err
-  python bench.py --steps 20 --warmup 3 --engine '{"shift": 0}' $Q > $OUT/bench_C3_round2_kernels.json 2>> $OUT/bench.err
+  python bench.py --steps 20 --warmup 3 --engine '{"shift_wide": 0}' $Q --no-materialised > $OUT/bench_C3_round5_tiles.json 2>> $OUT/bench.err
+  python bench.py --steps 20 --warmup 3 --engine '{"shift_wide": 0, "shift_tail": 0}' $Q --no-materialised > $OUT/bench_C3_round3_tiles.json 2>> $OUT/bench.err
+  python bench.py --steps 20 --warmup 3 --engine '{"shift": 0}' $Q --no-materialised > $OUT/bench_C3_round2_kernels.json 2>> $OUT/bench.err
   python bench.py --config C2 --steps 30 --warmup 3 --no-cpu-baseline --no-materialised > $OUT/bench_C2.json 2>> $OUT/bench.err
   for cfg in C1 E1 E2 E2F; do for k in 1 8; do
     python bench.py --config $cfg --steps 400 --warmup 8 --steps-per-launch $k --no-cpu-baseline --no-materialised --no-screened --no-table-switch > $OUT/bench_${cfg}_k$k.json 2>> $OUT/bench.err
@@ -69,6 +70,20 @@ if has stats; then
   python -c "
 import json; d=json.loads(open('$OUT/bench_C3_headline_only_under_rocprof.json').read().strip().splitlines()[-1]); print('bench line under rocprof: kernel avg_ms', d['kernel']['avg_ms'], 'launches', d['kernel']['launches'], 'ms/step', d['ms_per_step'])"
   find $OUT/prof -name "*.csv" -size +1M -delete
+  # (round 6) the same kind of line for the other kernels beside their HIP-event times: the
+  # locate window's volume and marginal-map launches, a C4 slab's detect, a 128-row table's row-block kernel
+  stat() {  # tag, tune.py arguments...
+    local tag=$1; shift
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$tag -o $tag -- \
+        python $ROOT/tools/tune.py --reps 6 --sweep '[{}]' "$@" > $OUT/stats_$tag.log 2>&1
+    find $OUT/prof_$tag -name "*kernel_stats.csv" -exec cp {} $OUT/${tag}_kernel_stats.csv \;
+    grep -E "stack_shift|Name" $OUT/${tag}_kernel_stats.csv | head -3; grep -E "ms|kernel" $OUT/stats_$tag.log | tail -2
+    find $OUT/prof_$tag -name "*.csv" -size +1M -delete
+  }
+  stat C3L_volume --config C3 --ns 401 --volume
+  stat C3L_marginal --config C3 --ns 401 --marginal
+  stat C4_slab --config C4 --x-range 150,200
+  stat rows128 --config C3 --rows 128 --ns 1536
   cd $ROOT
 fi
 if has pmc; then
