@@ -58,7 +58,9 @@ for trial in range(trials):
                shift_tail=int(rng.integers(0, 2)),
                # (round 6: the fused detect on wide tiles where the table has that layout -- forced on small grids,
                # where the automatic rule would not take it)
-               shift_wide=int(rng.choice([1, 1, 0, -1])))
+               shift_wide=int(rng.choice([1, 1, 0, -1])),
+               # (... on row blocks: beyond 64 rows by itself, in a third of the trials whatever the row count)
+               shift_wide_rows=int(rng.choice([1, 1, 2])))
     if os.environ.get("QM_FUZZ_ONLY") and trial != int(os.environ["QM_FUZZ_ONLY"]):
         # (replay one trial of a seed: the random stream has to advance as in the full run, including
         # the draws the skipped checks would have made)
