@@ -9,6 +9,10 @@ for f in $O/bench_*.json $O/enqueue_*.json; do [ -f "$f" ] && cp $f profiles/${R
 [ -f $O/pytest_gpu.log ] && { tail -14 $O/pytest_gpu.log; tail -1 $O/smoke.log; } > profiles/${R}_pytest_gpu_tail.txt
 [ -f $O/bench_C3_headline_only_kernel_stats.csv ] && cp $O/bench_C3_headline_only_kernel_stats.csv profiles/${R}_bench_C3_headline_only_kernel_stats.csv
 [ -f $O/pmc_traffic.json ] && cp $O/pmc_traffic.json profiles/${R}_pmc_traffic.json
+# (round 6) --kernel-trace --stats lines of the other kernels: only the stacking kernels' rows
+for t in C3L_volume C3L_marginal C4_slab rows128; do
+  [ -f $O/${t}_kernel_stats.csv ] && { head -1 $O/${t}_kernel_stats.csv; grep -E "stack_shift" $O/${t}_kernel_stats.csv; } > profiles/${R}_${t}_kernel_stats.csv
+done
 [ -f $O/widen_rows.jsonl ] && cp $O/widen_rows.jsonl profiles/${R}_widen_rows.jsonl
 for pair in shift:C3shift locate:C3locate marginal:C3marginal C4slab:C4slab; do
   k=${pair%%:*}; n=${pair##*:}
