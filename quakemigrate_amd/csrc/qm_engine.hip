@@ -311,7 +311,10 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     const int64_t wide_work = (int64_t)((e->g.nx + 7) / 8) * ((e->g.ny + 7) / 8) * ((e->g.nz + 15) / 16) *
                               ((n_chunk + qm::kShiftWideKT - 1) / qm::kShiftWideKT);
     if (shift && shift_mode == qm::kShiftDetect && e->cfg_shift_wide != 0 && n_chunk >= qm::kShiftWideKT &&
+        // (tie_rule = 1 re-stacks one SET of bricks per sample: the wide layout's few long workgroups publish sets
+        // of tens of thousands of nodes -- that step keeps the 256-sample tiles' sets of four bricks)
         (e->cfg_shift_wide == 1 || (wide_work >= 8 * (int64_t)e->n_cu && n_chunk >= 4 * qm::kShiftWideKT &&
+                                    !e->cfg_tie_rule &&
                                     std::min(e->g.nx, std::min(e->g.ny, e->g.nz)) >= 8)) &&   // (thin boxes of a
                                     // rank's column partition: their 8 x 8 x 16 bricks would be mostly empty)
         e->cfg_shift_waves == 0) {

@@ -586,7 +586,7 @@ def test_headline_kernels_stay_in_registers(tmp_path):
                           stderr=subprocess.DEVNULL)
     sasm = next(tmp_path.glob("s-hip-amdgcn-*.s")).read_text()
     found = re.findall(r"\.set (\S*stack_shift\w*_kernel\S*)\.num_vgpr, (\d+)", sasm)
-    assert len(found) == 12, found
+    assert len(found) == 13, found                          # (+ the wide tiles' row-block kernel: not a template)
     for name, vgprs in found:
         if "Li12E" in name:                                # the opt-in 12-wave shape: three per SIMD
             assert int(vgprs) <= 168, (name, vgprs)
@@ -608,9 +608,16 @@ def test_headline_kernels_stay_in_registers(tmp_path):
         import check_shift_isa
     finally:
         sys.path.pop(0)
-    first_hard = check_shift_isa.first_hard_register(
-        (ROOT / "quakemigrate_amd" / "csrc" / "qm_shift_asm.inc").read_text())
+    inc_text = (ROOT / "quakemigrate_amd" / "csrc" / "qm_shift_asm.inc").read_text()
+    first_hard = check_shift_isa.first_hard_register(inc_text)
     assert check_shift_isa.check(sasm, first_hard) > 300
+    # (round 6: the wide tiles' row-block kernel keeps 96 accumulators from kShiftWideBlockVgprs up)
+    wide_first = check_shift_isa.first_hard_register(inc_text, wide=True)
+    assert check_shift_isa.check_all(sasm, inc_text) > 400
+    at = sasm.index(";;#ASMSTART", sasm.index(check_shift_isa.WIDE_ROW_BLOCK_KERNELS[0] + ":"))
+    bad = sasm[:at] + "\tv_mov_b32_e32 v%d, 0\n" % (wide_first + 95) + sasm[at:]
+    with pytest.raises(AssertionError, match="compiler code touches"):
+        check_shift_isa.check_all(bad, inc_text)
     # ... and it does catch a violation: a compiler-looking instruction on v80 outside the asm blocks
     at = sasm.index(";;#ASMSTART", sasm.index(check_shift_isa.ROW_BLOCK_KERNELS[0] + ":"))
     bad = sasm[:at] + "\tv_mov_b32_e32 v%d, 0\n" % first_hard + sasm[at:]
