@@ -125,8 +125,12 @@ int qm_engine_synchronize(qm_engine *e);
  *                                                within two ulps of a sample's largest compared on a correctly
  *                                                rounded exp(sum / available), lowest index among equal values
  *                                                (migratelib.c:98-105 as its scalar-libm build computes it);
- *                                                final series of detect / detect_batch (step by step) /
- *                                                migrate / marginal; values unchanged
+ *                                                final series of detect / detect_batch (the step axis kept) /
+ *                                                migrate / marginal, and sharded detects through
+ *                                                qm_engine_tie_partial / _tie_fold; values unchanged
+ * tie_sets              0 / 1 [1]                (measurements) 1: with tie_rule = 1 the shift-reuse fused detect
+ *                                                publishes a partial set per brick, the refinement re-stacks one
+ *                                                brick per sample; 0: sets of four bricks from more workgroups
  * -- layout of the round-2 kernels (qm_kernels.hpp, qm_pair.hpp) --
  * brick_x, _y, _z       0..64 [0 = automatic]    node-brick shape; automatic = the largest of 8x8x8 .. 1x1x1
  *                                                whose windows fit LDS for >= 99.5 % of the bricks
@@ -170,6 +174,11 @@ int qm_engine_synchronize(qm_engine *e);
  * screen_pairs          0, 1, 2, 4 [0]           pairs of samples per lane in the sweep
  * screen_big            -1, 0, 1 [-1]            one 16-wave workgroup with 160 KB
  * screen_brick16        0 / 1 [0]                also try 16x8x8 bricks
+ * -- the continuous pipeline (part 3) --
+ * stream_pull           -1, 0, 1 [-1]            a slot's pinned inputs are PULLED by a small kernel on the engine's
+ *                                                stream instead of copied by a command on a second stream: -1 =
+ *                                                slots of <= 1 MB (example-sized grids, few steps per launch), 1 =
+ *                                                always, 0 = never; same results
  * -- measurement --
  * log_timing            0 / 1 [0]                HIP events around every stacking launch (qm_engine_kernel_log)
  *
@@ -273,6 +282,23 @@ int qm_engine_finalize(qm_engine *e, const double *d_part_max,
 int qm_engine_finalize_packed(qm_engine *e, const double *d_packed, int32_t n_sets,
                               int32_t n_samples, int64_t n_nodes_total, double *max_coa,
                               double *max_norm_coa, int64_t *max_coa_idx, int out_on_device);
+
+/* "tie_rule" = 1 on a sharded detect -- the reference's arg-max rule on near-ties (migratelib.c:98-105: strict
+ * '>' over EXPONENTIATED stacks) across ranks.  After the exchange of the partials:
+ * qm_engine_tie_partial examines the partial sets this engine's last qm_engine_detect_partial of the same step
+ * left behind against the GRID's largest z per sample (taken from d_packed = the gathered partials, f64
+ * [n_sets][3][n_samples] as for qm_engine_finalize_packed) and writes d_tie_packed f64 [2][n_samples] (bit
+ * patterns): row 0 the largest correctly rounded exp among its nodes within the slack (0: none), row 1 the
+ * lowest GLOBAL node index reaching it -- ready for one more all-gather;
+ * qm_engine_tie_fold takes the gathered [n_sets][2][n_samples] and overwrites, in the device series
+ * d_max_coa_idx [n_samples], every sample some rank refined: largest exp, lowest index among the ranks reaching
+ * it (what the reference's loop over ascending flat indices returns).  Samples nobody refined keep the default
+ * rule's index.  Both calls only enqueue. */
+int qm_engine_tie_partial(qm_engine *e, const double *log_onsets, int onsets_on_device,
+                          int32_t t_samples, int32_t fsmp, int32_t lsmp, int32_t available,
+                          const double *d_packed, int32_t n_sets, double *d_tie_packed);
+int qm_engine_tie_fold(qm_engine *e, const double *d_tie_gathered, int32_t n_sets, int32_t n_samples,
+                       int64_t *d_max_coa_idx);
 
 /* Materialising step (locate): volume f64 [n_nodes_local][n_samples] is written
  * (accumulate != 0: added on top of its current content first, the reference's

@@ -39,14 +39,15 @@ def run(lib, lon, tt, fsmp, lsmp, avail):
     return a, b, c
 
 
-def mirror_family(rng, ns=512):
+def mirror_family(rng, ns=512, shape=(10, 8, 6)):
     """station pairs mirrored about the grid's mid-plane, seen with the same onset function: every
     sample's maximum is a near-tie between a node and its mirror image (tools/near_tie_study.py)"""
-    nx, ny, nz, half = 10, 8, 6, 5
+    (nx, ny, nz), half = shape, 5
     g = np.stack(np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij"), -1) * 0.5
-    st = rng.uniform([0, 0, 0], [4.5, 3.5, 0], size=(half, 3))
+    span = 0.5 * (nx - 1)
+    st = rng.uniform([0, 0, 0], [span, 0.5 * (ny - 1), 0], size=(half, 3))
     mirror = st.copy()
-    mirror[:, 0] = 4.5 - mirror[:, 0]
+    mirror[:, 0] = span - mirror[:, 0]
     xyz = np.concatenate([st, mirror])
     tt = np.stack([np.rint(np.sqrt(((g - p) ** 2).sum(-1)) / 3.0 * 50) for p in xyz], -1).astype(np.int32)
     lsmp = int(tt.max()) + 5
@@ -76,6 +77,16 @@ def main():
         mirror_max_norm_coa_scalar=ms[1])
     print("permuted twins: scalar vs -Ofast differ on", float(np.mean(pv[2] != ps[2])),
           "; mirror twins:", float(np.mean(mv[2] != ms[2])))
+    # Round 6: the same family on a grid of many bricks (a node and its mirror image lie in DIFFERENT bricks, 45 of
+    # 8x8x8 / 30 of 8x8x16 nodes) and a scan that holds wide tiles: what the per-brick partial sets of tie_rule = 1
+    # and its sharded form are pinned on (near_ties_bricks.npz)
+    on, btt, fsmp, lsmp, avail = mirror_family(np.random.default_rng(11), ns=1600, shape=(40, 24, 20))
+    blon = np.ascontiguousarray(np.log(np.clip(on, 0.01, np.inf)))
+    bv, bs = run(vec, blon, btt, fsmp, lsmp, avail), run(scalar, blon, btt, fsmp, lsmp, avail)
+    np.savez_compressed(
+        OUT / "near_ties_bricks.npz", meta=np.array(meta), onsets=on, traveltimes=btt, fsmp=fsmp, lsmp=lsmp,
+        available=avail, idx_vec=bv[2], idx_scalar=bs[2], max_coa_scalar=bs[0], max_norm_coa_scalar=bs[1])
+    print("mirror twins on (40, 24, 20): scalar vs -Ofast differ on", float(np.mean(bv[2] != bs[2])))
 
 
 if __name__ == "__main__":

@@ -93,6 +93,9 @@ qmlib.qm_engine_finalize.argtypes = [_vp, _vp, _vp, _vp, c_int32, c_int32,
                                      c_int64, _vp, _vp, _vp, ctypes.c_int]
 qmlib.qm_engine_finalize_packed.argtypes = [_vp, _vp, c_int32, c_int32, c_int64, _vp, _vp,
                                             _vp, ctypes.c_int]
+qmlib.qm_engine_tie_partial.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32, c_int32, c_int32, _vp,
+                                        c_int32, _vp]
+qmlib.qm_engine_tie_fold.argtypes = [_vp, _vp, c_int32, c_int32, _vp]
 qmlib.qm_engine_migrate.argtypes = [_vp, _vp, ctypes.c_int, c_int32, c_int32,
                                     c_int32, c_int32, c_int64, _vp, ctypes.c_int,
                                     ctypes.c_int, _vp, _vp, _vp, ctypes.c_int]
@@ -447,6 +450,31 @@ class Engine:
         _check(qmlib.qm_engine_finalize_packed(self._h, pp, int(n_sets), int(n_samples),
                                                int(n_nodes_total), pa, pb, pc, da))
         return out
+
+    def tie_partial(self, log_onsets, fsmp, lsmp, available, packed, n_sets, tie_packed):
+        """``tie_rule = 1`` on a sharded detect: this engine's near-tie candidates of the step its last
+        :meth:`detect_partial` computed, against the grid's maxima in ``packed`` (the gathered partials,
+        device float64 [n_sets][3][n_samples]) -> ``tie_packed`` device float64 [2][n_samples] (bit
+        patterns: largest correctly rounded exp, lowest global index reaching it)."""
+        rows, t_samples = (int(v) for v in log_onsets.shape)
+        self._check_rows(rows)
+        po, dev_on = self._ptr(log_onsets, np.float64)
+        n = max(t_samples - int(fsmp) - int(lsmp), 0)
+        pp, dev = self._ptr(packed, np.float64, 3 * int(n_sets) * n)
+        pt, dev_t = self._ptr(tie_packed, np.float64, 2 * n)
+        if not (dev and dev_t):
+            raise ValueError("tie_partial reads and writes device buffers")
+        _check(qmlib.qm_engine_tie_partial(self._h, po, dev_on, t_samples, int(fsmp), int(lsmp),
+                                           int(available), pp, int(n_sets), pt))
+
+    def tie_fold(self, tie_gathered, n_sets, n_samples, idx):
+        """The gathered ``[n_sets][2][n_samples]`` outcomes of :meth:`tie_partial` folded into the
+        device index series ``idx`` (in place)."""
+        pg, dev = self._ptr(tie_gathered, np.float64, 2 * int(n_sets) * int(n_samples))
+        pi, dev_i = self._ptr(idx, np.int64, int(n_samples))
+        if not (dev and dev_i):
+            raise ValueError("tie_fold reads and writes device buffers")
+        _check(qmlib.qm_engine_tie_fold(self._h, pg, int(n_sets), int(n_samples), pi))
 
     def migrate(self, log_onsets, fsmp, lsmp, available, map4d, scan_out=None,
                 accumulate=False, n_nodes_total=None):

@@ -111,14 +111,17 @@ MARGINAL_DEGREE = 8      # 2^f of the marginalised map's terms: the polynomial o
                          # term positive -- the map inherits at most that (tests: 1e-12)
 
 
-def configure(lds_state, far=False, lazy=False, block=False, spl=4, contig=False, marginal=False):
+def configure(lds_state, far=False, lazy=False, block=False, spl=4, contig=False, marginal=False, bmax=False):
     """Register plan.  far: plane B is addressed through a second register (see PLANE8).  lds_state = False: the wavefront's running (max, sum, index) are inline-asm
     operands (20 VGPRs the compiler places below VB).  True: they live in LDS and are read and
     written by the group merge, the per-node temporaries move into window 1 -- 167 VGPRs in all,
     three wavefronts per SIMD."""
     global LDS_STATE, FAR, PLANE, VB, ACC, WIN, VADDR, VADDRB, VNODE, VC, VPF, VZERO, VEND, VMAG
-    global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR, LAZY, BLOCK, SPL, CONTIG, MARGINAL, VDUMMY
+    global F, P, KI, GMAX, GIDX, TT, GSUM, MAXR, SUMR, IDXR, LAZY, BLOCK, SPL, CONTIG, MARGINAL, VDUMMY, BMAX
     BLOCK = block            # one group per call, accumulators kept between calls (row blocks)
+    BMAX = bmax              # groups whose largest z comes within the tie slack of the wavefront's running maximum
+                             # also raise the BRICK's row of maxima in global memory (tie_rule = 1, see brick_max)
+    assert not bmax or (spl == 6 and not block and not lds_state)
     configure_scalars(PACKED_BLOCKS if block else PACKED_GROUPS)
     global AS
     SPL = spl                # samples per lane (4: full tiles; 1..3: tail tiles; 6: WIDE tiles of 384 samples)
@@ -735,12 +738,17 @@ def epilogue(e, degree, volume):
         # compares, once per group and sample slot -- into the dead TT registers)
         for k in range(SPL):
             e(f"v_mul_f64 {v2(TT + 2 * k)}, {v2(GMAX + 2 * k)}, %[scale]")
-        e(f"v_cmp_ge_f64 {s2(ST)}, {v2(TT)}, {MAXR[0]}")
-        for k in range(1, SPL):
-            e(f"v_cmp_ge_f64 vcc, {v2(TT + 2 * k)}, {MAXR[k]}")
-            e(f"s_or_b64 {s2(ST)}, {s2(ST)}, vcc")
-        e(f"s_cmp_eq_u64 {s2(ST)}, 0")
-        e(f"s_cbranch_scc1 {done}")
+        if BMAX:
+            # (the test below on z + slack instead of z: a group that comes NEAR the running maximum takes the
+            # branch too, leaves its maxima in the brick's row and falls into the per-slot test on z itself)
+            brick_max(e, TT, done)
+        else:
+            e(f"v_cmp_ge_f64 {s2(ST)}, {v2(TT)}, {MAXR[0]}")
+            for k in range(1, SPL):
+                e(f"v_cmp_ge_f64 vcc, {v2(TT + 2 * k)}, {MAXR[k]}")
+                e(f"s_or_b64 {s2(ST)}, {s2(ST)}, vcc")
+            e(f"s_cmp_eq_u64 {s2(ST)}, 0")
+            e(f"s_cbranch_scc1 {done}")
         # yes: the eight nodes' flat indices into the (dead) F registers, then per sample slot k
         # that reached: the lowest node whose z equals the group's maximum (descending, so the
         # lowest is written last; nodes outside the grid hold NaN); a maximum of -inf has no node
@@ -772,6 +780,10 @@ def epilogue(e, degree, volume):
             e(f"{nxt}:")
         e(f"{done}:")
         return
+    if BMAX:
+        far = e.label("bf")
+        brick_max(e, GMAX, far)
+        e(f"{far}:")
     # merge into the wave's running pair: larger z, ties -> lower flat index
     if LDS_STATE:
         # the wavefront's running state lives in LDS (5 chunks of 64 lanes x 16 bytes): maxima into
@@ -794,6 +806,41 @@ def epilogue(e, degree, volume):
         for c, reg in enumerate((F, F + 4, P, P + 4, TT)):
             e(f"ds_write_b128 %[state], v[{reg}:{reg + 3}] offset:{c * STATE_CHUNK}")
     e(f"{done}:")
+
+
+def brick_max(e, zreg, skip):
+    """tie_rule = 1 on wide tiles (qm_ties.hpp): the refinement stacks again, per sample, the bricks whose largest
+    z lies within the slack of the sample's maximum -- it needs to know them.  A node within the slack of the
+    FINAL maximum is within the slack of the wavefront's running maximum when its group is merged (the running
+    one is never larger), so: the group's maxima z_k (one per sample slot; present in both flavours at the merge)
+    are tested as z_k + 2 slack(z_k) >= running maximum (twice the refinement's slack 4e-16 + 2^-50 |z|: the sum
+    is rounded, and the slack is taken at z_k instead of the final maximum); a group no lane of which passes
+    branches to `skip` -- the lazy flavour's own branch to its arg-max recovery, slightly widened --, in the
+    others the lanes that pass raise the brick's row in global memory with an atomic maximum (the eight wavefronts
+    of a workgroup share a brick's samples; rows start at -inf: qm_engine.hip fills them; a lane's running
+    maximum is reached ~ln(groups) times in a walk: a few million atomics per C3 step).  Two VALU instructions
+    per sample slot and group into the dead F registers, no register of its own: the row's address is
+    %[brow] + the lane's LDS address (48 lane + the window base, which %[brow] has had subtracted)."""
+    for k in range(SPL):
+        e(f"v_fma_f64 {v2(F + 2 * k)}, |{v2(zreg + 2 * k)}|, %[slkrel], {v2(zreg + 2 * k)}")
+    for k in range(SPL):
+        e(f"v_add_f64 {v2(F + 2 * k)}, {v2(F + 2 * k)}, %[slkabs]")
+    e(f"v_cmp_ge_f64 {s2(ST)}, {v2(F)}, {MAXR[0]}")
+    for k in range(1, SPL):
+        e(f"v_cmp_ge_f64 vcc, {v2(F + 2 * k)}, {MAXR[k]}")
+        e(f"s_or_b64 {s2(ST)}, {s2(ST)}, vcc")
+    e(f"s_cmp_eq_u64 {s2(ST)}, 0")
+    e(f"s_cbranch_scc1 {skip}")
+    # (only the lanes that passed, slot by slot: a wavefront has 384 running maxima, SOME lane's is reached by most
+    # groups of a walk's first half -- all lanes' atomics on every such group cost the C3 step 18 %)
+    for k in range(SPL):
+        nxt = e.label("bk")
+        e(f"v_cmp_ge_f64 vcc, {v2(F + 2 * k)}, {MAXR[k]}")
+        e(f"s_cbranch_vccz {nxt}")
+        e("s_mov_b64 exec, vcc")
+        e(f"global_atomic_max_f64 %[lane], {v2(zreg + 2 * k)}, %[brow] offset:{8 * k}")
+        e("s_mov_b64 exec, -1")
+        e(f"{nxt}:")
 
 
 def body(degree, volume):
@@ -929,8 +976,8 @@ def body(degree, volume):
     return e.lines
 
 
-def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False, marginal=False):
-    configure(lds_state, far, lazy, block, spl, contig, marginal)
+def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False, marginal=False, bmax=False):
+    configure(lds_state, far, lazy, block, spl, contig, marginal, bmax)
     lines = body(degree, volume)
     # the stream pointer lives in a hard SGPR pair (the halves of an s[lo:hi] operand cannot be
     # named in inline asm): it is handed over as two 32-bit scalars
@@ -939,7 +986,7 @@ def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False,
     print()
     print(f"// degree-{degree} 2^f{', marginalised map' if marginal else ', values stored' if volume else ''}"
           f"{', running state in LDS' if lds_state else ''}{', far plane' if far else ''}"
-          f"{', arg-max recovered lazily' if lazy else ''}"
+          f"{', arg-max recovered lazily' if lazy else ''}{', brick maxima into LDS' if bmax else ''}"
           f"{', ONE group, one block of its rows per call (flags: 1 = first block, 2 = last)' if block else ''}"
           f"{f', WIDE tile of {spl} samples per lane, contiguous row windows from even samples' if spl == 6 else f', TAIL tile of {spl} sample(s) per lane, contiguous row windows' if contig else ''}; "
           f"window of up to {WMAX} doubles; "
@@ -951,7 +998,7 @@ def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False,
           + "int npairs, unsigned lane_addr, "
           + ("const ShiftStageNext &stage, " if block and STAGE_IN_LOOP and not far else "")
           + ("unsigned state_addr, " if lds_state else "")
-          + ("unsigned lane_addr_b, " if far else "") + "int nz, "
+          + ("unsigned lane_addr_b, " if far else "") + ("const void *brick_row, " if bmax else "") + "int nz, "
           f"int nynz, double scale, const double (&c)[{degree + 1}]"
           + (f", double *marg_tile, const double (&w)[{spl}], unsigned node_off, unsigned lane_x16, "
              f"unsigned lane_x32" if marginal else
@@ -989,6 +1036,9 @@ def emit(degree, volume, lds_state, far, lazy, block, name, spl=4, contig=False,
         ins += ['[state] "v"(state_addr)']
     if far:
         ins += ['[laneb] "v"(lane_addr_b)']
+    if bmax:
+        # (slack: twice qm_ties.hpp's tie_slack -- 2^-49 |z| + 8e-16)
+        ins += ['[brow] "s"(brick_row)', '[slkrel] "s"(0x1p-49)', '[slkabs] "s"(8.0e-16)']
     if block:
         ins += ['[flags] "s"(flags)']
     if block and STAGE_IN_LOOP and not far:
@@ -1084,6 +1134,9 @@ def main():
     # sample: 48 adds per register window instead of 32, 0.19 instead of 0.28 LDS reads per add at C3
     emit(8, False, False, False, False, False, "shift_wide_detect", 6, True)
     emit(8, False, False, False, True, False, "shift_wide_detect_lazy", 6, True)
+    # ... with the brick maxima tie_rule = 1 refines from (brick_max)
+    emit(8, False, False, False, False, False, "shift_wide_detect_bmax", 6, True, bmax=True)
+    emit(8, False, False, False, True, False, "shift_wide_detect_bmax_lazy", 6, True, bmax=True)
     # ... and on ROW BLOCKS (tables whose 384-sample windows do not fit a CU's LDS all at once: 33 rows and up):
     # one group per wavefront, blocks of <= 20 rows through a double-buffered LDS, staged by the loop itself
     emit(8, False, False, False, False, True, "shift_wide_rows", 6, True)

@@ -193,7 +193,10 @@ int launch_shift_path(qm_engine *e, const ShiftLayout &L, qm::StackArgs &a, int 
         s.stage_reach = L.stage_reach;
         // groups a wavefront sees before its running maximum is reset: bricks per workgroup x
         // groups per (brick, wavefront)
-        const int64_t life = ((int64_t)L.g.nbricks / std::max(1, a.ngroups)) *
+        // (brick maxima, tie_rule = 1: the wide tiles' loop raises them itself -- the running maximum lives as long
+        // as ever --, the other tiles fold and reset it after every brick)
+        const bool per_brick = a.brick_max && a.wide_tiles == 0;
+        const int64_t life = (per_brick ? 1 : (int64_t)L.g.nbricks / std::max(1, a.ngroups)) *
                              std::max(1, L.g.brick_nodes / 8 / L.nw);
         s.lazy = e->cfg_shift_lazy >= 0 ? e->cfg_shift_lazy : (life >= qm::kShiftLazyGroups ? 1 : 0);
         if (L.nblk > 1 && !L.direct) s.lazy = 0;    // (the register-staged form: eager only)
@@ -214,6 +217,8 @@ int launch_shift_path(qm_engine *e, const ShiftLayout &L, qm::StackArgs &a, int 
         else if (mode == qm::kShiftVolume && big) QM_TABLE(qm::launch_shift_volume8(s, shape));
         else if (mode == qm::kShiftVolume) QM_TABLE(qm::launch_shift_volume(s, shape));
         else if (L.nw == qm::kShiftWaves3) QM_TABLE(qm::launch_shift_detect3(s, shape));
+        else if (a.brick_max && big) QM_TABLE(qm::launch_shift_detect8_sets(s, shape));
+        else if (a.brick_max) QM_TABLE(qm::launch_shift_detect_sets(s, shape));
         else if (big) QM_TABLE(qm::launch_shift_detect8(s, shape));
         else QM_TABLE(qm::launch_shift_detect(s, shape));
         e->last_kernel = 3;
@@ -227,6 +232,7 @@ int launch_shift_path(qm_engine *e, const ShiftLayout &L, qm::StackArgs &a, int 
         a.brick_list = L.list.p;
         a.n_list = L.n_list;
         a.tail_spl = 0;                                // (its own whole tiles of 256 samples, clamped)
+        a.brick_max = nullptr;
         a.wide_tiles = 0;
         a.ntiles = (a.n_chunk + qm::kShiftKT - 1) / qm::kShiftKT;
         if (launch_direct(e, a, 4, volume, groups_direct, threads, publish_bytes)) return 1;
@@ -311,10 +317,10 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     const int64_t wide_work = (int64_t)((e->g.nx + 7) / 8) * ((e->g.ny + 7) / 8) * ((e->g.nz + 15) / 16) *
                               ((n_chunk + qm::kShiftWideKT - 1) / qm::kShiftWideKT);
     if (shift && shift_mode == qm::kShiftDetect && e->cfg_shift_wide != 0 && n_chunk >= qm::kShiftWideKT &&
-        // (tie_rule = 1 re-stacks one SET of bricks per sample: the wide layout's few long workgroups publish sets
-        // of tens of thousands of nodes -- that step keeps the 256-sample tiles' sets of four bricks)
+        // (tie_rule = 1 WITHOUT a set per brick -- tie_sets = 0, round 5's form -- re-stacks one set of bricks per
+        // sample: the wide layout's few long workgroups would publish sets of tens of thousands of nodes)
         (e->cfg_shift_wide == 1 || (wide_work >= 8 * (int64_t)e->n_cu && n_chunk >= 4 * qm::kShiftWideKT &&
-                                    !e->cfg_tie_rule &&
+                                    (!e->cfg_tie_rule || e->cfg_tie_sets) &&
                                     std::min(e->g.nx, std::min(e->g.ny, e->g.nz)) >= 8)) &&   // (thin boxes of a
                                     // rank's column partition: their 8 x 8 x 16 bricks would be mostly empty)
         e->cfg_shift_waves == 0) {
@@ -391,7 +397,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     const int lds_blocks_per_cu =
         shift ? (L->nw == qm::kShiftWaves ? 2 : 1) : jp > 0 ? 1
                : std::max(1, std::min(160 * 1024 / std::max(1, e->cfg_lds_bytes), 2048 / threads));
-    int groups_lds = 0, groups_direct = 0;
+    int groups_lds = 0, groups_direct = 0, brick_rows = 0;
     if (use_lds) {
         // (several timesteps per launch: the group count is the single step's -- the groups are the
         // order in which a sample's coalescence is summed over the nodes, and a step's result must
@@ -419,9 +425,14 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
         // smaller sets -- the refinement's cost falls with the set size, the stacking launch loses ~1 %)
         groups_lds = e->cfg_groups > 0 ? std::min(e->cfg_groups, nbricks_now)
                                        : auto_groups(e, a.ntiles, nbricks_now, lds_blocks_per_cu, rounds);
-        if (e->cfg_tie_rule && want_scan && !e->user_rounds && e->cfg_groups == 0) {
-            // ... but never sets of fewer than four bricks: the workgroup's fixed costs (C2: +8 % on the
-            // stacking launch at one brick per set)
+        // Round 6: the shift-reuse fused detect leaves the largest z PER BRICK and sample beside its workgroups'
+        // partial sets (StackArgs::brick_max): the refinement stacks one brick per sample, the launch keeps its
+        // group count -- and its bits
+        brick_rows = (e->cfg_tie_rule && want_scan && e->cfg_tie_sets && shift && shift_mode == qm::kShiftDetect &&
+                      L->nblk == 1 && L->nw != qm::kShiftWaves3 && !(L->wide && L->direct)) ? nbricks_now : 0;
+        if (e->cfg_tie_rule && want_scan && !brick_rows && !e->user_rounds && e->cfg_groups == 0) {
+            // ... the other kernels: eight times as many, smaller sets, but never sets of fewer than four bricks:
+            // the workgroup's fixed costs (C2: +8 % on the stacking launch at one brick per set)
             const int fine = auto_groups(e, a.ntiles, std::max(1, nbricks_now / 4), lds_blocks_per_cu,
                                          8 * (rounds > 0 ? rounds : e->cfg_rounds));
             groups_lds = std::max(groups_lds, fine);
@@ -436,13 +447,26 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     if (want_scan) {
         const size_t need = (size_t)sets * steps * n_chunk;
         if (e->d_pmax.ensure(need) || e->d_psum.ensure(need) || e->d_pidx.ensure(need)) return 1;
+        if (brick_rows && e->d_bmax.ensure((size_t)brick_rows * steps * n_chunk)) return 1;
+    }
+    a.brick_max = brick_rows ? e->d_bmax.p : nullptr;
+    if (brick_rows && a.wide_tiles > 0) {
+        // (the wide tiles' loop raises its rows by atomic maxima, and only where a group comes near the running
+        // maximum: they start at -inf; the other tiles write theirs whole)
+        const size_t n = (size_t)brick_rows * steps * n_chunk;
+        hipLaunchKernelGGL(qm::fill_kernel, dim3((unsigned)std::min<size_t>((n + 1023) / 1024, 65535)), dim3(256), 0,
+                           e->stream, e->d_bmax.p, n, -std::numeric_limits<double>::infinity());
+        QM_HIP(hipGetLastError());
     }
     a.part_max = e->d_pmax.p;
     a.part_idx = e->d_pidx.p;
     a.part_sum = e->d_psum.p;
     *n_sets = sets;
+    e->last_sets = sets;
+    e->last_scan_n = steps * n_chunk;
     e->last_g = a.g;
     e->last_groups_lds = groups_lds;
+    e->last_brick_rows = brick_rows;
     e->last_groups_direct = groups_direct;
     e->last_list = !use_direct || e->cfg_force_direct ? nullptr
                    : shift ? L->list.p : jp > 0 ? e->d_pwide.p : e->d_wide.p;
@@ -496,10 +520,16 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
 int combine(qm_engine *e, const double *pmax, const int64_t *pidx, const double *psum, int sets,
             int n, int mode, int64_t node_offset, int64_t n_nodes_total, double *o_max,
             double *o_second, int64_t *o_idx, const int32_t *run_if, int64_t set_stride) {
+    // (tie_rule = 1 with a row of maxima per brick: the fold of the workgroups' own sets also leaves the largest z)
+    double *o_z = nullptr;
+    if (e->cfg_tie_rule && e->last_brick_rows > 0 && pmax == e->d_pmax.p && run_if == nullptr) {
+        if (e->d_tie_zext.ensure(n)) return 1;
+        o_z = e->d_tie_zext.p;
+    }
     hipLaunchKernelGGL(qm::combine_kernel, dim3((n + qm::kWave - 1) / qm::kWave),
                        dim3(qm::kCombineWaves * qm::kWave), 0,
                        e->stream, pmax, pidx, psum, sets, n, set_stride > 0 ? set_stride : (int64_t)n,
-                       mode, node_offset, (double)n_nodes_total, o_max, o_second, o_idx, run_if);
+                       mode, node_offset, (double)n_nodes_total, o_max, o_second, o_idx, run_if, o_z);
     QM_HIP(hipGetLastError());
     return 0;
 }
@@ -524,6 +554,7 @@ int detect_core(qm_engine *e, const double *d_on, int T, int fsmp, int ns, int a
     if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, &sets, false, 0, 0,
                   run_if))
         return 1;
+    e->last_sets_own = !screened;                       // (d_pmax holds the float64 launch's sets for certain)
     if (combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, ns, mode, e->node_offset,
                 n_nodes_total, o_max, o_second, o_idx, run_if))
         return 1;
@@ -534,10 +565,14 @@ int detect_core(qm_engine *e, const double *d_on, int T, int fsmp, int ns, int a
     return 0;
 }
 
-// tie_rule = 1 (qm_ties.hpp): the index series of the launch whose partial sets lie in d_pmax, refined
+// tie_rule = 1 (qm_ties.hpp): the index series of the launch whose partial sets lie in d_pmax, refined.
+// n_steps > 1: the launch held several timesteps (sets [sets][n_steps * n_chunk], step k's onsets step_stride
+// doubles behind step 0's).  zext / o_key: a sharded detect's engine -- its sets against the grid's maxima, the
+// outcome exported (tie_export_kernel) instead of applied.
 int refine_ties(qm_engine *e, const double *d_on, int T, int fsmp, int available, int sample0,
-                int n_chunk, int sets, int64_t *o_idx) {
-    const int n = n_chunk;
+                int n_chunk, int sets, int64_t *o_idx, int n_steps, int64_t step_stride,
+                const double *zext, unsigned long long *o_key) {
+    const int n = n_chunk * std::max(1, n_steps);
     const int max_pairs = qm::kTieMaxSets * n;
     const int max_cands = 4 * n + 65536;
     if (e->d_tie_z.ensure(n) || e->d_tie_pairs.ensure(2 * (size_t)max_pairs) || e->d_tie_imin.ensure(n) ||
@@ -547,9 +582,16 @@ int refine_ties(qm_engine *e, const double *d_on, int T, int fsmp, int available
     hipStream_t s = e->stream;
     QM_HIP(hipMemsetAsync(e->d_tie_count.p, 0, 4 * sizeof(int32_t), s));
     int2 *pairs = reinterpret_cast<int2 *>(e->d_tie_pairs.p);
+    // (brick maxima: the sample's largest z is already in the workgroups' few partial sets; the per-brick rows are
+    // read once, for the candidates)
+    // (... and the sample's largest z came out of the combine that preceded this call)
+    const int rows = e->last_brick_rows;
+    if (rows > 0 && !zext) zext = e->d_tie_zext.p;
     hipLaunchKernelGGL(qm::tie_pairs_kernel, dim3((n + 63) / 64), dim3(64, qm::kTieSetLanes), 0, s,
-                       (const double *)e->d_pmax.p, sets, n, (int64_t)n, e->d_tie_z.p, pairs,
-                       e->d_tie_count.p, max_pairs, e->d_tie_emax.p, e->d_tie_imin.p, e->d_tie_count.p + 1);
+                       rows > 0 ? (const double *)e->d_bmax.p : (const double *)e->d_pmax.p, rows > 0 ? rows : sets,
+                       (const double *)e->d_pmax.p + (int64_t)e->last_groups_lds * n,
+                       rows > 0 ? e->last_groups_direct : 0, n, (int64_t)n, e->d_tie_z.p, pairs,
+                       e->d_tie_count.p, max_pairs, e->d_tie_emax.p, e->d_tie_imin.p, e->d_tie_count.p + 1, zext);
     QM_HIP(hipGetLastError());
     // How many pairs there are is known on the device only, and nobody waits for it: the evaluation is
     // launched for what a generic step has (one pair per sample) with room to spare; workgroups beyond the
@@ -562,15 +604,18 @@ int refine_ties(qm_engine *e, const double *d_on, int T, int fsmp, int available
     a.onsets = d_on;
     a.lut = e->d_lut.p;
     a.T = T; a.fsmp = fsmp; a.sample0 = sample0; a.n_chunk = n;
+    a.ns_step = n_steps > 1 ? n_chunk : 0;
+    a.step_stride = step_stride;
     a.z_scale = 1.4426950408889634074 / (double)available;
     a.recip = 1.0 / (double)available;
     a.groups_lds = e->last_groups_lds;
     a.groups_direct = e->last_groups_direct;
+    a.brick_rows = rows;
     a.brick_list = e->last_list;
     a.n_list = e->last_n_list;
     // workgroups per pair: ~2048 nodes each
     const int64_t per_set = (int64_t)e->n_nodes / std::max(1, e->last_groups_lds + e->last_groups_direct);
-    a.chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, per_set / 2048));
+    a.chunks = rows > 0 ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(64, per_set / 2048));   // (rows: a brick)
     a.zbest = e->d_tie_z.p;
     a.pairs = pairs;
     a.n_pairs = e->d_tie_count.p;
@@ -584,8 +629,13 @@ int refine_ties(qm_engine *e, const double *d_on, int T, int fsmp, int available
     hipLaunchKernelGGL(qm::tie_eval_kernel<0>, dim3(grid), dim3(256), 0, s, a);
     hipLaunchKernelGGL(qm::tie_pick_kernel, dim3(256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(qm::tie_eval_kernel<1>, dim3(grid), dim3(256), 0, s, a);   // (returns at once unless the list overflowed)
-    hipLaunchKernelGGL(qm::tie_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
-                       (const int32_t *)e->d_tie_imin.p, n, e->node_offset, o_idx + sample0);
+    if (o_key)
+        hipLaunchKernelGGL(qm::tie_export_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
+                           (const unsigned long long *)e->d_tie_emax.p, (const int32_t *)e->d_tie_imin.p, n,
+                           e->node_offset, o_key, o_idx);
+    else
+        hipLaunchKernelGGL(qm::tie_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
+                           (const int32_t *)e->d_tie_imin.p, n, e->node_offset, o_idx + sample0);
     QM_HIP(hipGetLastError());
     return 0;
 }
@@ -681,7 +731,7 @@ void qm_engine_destroy(qm_engine *e) {
     e->d_onq.release(); e->d_sparams.release();
     e->d_cell.release(); e->d_gmax.release(); e->d_pm.release(); e->d_rowmax.release(); e->d_ssum.release();
     e->d_cand_z.release(); e->d_cand_idx.release();
-    e->d_tie_z.release(); e->d_tie_pairs.release(); e->d_tie_imin.release(); e->d_tie_count.release();
+    e->d_bmax.release(); e->d_tie_zext.release(); e->d_tie_zgrid.release(); e->d_tie_z.release(); e->d_tie_pairs.release(); e->d_tie_imin.release(); e->d_tie_count.release();
     e->d_tie_emax.release(); e->d_tie_cands.release(); e->d_tie_keys.release();
     if (e->h_flags) (void)hipHostFree(e->h_flags);
     for (hipEvent_t ev : e->ev_log) (void)hipEventDestroy(ev);
@@ -779,6 +829,8 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
     } else if (k == "tie_rule") {
         if (v != 0 && v != 1) return fail("tie_rule must be 0 (largest sum) or 1 (the reference's exp rule)");
         e->cfg_tie_rule = (int)v;
+    } else if (k == "tie_sets") {
+        e->cfg_tie_sets = v ? 1 : 0;
     } else if (k == "shift_lazy") {
         if (v < -1 || v > 1) return fail("shift_lazy must be -1 (automatic), 0 or 1");
         e->cfg_shift_lazy = (int)v;
@@ -795,6 +847,9 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
         if (v < -1 || v > 1) return fail("screen_big must be -1 (automatic), 0 or 1");
         e->cfg_screen_big = (int)v;
         e->screen_kt = 0;
+    } else if (k == "stream_pull") {
+        if (v < -1 || v > 1) return fail("stream_pull must be -1 (slots of <= 1 MB), 0 (never) or 1 (always)");
+        e->cfg_stream_pull = (int)v;
     } else if (k == "log_timing") {
         e->log_timing = v != 0;
         e->ev_used = 0;
@@ -849,6 +904,10 @@ int qm_engine_get(qm_engine *e, const char *key, int64_t *v) {
         *v = e->shw.ok && e->shw.group_rows > 0 ? (e->shw.wquads * 4 * 1000) / (e->shw.group_rows * 48) : 0;
     else if (k == "steps_per_launch") *v = e->last_batched;
     else if (k == "tie_rule") *v = e->cfg_tie_rule;
+    else if (k == "tie_sets") *v = e->cfg_tie_sets;
+    else if (k == "stream_pull") *v = e->cfg_stream_pull;
+    else if (k == "tie_brick_rows") *v = e->last_brick_rows;
+
     else if (k == "tie_refined_steps") *v = e->tie_refined_steps;
     else if (k == "tie_overflow_samples" || k == "tie_pairs") {
         if (e->tie_counts_pending) {                       // (the last refinement's counters: now)
@@ -990,13 +1049,17 @@ int qm_engine_detect_batch(qm_engine *e, const double *log_onsets, int onsets_on
     if (stage_out(e, n_all, out_on_device, max_coa, max_norm_coa, max_coa_idx, &st)) return 1;
     bool batched = false;
     int sets = 0;
-    if (n_steps > 1 && !e->cfg_screen && !e->cfg_tie_rule) {
+    if (n_steps > 1 && !e->cfg_screen) {
         if (run_stack(e, d_on, T, fsmp, ns, available, 0, ns, nullptr, 0, 0, true, &sets, false, 0, 0,
                       nullptr, n_steps, (int64_t)per_step, &batched))
             return 1;
         // partial sets [sets][n_steps * ns] -> the steps' series back to back
         if (batched && combine(e, e->d_pmax.p, e->d_pidx.p, e->d_psum.p, sets, n_all, 1, e->node_offset,
                                n_nodes_total, st.a, st.b, st.i))
+            return 1;
+        // (tie_rule = 1 keeps the step axis: the refinement reads the launch's sets with sample t = step * ns + ...)
+        if (batched && e->cfg_tie_rule &&
+            refine_ties(e, d_on, T, fsmp, available, 0, ns, sets, st.i, n_steps, (int64_t)per_step))
             return 1;
     }
     if (!batched)                                       // step by step (a single step, the screened
@@ -1006,6 +1069,46 @@ int qm_engine_detect_batch(qm_engine *e, const double *log_onsets, int onsets_on
                 return 1;
     e->last_batched = batched ? n_steps : 1;
     return fetch_out(e, n_all, out_on_device, st, max_coa, max_norm_coa, max_coa_idx);
+}
+
+// tie_rule = 1 on a sharded detect (qm_ties.hpp, tie_export_kernel / tie_fold_kernel): after the exchange of
+// the ranks' partials, every engine examines the sets its last qm_engine_detect_partial left behind against the
+// GRID's maxima ...
+int qm_engine_tie_partial(qm_engine *e, const double *log_onsets, int onsets_on_device, int32_t T,
+                          int32_t fsmp, int32_t lsmp, int32_t available, const double *d_packed,
+                          int32_t n_sets, double *d_tie_packed) {
+    if (!e || !log_onsets || !d_packed || !d_tie_packed) return fail("qm_engine_tie_partial: NULL argument");
+    if (n_sets < 1) return fail("qm_engine_tie_partial: empty input");
+    DeviceGuard guard(e->device);
+    int ns = 0;
+    if (check_step(e, T, fsmp, lsmp, available, &ns)) return 1;
+    if (!e->cfg_tie_rule) return fail("qm_engine_tie_partial: the engine was not configured with tie_rule = 1");
+    if (e->last_scan_n != ns || e->last_sets < 1 || !e->last_sets_own)
+        return fail("qm_engine_tie_partial: no partial sets of a float64 detect of %d samples on this engine "
+                    "(call qm_engine_detect_partial for the step first; the screened sweep leaves none)", ns);
+    const double *d_on = nullptr;
+    if (stage_onsets(e, log_onsets, onsets_on_device, T, &d_on)) return 1;
+    // the grid's largest z per sample: the fold of the gathered maxima (rows [s][0] of [n_sets][3][ns])
+    if (e->d_tie_zgrid.ensure(ns)) return 1;
+    hipLaunchKernelGGL(qm::tie_zmax_kernel, dim3((ns + 255) / 256), dim3(256), 0, e->stream, d_packed, (int)n_sets,
+                       ns, 3 * (int64_t)ns, e->d_tie_zgrid.p);
+    QM_HIP(hipGetLastError());
+    return refine_ties(e, d_on, T, fsmp, available, 0, ns, e->last_sets,
+                       reinterpret_cast<int64_t *>(d_tie_packed + ns), 1, 0, e->d_tie_zgrid.p,
+                       reinterpret_cast<unsigned long long *>(d_tie_packed));
+}
+
+// ... and folds the gathered outcomes [n_sets][2][n_samples] into the index series (device, in place).
+int qm_engine_tie_fold(qm_engine *e, const double *d_tie_gathered, int32_t n_sets, int32_t n_samples,
+                       int64_t *d_max_coa_idx) {
+    if (!e || !d_tie_gathered || !d_max_coa_idx) return fail("qm_engine_tie_fold: NULL argument");
+    if (n_sets < 1 || n_samples < 1) return fail("qm_engine_tie_fold: empty input");
+    DeviceGuard guard(e->device);
+    hipLaunchKernelGGL(qm::tie_fold_kernel, dim3((n_samples + 255) / 256), dim3(256), 0, e->stream,
+                       reinterpret_cast<const unsigned long long *>(d_tie_gathered), (int)n_sets, (int)n_samples,
+                       d_max_coa_idx);
+    QM_HIP(hipGetLastError());
+    return 0;
 }
 
 int qm_engine_migrate(qm_engine *e, const double *log_onsets, int onsets_on_device, int32_t T,

@@ -244,8 +244,13 @@ struct qm_engine : TableState {
                                             // they fit and the scan holds at least one, 0 never, 1 as -1 (explicit)
     int cfg_shift_wide_rows = 1;            // ... on ROW BLOCKS where the windows of all rows do not fit (0: never,
                                             // 2: row blocks whatever fits -- tests)
+    int cfg_stream_pull = -1;               // qm_stream: a slot's pinned inputs pulled by a kernel on the engine's stream
+                                            // instead of a copy command on another (-1: slots of <= 1 MB, 0, 1)
     int cfg_tie_rule = 0;                   // 0: largest float64 sum, lowest index among equal ones (default);
                                             // 1: the reference's rule on near-ties (qm_ties.hpp)
+    int cfg_tie_sets = 1;                   // ... refined from a partial set PER BRICK where the stacking kernel has
+                                            // that flavour (the shift-reuse fused detect); 0: round 5's sets of
+                                            // four bricks everywhere (measurements)
 
     // per-step scratch of the screened detect (qm_screen.hpp) and its statistics
     DevBuf<int32_t> d_scalar, d_counts, d_cells, d_work, d_flags;
@@ -264,6 +269,12 @@ struct qm_engine : TableState {
     // which bricks the partial sets of the last stacking launch stand for (qm_ties.hpp)
     qm::GridDesc last_g{};
     int last_groups_lds = 0, last_groups_direct = 0, last_n_list = 0;
+    int last_brick_rows = 0;                            // (a row of maxima per brick besides: StackArgs::brick_max)
+    DevBuf<double> d_bmax;
+    int last_sets = 0, last_scan_n = 0;                 // their number, the samples each one spans
+    bool last_sets_own = false;                         // ... left by a float64 detect (not by the screened sweep)
+    DevBuf<double> d_tie_zext;                          // the largest z per sample, left by the combine of the own sets
+    DevBuf<double> d_tie_zgrid;                         // sharded detects: the GRID's largest z per sample
     const int32_t *last_list = nullptr;
     DevBuf<double> d_tie_z;
     DevBuf<int32_t> d_tie_pairs, d_tie_imin, d_tie_count, d_tie_cands;
@@ -348,7 +359,8 @@ int combine(qm_engine *e, const double *pmax, const int64_t *pidx, const double 
             double *o_second, int64_t *o_idx, const int32_t *run_if = nullptr,
             int64_t set_stride = 0);
 int refine_ties(qm_engine *e, const double *d_on, int T, int fsmp, int available, int sample0,
-                int n_chunk, int sets, int64_t *o_idx);
+                int n_chunk, int sets, int64_t *o_idx, int n_steps = 1, int64_t step_stride = 0,
+                const double *zext = nullptr, unsigned long long *o_key = nullptr);
 int detect_core(qm_engine *e, const double *d_on, int T, int fsmp, int ns, int available, int mode,
                 int64_t n_nodes_total, double *o_max, double *o_second, int64_t *o_idx);
 int check_step(qm_engine *e, int T, int fsmp, int lsmp, int available, int *n_samples);

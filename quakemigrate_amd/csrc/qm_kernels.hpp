@@ -70,6 +70,8 @@ struct StackArgs {
     int64_t *part_idx;             // [sets][n_chunk]  local flat node index
     double *part_sum;              // [sets][n_chunk]
     int set0;                      // first partial set written by this launch
+    double *brick_max;             // [nbricks][part_stride] shift-reuse fused detect, tie_rule = 1: the largest z per
+                                   // brick and sample besides the workgroups' partial sets (nullptr: not wanted)
     int want_scan;                 // write partials at all
     double *marginal;              // [ntiles][n_nodes] per-tile sums over samples [m0, m1) of the
     int m0, m1;                    //   coalescence (VOLUME kernels; replaces the volume store)
@@ -111,6 +113,7 @@ __device__ __forceinline__ StackArgs step_view(StackArgs a) {
         a.part_max += (int64_t)step * a.n_chunk;
         a.part_idx += (int64_t)step * a.n_chunk;
         a.part_sum += (int64_t)step * a.n_chunk;
+        if (a.brick_max) a.brick_max += (int64_t)step * a.n_chunk;
     }
     return a;
 }
@@ -1547,7 +1550,8 @@ __global__ __launch_bounds__(kCombineWaves * kWave) void combine_kernel(
     const double *__restrict__ part_sum, int n_sets, int n, int64_t set_stride, int mode,
     int64_t node_offset, double n_nodes_total, double *__restrict__ out_max,
     double *__restrict__ out_norm_or_sum, int64_t *__restrict__ out_idx,
-    const int32_t *__restrict__ run_if) {
+    const int32_t *__restrict__ run_if, double *__restrict__ out_z) {
+    // (out_z, optional: the largest log2-domain maximum itself -- what tie_rule = 1 measures its slack from)
     // 16 wavefronts split the sets (wave w: sets w, w + 16, ...), four sets' loads in flight per
     // wave: a scan of a few hundred samples has only a handful of 64-sample columns, so the sets
     // are where the parallelism is (Icequake-sized step, 625 samples x 576 sets: 48 -> ~9 us,
@@ -1596,6 +1600,7 @@ __global__ __launch_bounds__(kCombineWaves * kWave) void combine_kernel(
         }
     }
     if (bi != kNoIndex) bi += node_offset;
+    if (out_z) out_z[t] = best;
     if (mode == 0) {
         out_max[t] = best;
         out_norm_or_sum[t] = total;

@@ -1,0 +1,15 @@
+// stack_shift_kernel<kShiftDetect, NW, SETS = true> (qm_shift.hpp): the fused detect that publishes a partial
+// set per brick of a workgroup's walk -- what "tie_rule" = 1 refines from (qm_ties.hpp); a unit of its own so that
+// it compiles beside qm_launch_shift.hip
+#define QM_SHIFT_TU 2
+#include "qm_launch.hpp"
+#include "qm_shift.hpp"
+
+namespace qm {
+hipError_t launch_shift_detect_sets(const ShiftArgs &a, const LaunchShape &s) {
+    return launch_with_lds(&stack_shift_kernel<kShiftDetect, kShiftWaves, true>, a, s);
+}
+hipError_t launch_shift_detect8_sets(const ShiftArgs &a, const LaunchShape &s) {
+    return launch_with_lds(&stack_shift_kernel<kShiftDetect, kShiftWaves8, true>, a, s);
+}
+}  // namespace qm

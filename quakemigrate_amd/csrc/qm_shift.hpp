@@ -151,6 +151,8 @@ hipError_t launch_shift_rows2_volume(const ShiftArgs &a, const LaunchShape &s);
 hipError_t launch_shift_rows4(const ShiftArgs &a, const LaunchShape &s);    // ... two 4-wave workgroups per CU
 hipError_t launch_shift_rows4_volume(const ShiftArgs &a, const LaunchShape &s);
 hipError_t launch_shift_wide_rows(const ShiftArgs &a, const LaunchShape &s);    // row blocks on wide tiles
+hipError_t launch_shift_detect_sets(const ShiftArgs &a, const LaunchShape &s);  // qm_launch_shift_sets.hip: a partial
+hipError_t launch_shift_detect8_sets(const ShiftArgs &a, const LaunchShape &s); // set per brick (tie_rule = 1)
 
 // valid 2x2x2 groups of a brick form a box [0,cx) x [0,cy) x [0,cz) in group coordinates
 __device__ __forceinline__ void shift_group_box(const GridDesc &g, int b, int &x0, int &y0, int &z0,
@@ -556,7 +558,11 @@ __device__ __forceinline__ void shift_publish(const StackArgs &a, double *win, c
 // (WIDE_LAZY: the wide tile's loop flavour, chosen outside the brick loop -- with both flavours' asm statements
 // in one loop the compiler shuffled the 30 registers of running state between their operand assignments and
 // spilled them around every brick)
-template <int MODE, int NW, int J, bool WIDE_LAZY = false>
+// (SETS: the kernel flavours that also leave the largest z per BRICK and sample (a.brick_max), below -- flavours
+// of their own because the extra code costs the plain kernels registers: nine spilled in the wide tile's loop.
+// 1: the wavefronts' running maxima are folded and reset after every brick; 2, wide tiles: the generated loop
+// raises the brick's row itself, the running state is the plain kernel's)
+template <int MODE, int NW, int J, bool WIDE_LAZY = false, int SETS = 0>
 __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, const ShiftWork &work,
                                            int lane, int wave) {
     constexpr bool kLdsState = NW == kShiftWaves3;
@@ -564,6 +570,8 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
     constexpr bool kTail = J != 4;                      // (contiguous row windows)
     static_assert(!(kTail && kLdsState), "the 12-wave shape has no tail flavours");
     static_assert(!kWide || (MODE == kShiftDetect && NW == kShiftWaves8), "wide tiles: fused detect, 8 waves");
+    static_assert(!SETS || (MODE == kShiftDetect && !kLdsState), "brick maxima: fused detect, 4 or 8 waves");
+    static_assert(SETS != 2 || kWide, "brick maxima from the generated loop: wide tiles");
     const StackArgs &a = s.a;
     const GridDesc &g = a.g;
     const int tile = work.tile, group = work.group, t_first = work.t_first;
@@ -624,7 +632,57 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
     double *const vol_tile = a.volume + t_first;
     const unsigned vol_stride_bytes = (unsigned)(a.vol_stride * 8);
     (void)marg_tile; (void)vol_tile; (void)vol_stride_bytes;
+    // Brick maxima (SETS; tie_rule = 1, qm_ties.hpp): besides its partial set the workgroup leaves, per brick of its
+    // walk and sample of the tile, the largest z -- a.brick_max[brick][sample] -- so that the refinement stacks ONE
+    // brick again per sample instead of everything a workgroup owns.
+    //   SETS = 1: the wavefronts' (max, index) are folded after every brick -- across the wavefronts through LDS
+    //   into the brick's row, and into the walk's own pair (wmax, widx: touched once per brick, the compiler may
+    //   keep them in scratch) -- and start the next brick from (-inf, none); the sums run on.
+    //   SETS = 2 (wide tiles): the generated loop itself raises the row, by atomic maxima from the groups that come
+    //   within the tie slack of the wavefront's running maximum (gen_shift_asm.py, brick_max: the others cannot
+    //   hold a candidate); rows start at -inf (the engine fills them); the running state is the plain kernel's.
+    double wmax[J];
+    int widx[J];
+    (void)wmax; (void)widx;
+    const int64_t brow_stride = a.part_stride ? a.part_stride : a.n_chunk;
+    if constexpr (SETS == 1) {
+#pragma unroll
+        for (int k = 0; k < J; ++k) {
+            wmax[k] = -__builtin_inf();
+            widx[k] = INT32_MAX;
+        }
+    }
+    // SETS = 1: the row of brick b from the wavefronts' registers (call behind a barrier that follows the brick)
+    auto brick_row = [&](int b) {
+        constexpr int KT = kWave * J;
+#pragma unroll
+        for (int k = 0; k < J; ++k) win[wave * KT + J * lane + k] = vmax[k];
+        __syncthreads();
+        const int j = threadIdx.x;
+        if (j < KT && t_first + j < a.n_chunk) {
+            double best = win[j];
+            for (int w = 1; w < NW; ++w) best = win[w * KT + j] > best ? win[w * KT + j] : best;
+            a.brick_max[(int64_t)b * brow_stride + t_first + j] = best;
+        }
+#pragma unroll
+        for (int k = 0; k < J; ++k) {
+            if (better(vmax[k], vidx[k], wmax[k], widx[k])) {
+                wmax[k] = vmax[k];
+                widx[k] = vidx[k];
+            }
+            vmax[k] = -__builtin_inf();
+            vidx[k] = INT32_MAX;
+        }
+    };
+    int prev = -1;                                                 // the brick whose row is still to be written
     for (int b = group; b < g.nbricks; b += a.ngroups) {
+        if constexpr (SETS == 1) {
+            if (prev >= 0) {
+                __syncthreads();                                   // (the brick is done in every wavefront)
+                brick_row(prev);
+            }
+            prev = b;
+        }
         if (!s.sfit[b]) continue;                     // direct kernel's job
 #ifdef QM_SHIFT_EXP_NOSTAGE                            // timing experiment (wrong results): the first
                                                       // brick's windows for all, no barriers
@@ -679,7 +737,17 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
         else                                                                                          \
             shift_tail##JJ##_detect(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz,         \
                                     a.z_scale, c)
-        if constexpr (kWide && WIDE_LAZY)
+        // (SETS = 2: the brick's row of this tile, such that row + the lane's LDS window address = its six samples)
+        const char *const brow = reinterpret_cast<const char *>(a.brick_max + (int64_t)b * brow_stride + t_first) -
+                                 lds_base;
+        (void)brow;
+        if constexpr (kWide && WIDE_LAZY && SETS == 2)
+            shift_wide_detect_bmax_lazy(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr,
+                                        brow, nz, nynz, a.z_scale, c);
+        else if constexpr (kWide && SETS == 2)
+            shift_wide_detect_bmax(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr,
+                                   brow, nz, nynz, a.z_scale, c);
+        else if constexpr (kWide && WIDE_LAZY)
             shift_wide_detect_lazy(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz,
                                    a.z_scale, c);
         else if constexpr (kWide)
@@ -701,7 +769,7 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
             shift_groups_volume8(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, lane_addr_b, nz, nynz,
                                  a.z_scale, c, vol_tile, vol_stride_bytes, (unsigned)lane * 32u, store_lanes);
         else if constexpr (NW == kShiftWaves8) {
-            if (s.lazy)
+            if (s.lazy && SETS != 1)                  // (a running maximum reset after every brick: eager)
                 shift_groups_detect8_lazy(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, lane_addr_b, nz,
                                           nynz, a.z_scale, c);
             else
@@ -711,7 +779,7 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
         else if constexpr (MODE == kShiftVolume)
             shift_groups_volume(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz, a.z_scale, c,
                                 vol_tile, vol_stride_bytes, (unsigned)lane * 32u, store_lanes);
-        else if (s.lazy)
+        else if (s.lazy && SETS != 1)
             shift_groups_detect_lazy(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz, a.z_scale, c);
         else
             shift_groups_detect(vmax, vsum, vidx, run, mine, next_run, next_off, next_meta, npairs, lane_addr, nz, nynz, a.z_scale, c);
@@ -727,10 +795,19 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
     }
     // cross-wave combine through LDS: thread k of the workgroup owns sample k of the tile
     __syncthreads();
+    if constexpr (SETS == 1) {
+        brick_row(prev);                                           // the walk's last brick
+#pragma unroll
+        for (int k = 0; k < J; ++k) {
+            vmax[k] = wmax[k];
+            vidx[k] = widx[k];
+        }
+        __syncthreads();
+    }
     shift_publish<NW, J>(a, win, vmax, vsum, vidx, wave, lane, group, t_first);
 }
 
-template <int MODE, int NW>
+template <int MODE, int NW, bool SETS = false>   // (SETS: also a.brick_max, see shift_tile)
 __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_shift_kernel(ShiftArgs s) {
     static_assert(NW == kShiftWaves || NW == kShiftWaves8 || (NW == kShiftWaves3 && MODE == kShiftDetect),
                   "workgroup shapes: 4 or 8 waves, or 12 (detect only)");
@@ -742,16 +819,20 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
     if (!work.run) return;
     if constexpr (MODE == kShiftDetect && NW == kShiftWaves8) {
         if (work.spl == kShiftWideSpl) {
-            if (s.lazy) return shift_tile<MODE, NW, kShiftWideSpl, true>(s, win, work, lane, wave);
-            return shift_tile<MODE, NW, kShiftWideSpl, false>(s, win, work, lane, wave);
+            if constexpr (SETS) {
+                if (s.lazy) return shift_tile<MODE, NW, kShiftWideSpl, true, 2>(s, win, work, lane, wave);
+                return shift_tile<MODE, NW, kShiftWideSpl, false, 2>(s, win, work, lane, wave);
+            }
+            if (s.lazy) return shift_tile<MODE, NW, kShiftWideSpl, true, 0>(s, win, work, lane, wave);
+            return shift_tile<MODE, NW, kShiftWideSpl, false, 0>(s, win, work, lane, wave);
         }
     }
     if constexpr (NW != kShiftWaves3) {
-        if (work.spl == 3) return shift_tile<MODE, NW, 3>(s, win, work, lane, wave);
-        if (work.spl == 2) return shift_tile<MODE, NW, 2>(s, win, work, lane, wave);
-        if (work.spl == 1) return shift_tile<MODE, NW, 1>(s, win, work, lane, wave);
+        if (work.spl == 3) return shift_tile<MODE, NW, 3, false, SETS ? 1 : 0>(s, win, work, lane, wave);
+        if (work.spl == 2) return shift_tile<MODE, NW, 2, false, SETS ? 1 : 0>(s, win, work, lane, wave);
+        if (work.spl == 1) return shift_tile<MODE, NW, 1, false, SETS ? 1 : 0>(s, win, work, lane, wave);
     }
-    shift_tile<MODE, NW, 4>(s, win, work, lane, wave);
+    shift_tile<MODE, NW, 4, false, SETS ? 1 : 0>(s, win, work, lane, wave);
 }
 
 // Tables of more rows than a CU's LDS holds windows for (> 64): ROW BLOCKS.  A brick is as many
@@ -1176,6 +1257,7 @@ __device__ __forceinline__ void shift_wide_rows_body(const ShiftArgs &s, double 
     shift_publish<NW, J>(a, win, vmax, vsum, vidx, wave, lane, group, t_first);
 }
 
+#if QM_SHIFT_TU == 1                                    // (the one kernel here that is no template: one unit's)
 __global__ __attribute__((amdgpu_flat_work_group_size(kShiftWaves8 * kWave, kShiftWaves8 * kWave),
                           amdgpu_waves_per_eu(9, 9)))
 void stack_shift_wide_rows_kernel(ShiftArgs s) {
@@ -1183,6 +1265,7 @@ void stack_shift_wide_rows_kernel(ShiftArgs s) {
     if (s.lazy) shift_wide_rows_body<true>(s, win);
     else shift_wide_rows_body<false>(s, win);
 }
+#endif
 
 // Row blocks, third form (round 4): TWO 4-wave workgroups per CU, 80 KB each -- the shape of the
 // tables of up to ~32 rows, for the same reason: the two wavefronts of a SIMD then belong to

@@ -7,6 +7,10 @@
 //
 //   caller's thread : qm_stream_push   CPU copy of a step's log-onsets into the slot's PINNED input
 //   copy stream     : H2D of the slot's inputs                 (overlaps the previous launch's kernel)
+//                     -- or, for slots of up to kPullBytes (the example-sized grids, one timestep per launch: a
+//                     step is a fraction of a millisecond and the wait for another stream's copy costs a quarter
+//                     of it), NO copy command at all: a small kernel on the engine's stream PULLS the pinned
+//                     input over the bus into the slot's device buffer, in order before the detect launch
 //   engine's stream : ONE fused-detect launch for the slot's K steps (qm_engine_detect_batch); its
 //                     combine kernel writes the results, packed as [3][K x n_samples] float64, STRAIGHT
 //                     into the slot's pinned host buffer (a few KB per timestep; no D2H command)
@@ -45,9 +49,28 @@ struct qm_stream {
     std::deque<int> order;              // slots in flight, oldest first
     int fill_slot = 0, fill_n = 0;      // slot being filled, steps pushed into it so far
     int64_t launched_steps = 0, popped_steps = 0, launches = 0;
+    bool pulled = false;                // the last launch's inputs were pulled by a kernel (no copy command)
 };
 
 namespace {
+
+// Slots this small are pulled by a kernel instead of copied by a command on another stream (round 6).  One
+// timestep per launch on the example-sized grids ran at x1.27-1.30 of the resident step with the copy command --
+// back to back under the tracer, so not the copy's duration: the dependency across two streams (a signal the
+// runtime's host thread has to forward) -- profiles/r06_trace_stream_k1.json.  A kernel that reads pinned host
+// memory moves ~170 KB (C1) in a few microseconds and needs no event: the engine's stream orders it.  Large
+// slots (C3: 1.5 MB per timestep, 41 ms of kernel to hide the copy behind) keep the copy stream.
+constexpr size_t kPullBytes = 1u << 20;
+
+using pull2 = double __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void pull_kernel(const pull2 *__restrict__ src, pull2 *__restrict__ dst,
+                                                   size_t n2, const double *__restrict__ src1, double *__restrict__ dst1,
+                                                   size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride)
+        dst[i] = __builtin_nontemporal_load(src + i);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) dst1[n - 1] = src1[n - 1];
+}
 
 size_t step_in(const qm_stream *s) { return (size_t)s->n_rows * s->T; }
 
@@ -92,10 +115,20 @@ int launch_slot(qm_stream *s) {
                     (unsigned long long)(e->have_lut ? e->serial : 0), e->have_lut ? e->g.n_rows : 0,
                     (unsigned long long)s->table_serial, s->n_rows);
     const size_t kns = (size_t)s->K * s->ns;
-    QM_HIP(hipMemcpyAsync(sl.d_on, sl.h_on, (size_t)n * step_in(s) * sizeof(double), hipMemcpyHostToDevice,
-                          s->copy_stream));
-    QM_HIP(hipEventRecord(sl.copied, s->copy_stream));
-    QM_HIP(hipStreamWaitEvent(e->stream, sl.copied, 0));
+    const size_t words = (size_t)n * step_in(s);
+    const bool pull = e->cfg_stream_pull > 0 || (e->cfg_stream_pull < 0 && words * sizeof(double) <= kPullBytes);
+    if (pull) {
+        const unsigned blocks = (unsigned)std::min<size_t>(4 * (size_t)e->n_cu, (words / 2 + 255) / 256 + 1);
+        hipLaunchKernelGGL(pull_kernel, dim3(blocks), dim3(256), 0, e->stream,
+                           reinterpret_cast<const pull2 *>(sl.h_on), reinterpret_cast<pull2 *>(sl.d_on),
+                           words / 2, (const double *)sl.h_on, sl.d_on, words);
+        QM_HIP(hipGetLastError());
+    } else {
+        QM_HIP(hipMemcpyAsync(sl.d_on, sl.h_on, words * sizeof(double), hipMemcpyHostToDevice, s->copy_stream));
+        QM_HIP(hipEventRecord(sl.copied, s->copy_stream));
+        QM_HIP(hipStreamWaitEvent(e->stream, sl.copied, 0));
+    }
+    s->pulled = pull;
     // The results are a few KB per timestep: the combine kernel writes them STRAIGHT into the slot's
     // pinned host buffer (pinned memory is device-accessible under one address; the event behind the
     // launch makes them visible to the host) -- no D2H copy command, no third stream.  (With a copy on a

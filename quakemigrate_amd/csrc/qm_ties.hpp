@@ -117,6 +117,8 @@ __host__ __device__ inline double exp_correctly_rounded(double x) {
 
 // ---- the refinement ---------------------------------------------------------------------------
 constexpr int kTieMaxSets = 8;          // candidate sets per sample beyond which the default index stays
+constexpr unsigned long long kTieOverflowKey = ~0ull;   // ... marked so in the sample's exp slot (no double's bits
+                                                        // that a finite stack produces)
 
 __host__ __device__ __forceinline__ double tie_slack(double zb) {
     return 4.0e-16 + 0x1p-50 * (zb < 0 ? -zb : zb);
@@ -131,6 +133,10 @@ struct TieArgs {
     int groups_lds, groups_direct; // set s < groups_lds: bricks s, s + groups_lds, ...; else the direct launch's
     const int32_t *brick_list;     // ... bricks list[i], i = s - groups_lds, + groups_direct, ... (nullptr: all)
     int n_list;
+    int brick_rows;                // > 0 (StackArgs::brick_max, round 6): the LDS launch left a row of maxima per BRICK
+                                   // -- set s < brick_rows is brick s alone --, the direct launch's sets follow
+    int ns_step;                   // several timesteps in one launch (> 0): sample t of the series belongs to step
+    int64_t step_stride;           // t / ns_step, whose onsets start step_stride doubles further on
     int chunks;                    // workgroups per (set, sample) pair
     const double *zbest;           // [n_chunk] largest z over the sets
     const int2 *pairs;             // work list: (set, sample)
@@ -148,20 +154,29 @@ struct TieArgs {
 // single thread per sample would walk thousands of sets one load at a time): the largest z over the
 // sets, the sets within the slack -> work list.
 constexpr int kTieSetLanes = 16;
+// (two sources of maxima: sets [0, sets) of pmax, then sets_b more of pmax_b -- the per-brick rows of the
+// shift-reuse detect and the direct launch's partial sets behind them)
 __global__ __launch_bounds__(64 * kTieSetLanes) void tie_pairs_kernel(
-    const double *__restrict__ pmax, int sets, int n, int64_t set_stride, double *__restrict__ zbest,
+    const double *__restrict__ pmax, int sets, const double *__restrict__ pmax_b, int sets_b, int n,
+    int64_t set_stride, double *__restrict__ zbest,
     int2 *__restrict__ pairs, int32_t *__restrict__ n_pairs, int max_pairs, unsigned long long *__restrict__ emax,
-    int32_t *__restrict__ imin, int32_t *__restrict__ overflow) {
+    int32_t *__restrict__ imin, int32_t *__restrict__ overflow, const double *__restrict__ zext) {
     __shared__ double smax[kTieSetLanes][64];
     __shared__ int scount[kTieSetLanes][64];
     __shared__ int sbase[64];
     const int x = threadIdx.x, y = threadIdx.y;
     const int t = blockIdx.x * 64 + x;
     const bool live = t < n;
+    // (zext: the largest z over EVERY rank's sets of a sharded detect -- this engine's sets are examined against
+    // the grid's maximum, not their own)
+    auto at = [&](int s) { return s < sets ? pmax[(int64_t)s * set_stride + t]
+                                           : pmax_b[(int64_t)(s - sets) * set_stride + t]; };
+    const int all = sets + sets_b;
     double zb = -__builtin_inf();
-    if (live)
-        for (int s = y; s < sets; s += kTieSetLanes) {
-            const double v = pmax[(int64_t)s * set_stride + t];
+    if (live && zext) zb = zext[t];
+    if (live && !zext)
+        for (int s = y; s < all; s += kTieSetLanes) {
+            const double v = at(s);
             zb = v > zb ? v : zb;                               // (a NaN never wins)
         }
     smax[y][x] = zb;
@@ -171,7 +186,7 @@ __global__ __launch_bounds__(64 * kTieSetLanes) void tie_pairs_kernel(
     const double lo = zb - tie_slack(zb);
     int count = 0;
     if (live && finite)
-        for (int s = y; s < sets; s += kTieSetLanes) count += pmax[(int64_t)s * set_stride + t] >= lo ? 1 : 0;
+        for (int s = y; s < all; s += kTieSetLanes) count += at(s) >= lo ? 1 : 0;
     scount[y][x] = count;
     __syncthreads();
     if (y == 0 && live) {
@@ -182,6 +197,7 @@ __global__ __launch_bounds__(64 * kTieSetLanes) void tie_pairs_kernel(
         imin[t] = INT32_MAX;
         int base = -1;
         if (total > kTieMaxSets) {
+            emax[t] = kTieOverflowKey;                          // (no pair of this sample: nobody touches it again)
             atomicAdd(overflow, 1);
         } else if (total > 0) {
             base = atomicAdd(n_pairs, total);
@@ -194,10 +210,10 @@ __global__ __launch_bounds__(64 * kTieSetLanes) void tie_pairs_kernel(
     }
     __syncthreads();
     if (!live || !finite || sbase[x] < 0) return;
-    int at = sbase[x];
-    for (int k = 0; k < y; ++k) at += scount[k][x];
-    for (int s = y; s < sets; s += kTieSetLanes)
-        if (pmax[(int64_t)s * set_stride + t] >= lo) pairs[at++] = make_int2(s, t);
+    int slot = sbase[x];
+    for (int k = 0; k < y; ++k) slot += scount[k][x];
+    for (int s = y; s < all; s += kTieSetLanes)
+        if (at(s) >= lo) pairs[slot++] = make_int2(s, t);
 }
 
 // Workgroup = (pair, chunk): the nodes of the pair's set, for the pair's one sample.
@@ -212,11 +228,15 @@ __global__ __launch_bounds__(256) void tie_eval_kernel(TieArgs a) {
         const int2 w = a.pairs[pair];
         const int set = w.x, t = w.y;
         const double zb = a.zbest[t], lo = zb - tie_slack(zb);
-        const int64_t col = (int64_t)t + a.sample0 + a.fsmp;
-        const bool direct = set >= a.groups_lds;
-        const int first = direct ? set - a.groups_lds : set;
+        const int kstep = a.ns_step > 0 ? t / a.ns_step : 0;
+        const double *onsets = a.onsets + (int64_t)kstep * a.step_stride;
+        const int64_t col = (int64_t)(t - kstep * a.ns_step) + a.sample0 + a.fsmp;
+        const int sets_lds = a.brick_rows > 0 ? a.brick_rows : a.groups_lds;
+        const bool direct = set >= sets_lds;
         const int step = direct ? a.groups_direct : a.groups_lds;
-        const int n_list = direct ? (a.brick_list ? a.n_list : g.nbricks) : g.nbricks;
+        const int first = direct ? set - sets_lds : set;
+        int n_list = direct ? (a.brick_list ? a.n_list : g.nbricks) : g.nbricks;
+        if (!direct && a.brick_rows > 0) n_list = first + 1;        // (the one brick)
         unsigned long long best = 0ull;
         int best_node = INT32_MAX;
         for (int i = first + chunk * step; i < n_list; i += a.chunks * step) {
@@ -228,10 +248,24 @@ __global__ __launch_bounds__(256) void tie_eval_kernel(TieArgs a) {
                 const int node = brick_walk_node(g, x0, y0, z0, vy, vz, m);
                 const int32_t *row = a.lut + (int64_t)node * S;
                 double stack = 0.0;
-                for (int r = 0; r < S; ++r) {               // ascending rows: migratelib.c:54-59
+                // ascending rows, one add each (migratelib.c:54-59); six rows' loads in flight at a time -- the
+                // two dependent loads per row one after the other made this kernel 1.35 ms of a C3 step
+                constexpr int U = 6;
+                int r = 0;
+                for (; r + U <= S; r += U) {
+                    int d[U];
+                    double v[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) d[u] = row[r + u];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) v[u] = onsets[(int64_t)(r + u) * a.T + (d[u] < 0 ? 0 : d[u]) + col];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) stack += v[u];
+                }
+                for (; r < S; ++r) {
                     int d = row[r];
                     d = d < 0 ? 0 : d;
-                    stack += a.onsets[(int64_t)r * a.T + d + col];
+                    stack += onsets[(int64_t)r * a.T + d + col];
                 }
                 if (!(stack * a.z_scale >= lo)) continue;
                 const double e = exp_correctly_rounded(stack * a.recip);
@@ -277,6 +311,55 @@ __global__ __launch_bounds__(256) void tie_apply_kernel(const int32_t *__restric
                                                         int64_t node_offset, int64_t *__restrict__ o_idx) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n && imin[t] != INT32_MAX) o_idx[t] = node_offset + imin[t];
+}
+
+// Sharded detects: an engine's refinement against the grid's maxima leaves, per sample, the largest correctly
+// rounded exp among ITS nodes within the slack (0: none; kTieOverflowKey: more candidate sets than it follows) and
+// the lowest GLOBAL index reaching it -- packed [2][n] for one all-gather --, and every rank folds the ranks'
+// pairs: the largest exp, the lowest index among the ranks that reach it.  A sample that overflowed anywhere
+// keeps the default rule's index on every rank.
+__global__ __launch_bounds__(256) void fill_kernel(double *__restrict__ p, size_t n, double v) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+__global__ __launch_bounds__(256) void tie_zmax_kernel(const double *__restrict__ pmax, int sets, int n,
+                                                       int64_t set_stride, double *__restrict__ zmax) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double zb = -__builtin_inf();
+    for (int s = 0; s < sets; ++s) {
+        const double v = pmax[(int64_t)s * set_stride + t];
+        zb = v > zb ? v : zb;
+    }
+    zmax[t] = zb;
+}
+__global__ __launch_bounds__(256) void tie_export_kernel(const unsigned long long *__restrict__ emax,
+                                                         const int32_t *__restrict__ imin, int n,
+                                                         int64_t node_offset, unsigned long long *__restrict__ o_key,
+                                                         int64_t *__restrict__ o_idx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const bool none = imin[t] == INT32_MAX;
+    o_key[t] = (none && emax[t] != kTieOverflowKey) ? 0ull : emax[t];
+    o_idx[t] = none ? INT64_MAX : node_offset + imin[t];
+}
+__global__ __launch_bounds__(256) void tie_fold_kernel(const unsigned long long *__restrict__ packed, int sets, int n,
+                                                       int64_t *__restrict__ o_idx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    unsigned long long best = 0ull;
+    int64_t at = INT64_MAX;
+    for (int s = 0; s < sets; ++s) {
+        const unsigned long long key = packed[(int64_t)s * 2 * n + t];
+        const int64_t i = (int64_t)packed[(int64_t)s * 2 * n + n + t];
+        if (key > best) {
+            best = key;
+            at = i;
+        } else if (key == best && i < at) {
+            at = i;
+        }
+    }
+    if (best != 0ull && best != kTieOverflowKey && at != INT64_MAX) o_idx[t] = at;
 }
 #endif  // QM_TU_STEPS
 

@@ -28,8 +28,12 @@ CPU tests.  Two equivalent forms:
 
 Both reproduce the reference's tie-break (strict '>' in ascending node order,
 migratelib.c:102) exactly, because equal maxima on two ranks resolve to the lower
-global index.  torch supplies the process group and the device buffers -- plumbing,
-not the hot path.
+global index.  Engines configured with ``tie_rule = 1`` (the reference's rule on NEAR-ties,
+csrc/qm_ties.hpp) add a second, smaller exchange behind the first: every rank examines its
+own partial sets against the grid's maxima (``Engine.tie_partial``), one all-gather of a
+``[2][n_samples]`` buffer (largest correctly rounded exp, lowest global index reaching it)
+and a device fold (``Engine.tie_fold``) give every rank the refined index series.  torch
+supplies the process group and the device buffers -- plumbing, not the hot path.
 """
 
 from __future__ import annotations
@@ -138,6 +142,18 @@ def all_gather_packed(packed, gathered, group=None):
     return gathered
 
 
+def fold_ties_torch(tie_gathered, idx):
+    """The fold of ``Engine.tie_fold`` stated with torch ops (CPU tests): ``tie_gathered`` int64 bit
+    patterns ``[n_sets][2][n_samples]`` (exp keys -- positive doubles order as integers; -1 = a rank
+    that followed too many candidate sets --, global indices), ``idx`` the default rule's series."""
+    keys, at = tie_gathered[:, 0, :], tie_gathered[:, 1, :]
+    overflow = (keys == -1).any(dim=0)
+    best = keys.max(dim=0).values
+    cand = torch.where(keys == best.unsqueeze(0), at, torch.full_like(at, INT64_MAX)).min(dim=0).values
+    take = (best > 0) & ~overflow & (cand != INT64_MAX)
+    return torch.where(take, cand, idx)
+
+
 def combine_packed_torch(gathered, n_nodes_total):
     """The fold of ``Engine.finalize_packed`` stated with torch ops (CPU tests; any device)."""
     return combine_partials_local(gathered[:, 0, :], gathered[:, 1, :].view(torch.int64),
@@ -214,6 +230,14 @@ class ShardedDetector:
         self.out = (torch.empty(ns, dtype=torch.float64, device=self.device),
                     torch.empty(ns, dtype=torch.float64, device=self.device),
                     torch.empty(ns, dtype=torch.int64, device=self.device))
+        # tie_rule = 1: a rank's outcome (exp bits, index bits) and the gathered ones; every rank of the
+        # group must be configured alike (the second exchange is a collective)
+        self.tie_rule = bool(engine.get("tie_rule")) if hasattr(engine, "get") else False
+        if self.tie_rule and exchange != "packed":
+            raise ValueError("tie_rule = 1 on a sharded detect uses the packed exchange")
+        self.tie_packed = torch.zeros((2, ns), dtype=torch.float64, device=self.device)
+        self.tie_packed[1].view(torch.int64).fill_(INT64_MAX)
+        self.tie_gathered = torch.empty((self.world, 2, ns), dtype=torch.float64, device=self.device)
         self._bound = None
 
     def _bind_stream(self):
@@ -249,8 +273,15 @@ class ShardedDetector:
                 dst.copy_(src)
             return out
         all_gather_packed(self.packed, self.gathered, self.group)
-        return self.engine.finalize_packed(self.gathered, self.world, self.n_samples,
-                                           self.n_nodes_total, out=out)
+        out = self.engine.finalize_packed(self.gathered, self.world, self.n_samples,
+                                          self.n_nodes_total, out=out)
+        if self.tie_rule:
+            if self.engine.n_rows is not None:               # (an empty slab keeps the neutral outcome)
+                self.engine.tie_partial(log_onsets, fsmp, lsmp, available, self.gathered, self.world,
+                                        self.tie_packed)
+            all_gather_packed(self.tie_packed, self.tie_gathered, self.group)
+            self.engine.tie_fold(self.tie_gathered, self.world, self.n_samples, out[2])
+        return out
 
     def marginal_map(self, log_onsets, fsmp, lsmp, available, first_sample, end_sample, nx_total,
                      plane_shape=None):
@@ -314,6 +345,15 @@ class ColumnShardedDetector:
         self.out = (torch.empty(ns, dtype=torch.float64, device=self.device),
                     torch.empty(ns, dtype=torch.float64, device=self.device),
                     torch.empty(ns, dtype=torch.int64, device=self.device))
+        # tie_rule = 1 (as ShardedDetector): one outcome per box
+        rules = {bool(e.get("tie_rule")) for e in self.engines + [self.fold_engine]}
+        if len(rules) > 1:
+            raise ValueError("the engines of one rank must share their tie_rule")
+        self.tie_rule = rules.pop()
+        self.tie_packed = torch.zeros((MAX_BOXES, 2, ns), dtype=torch.float64, device=self.device)
+        self.tie_packed[:, 1].view(torch.int64).fill_(INT64_MAX)
+        self.tie_gathered = torch.empty((self.world, MAX_BOXES, 2, ns), dtype=torch.float64,
+                                        device=self.device)
         self._bound = None
 
     def _bind_stream(self):
@@ -335,5 +375,12 @@ class ColumnShardedDetector:
                                (self.packed[k, 0], self.packed[k, 1].view(torch.int64),
                                 self.packed[k, 2]))
         all_gather_packed(self.packed, self.gathered, self.group)
-        return self.fold_engine.finalize_packed(self.gathered, self.world * MAX_BOXES,
-                                                self.n_samples, self.n_nodes_total, out=out)
+        out = self.fold_engine.finalize_packed(self.gathered, self.world * MAX_BOXES,
+                                               self.n_samples, self.n_nodes_total, out=out)
+        if self.tie_rule:
+            for k, eng in enumerate(self.engines):
+                eng.tie_partial(log_onsets, fsmp, lsmp, available, self.gathered,
+                                self.world * MAX_BOXES, self.tie_packed[k])
+            all_gather_packed(self.tie_packed, self.tie_gathered, self.group)
+            self.fold_engine.tie_fold(self.tie_gathered, self.world * MAX_BOXES, self.n_samples, out[2])
+        return out

@@ -2596,7 +2596,10 @@ def test_streaming_detector_steps_per_launch(lib, oracle):
     eng = lib.Engine(0)
     eng.load_lut(case.traveltimes)
     base = None
-    for k in (1, 3, 4):
+    # (round 6: slots of <= 1 MB are PULLED by a kernel on the engine's stream instead of copied by a command on
+    # another -- 24 rows x 706 samples x K here: all of them; "stream_pull" = 0 is the copy stream of round 5)
+    for k, pull in ((1, -1), (3, -1), (4, -1), (1, 0), (3, 1)):
+        eng.config("stream_pull", pull)
         sd = StreamingDetector(eng, case.available, wins[0].shape[1], case.fsmp, case.lsmp,
                                case.available, depth=2, steps_per_launch=k)
         got = sd.run(iter(wins))
@@ -2959,8 +2962,123 @@ def test_tie_rule_exp_reproduces_the_references_scalar_build(lib, oracle, cfg):
         eng.marginal_map(lon, fsmp, lsmp, avail, 0, len(c), scan_out=series)
         assert np.array_equal(series[2], idx_scalar)
         k3 = eng.detect_batch(np.stack([lon, lon, lon]), fsmp, lsmp, avail)
-        assert all(np.array_equal(k3[2][k], idx_scalar) for k in range(3)) and eng.get("steps_per_launch") == 1
+        assert all(np.array_equal(k3[2][k], idx_scalar) for k in range(3)) and eng.get("steps_per_launch") == 3
         eng.close()
+
+
+@pytest.mark.parametrize("cfg", [{}, {"shift_wide": 1}, {"shift_wide": 1, "shift_lazy": 1}, {"shift_waves": 8},
+                                 {"shift_lazy": 1, "groups": 7}, {"tie_sets": 0}, {"shift": 0}],
+                         ids=["auto", "wide", "wide-lazy", "8-wave", "lazy-7-groups", "round-5-sets", "round-2-kernels"])
+def test_tie_rule_from_a_partial_set_per_brick(lib, oracle, cfg):
+    """Round 6: with tie_rule = 1 the shift-reuse fused detect publishes a partial set PER BRICK of a workgroup's
+    walk (4-wave, 8-wave and wide tiles; lazy and eager loops) and the refinement re-stacks one brick per sample.
+    Fixture near_ties_bricks: mirror twins on a (40, 24, 20) grid -- a node and its image lie in different bricks
+    -- whose every sample is a near-tie, index series of the reference's scalar-libm build
+    (oracle/make_golden_ties.py): equal on EVERY sample, values the default rule's bits, and K steps in one
+    launch keep both."""
+    g = load_golden("near_ties_bricks")
+    tt, fsmp, lsmp, avail = g["traveltimes"], int(g["fsmp"]), int(g["lsmp"]), int(g["available"])
+    lon = oracle.log_onsets(g["onsets"])
+    base = lib.Engine(0, **{k: v for k, v in cfg.items() if k != "tie_sets"})
+    base.load_lut(tt)
+    a0, b0, c0 = base.detect(lon, fsmp, lsmp, avail)
+    base.close()
+    assert 0.03 < np.mean(c0 != g["idx_scalar"]) < 0.2      # the default rule is the other one
+    eng = lib.Engine(0, tie_rule=1, **cfg)
+    eng.load_lut(tt)
+    a, b, c = eng.detect(lon, fsmp, lsmp, avail)
+    shift = cfg.get("shift", -1) != 0
+    assert eng.get("last_kernel") == (3 if shift else 1)
+    # (a row of maxima per brick -- 45 bricks of 8x8x8, 30 of 8x8x16 nodes; the wide tiles' loop raises them itself)
+    rows = eng.get("tie_brick_rows")
+    assert rows == (0 if not shift or cfg.get("tie_sets", 1) == 0 else 30 if "shift_wide" in cfg else 45), rows
+    if "shift_wide" in cfg:
+        assert eng.get("last_kernel_j") == 6
+    assert np.array_equal(c, g["idx_scalar"]), float(np.mean(c != g["idx_scalar"]))
+    assert np.array_equal(a, a0) and eng.get("tie_overflow_samples") == 0
+    np.testing.assert_allclose(b, b0, rtol=1e-13)
+    np.testing.assert_allclose(a, g["max_coa_scalar"], rtol=TIGHT)
+    np.testing.assert_allclose(b, g["max_norm_coa_scalar"], rtol=NORM)
+    # K = 1 / 2 / 5 timesteps per launch (different onsets per step: the twins' rows rolled): every step is
+    # its own single-step call, bit for bit, and the launch kept its step axis
+    steps = np.stack([np.roll(lon, 7 * k, axis=1) for k in range(5)])
+    single = [eng.detect(steps[k], fsmp, lsmp, avail) for k in range(5)]
+    for k in (1, 2, 5):
+        got = eng.detect_batch(steps[:k], fsmp, lsmp, avail)
+        assert eng.get("steps_per_launch") == k
+        for j in range(k):
+            assert all(np.array_equal(got[i][j], single[j][i]) for i in range(3)), (cfg, k, j)
+    eng.close()
+
+
+def _tie_sharded_rank(rank, world, port, tmp, columns):
+    """One rank of a sharded detect with tie_rule = 1 on the near_ties_bricks family (a node and its mirror
+    image live on DIFFERENT ranks: the mid-plane is the shard boundary), both ranks on GPU 0 over gloo."""
+    import os
+    import pathlib
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    from conftest import ROOT, load_golden as _load
+
+    sys.path.insert(0, str(ROOT))
+    from quakemigrate_amd import distributed as qd
+    from quakemigrate_amd.core import lib as _lib
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    g = _load("near_ties_bricks")
+    tt, fsmp, lsmp, avail = g["traveltimes"], int(g["fsmp"]), int(g["lsmp"]), int(g["available"])
+    nx, ny, nz = tt.shape[:3]
+    lon = torch.from_numpy(np.ascontiguousarray(np.log(np.clip(g["onsets"], 0.01, np.inf)))).cuda()
+    ns = lon.shape[1] - fsmp - lsmp
+    dev = torch.device("cuda", 0)
+    if columns:
+        boxes = qd.column_boxes(*qd.shard_columns(nx, ny, world, rank), ny)
+        engines = []
+        for (x0, x1, y0, y1) in boxes:
+            eng = _lib.Engine(0, tie_rule=1)
+            eng.load_lut(np.ascontiguousarray(tt[x0:x1, y0:y1]), node_offset=(x0 * ny + y0) * nz)
+            engines.append(eng)
+        sd = qd.ColumnShardedDetector(engines, nx * ny * nz, ns, dev, fold_engine=_lib.Engine(0, tie_rule=1))
+    else:
+        x0, x1 = qd.shard_planes(nx, world, rank)
+        eng = _lib.Engine(0, tie_rule=1)
+        eng.load_lut(np.ascontiguousarray(tt[x0:x1]), node_offset=x0 * ny * nz)
+        sd = qd.ShardedDetector(eng, nx * ny * nz, ns, dev)
+    first = tuple(t.clone() for t in sd.detect(lon, fsmp, lsmp, avail))
+    again = sd.detect(lon, fsmp, lsmp, avail)
+    torch.cuda.synchronize()
+    assert all(torch.equal(u, v) for u, v in zip(first, again))
+    np.savez(pathlib.Path(tmp) / f"tie{rank}.npz", a=first[0].cpu().numpy(), b=first[1].cpu().numpy(),
+             c=first[2].cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("columns", [False, True], ids=["planes", "columns"])
+def test_tie_rule_on_a_sharded_detect(lib, oracle, tmp_path, columns):
+    """tie_rule = 1 across ranks (qm_engine_tie_partial / qm_engine_tie_fold): two processes, the grid cut at its
+    mirror plane (plane slabs) or at a column in the middle of a plane (three boxes per rank), every rank refines
+    its own partial sets against the GRID's maxima, one more all-gather, a device fold -- the index series is the
+    reference's scalar-libm build's on every sample, on every rank (near_ties_bricks)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_tie_sharded_rank, args=(2, port, str(tmp_path), columns), nprocs=2, join=True)
+    g = load_golden("near_ties_bricks")
+    for rank in range(2):
+        got = np.load(tmp_path / f"tie{rank}.npz")
+        assert np.array_equal(got["c"], g["idx_scalar"]), float(np.mean(got["c"] != g["idx_scalar"]))
+        np.testing.assert_allclose(got["a"], g["max_coa_scalar"], rtol=TIGHT)
+        np.testing.assert_allclose(got["b"], g["max_norm_coa_scalar"], rtol=NORM)
 
 
 def test_tie_rule_exp_changes_nothing_where_the_maximum_stands_alone(lib, oracle):
@@ -2982,14 +3100,15 @@ def test_tie_rule_exp_changes_nothing_where_the_maximum_stands_alone(lib, oracle
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2]), recipe
         np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-13)
     case = synth.make_case("C3", step=1, grid=(24, 24, 16), rows=12, n_samples=130, quiet=True)
-    eng = lib.Engine(0, tie_rule=1, groups=64)
-    eng.load_lut(case.traveltimes)
-    a, b, c = eng.detect(oracle.log_onsets(case.onsets), case.fsmp, case.lsmp, case.available)
-    assert (c == 0).all() and eng.get("tie_overflow_samples") == 130
-    eng.close()
+    for sets in (0, 1):                                        # (a set per brick: 18 of them, all tied)
+        eng = lib.Engine(0, tie_rule=1, groups=64, tie_sets=sets)
+        eng.load_lut(case.traveltimes)
+        a, b, c = eng.detect(oracle.log_onsets(case.onsets), case.fsmp, case.lsmp, case.available)
+        assert (c == 0).all() and eng.get("tie_overflow_samples") == 130
+        eng.close()
     # ... and with few sets the refinement follows them: every node is a candidate (far more than the
     # candidate list holds: the second stacking pass takes over), all exps are equal, index 0
-    eng = lib.Engine(0, tie_rule=1, groups=4)
+    eng = lib.Engine(0, tie_rule=1, groups=4, tie_sets=0)
     eng.load_lut(case.traveltimes)
     a, b, c = eng.detect(oracle.log_onsets(case.onsets), case.fsmp, case.lsmp, case.available)
     assert (c == 0).all() and eng.get("tie_overflow_samples") == 0 and eng.get("tie_pairs") == 4 * 130

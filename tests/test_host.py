@@ -292,6 +292,92 @@ def test_exchange_partials_world_size_2_gloo(oracle, tmp_path):
         np.testing.assert_allclose(got["marg"], vol[..., 40:150].sum(axis=-1), rtol=1e-13)
 
 
+def _worker_ties(rank, world, port, tmp):
+    """tie_rule = 1 across ranks, stated with numpy / torch on CPU: the protocol of ShardedDetector's second
+    exchange (csrc/qm_ties.hpp: tie_export_kernel / tie_fold_kernel) on the near_ties_bricks family, the grid cut
+    at its mirror plane."""
+    import ctypes
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, str(ROOT))
+    from conftest import load_golden
+    from quakemigrate_amd import distributed as qd
+    from quakemigrate_amd.core import lib as qlib
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_golden("near_ties_bricks")
+    tt, fsmp, lsmp, avail = g["traveltimes"], int(g["fsmp"]), int(g["lsmp"]), int(g["available"])
+    nx, ny, nz, S = tt.shape
+    x0, x1 = qd.shard_planes(nx, world, rank)
+    lon = np.log(np.clip(g["onsets"], 0.01, np.inf))
+    ns = lon.shape[1] - fsmp - lsmp
+    flat = np.clip(tt[x0:x1].reshape(-1, S), 0, None)
+    stack = np.zeros((flat.shape[0], ns))
+    for r in range(S):                                   # ascending rows, one add each (migratelib.c:54-59)
+        stack += lon[r][fsmp + flat[:, r][:, None] + np.arange(ns)[None, :]]
+    offset = x0 * ny * nz
+    z = stack * (1.4426950408889634074 / avail)
+    first = np.argmax(z, axis=0)
+    packed = torch.empty((3, ns), dtype=torch.float64)
+    packed[0] = torch.from_numpy(z[first, np.arange(ns)])
+    packed[1].view(torch.int64).copy_(torch.from_numpy(first.astype(np.int64) + offset))
+    packed[2] = torch.from_numpy(np.exp2(z).sum(axis=0))
+    gathered = torch.empty((world, 3, ns), dtype=torch.float64)
+    qd.all_gather_packed(packed, gathered)
+    _, _, idx = qd.combine_packed_torch(gathered, nx * ny * nz)
+    # this rank's candidates against the GRID's maxima: within the slack, compared on a correctly rounded exp
+    zbest = gathered[:, 0, :].max(dim=0).values.numpy()
+    lo = zbest - (4.0e-16 + 2.0 ** -50 * np.abs(zbest))
+    tie = torch.zeros((2, ns), dtype=torch.float64)
+    keys, at = tie[0].view(torch.int64), tie[1].view(torch.int64)
+    at.fill_(qd.INT64_MAX)
+    exp_cr = qlib.qmlib.qm_exp_correctly_rounded
+    for t in range(ns):
+        cand = np.nonzero(z[:, t] >= lo[t])[0]
+        if len(cand) == 0:
+            continue
+        e = np.array([exp_cr(float(stack[n, t] * (1.0 / avail))) for n in cand])
+        keys[t] = int(np.float64(e.max()).view(np.int64))
+        at[t] = int(cand[np.argmax(e)]) + offset         # (first maximum = lowest index)
+    tie_gathered = torch.empty((world, 2, ns), dtype=torch.float64)
+    qd.all_gather_packed(tie, tie_gathered)
+    refined = qd.fold_ties_torch(tie_gathered.view(torch.int64), idx)
+    np.savez(pathlib.Path(tmp) / f"ties{rank}.npz", default=idx.numpy(), refined=refined.numpy(),
+             candidates=int((keys != 0).sum()))
+    dist.destroy_process_group()
+
+
+def test_tie_rule_exchange_world_size_2_gloo(built, tmp_path):
+    """The sharded form of tie_rule = 1 (SURVEY.md section 8e + migratelib.c:98-105): ranks exchange (largest
+    correctly rounded exp among their near-tied nodes, lowest global index reaching it) behind the partials and
+    fold -- on the mirror-twin family whose twins live on DIFFERENT ranks the folded index series equals the
+    reference's scalar-libm build on every sample, where the default rule differs on several per cent."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from conftest import load_golden
+    from quakemigrate_amd import distributed as qd
+
+    mp.spawn(_worker_ties, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    want = load_golden("near_ties_bricks")["idx_scalar"]
+    for rank in range(2):
+        got = np.load(tmp_path / f"ties{rank}.npz")
+        assert np.array_equal(got["refined"], want), float(np.mean(got["refined"] != want))
+        assert 0.03 < np.mean(got["default"] != want) < 0.2
+        assert got["candidates"] > 0.3 * len(want)           # (both ranks hold candidates for most samples)
+    # the fold itself: a rank that followed too many candidate sets (-1) keeps the default on every rank; equal
+    # exps go to the lowest index; samples nobody refined keep theirs
+    keys = torch.tensor([[5, 7, 0, -1, 9], [5, 3, 0, 8, 9]], dtype=torch.int64)
+    at = torch.tensor([[40, 11, qd.INT64_MAX, 3, 70], [30, 2, qd.INT64_MAX, 4, 60]], dtype=torch.int64)
+    default = torch.tensor([100, 101, 102, 103, 104], dtype=torch.int64)
+    got = qd.fold_ties_torch(torch.stack([keys, at], dim=1), default)
+    assert got.tolist() == [30, 11, 102, 103, 60]
+
+
 def _worker_columns(rank, world, port, tmp, grid, rows, ns, tag):
     """One rank of a column-partitioned detect on CPU: every box's partial set from the oracle, the packed
     all-gather + fold and the three-all-reduce form (quakemigrate_amd.distributed) -- SURVEY section 8e."""
