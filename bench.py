@@ -595,7 +595,14 @@ def main():
 
         sd = StreamingDetector(eng, S, t_samples, case.fsmp, case.lsmp, case.available,
                                n_nodes_total=n_norm, depth=3, device=dev, steps_per_launch=spl)
-        sd.run(host_onsets[i % n_pool] for i in range(2 * spl))     # set-up + warm
+        # set-up + warm.  Round 6 (tools/diag_stream.py with "stream_stamps"): ONCE per process, around the 180th
+        # launch of its first stream, the GPU's command processor sits idle for ~35 ms with launches queued --
+        # whatever they hold (no copies, no host writes, no events: the same), a pause does not move it, later
+        # streams of the process do not see it.  Inside a 400-step window of 0.4-ms steps that one stall read as
+        # "x1.27 with copies"; configurations whose launches are that short warm up past it (<= 0.5 s), and the
+        # line says how many launches that was.
+        warm_launches = 2 if elapsed / args.steps * spl * 256 > 0.5 else 256
+        sd.run(host_onsets[i % n_pool] for i in range(warm_launches * spl))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         got = sd.run(host_onsets[(args.warmup + i) % n_pool] for i in range(args.steps))
@@ -606,6 +613,8 @@ def main():
         result["step_with_copies"] = {
             "ms_per_step": dt * 1e3, "value": work_step / dt, "unit": "node-samples/s",
             "steps": args.steps, "identical_to_resident_run": bool(same),
+            "warmup_launches": warm_launches, "input": "pulled by a kernel" if sd.engine.get("stream_pull") != 0 and
+            8.0 * S * t_samples * spl <= (1 << 20) else "copy stream",
             "what": "per step: H2D of the log-onsets from pinned host memory "
                     f"({8.0 * S * t_samples / 1e6:.1f} MB) on a copy stream, fused detect, the three "
                     "series written by the launch straight into pinned host memory; the native "

@@ -180,6 +180,9 @@ int qm_engine_synchronize(qm_engine *e);
  *                                                slots of <= 1 MB (example-sized grids, few steps per launch), 1 =
  *                                                always, 0 = never; same results
  * -- measurement --
+ * stream_stamps         0 / 1 [0]                qm_stream: a one-thread kernel before and behind every launch stores
+ *                                                the GPU's clock; busy time per launch and the gaps between launches
+ *                                                go to stderr when the stream is destroyed
  * log_timing            0 / 1 [0]                HIP events around every stacking launch (qm_engine_kernel_log)
  *
  * read-outs (qm_engine_get), besides the keys above: n_cu, n_nodes, n_rows, nx, ny, nz, n_bricks,

@@ -850,6 +850,8 @@ int qm_engine_config(qm_engine *e, const char *key, int64_t v) {
     } else if (k == "stream_pull") {
         if (v < -1 || v > 1) return fail("stream_pull must be -1 (slots of <= 1 MB), 0 (never) or 1 (always)");
         e->cfg_stream_pull = (int)v;
+    } else if (k == "stream_stamps") {
+        e->cfg_stream_stamps = v ? 1 : 0;
     } else if (k == "log_timing") {
         e->log_timing = v != 0;
         e->ev_used = 0;

@@ -246,6 +246,7 @@ struct qm_engine : TableState {
                                             // 2: row blocks whatever fits -- tests)
     int cfg_stream_pull = -1;               // qm_stream: a slot's pinned inputs pulled by a kernel on the engine's stream
                                             // instead of a copy command on another (-1: slots of <= 1 MB, 0, 1)
+    int cfg_stream_stamps = 0;              // qm_stream, measurement: GPU-clock stamps around every launch (stderr digest)
     int cfg_tie_rule = 0;                   // 0: largest float64 sum, lowest index among equal ones (default);
                                             // 1: the reference's rule on near-ties (qm_ties.hpp)
     int cfg_tie_sets = 1;                   // ... refined from a partial set PER BRICK where the stacking kernel has

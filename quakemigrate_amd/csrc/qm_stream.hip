@@ -49,6 +49,7 @@ struct qm_stream {
     std::deque<int> order;              // slots in flight, oldest first
     int fill_slot = 0, fill_n = 0;      // slot being filled, steps pushed into it so far
     int64_t launched_steps = 0, popped_steps = 0, launches = 0;
+    unsigned long long *h_stamp = nullptr;   // ("stream_stamps") pinned [2][4096]
     bool pulled = false;                // the last launch's inputs were pulled by a kernel (no copy command)
 };
 
@@ -72,6 +73,9 @@ __global__ __launch_bounds__(256) void pull_kernel(const pull2 *__restrict__ src
     if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) dst1[n - 1] = src1[n - 1];
 }
 
+// ("stream_stamps": the GPU's own clock before and behind every launch of a stream, digested at its destruction)
+__global__ void stamp_kernel(unsigned long long *slot) { *slot = wall_clock64(); }
+
 size_t step_in(const qm_stream *s) { return (size_t)s->n_rows * s->T; }
 
 int alive(const qm_stream *s, const char *what) {
@@ -92,6 +96,25 @@ void free_slot(qm_stream::Slot &sl) {
 // everything the stream holds on its engine's device goes back (the engine's device is current)
 void release_stream(qm_stream *s) {
     (void)hipStreamSynchronize(s->e->stream);
+    if (s->h_stamp) {
+        // launch i: [begin_i, end_i]; gap_i = begin_i - end_(i-1)   (wall_clock64: 100 MHz)
+        const int n = (int)std::min<int64_t>(s->launches, 4096);
+        std::vector<double> busy, gap;
+        for (int i = 8; i < n; ++i) {
+            busy.push_back((double)(s->h_stamp[4096 + i] - s->h_stamp[i]) * 0.01);
+            gap.push_back((double)(s->h_stamp[i] - s->h_stamp[4096 + i - 1]) * 0.01);
+        }
+        for (int i = 0; i < (int)gap.size(); ++i)
+            if (gap[i] > 200.0) std::fprintf(stderr, "qm_stream stamps: gap of %.1f us before launch %d\n", gap[i], i + 8);
+        std::sort(busy.begin(), busy.end());
+        std::sort(gap.begin(), gap.end());
+        if (!busy.empty())
+            std::fprintf(stderr, "qm_stream stamps: %d launches; launch busy us median %.1f p90 %.1f; gap between launches "
+                         "us median %.1f p90 %.1f max %.1f\n", n, busy[busy.size() / 2], busy[busy.size() * 9 / 10],
+                         gap[gap.size() / 2], gap[gap.size() * 9 / 10], gap.back());
+        (void)hipHostFree(s->h_stamp);
+        s->h_stamp = nullptr;
+    }
     if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
     {
         PoolReleaseScope one_wait;
@@ -117,6 +140,16 @@ int launch_slot(qm_stream *s) {
     const size_t kns = (size_t)s->K * s->ns;
     const size_t words = (size_t)n * step_in(s);
     const bool pull = e->cfg_stream_pull > 0 || (e->cfg_stream_pull < 0 && words * sizeof(double) <= kPullBytes);
+    // ("stream_stamps" = 1, measurement: the GPU's clock before and behind every launch -- two one-thread kernels;
+    // the digest goes to stderr when the stream is destroyed.  What found round 6's one-off stall: tools/diag_stream.py)
+    const bool stamps = e->cfg_stream_stamps != 0;
+    constexpr int kStamps = 4096;
+    if (stamps && !s->h_stamp) {
+        QM_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_stamp), 2 * kStamps * sizeof(unsigned long long),
+                             hipHostMallocDefault));
+        std::memset(s->h_stamp, 0, 2 * kStamps * sizeof(unsigned long long));
+    }
+    if (stamps) hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, e->stream, s->h_stamp + (s->launches % kStamps));
     if (pull) {
         const unsigned blocks = (unsigned)std::min<size_t>(4 * (size_t)e->n_cu, (words / 2 + 255) / 256 + 1);
         hipLaunchKernelGGL(pull_kernel, dim3(blocks), dim3(256), 0, e->stream,
@@ -138,6 +171,8 @@ int launch_slot(qm_stream *s) {
     if (qm_engine_detect_batch(e, sl.d_on, 1, n, s->T, s->fsmp, s->lsmp, s->available, s->n_nodes_total,
                                out, out + kns, reinterpret_cast<int64_t *>(out + 2 * kns), 1))
         return 1;
+    if (stamps)
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, e->stream, s->h_stamp + kStamps + (s->launches % kStamps));
     QM_HIP(hipEventRecord(sl.done, e->stream));
     sl.n = n;
     sl.taken = 0;

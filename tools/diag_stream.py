@@ -1,6 +1,7 @@
 """Where does the native streaming pipeline (qm_stream_*) spend its time?  (development aid)
 
-usage: diag_stream.py CONFIG K [depth] [steps]
+usage: diag_stream.py CONFIG K [depth] [steps] [engine config json, e.g. '{"stream_stamps": 1}']
+       (DIAG_WARM = launches before the clock starts, DIAG_SLEEP = seconds of pause before it)
 Prints per step: wall with the copies inside, the stacking kernel's own time (HIP events), the host's time in
 push / pop, against the resident step."""
 import json
@@ -22,7 +23,7 @@ steps = int(sys.argv[4]) if len(sys.argv) > 4 else 400
 case = synth.make_case(cfg, step=0)
 wins = [np.ascontiguousarray(np.log(np.clip(synth.make_case(cfg, step=s, table=False).onsets, 0.01, np.inf)))
         for s in range(8)]
-eng = lib.Engine(0)
+eng = lib.Engine(0, **(json.loads(sys.argv[5]) if len(sys.argv) > 5 else {}))
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 eng.load_lut(case.traveltimes)
 S, T = wins[0].shape
@@ -37,10 +38,13 @@ for _ in range(steps // K):
 torch.cuda.synchronize()
 resident = (time.perf_counter() - t0) / (steps // K * K)
 sd = StreamingDetector(eng, S, T, case.fsmp, case.lsmp, case.available, depth=depth, steps_per_launch=K)
-sd.run(wins[i % 8] for i in range(4 * K))
+import os
+sd.run(wins[i % 8] for i in range(int(os.environ.get("DIAG_WARM", 4)) * K))
+time.sleep(float(os.environ.get("DIAG_SLEEP", 0)))
 eng.config("log_timing", 1)
 t_push = t_pop = 0.0
 n_full = 0
+slow = []                                    # host calls of more than 2 ms: (step, call, ms)
 t0 = time.perf_counter()
 done = 0
 for i in range(steps):
@@ -49,12 +53,16 @@ for i in range(steps):
         a = time.perf_counter()
         ok = sd.push(w)
         t_push += time.perf_counter() - a
+        if time.perf_counter() - a > 2e-3:
+            slow.append((i, "push", round((time.perf_counter() - a) * 1e3, 2)))
         if ok:
             break
         n_full += 1
         a = time.perf_counter()
         sd.pop(min(K, sd.pending()[0]))
         t_pop += time.perf_counter() - a
+        if time.perf_counter() - a > 2e-3:
+            slow.append((i, "pop", round((time.perf_counter() - a) * 1e3, 2)))
         done += K
 sd.flush()
 a = time.perf_counter()
@@ -67,4 +75,5 @@ print(json.dumps({"config": cfg, "K": K, "depth": depth, "steps": steps, "reside
                   "with_copies_ms": round(wall * 1e3, 4), "ratio": round(wall / resident, 3),
                   "kernel_ms_per_step": round(kms / steps, 4), "launches": calls,
                   "host_push_ms_per_step": round(t_push / steps * 1e3, 4),
-                  "host_pop_ms_per_step": round(t_pop / steps * 1e3, 4), "ring_full": n_full}))
+                  "host_pop_ms_per_step": round(t_pop / steps * 1e3, 4), "ring_full": n_full,
+                  "slow_host_calls": slow}))
