@@ -1,4 +1,4 @@
-// stack_shift_kernel<kShiftDetect, NW, SETS = true> (qm_shift.hpp): the fused detect that publishes a partial
+// stack_shift_bricks_kernel<NW> (qm_shift.hpp): the fused detect that publishes a partial
 // set per brick of a workgroup's walk -- what "tie_rule" = 1 refines from (qm_ties.hpp); a unit of its own so that
 // it compiles beside qm_launch_shift.hip
 #define QM_SHIFT_TU 2
@@ -7,9 +7,9 @@
 
 namespace qm {
 hipError_t launch_shift_detect_sets(const ShiftArgs &a, const LaunchShape &s) {
-    return launch_with_lds(&stack_shift_kernel<kShiftDetect, kShiftWaves, true>, a, s);
+    return launch_with_lds(&stack_shift_bricks_kernel<kShiftWaves>, a, s);
 }
 hipError_t launch_shift_detect8_sets(const ShiftArgs &a, const LaunchShape &s) {
-    return launch_with_lds(&stack_shift_kernel<kShiftDetect, kShiftWaves8, true>, a, s);
+    return launch_with_lds(&stack_shift_bricks_kernel<kShiftWaves8>, a, s);
 }
 }  // namespace qm

@@ -807,11 +807,10 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
     shift_publish<NW, J>(a, win, vmax, vsum, vidx, wave, lane, group, t_first);
 }
 
-template <int MODE, int NW, bool SETS = false>   // (SETS: also a.brick_max, see shift_tile)
-__global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_shift_kernel(ShiftArgs s) {
+template <int MODE, int NW, bool SETS>           // (SETS: also a.brick_max, see shift_tile)
+__device__ __forceinline__ void stack_shift_body(ShiftArgs &s, double *win) {
     static_assert(NW == kShiftWaves || NW == kShiftWaves8 || (NW == kShiftWaves3 && MODE == kShiftDetect),
                   "workgroup shapes: 4 or 8 waves, or 12 (detect only)");
-    extern __shared__ __attribute__((aligned(16))) double win[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if constexpr (MODE == kShiftDetect) s.a = step_view(s.a);   // (several timesteps per launch: this workgroup's)
@@ -833,6 +832,18 @@ __global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_
         if (work.spl == 1) return shift_tile<MODE, NW, 1, false, SETS ? 1 : 0>(s, win, work, lane, wave);
     }
     shift_tile<MODE, NW, 4, false, SETS ? 1 : 0>(s, win, work, lane, wave);
+}
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * kWave, NW == kShiftWaves3 ? 3 : 2) void stack_shift_kernel(ShiftArgs s) {
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    stack_shift_body<MODE, NW, false>(s, win);
+}
+// the fused detect that also leaves a row of maxima per BRICK (StackArgs::brick_max; tie_rule = 1, qm_ties.hpp)
+template <int NW>
+__global__ __launch_bounds__(NW * kWave, 2) void stack_shift_bricks_kernel(ShiftArgs s) {
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    stack_shift_body<kShiftDetect, NW, true>(s, win);
 }
 
 // Tables of more rows than a CU's LDS holds windows for (> 64): ROW BLOCKS.  A brick is as many

@@ -157,6 +157,8 @@ int launch_slot(qm_stream *s) {
                            words / 2, (const double *)sl.h_on, sl.d_on, words);
         QM_HIP(hipGetLastError());
     } else {
+        if (!s->copy_stream && acquire_stream(e->device, &s->copy_stream) != hipSuccess)
+            return fail("qm_stream: no HIP stream for the input copies");
         QM_HIP(hipMemcpyAsync(sl.d_on, sl.h_on, words * sizeof(double), hipMemcpyHostToDevice, s->copy_stream));
         QM_HIP(hipEventRecord(sl.copied, s->copy_stream));
         QM_HIP(hipStreamWaitEvent(e->stream, sl.copied, 0));
@@ -219,8 +221,7 @@ int qm_stream_create(qm_engine *e, int32_t t_samples, int32_t fsmp, int32_t lsmp
         qm_stream_destroy(s);
         return rc;
     };
-    if (acquire_stream(e->device, &s->copy_stream) != hipSuccess)
-        return bail(fail("qm_stream_create: no HIP stream"));
+    // (the copy stream is taken at the first launch that copies: slots that are pulled never need one)
     s->slots.resize((size_t)depth);
     const size_t in_bytes = (size_t)s->K * step_in(s) * sizeof(double);
     const size_t out_bytes = 3 * (size_t)s->K * ns * sizeof(double);

@@ -665,14 +665,17 @@ def test_headline_kernels_stay_in_registers(tmp_path):
                      "template __global__ void qm::stack_shift_rows2_kernel<false, 8>(qm::ShiftArgs);\n"
                      "template __global__ void qm::stack_shift_rows2_kernel<true, 8>(qm::ShiftArgs);\n"
                      "template __global__ void qm::stack_shift_rows4_kernel<false>(qm::ShiftArgs);\n"
-                     "template __global__ void qm::stack_shift_rows4_kernel<true>(qm::ShiftArgs);\n")
+                     "template __global__ void qm::stack_shift_rows4_kernel<true>(qm::ShiftArgs);\n"
+                     # (round 6: the fused detect that also leaves a row of maxima per brick, tie_rule = 1)
+                     "template __global__ void qm::stack_shift_bricks_kernel<4>(qm::ShiftArgs);\n"
+                     "template __global__ void qm::stack_shift_bricks_kernel<8>(qm::ShiftArgs);\n")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17",
                            f"-I{ROOT / 'quakemigrate_amd' / 'csrc'}", "-c", str(shift), "-o",
                            str(tmp_path / "s.o"), "--save-temps"], cwd=tmp_path,
                           stderr=subprocess.DEVNULL)
     sasm = next(tmp_path.glob("s-hip-amdgcn-*.s")).read_text()
     found = re.findall(r"\.set (\S*stack_shift\w*_kernel\S*)\.num_vgpr, (\d+)", sasm)
-    assert len(found) == 13, found                          # (+ the wide tiles' row-block kernel: not a template)
+    assert len(found) == 15, found                          # (+ the wide tiles' row-block kernel: not a template)
     for name, vgprs in found:
         if "Li12E" in name:                                # the opt-in 12-wave shape: three per SIMD
             assert int(vgprs) <= 168, (name, vgprs)

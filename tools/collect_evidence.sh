@@ -14,6 +14,10 @@ for t in C3L_volume C3L_marginal C4_slab rows128; do
   [ -f $O/${t}_kernel_stats.csv ] && { head -1 $O/${t}_kernel_stats.csv; grep -E "stack_shift" $O/${t}_kernel_stats.csv; } > profiles/${R}_${t}_kernel_stats.csv
 done
 [ -f $O/widen_rows.jsonl ] && cp $O/widen_rows.jsonl profiles/${R}_widen_rows.jsonl
+# (round 6, second half) the opt-in tie_rule = 1 beside the default engine; the stream pipeline's one-off stall
+[ -f $O/tie_ab.txt ] && cp $O/tie_ab.txt profiles/${R}_tie_ab.txt
+[ -f $O/C3_tie_rule_kernel_stats.csv ] && { head -1 $O/C3_tie_rule_kernel_stats.csv; grep -E "stack_shift|tie_|fill_|combine" $O/C3_tie_rule_kernel_stats.csv; } > profiles/${R}_C3_tie_rule_kernel_stats.csv
+[ -f $O/stream_stall.txt ] && cp $O/stream_stall.txt profiles/${R}_stream_stall.txt
 for pair in shift:C3shift locate:C3locate marginal:C3marginal C4slab:C4slab; do
   k=${pair%%:*}; n=${pair##*:}
   [ -d $O/pmc_$k ] || continue

@@ -10,11 +10,15 @@
 #   pmc      separate rocprofv3 --pmc passes (SQ, GRBM, FETCH_SIZE, WRITE_SIZE) over the detect, locate-volume,
 #            marginal-map launches at C3 and the detect launch on a C4 slab; the traffic file bench.py reads
 #   widen    the rows SURVEY 8(f) marks next + the drop-in migrate's volume rate
+#   tie      the opt-in tie_rule = 1 beside the default engine (C3 / C2 / C1; round 5's form of it: tie_sets = 0), the
+#            kernel stats of a C3 step with the rule on
+#   stall    one timestep per launch on example-sized grids: the GPU-clock stamps around every launch of a process's
+#            first stream (the one-off stall), the rate behind it, later streams of the same process
 # usage: tools/round_evidence.sh <tag> [part ...]      (default: all parts)     outputs: gpurun_out/<tag>/
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:?tag}; shift
-PARTS=${*:-suite bench ranks stats pmc widen}
+PARTS=${*:-suite bench ranks stats pmc widen tie stall}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
@@ -96,4 +100,28 @@ if has pmc; then
 fi
 if has widen; then
   python tools/widen_bench.py > $OUT/widen_rows.jsonl 2> $OUT/widen.err; cat $OUT/widen_rows.jsonl
+fi
+if has tie; then
+  for c in C3 C2 C1; do
+    python tools/ab.py --config $c --steps 8 --engines '[{}, {"tie_rule": 1}, {"tie_rule": 1, "tie_sets": 0}]' - 2>&1 | grep -v amdgpu.ids
+  done | tee $OUT/tie_ab.txt
+  ( cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_tie -o tie -- \
+        python $ROOT/tools/tune.py --config C3 --reps 6 --sweep '[{"tie_rule": 1}]' > $OUT/stats_tie.log 2>&1
+    find $OUT/prof_tie -name "*kernel_stats.csv" -exec cp {} $OUT/C3_tie_rule_kernel_stats.csv \;
+    find $OUT/prof_tie -name "*.csv" -size +1M -delete )
+  grep -E "stack_shift|tie_|fill_|combine|Name" $OUT/C3_tie_rule_kernel_stats.csv | cut -c1-150
+fi
+if has stall; then
+  { echo "# C1, one timestep per launch, depth 3: GPU-clock stamps around every launch of the process's first stream"
+    python tools/diag_stream.py C1 1 3 600 '{"stream_stamps": 1}' 2>&1 | grep -v amdgpu.ids
+    echo "# the same with the copy stream instead of the pull kernel"
+    python tools/diag_stream.py C1 1 3 600 '{"stream_stamps": 1, "stream_pull": 0}' 2>&1 | grep -v amdgpu.ids
+    echo "# a pause of 0.3 s before the clock starts does not move it"
+    DIAG_SLEEP=0.3 python tools/diag_stream.py C1 1 3 600 2>&1 | grep -v amdgpu.ids
+    echo "# 300 launches before the clock starts: the rate behind it (C1, E2, E1 at K = 1; C1 at K = 8)"
+    for c in C1 E2 E1; do DIAG_WARM=300 python tools/diag_stream.py $c 1 3 600 '{"stream_stamps": 1}' 2>&1 | grep -v amdgpu.ids; done
+    DIAG_WARM=40 python tools/diag_stream.py C1 8 3 800 2>&1 | grep -v amdgpu.ids
+    echo "# three streams one after the other in one process, then detect + device synchronisation per step"
+    python tools/diag_stall.py 2>&1 | grep -v amdgpu.ids; } | cut -c1-420 | tee $OUT/stream_stall.txt
 fi
