@@ -573,6 +573,7 @@ int refine_ties(qm_engine *e, const double *d_on, int T, int fsmp, int available
                 int n_chunk, int sets, int64_t *o_idx, int n_steps, int64_t step_stride,
                 const double *zext, unsigned long long *o_key) {
     const int n = n_chunk * std::max(1, n_steps);
+    if (n > INT32_MAX / (2 * qm::kTieMaxSets)) return fail("tie_rule: %d samples in one launch are too many", n);
     const int max_pairs = qm::kTieMaxSets * n;
     const int max_cands = 4 * n + 65536;
     if (e->d_tie_z.ensure(n) || e->d_tie_pairs.ensure(2 * (size_t)max_pairs) || e->d_tie_imin.ensure(n) ||

@@ -142,8 +142,8 @@ int launch_slot(qm_stream *s) {
     const bool pull = e->cfg_stream_pull > 0 || (e->cfg_stream_pull < 0 && words * sizeof(double) <= kPullBytes);
     // ("stream_stamps" = 1, measurement: the GPU's clock before and behind every launch -- two one-thread kernels;
     // the digest goes to stderr when the stream is destroyed.  What found round 6's one-off stall: tools/diag_stream.py)
-    const bool stamps = e->cfg_stream_stamps != 0;
     constexpr int kStamps = 4096;
+    const bool stamps = e->cfg_stream_stamps != 0 && s->launches < kStamps;   // (the first 4096 launches of a stream)
     if (stamps && !s->h_stamp) {
         QM_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_stamp), 2 * kStamps * sizeof(unsigned long long),
                              hipHostMallocDefault));
