@@ -8,7 +8,7 @@ does not qualify at all), quantised onsets in half of the trials (exact ties), n
 group counts: the automatic engine against Engine(shift=0) (maxima bit for bit, indices) and the
 oracle; every fourth trial also the volume-writing variant against the oracle's volume, every third
 the marginalised map of a random window against the time sum of that volume, every fifth a batch of
-two or three timesteps in one launch against the steps one by one, every seventh the opt-in tie_rule = 1
+two or three timesteps in one launch against the steps one by one, every fourth the opt-in tie_rule = 1 (alone and with two timesteps in one launch; every eighth on round 5's sets of bricks)
 against the oracle's restatement of the reference's exp rule.  Round 6: three trials in ten scan 384-2100
 samples, and half of all trials ask for the WIDE tiles (six samples per lane) wherever the scan holds one.
 On a mismatch the trial's diagnosis is printed before the assertion (which kernel, which nodes and
@@ -131,15 +131,26 @@ for trial in range(trials):
                                                err_msg=str((trial, grid, S, ns, i0, i1, cfg)))
                     assert np.array_equal(series[2], want[2]) and np.array_equal(series[0], res_first[0]), \
                         (trial, "marginal scan", cfg)
-                if trial % 7 == 0:                                 # (round 5) the opt-in exp rule on near-ties
-                    te = lib.Engine(0, tie_rule=1, **cfg)
+                if trial % 4 == 0:                                 # (round 5) the opt-in exp rule on near-ties
+                    # (round 6: the shift-reuse fused detect refines from a row of maxima per brick; every other
+                    # tie trial on round 5's sets of bricks instead)
+                    te = lib.Engine(0, tie_rule=1, tie_sets=int(trial % 8 != 0), **cfg)
                     te.load_lut(tt)
                     tied = te.detect(lon, fsmp, lsmp, avail)
-                    if te.get("tie_overflow_samples") == 0:
+                    clean = te.get("tie_overflow_samples") == 0
+                    if clean:
                         rule = qm_oracle.np_argmax_exp_rule(lon, tt, fsmp, lsmp, avail, prelogged=True)
-                        assert np.array_equal(tied[2], rule), (trial, "tie_rule", cfg, np.flatnonzero(tied[2] != rule)[:8])
+                        assert np.array_equal(tied[2], rule), (trial, "tie_rule", cfg, te.get("tie_brick_rows"),
+                                                               np.flatnonzero(tied[2] != rule)[:8])
                     assert np.array_equal(tied[0], res_first[0]), (trial, "tie_rule values")
                     np.testing.assert_allclose(tied[1], res_first[1], rtol=1e-13)
+                    if ns >= 8:
+                        # ... and two timesteps in one launch keep the refinement, step for step
+                        other = np.ascontiguousarray(lon[:, ::-1])
+                        want_other = te.detect(other, fsmp, lsmp, avail)
+                        both = te.detect_batch(np.stack([lon, other]), fsmp, lsmp, avail)
+                        assert all(np.array_equal(both[i][0], tied[i]) and np.array_equal(both[i][1], want_other[i])
+                                   for i in range(3)), (trial, "tie_rule in a batch", cfg, te.get("steps_per_launch"))
                     te.close()
                 if trial % 5 == 0:
                     lons = np.stack([lon] + [np.roll(lon, 7 * (j + 1), axis=1) for j in range(k - 1)])
