@@ -207,10 +207,15 @@ def np_find_max_coa(map4d):
 def np_argmax_exp_rule(onsets, traveltimes, first_idx, last_idx, available, prelogged=False):
     """
     The reference's arg-max as its scalar-libm build computes it (migratelib.c:60-62 then :98-105):
-    stacks in ascending row order, x = stack * (1 / available), a correctly rounded exp(x) --
-    80-bit arithmetic rounded to float64 here -- and the FIRST node reaching the largest value.
+    stacks in ascending row order, x = stack * (1 / available), a correctly rounded exp(x) and the
+    FIRST node reaching the largest value.  exp: 80-bit arithmetic rounded to float64 for every
+    node-sample, and -- round 6 -- for the nodes that can tie with a sample's largest x (within a few
+    ulps of it) a 200-bit evaluation rounded once (mpmath): the 80-bit value rounded a second time is
+    off by an ulp about once in a few thousand arguments, which the larger fixture near_ties_bricks
+    caught on one sample of 1600 (x = 0.6018873029417819: ...994, not ...992).
     What the engine's opt-in ``tie_rule = 1`` is specified as (csrc/qm_ties.hpp); pinned on
-    tests/golden/near_ties_scalar.npz (the reference's two C files built with -fno-tree-vectorize).
+    tests/golden/near_ties_scalar.npz and near_ties_bricks.npz (the reference's two C files built with
+    -fno-tree-vectorize).
     """
     lon = onsets if prelogged else log_onsets(onsets)
     *grid, n_rows = traveltimes.shape
@@ -223,7 +228,19 @@ def np_argmax_exp_rule(onsets, traveltimes, first_idx, last_idx, available, prel
         acc += lon[r][tt[:, r][:, None] + first_idx + k]
     x = acc * (1.0 / float(available))            # the product the -Ofast builds form
     coa = np.exp(x.astype(np.longdouble)).astype(np.float64)
-    return np.argmax(coa, axis=0).astype(np.int64)
+    out = np.argmax(coa, axis=0).astype(np.int64)
+    try:
+        import mpmath
+    except ImportError:                            # (the 80-bit evaluation alone: see above)
+        return out
+    xmax = x.max(axis=0)
+    near = x >= xmax - (1e-15 + 1e-15 * np.abs(xmax))
+    with mpmath.workprec(200):
+        for t in np.flatnonzero(near.sum(axis=0) > 1):
+            nodes = np.flatnonzero(near[:, t])
+            vals = [float(mpmath.exp(mpmath.mpf(float(x[n, t])))) for n in nodes]
+            out[t] = nodes[int(np.argmax(vals))]   # (first maximum = lowest index)
+    return out
 
 
 # --------------------------------------------------------------------------

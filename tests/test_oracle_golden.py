@@ -255,3 +255,13 @@ def test_exp_rule_restatement_matches_the_references_scalar_build(oracle):
                                     int(t["mirror_lsmp"]), int(t["mirror_available"]))
     assert np.array_equal(idx, t["mirror_idx_scalar"])
     assert 0.06 < np.mean(idx != t["mirror_idx_vec"]) < 0.10
+    # round 6: the mirror family on a grid of many bricks, 1600 samples (what the per-brick refinement and its
+    # sharded form are pinned on); the reference's values of that run beside the oracle's detect
+    b = load_golden("near_ties_bricks")
+    args = (b["onsets"], b["traveltimes"], int(b["fsmp"]), int(b["lsmp"]), int(b["available"]))
+    idx = oracle.np_argmax_exp_rule(*args)
+    assert np.array_equal(idx, b["idx_scalar"])
+    assert 0.04 < np.mean(idx != b["idx_vec"]) < 0.10
+    got = oracle.detect(*args, threads=4)
+    np.testing.assert_allclose(got[0], b["max_coa_scalar"], rtol=1e-13)
+    np.testing.assert_allclose(got[1], b["max_norm_coa_scalar"], rtol=1e-12)
