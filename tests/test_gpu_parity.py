@@ -3011,7 +3011,7 @@ def test_tie_rule_from_a_partial_set_per_brick(lib, oracle, cfg):
     eng.close()
 
 
-def _tie_sharded_rank(rank, world, port, tmp, columns):
+def _tie_sharded_rank(rank, world, port, tmp, columns, wide=False):
     """One rank of a sharded detect with tie_rule = 1 on the near_ties_bricks family (a node and its mirror
     image live on DIFFERENT ranks: the mid-plane is the shard boundary), both ranks on GPU 0 over gloo."""
     import os
@@ -3037,30 +3037,34 @@ def _tie_sharded_rank(rank, world, port, tmp, columns):
     lon = torch.from_numpy(np.ascontiguousarray(np.log(np.clip(g["onsets"], 0.01, np.inf)))).cuda()
     ns = lon.shape[1] - fsmp - lsmp
     dev = torch.device("cuda", 0)
+    extra = {"shift_wide": 1} if wide else {}               # (wide tiles: the rows come from the loop's atomic maxima)
     if columns:
         boxes = qd.column_boxes(*qd.shard_columns(nx, ny, world, rank), ny)
         engines = []
         for (x0, x1, y0, y1) in boxes:
-            eng = _lib.Engine(0, tie_rule=1)
+            eng = _lib.Engine(0, tie_rule=1, **extra)
             eng.load_lut(np.ascontiguousarray(tt[x0:x1, y0:y1]), node_offset=(x0 * ny + y0) * nz)
             engines.append(eng)
         sd = qd.ColumnShardedDetector(engines, nx * ny * nz, ns, dev, fold_engine=_lib.Engine(0, tie_rule=1))
     else:
         x0, x1 = qd.shard_planes(nx, world, rank)
-        eng = _lib.Engine(0, tie_rule=1)
+        eng = _lib.Engine(0, tie_rule=1, **extra)
         eng.load_lut(np.ascontiguousarray(tt[x0:x1]), node_offset=x0 * ny * nz)
         sd = qd.ShardedDetector(eng, nx * ny * nz, ns, dev)
     first = tuple(t.clone() for t in sd.detect(lon, fsmp, lsmp, avail))
     again = sd.detect(lon, fsmp, lsmp, avail)
     torch.cuda.synchronize()
     assert all(torch.equal(u, v) for u, v in zip(first, again))
+    kernels = [(e.get("last_kernel"), e.get("last_kernel_j"), e.get("tie_brick_rows"))
+               for e in (engines if columns else [eng])]
     np.savez(pathlib.Path(tmp) / f"tie{rank}.npz", a=first[0].cpu().numpy(), b=first[1].cpu().numpy(),
-             c=first[2].cpu().numpy())
+             c=first[2].cpu().numpy(), kernels=np.array(kernels))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("columns", [False, True], ids=["planes", "columns"])
-def test_tie_rule_on_a_sharded_detect(lib, oracle, tmp_path, columns):
+@pytest.mark.parametrize("columns,wide", [(False, False), (True, False), (False, True)],
+                         ids=["planes", "columns", "planes-wide-tiles"])
+def test_tie_rule_on_a_sharded_detect(lib, oracle, tmp_path, columns, wide):
     """tie_rule = 1 across ranks (qm_engine_tie_partial / qm_engine_tie_fold): two processes, the grid cut at its
     mirror plane (plane slabs) or at a column in the middle of a plane (three boxes per rank), every rank refines
     its own partial sets against the GRID's maxima, one more all-gather, a device fold -- the index series is the
@@ -3072,10 +3076,12 @@ def test_tie_rule_on_a_sharded_detect(lib, oracle, tmp_path, columns):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_tie_sharded_rank, args=(2, port, str(tmp_path), columns), nprocs=2, join=True)
+    mp.spawn(_tie_sharded_rank, args=(2, port, str(tmp_path), columns, wide), nprocs=2, join=True)
     g = load_golden("near_ties_bricks")
     for rank in range(2):
         got = np.load(tmp_path / f"tie{rank}.npz")
+        if not columns:                                     # the slab's kernel: shift-reuse, a row per brick
+            assert tuple(got["kernels"][0][:2]) == (3, 6 if wide else 4) and got["kernels"][0][2] > 0, got["kernels"]
         assert np.array_equal(got["c"], g["idx_scalar"]), float(np.mean(got["c"] != g["idx_scalar"]))
         np.testing.assert_allclose(got["a"], g["max_coa_scalar"], rtol=TIGHT)
         np.testing.assert_allclose(got["b"], g["max_norm_coa_scalar"], rtol=NORM)
