@@ -36,6 +36,9 @@ One JSON line on stdout (rank 0).  Besides the contract's keys it carries
                   of the three series inside the timed region, overlapped on HIP streams
                   (SURVEY.md section 8d's PCIe-inclusive step; never ``value``);
   screened_optin : see above;
+  tie_rule_optin : the same steps on Engine(tie_rule=1) -- the reference's arg-max rule on near-ties
+                  (migratelib.c:98-105), opt-in -- beside the default engine: ms per step, ratio,
+                  identical series on this (generic) data;
   roofline_materialised : the locate-style variant that writes the 4-D volume
                   (8 B per node-sample of real HBM traffic), the figure the
                   north-star's ">= 50 % of HBM" maps to;
@@ -664,6 +667,42 @@ def main():
             "vs_float64": {"max_coa_idx_identical": same_idx, "max_coa_identical": same_coa,
                            "max_norm_coa_max_rel_diff": norm_rel}}
         sx.close()
+
+    # ---- the opt-in tie_rule = 1 (the reference's arg-max rule on near-ties) on the same steps ----
+    if not screened and world == 1 and not streaming and not args.no_screened and not tunables.get("tie_rule"):
+        tx = lib.Engine(local_rank, **dict(tunables, tie_rule=1))
+        tx.set_stream(torch.cuda.current_stream().cuda_stream)
+        tx.load_lut(case.traveltimes, node_offset=x_range[0] * ny * nz)
+        out_t = tuple(torch.empty_like(o) for o in out)
+        n_t = max(2, min(args.steps, 10))
+        for i in range(2):
+            tx.detect(onsets_dev[(last - 1 + i) % n_pool], case.fsmp, case.lsmp, case.available, n_nodes_total=n_norm,
+                      out=out_t)
+        torch.cuda.synchronize()
+        same_idx = bool(torch.equal(out_t[2], res[2]))          # (generic data: no near-ties, the same series)
+        same_coa = bool(torch.equal(out_t[0], res[0]))
+        norm_rel = float(((out_t[1] - res[1]).abs() / res[1]).max().item())
+        tx.config("log_timing", 1)
+        t0 = time.perf_counter()
+        for i in range(n_t):
+            tx.detect(onsets_dev[i % n_pool], case.fsmp, case.lsmp, case.available, n_nodes_total=n_norm, out=out_t)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_t
+        tk_ms, tk_calls = tx.kernel_log()
+        result["tie_rule_optin"] = {
+            "what": "Engine(tie_rule=1), NOT the default: nodes whose sums lie within two ulps of a sample's largest "
+                    "are compared on a correctly rounded exp(sum / available), lowest index among equal values -- "
+                    "migratelib.c:98-105 as the reference's scalar-libm build computes it (DESIGN.md section 1, "
+                    "csrc/qm_ties.hpp).  The stacking kernel also leaves the largest value per brick and sample; "
+                    "the refinement re-stacks one brick per sample",
+            "ms_per_step": dt * 1e3, "value": work_step / dt, "unit": "node-samples/s", "steps": n_t,
+            "vs_default_ms_per_step": dt / (elapsed / args.steps),
+            "stacking_kernel_avg_ms": tk_ms / max(tk_calls, 1), "brick_rows": tx.get("tie_brick_rows"),
+            "candidate_pairs_last_step": tx.get("tie_pairs"), "overflow_samples": tx.get("tie_overflow_samples"),
+            "vs_default": {"max_coa_idx_identical": same_idx, "max_coa_identical": same_coa,
+                           "max_norm_coa_max_rel_diff": norm_rel}}
+        assert same_idx and same_coa and norm_rel < 1e-12, result["tie_rule_optin"]
+        tx.close()
 
     # ---- locate-style materialising variant on the same grid (HBM-write bound) ------
     if not args.no_materialised and world == 1 and cfg_name == "C3" and not streaming:
