@@ -192,7 +192,8 @@ int qm_engine_synchronize(qm_engine *e);
  * shift_tail_spl; shift_wide_ok, shift_wide_tiles (of the last launch), shift_wide_brick_nodes,
  * shift_wide_direct_bricks, shift_wide_row_blocks, shift_wide_operands_per_add_x1000; pair_brick_nodes, pair_wide_bricks, pair_tile; screened_steps, fallback_steps,
  * last_candidates, screen_brick_nodes; tie_refined_steps, tie_pairs and tie_overflow_samples (of the last
- * refined launch);
+ * refined launch), tie_brick_rows (rows of per-brick maxima the last stacking launch left: 0 = it refined from
+ * sets of bricks);
  * table_hits, table_misses, table_evictions, tables_parked, table_bytes, tables_parked_bytes. */
 int qm_engine_config(qm_engine *e, const char *key, int64_t value);
 int qm_engine_get(qm_engine *e, const char *key, int64_t *value);
