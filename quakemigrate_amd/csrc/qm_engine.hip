@@ -317,7 +317,7 @@ int run_stack(qm_engine *e, const double *d_onsets, int T, int fsmp, int n_sampl
     const int64_t wide_work = (int64_t)((e->g.nx + 7) / 8) * ((e->g.ny + 7) / 8) * ((e->g.nz + 15) / 16) *
                               ((n_chunk + qm::kShiftWideKT - 1) / qm::kShiftWideKT);
     if (shift && shift_mode == qm::kShiftDetect && e->cfg_shift_wide != 0 && n_chunk >= qm::kShiftWideKT &&
-        // (tie_rule = 1 WITHOUT a set per brick -- tie_sets = 0, round 5's form -- re-stacks one set of bricks per
+        // (tie_rule = 1 WITHOUT a row of maxima per brick -- tie_sets = 0, round 5's form -- re-stacks one set of bricks per
         // sample: the wide layout's few long workgroups would publish sets of tens of thousands of nodes)
         (e->cfg_shift_wide == 1 || (wide_work >= 8 * (int64_t)e->n_cu && n_chunk >= 4 * qm::kShiftWideKT &&
                                     (!e->cfg_tie_rule || e->cfg_tie_sets) &&

@@ -1,6 +1,6 @@
-// stack_shift_bricks_kernel<NW> (qm_shift.hpp): the fused detect that publishes a partial
-// set per brick of a workgroup's walk -- what "tie_rule" = 1 refines from (qm_ties.hpp); a unit of its own so that
-// it compiles beside qm_launch_shift.hip
+// stack_shift_bricks_kernel<NW> (qm_shift.hpp): the fused detect that also leaves the largest z per BRICK and sample
+// (StackArgs::brick_max) -- what "tie_rule" = 1 refines from (qm_ties.hpp); a unit of its own so that it compiles
+// beside qm_launch_shift.hip
 #define QM_SHIFT_TU 2
 #include "qm_launch.hpp"
 #include "qm_shift.hpp"

@@ -12,8 +12,10 @@
 // behind (the partial sets: per (set of bricks, sample) the largest z):
 //   1. tie_pairs_kernel: per sample the largest z over the sets, and the sets whose maximum lies
 //      within `slack` of it -- only they can hold a node whose exp() ties with the maximum's.  Generic
-//      data: one (set, sample) pair per sample.  (With the rule on, a launch publishes eight times as
-//      many, smaller sets -- run_stack --: what a pair costs is its set's nodes.)
+//      data: one (set, sample) pair per sample.  What a pair costs is its set's nodes: round 6, the
+//      shift-reuse fused detect leaves a ROW OF MAXIMA PER BRICK beside its partial sets
+//      (StackArgs::brick_max, stack_shift_bricks_kernel) and a "set" is one brick; the other kernels
+//      publish eight times as many, smaller sets (four bricks) with the rule on -- run_stack.
 //   2. tie_eval_kernel: every node of such a set is stacked again for that ONE sample, rows in
 //      ascending order (the reference's sum, bit for bit); nodes within the slack form x = stack *
 //      (1 / available) as the reference does and a CORRECTLY ROUNDED exp(x) (double-double
@@ -27,6 +29,9 @@
 // A sample with more than kTieMaxSets candidate sets (flat data: everything ties) keeps the default
 // rule's index, which for EQUAL sums is the reference's; the count is reported
 // (qm_engine_get "tie_overflow_samples").
+// Sharded detects (round 6): tie_zmax_kernel takes the GRID's largest z per sample from the gathered partials,
+// steps 1-2 run against it on every rank's own sets, tie_export_kernel leaves (largest exp, lowest global
+// index reaching it) per sample for one more all-gather, tie_fold_kernel folds the ranks' pairs.
 // slack: exp(x1) and exp(x2) can round to one double only if |x1 - x2| <= 2^-52 (one ulp of the result,
 // relative), i.e. |z1 - z2| <= 1.4427 * 2^-52; z and x are both products of the same stack with a
 // rounded constant (half an ulp each, relative).  slack = 4e-16 + 2^-50 |z| covers both with room; a
