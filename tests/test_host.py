@@ -609,6 +609,26 @@ def test_generated_shift_loop_is_current_whatever_the_environment_holds():
     assert variant != gen and "overlay=PF_AHEAD=32" in variant and "overlay=none" in gen
 
 
+def test_stored_hbm_traffic_was_measured_on_this_trees_kernels():
+    """bench.py reports `roofline.traffic` from the newest profiles/r*_pmc_traffic.json only while the stacking
+    kernels' sources still hash to what the PMC passes ran on (tools/pmc_traffic.py: kernel_code_digest) -- a
+    stale file turns the driver's bench line's traffic into null.  The committed file must belong to the
+    committed kernels (a comment edit in qm_shift.hpp counts: re-run `tools/round_evidence.sh <tag> pmc`)."""
+    import glob
+    import json
+
+    sys.path.insert(0, str(ROOT / "tools"))
+    try:
+        import pmc_traffic
+    finally:
+        sys.path.pop(0)
+    files = sorted(glob.glob(str(ROOT / "profiles" / "r*_pmc_traffic.json")))
+    assert files, "no stored traffic figure"
+    stored = json.load(open(files[-1]))
+    assert stored["_kernel_code"] == pmc_traffic.kernel_code_digest(), files[-1]
+    assert stored["C3:detect"]["kernel"] == "void qm::stack_shift_kernel<0, 8>"      # (the name bench.py asks for)
+
+
 def test_library_exports_only_the_c_abi_and_says_what_it_was_built_from(built):
     """`nm -D`: the symbols include/qmhip.h declares and nothing else (csrc/qmhip.map; the kernels' host stubs
     and the engine's C++ internals used to be visible beside them); qm_build_info() names the product
