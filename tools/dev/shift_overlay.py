@@ -9,6 +9,7 @@ variant this script imports it, sets module constants named on the command line 
 Timing experiments (WRONG RESULTS by construction -- what a component of the loop costs in situ):
 `DROP=<regex>` leaves out every emitted instruction that matches, `ONLY=<name regex>` restricts that to the
 flavours whose function name matches, e.g. DROP='ds_read_b128' ONLY='shift_wide'.
+`SUM_DEGREE=<6..10>`: the fused detect's 2^f polynomial at another degree (with -DQM_EXP2_DEGREE_SUM=<same>).
 
 tools/shift_variants.sh builds a library per variant around such a file; nothing of it reaches
 `__graft_entry__.build()`, which regenerates the committed qm_shift_asm.inc from the product constants
@@ -27,14 +28,25 @@ def main(argv):
     import re
 
     drop = only = None
+    sum_degree = None
     for item in list(argv):
         name, _, value = item.partition("=")
-        if name in ("DROP", "ONLY"):
+        if name in ("DROP", "ONLY", "SUM_DEGREE"):
             argv.remove(item)
             if name == "DROP":
                 drop = re.compile(value)
-            else:
+            elif name == "ONLY":
                 only = re.compile(value)
+            else:
+                sum_degree = int(value)
+    if sum_degree is not None:
+        # (right results to that polynomial's accuracy: the 2^f of the fused detect's running sums -- degree 8 in
+        # the product, 7.8e-13 -- at another degree; build the unit with -DQM_EXP2_DEGREE_SUM=<the same>)
+        emit_product = gen.emit
+
+        def emit_degree(degree, volume, *rest, **kw):
+            emit_product(sum_degree if (degree == 8 and not volume) else degree, volume, *rest, **kw)
+        gen.emit = emit_degree
     if drop is not None:
         emit = gen.emit
         plain = gen.Emitter.__call__
