@@ -515,10 +515,15 @@ __device__ __forceinline__ void shift_reset(double (&vmax)[J], double (&vsum)[J]
 // The workgroup's wavefronts hold (max, sum, index) of the tile's 64 J samples, J per lane:
 // combine them through LDS (thread k owns sample k) and publish the workgroup's partial set.
 // Call after a barrier behind the last use of `win`.
+// (t_own: the first sample the tile is there for.  A tile pulled back over its predecessor computes that one's last
+// samples a second time; it publishes its OWN only -- round 6: the two used to write the same entries, which is
+// harmless while both run the same loop flavour and a last-bits race in max_norm_coa when they do not: with
+// tie_rule = 1 a wide tile runs the lazy loop and the 256-sample tile behind it the eager one, whose sums' terms
+// differ in the last bits; found by the fuzz campaign as a batch that differed from its steps in one sample.)
 template <int NW, int J = 4>
 __device__ __forceinline__ void shift_publish(const StackArgs &a, double *win, const double (&vmax)[J],
                                               const double (&vsum)[J], const int (&vidx)[J], int wave,
-                                              int lane, int group, int t_first) {
+                                              int lane, int group, int t_first, int t_own = 0) {
     constexpr int KT = kWave * J;
     double *smax = win, *ssum = win + NW * KT;
     int *sidx = reinterpret_cast<int *>(win + 2 * NW * KT);
@@ -544,7 +549,7 @@ __device__ __forceinline__ void shift_publish(const StackArgs &a, double *win, c
         }
     }
     const int t = t_first + k;
-    if (t < a.n_chunk) {
+    if (t < a.n_chunk && t >= t_own) {
         const int64_t o = (int64_t)(a.set0 + group) * (a.part_stride ? a.part_stride : a.n_chunk) + t;
         a.part_max[o] = best;
         a.part_idx[o] = bi == INT32_MAX ? kNoIndex : (int64_t)bi;
@@ -659,7 +664,7 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
         for (int k = 0; k < J; ++k) win[wave * KT + J * lane + k] = vmax[k];
         __syncthreads();
         const int j = threadIdx.x;
-        if (j < KT && t_first + j < a.n_chunk) {
+        if (j < KT && t_first + j < a.n_chunk && t_first + j >= work.t_own) {     // (its own samples, as shift_publish)
             double best = win[j];
             for (int w = 1; w < NW; ++w) best = win[w * KT + j] > best ? win[w * KT + j] : best;
             a.brick_max[(int64_t)b * brow_stride + t_first + j] = best;
@@ -804,7 +809,7 @@ __device__ __forceinline__ void shift_tile(const ShiftArgs &s, double *win, cons
         }
         __syncthreads();
     }
-    shift_publish<NW, J>(a, win, vmax, vsum, vidx, wave, lane, group, t_first);
+    shift_publish<NW, J>(a, win, vmax, vsum, vidx, wave, lane, group, t_first, work.t_own);
 }
 
 template <int MODE, int NW, bool SETS>           // (SETS: also a.brick_max, see shift_tile)

@@ -149,6 +149,15 @@ for trial in range(trials):
                         other = np.ascontiguousarray(lon[:, ::-1])
                         want_other = te.detect(other, fsmp, lsmp, avail)
                         both = te.detect_batch(np.stack([lon, other]), fsmp, lsmp, avail)
+                        for j, one in enumerate((tied, want_other)):
+                            for i in range(3):
+                                if not np.array_equal(both[i][j], one[i]):
+                                    bad = np.flatnonzero(both[i][j] != one[i])
+                                    print("TIE BATCH MISMATCH", trial, grid, S, ns, cfg, "step", j, "array", i, "bad samples",
+                                          len(bad), bad[:12], "batch", both[i][j][bad[:6]], "single", one[i][bad[:6]],
+                                          "rows", te.get("tie_brick_rows"), "overflow", te.get("tie_overflow_samples"),
+                                          "kernel", te.get("last_kernel"), te.get("last_kernel_j"), "wide tiles",
+                                          te.get("shift_wide_tiles"), flush=True)
                         assert all(np.array_equal(both[i][0], tied[i]) and np.array_equal(both[i][1], want_other[i])
                                    for i in range(3)), (trial, "tie_rule in a batch", cfg, te.get("steps_per_launch"))
                     te.close()
