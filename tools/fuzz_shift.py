@@ -8,7 +8,7 @@ does not qualify at all), quantised onsets in half of the trials (exact ties), n
 group counts: the automatic engine against Engine(shift=0) (maxima bit for bit, indices) and the
 oracle; every fourth trial also the volume-writing variant against the oracle's volume, every third
 the marginalised map of a random window against the time sum of that volume, every fifth a batch of
-two or three timesteps in one launch against the steps one by one, every fourth the opt-in tie_rule = 1 (alone and with two timesteps in one launch; every eighth on round 5's sets of bricks)
+two or three timesteps in one launch against the steps one by one, every fourth the opt-in tie_rule = 1 (alone and with two timesteps in one launch; every eighth on round 5's sets of bricks; every twelfth also sharded over two engines through qm_engine_tie_partial / _tie_fold)
 against the oracle's restatement of the reference's exp rule.  Round 6: three trials in ten scan 384-2100
 samples, and half of all trials ask for the WIDE tiles (six samples per lane) wherever the scan holds one.
 On a mismatch the trial's diagnosis is printed before the assertion (which kernel, which nodes and
@@ -161,6 +161,40 @@ for trial in range(trials):
                         assert all(np.array_equal(both[i][0], tied[i]) and np.array_equal(both[i][1], want_other[i])
                                    for i in range(3)), (trial, "tie_rule in a batch", cfg, te.get("steps_per_launch"))
                     te.close()
+                    if trial % 12 == 0 and grid[0] >= 2:
+                        # ... and sharded: the grid cut into two x-slabs on two engines, the exchange of
+                        # distributed.ShardedDetector done by hand in this process (partials -> packed fold ->
+                        # every engine's candidates against the GRID's maxima -> fold of the outcomes)
+                        import torch
+                        from quakemigrate_amd import distributed as qd
+                        mx = grid[0] // 2
+                        slabs = [(0, mx), (mx, grid[0])]
+                        engs = []
+                        for x0, x1 in slabs:
+                            se = lib.Engine(0, tie_rule=1, **cfg)
+                            se.set_stream(torch.cuda.current_stream().cuda_stream)    # (one stream orders the engines)
+                            se.load_lut(np.ascontiguousarray(tt[x0:x1]), node_offset=x0 * grid[1] * grid[2])
+                            engs.append(se)
+                        dlon = torch.from_numpy(lon).cuda()
+                        gathered = torch.empty((2, 3, ns), dtype=torch.float64, device="cuda")
+                        for r, se in enumerate(engs):
+                            se.detect_partial(dlon, fsmp, lsmp, avail, (gathered[r, 0], gathered[r, 1].view(torch.int64),
+                                                                        gathered[r, 2]))
+                        out = tuple(torch.empty(ns, dtype=d, device="cuda") for d in (torch.float64, torch.float64, torch.int64))
+                        engs[0].finalize_packed(gathered, 2, ns, int(np.prod(grid)), out=out)
+                        tgat = torch.zeros((2, 2, ns), dtype=torch.float64, device="cuda")
+                        for r, se in enumerate(engs):
+                            se.tie_partial(dlon, fsmp, lsmp, avail, gathered, 2, tgat[r])
+                        engs[0].tie_fold(tgat, 2, ns, out[2])
+                        torch.cuda.synchronize()
+                        over = sum(se.get("tie_overflow_samples") for se in engs)
+                        if over == 0 and clean:
+                            got_idx = out[2].cpu().numpy()
+                            assert np.array_equal(got_idx, rule), (trial, "sharded tie_rule", cfg, grid,
+                                                                   np.flatnonzero(got_idx != rule)[:8])
+                        assert np.array_equal(out[0].cpu().numpy(), res_first[0]), (trial, "sharded tie_rule values")
+                        for se in engs:
+                            se.close()
                 if trial % 5 == 0:
                     lons = np.stack([lon] + [np.roll(lon, 7 * (j + 1), axis=1) for j in range(k - 1)])
                     both = eng.detect_batch(lons, fsmp, lsmp, avail)
