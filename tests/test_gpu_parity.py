@@ -3011,6 +3011,59 @@ def test_tie_rule_from_a_partial_set_per_brick(lib, oracle, cfg):
     eng.close()
 
 
+def test_tie_rule_at_the_c3_size_on_mirror_twins(lib, oracle):
+    """BASELINE's C3 size with REAL near-ties everywhere: 15 stations and their mirror images about the grid's mid
+    x-plane, seen with the same onset rows -- node (i, j, k) and node (200 - i, j, k) stack the same multiset of
+    log-onsets in another row order, so every sample's maximum is a near-tie between two nodes 4 700 bricks
+    apart.  tie_rule = 1 on the wide tiles (4 732 bricks of 8x8x16 nodes, sixteen long workgroups, lazy loop: the
+    rows of brick maxima come from the loop's gated atomic maxima) equals the oracle's restatement of the
+    reference's rule (migratelib.c:98-105; correctly rounded exp, first maximum) on every sample of four time
+    chunks -- two of them around samples where the default rule picks the other twin --, values are the default engine's bits, and two
+    timesteps in one launch keep all of it."""
+    cfg = synth.CONFIGS["C3"]
+    grid, rate, S, half = cfg["grid"], cfg["rate"], 30, 15
+    rng = np.random.default_rng(31)
+    span = (grid[0] - 1) * cfg["spacing"]
+    st = synth.station_positions(rng, grid, cfg["spacing"], half)
+    mirror = st.copy()
+    mirror[:, 0] = span - mirror[:, 0]
+    stations = np.concatenate([st, mirror])
+    vel = np.array(([cfg["vp"]] * 8 + [cfg["vs"]] * 7) * 2)
+    tt = synth.homogeneous_lut(grid, cfg["spacing"], stations, vel, rate)
+    fsmp, ns = 100, 1920                                          # five wide tiles
+    lsmp = int(tt.max()) + 20
+    rows = np.clip(rng.lognormal(0, 0.5, size=(half, fsmp + ns + lsmp)), 0.4, np.inf)
+    onsets = np.ascontiguousarray(np.concatenate([rows, rows]))
+    lon = oracle.log_onsets(onsets)
+    base = lib.Engine(0)
+    base.load_lut(tt)
+    a0, b0, c0 = base.detect(lon, fsmp, lsmp, S)
+    assert base.get("last_kernel") == 3 and base.get("last_kernel_j") == 6
+    base.close()
+    eng = lib.Engine(0, tie_rule=1)
+    eng.load_lut(tt)
+    a, b, c = eng.detect(lon, fsmp, lsmp, S)
+    assert eng.get("last_kernel") == 3 and eng.get("last_kernel_j") == 6 and eng.get("shift_wide_tiles") == 5
+    assert eng.get("tie_brick_rows") == 4732 and eng.get("tie_overflow_samples") == 0
+    assert np.array_equal(a, a0) and np.array_equal(b, b0)       # (the same launch shape: the same bits)
+    # (the default rule -- the larger of two sums an ulp or two apart -- picks the other twin on 0.7 % of these
+    # samples: the chunks are placed on some of them, and on samples where both rules agree)
+    flips = np.flatnonzero(c != c0)
+    assert 0.002 < len(flips) / ns < 0.3
+    for k0 in (0, int(flips[0]) - 3, int(flips[len(flips) // 2]) - 3, ns - 8):
+        k0 = min(max(k0, 0), ns - 8)
+        nk = 8
+        chunk = onsets[:, k0:k0 + fsmp + nk + lsmp]
+        rule = oracle.np_argmax_exp_rule(chunk, tt, fsmp, lsmp, S)
+        assert np.array_equal(c[k0:k0 + nk], rule), (k0, c[k0:k0 + nk], rule)
+    two = eng.detect_batch(np.stack([lon, np.roll(lon, 11, axis=1)]), fsmp, lsmp, S)
+    assert eng.get("steps_per_launch") == 2
+    assert all(np.array_equal(two[i][0], x) for i, x in enumerate((a, b, c)))
+    second = eng.detect(np.roll(lon, 11, axis=1), fsmp, lsmp, S)
+    assert all(np.array_equal(two[i][1], second[i]) for i in range(3))
+    eng.close()
+
+
 def _tie_sharded_rank(rank, world, port, tmp, columns, wide=False):
     """One rank of a sharded detect with tie_rule = 1 on the near_ties_bricks family (a node and its mirror
     image live on DIFFERENT ranks: the mid-plane is the shard boundary), both ranks on GPU 0 over gloo."""
