@@ -4,11 +4,11 @@
 Random grids (every dimension >= 2), 1-64 rows (both workgroup shapes; a fifth of the trials 65-200 rows: row blocks
 in any of their three forms), 1-900 scanned samples (round 4: every tail-tile length, with and without tail tiles), coherent tables of random
 steepness (in 30 % of the trials with a few steep rows: bricks on the direct kernel, or a table that
-does not qualify at all), quantised onsets in half of the trials (exact ties), negative delays, random `available` and
+does not qualify at all), quantised onsets in half of the trials (exact ties),  negative delays, random `available` and
 group counts: the automatic engine against Engine(shift=0) (maxima bit for bit, indices) and the
 oracle; every fourth trial also the volume-writing variant against the oracle's volume, every third
 the marginalised map of a random window against the time sum of that volume, every fifth a batch of
-two or three timesteps in one launch against the steps one by one, every fourth the opt-in tie_rule = 1 (alone and with two timesteps in one launch; every eighth on round 5's sets of bricks; every twelfth also sharded over two engines through qm_engine_tie_partial / _tie_fold)
+two or three timesteps in one launch against the steps one by one, every fourth the opt-in tie_rule = 1 (alone and with two timesteps in one launch; every eighth on round 5's sets of bricks; every twelfth also sharded over two engines through qm_engine_tie_partial / _tie_fold; an eighth of the trials also on MIRROR TWINS made from the trial's table -- near-ties at every sample)
 against the oracle's restatement of the reference's exp rule.  Round 6: three trials in ten scan 384-2100
 samples, and half of all trials ask for the WIDE tiles (six samples per lane) wherever the scan holds one.
 On a mismatch the trial's diagnosis is printed before the assertion (which kernel, which nodes and
@@ -161,6 +161,31 @@ for trial in range(trials):
                         assert all(np.array_equal(both[i][0], tied[i]) and np.array_equal(both[i][1], want_other[i])
                                    for i in range(3)), (trial, "tie_rule in a batch", cfg, te.get("steps_per_launch"))
                     te.close()
+                    if trial % 8 == 4 and S % 2 == 0 and S >= 2:
+                        # (round 6) MIRROR TWINS: the second half of the rows are the first half's stations mirrored
+                        # about the grid's mid x-plane, seen with the same log-onsets -- node (i, j, k) and node
+                        # (nx - 1 - i, j, k) stack the same multiset in another row order: every sample's maximum
+                        # is a NEAR-tie (0-2 ulps) between two nodes of different bricks.  The rule against the
+                        # oracle's restatement; the values against the default engine on the same data.
+                        tt_m, lon_m = tt.copy(), np.ascontiguousarray(np.log(np.clip(
+                            np.random.default_rng(trial).lognormal(0, 0.6, size=(S, T)), 0.01, None)))
+                        tt_m[..., S // 2:] = tt_m[::-1, ..., :S // 2]
+                        lon_m[S // 2:] = lon_m[:S // 2]
+                        dm = lib.Engine(0, **cfg)
+                        dm.load_lut(tt_m)
+                        base_m = dm.detect(lon_m, fsmp, lsmp, avail)
+                        dm.close()
+                        tm = lib.Engine(0, tie_rule=1, **cfg)
+                        tm.load_lut(tt_m)
+                        tied_m = tm.detect(lon_m, fsmp, lsmp, avail)
+                        if tm.get("tie_overflow_samples") == 0:
+                            rule_m = qm_oracle.np_argmax_exp_rule(lon_m, tt_m, fsmp, lsmp, avail, prelogged=True)
+                            assert np.array_equal(tied_m[2], rule_m), (trial, "tie_rule on mirror twins", cfg, grid, S, ns,
+                                                                       tm.get("tie_brick_rows"), tm.get("last_kernel"),
+                                                                       np.flatnonzero(tied_m[2] != rule_m)[:8])
+                        assert np.array_equal(tied_m[0], base_m[0]), (trial, "tie_rule on mirror twins: values")
+                        np.testing.assert_allclose(tied_m[1], base_m[1], rtol=1e-13)
+                        tm.close()
                     if trial % 12 == 0 and grid[0] >= 2:
                         # ... and sharded: the grid cut into two x-slabs on two engines, the exchange of
                         # distributed.ShardedDetector done by hand in this process (partials -> packed fold ->
