@@ -142,6 +142,21 @@ def all_gather_packed(packed, gathered, group=None):
     return gathered
 
 
+def _agreed_on_all_ranks(flag, device, group=None):
+    """``flag`` (a bool every rank brings) if all ranks of the group bring the same one; ValueError otherwise.  One
+    small all-reduce at construction: a detector whose ranks disagree on ``tie_rule`` would leave some of them
+    waiting in the second exchange for the others."""
+    import torch.distributed as dist
+
+    on = torch.device("cpu") if _backend(group) == "gloo" else device
+    both = torch.tensor([int(bool(flag)), -int(bool(flag))], dtype=torch.int64, device=on)
+    dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)          # (max, -min) in one message
+    if int(both[0]) != -int(both[1]):
+        raise ValueError("the ranks of a sharded detector must share their engines' tie_rule "
+                         f"(this rank: {int(bool(flag))})")
+    return bool(flag)
+
+
 def fold_ties_torch(tie_gathered, idx):
     """The fold of ``Engine.tie_fold`` stated with torch ops (CPU tests): ``tie_gathered`` int64 bit
     patterns ``[n_sets][2][n_samples]`` (exp keys -- positive doubles order as integers; -1 = a rank
@@ -232,7 +247,8 @@ class ShardedDetector:
                     torch.empty(ns, dtype=torch.int64, device=self.device))
         # tie_rule = 1: a rank's outcome (exp bits, index bits) and the gathered ones; every rank of the
         # group must be configured alike (the second exchange is a collective)
-        self.tie_rule = bool(engine.get("tie_rule")) if hasattr(engine, "get") else False
+        self.tie_rule = _agreed_on_all_ranks(engine.get("tie_rule") if hasattr(engine, "get") else False,
+                                             self.device, group)
         if self.tie_rule and exchange != "packed":
             raise ValueError("tie_rule = 1 on a sharded detect uses the packed exchange")
         self.tie_packed = torch.zeros((2, ns), dtype=torch.float64, device=self.device)
@@ -349,7 +365,7 @@ class ColumnShardedDetector:
         rules = {bool(e.get("tie_rule")) for e in self.engines + [self.fold_engine]}
         if len(rules) > 1:
             raise ValueError("the engines of one rank must share their tie_rule")
-        self.tie_rule = rules.pop()
+        self.tie_rule = _agreed_on_all_ranks(rules.pop(), self.device, group)
         self.tie_packed = torch.zeros((MAX_BOXES, 2, ns), dtype=torch.float64, device=self.device)
         self.tie_packed[:, 1].view(torch.int64).fill_(INT64_MAX)
         self.tie_gathered = torch.empty((self.world, MAX_BOXES, 2, ns), dtype=torch.float64,

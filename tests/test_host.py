@@ -348,6 +348,27 @@ def _worker_ties(rank, world, port, tmp):
     refined = qd.fold_ties_torch(tie_gathered.view(torch.int64), idx)
     np.savez(pathlib.Path(tmp) / f"ties{rank}.npz", default=idx.numpy(), refined=refined.numpy(),
              candidates=int((keys != 0).sum()))
+
+    # a detector whose ranks disagree on tie_rule says so on every rank at construction (it would hang in the
+    # second exchange otherwise); ranks that agree construct
+    class _NoTable:
+        n_rows = None
+
+        def __init__(self, rule):
+            self.rule = rule
+
+        def get(self, key):
+            assert key == "tie_rule"
+            return self.rule
+
+    try:
+        qd.ShardedDetector(_NoTable(rank), 10, 5, "cpu")
+        raised = False
+    except ValueError as e:
+        raised = "tie_rule" in str(e)
+    assert raised
+    assert qd.ShardedDetector(_NoTable(1), 10, 5, "cpu").tie_rule is True
+    assert qd.ColumnShardedDetector([], 10, 5, "cpu", fold_engine=_NoTable(0)).tie_rule is False
     dist.destroy_process_group()
 
 
