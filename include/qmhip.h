@@ -127,7 +127,9 @@ int qm_engine_synchronize(qm_engine *e);
  *                                                (migratelib.c:98-105 as its scalar-libm build computes it);
  *                                                final series of detect / detect_batch (the step axis kept) /
  *                                                migrate / marginal, and sharded detects through
- *                                                qm_engine_tie_partial / _tie_fold; values unchanged
+ *                                                qm_engine_tie_partial / _tie_fold; values unchanged.  Device
+ *                                                memory: 8 bytes per brick (512-1024 nodes) and scanned sample
+ *                                                besides the partial sets (C3: 227 MB per timestep of a launch)
  * tie_sets              0 / 1 [1]                (measurements) 1: with tie_rule = 1 the shift-reuse fused detect
  *                                                publishes a partial set per brick, the refinement re-stacks one
  *                                                brick per sample; 0: sets of four bricks from more workgroups
