@@ -250,7 +250,36 @@ static int build_shift_tables(qm_engine *e, ShiftLayout &L, bool wide, bool wide
         n_candidates = 1;
     }
     const bool fixed = e->cfg_bx > 0 && !blocks;
-    const int n_shapes = fixed || blocks ? 1 : 5;
+    int n_shapes = fixed || blocks ? 1 : 5;
+    // Round 6: a grid whose extent along one axis ends a node or two into a brick (the Icequake-sized C1: 57 nodes
+    // in z = seven bricks of eight and one layer) pays a whole brick's staging and barriers for that layer.  Where a
+    // FLATTER brick along one axis fills the grid's bounding bricks at least 4 % better than 8x8x8, it is tried
+    // first (C1: 88 -> 94 %, a step 0.380 -> 0.363 ms at one timestep per launch, 0.352 -> 0.323 in the sweep;
+    // C3 and its slabs: equal utilisation either way, 8x8x8 stays -- flatter bricks cost them 3 %,
+    // profiles/r06b_ab_bricks.txt).  Four-wave shape only (tables of up to ~32 rows).
+    int shapes4[6][3];
+    for (int i = 0; i < 5; ++i)
+        for (int k = 0; k < 3; ++k) shapes4[i][k] = kShapes4[i][k];
+    if (!fixed && !blocks && !wide) {
+        auto filled = [&](int bx, int by, int bz) {
+            auto up = [](int n, int b) { return (int64_t)((n + b - 1) / b) * b; };
+            return (double)e->n_nodes / (double)(up(e->g.nx, bx) * up(e->g.ny, by) * up(e->g.nz, bz));
+        };
+        static const int kFlat[][3] = {{8, 8, 4}, {8, 4, 8}, {4, 8, 8}};
+        int best = -1;
+        double most = 1.04 * filled(8, 8, 8);
+        for (int i = 0; i < 3; ++i)
+            if (filled(kFlat[i][0], kFlat[i][1], kFlat[i][2]) > most) {
+                most = filled(kFlat[i][0], kFlat[i][1], kFlat[i][2]);
+                best = i;
+            }
+        if (best >= 0) {
+            for (int i = 5; i > 0; --i)
+                for (int k = 0; k < 3; ++k) shapes4[i][k] = shapes4[i - 1][k];
+            for (int k = 0; k < 3; ++k) shapes4[0][k] = kFlat[best][k];
+            n_shapes = 6;
+        }
+    }
     static const int kShapesBlocks[][3] = {{4, 4, 4}};
     static const int kShapesBlocks4[][3] = {{4, 4, 2}};
     int nw = candidates[0];
@@ -261,8 +290,9 @@ static int build_shift_tables(qm_engine *e, ShiftLayout &L, bool wide, bool wide
     for (int cand = 0; cand < n_candidates && !ok; ++cand) {
     nw = candidates[cand];
     const int (*kShapes)[3] = blocks ? (quad ? kShapesBlocks4 : kShapesBlocks) : wide ? kShapesWide
-                              : nw == qm::kShiftWaves3 ? kShapes12 : nw == qm::kShiftWaves8 ? kShapes8 : kShapes4;
-    for (int s = 0; s < n_shapes; ++s) {
+                              : nw == qm::kShiftWaves3 ? kShapes12 : nw == qm::kShiftWaves8 ? kShapes8 : shapes4;
+    const int n_try = kShapes == shapes4 ? n_shapes : std::min(n_shapes, 5);
+    for (int s = 0; s < n_try; ++s) {
         g = e->g;
         g.bx = std::min(even_up(fixed ? e->cfg_bx : kShapes[s][0]), even_up(g.nx));
         g.by = std::min(even_up(fixed ? e->cfg_by : kShapes[s][1]), even_up(g.ny));

@@ -2989,9 +2989,12 @@ def test_tie_rule_from_a_partial_set_per_brick(lib, oracle, cfg):
     a, b, c = eng.detect(lon, fsmp, lsmp, avail)
     shift = cfg.get("shift", -1) != 0
     assert eng.get("last_kernel") == (3 if shift else 1)
-    # (a row of maxima per brick -- 45 bricks of 8x8x8, 30 of 8x8x16 nodes; the wide tiles' loop raises them itself)
+    # (a row of maxima per brick -- 75 bricks of 8x8x4 nodes: 20 nodes in z fill bricks of four, not of eight; the
+    # 8-wave shape keeps 8x8x8: 45; wide tiles 30 of 8x8x16, whose loop raises the rows itself)
     rows = eng.get("tie_brick_rows")
-    assert rows == (0 if not shift or cfg.get("tie_sets", 1) == 0 else 30 if "shift_wide" in cfg else 45), rows
+    want_rows = (0 if not shift or cfg.get("tie_sets", 1) == 0 else 30 if "shift_wide" in cfg
+                 else 45 if cfg.get("shift_waves") == 8 else 75)
+    assert rows == want_rows, (rows, want_rows)
     if "shift_wide" in cfg:
         assert eng.get("last_kernel_j") == 6
     assert np.array_equal(c, g["idx_scalar"]), float(np.mean(c != g["idx_scalar"]))
